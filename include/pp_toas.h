@@ -1,0 +1,171 @@
+/*
+ * pp_toas.h -- C ABI of the MI355X wideband-TOA fit engine (libpptoas_hip.so).
+ *
+ * The reference (pennucci/PulsePortraiture) is pure Python with no FFI of its
+ * own; the drop-in boundary is therefore the Python call signature, and this
+ * header is what the Python shims in pulseportraiture_amd/ bind with ctypes
+ * (INTEGRATION.md shows the stub a maintainer would add to the reference).
+ * Each entry point names the reference interface it replaces (file:line under
+ * the reference tree).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types;
+ *   - every function returns an int status: PP_OK (0) or a negative PP_E*
+ *     code, with a human-readable message available from pp_last_error();
+ *     no exception crosses the boundary;
+ *   - per-subint numerical status goes in return_code[] (PP_RC_*), the fit
+ *     itself never fails the call (reference: pptoaslib.py:1016-1033);
+ *   - the caller owns every host buffer; the library copies what it needs and
+ *     keeps no host pointer after return.  Device scratch lives in the opaque
+ *     context.  One context per (host thread, GPU); calls on one context are
+ *     serialised by the caller.
+ *   - portraits are C-contiguous [nsub][nchan][nbin]; nbin is a power of two
+ *     in [32, 8192].
+ */
+#ifndef PP_TOAS_H
+#define PP_TOAS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_ABI_VERSION 1
+
+/* status codes */
+#define PP_OK 0
+#define PP_EINVAL (-1)   /* bad argument */
+#define PP_EHIP (-2)     /* HIP runtime error */
+#define PP_ENOMEM (-3)   /* device memory */
+#define PP_ESTATE (-4)   /* call order / missing model */
+
+/* sample types of portraits */
+#define PP_F64 0
+#define PP_F32 1
+
+/* per-subint return codes (return_code[]); 2 is what the reference's
+ * trust-ncg normally reports with gtol=-1 (pptoaslib.py:1002) */
+#define PP_RC_GRAD 0      /* gradient below tolerance */
+#define PP_RC_MAXITER 1   /* iteration limit */
+#define PP_RC_STALL 2     /* no predicted reduction left: converged to rounding */
+#define PP_RC_NAN 3       /* NaN / singular objective */
+
+typedef struct pp_ctx pp_ctx;
+
+/* ---- context ---------------------------------------------------------- */
+int pp_abi_version(void);
+const char* pp_last_error(void);
+int pp_create(int device_id, pp_ctx** out);
+int pp_destroy(pp_ctx* ctx);
+/* block until everything queued on the context's stream has finished */
+int pp_synchronize(pp_ctx* ctx);
+/* the hipStream_t the context launches on (as void*) */
+void* pp_stream(pp_ctx* ctx);
+
+/* Options (name, value):
+ *   "harm_eps"     relative |m_nk| threshold below which the model's trailing
+ *                  harmonics are dropped from the cross-spectrum (0 = keep all;
+ *                  default 2^-50, DESIGN.md "Harmonic truncation")
+ *   "max_iter"     trust-region iteration limit (default 64; reference: 1000)
+ *   "profile"      1 = record HIP events around every kernel (pp_kernel_times)
+ *   "check_every"  iterations between host checks of the active count
+ */
+int pp_set_option(pp_ctx* ctx, const char* name, double value);
+
+/* ---- model portraits ---------------------------------------------------- */
+/* Upload an nchan x nbin template into slot `slot` (0..PP_MAX_SLOTS-1), rFFT it
+ * on the device, zero the DC harmonic and keep sum_k |m_nk|^2 per channel.
+ * Replaces the model half of pptoaslib.py:978-979 (and pplib.py:2123-2124).
+ * `on_device` != 0 means `portrait` is a device pointer on this GPU. */
+#define PP_MAX_SLOTS 64
+int pp_model_set(pp_ctx* ctx, int slot, const void* portrait, int dtype,
+                 int on_device, int nchan, int nbin);
+/* number of harmonics (of nbin/2) kept for this slot after truncation */
+int pp_model_nharm(pp_ctx* ctx, int slot);
+
+/* ---- the batched fit ----------------------------------------------------- */
+typedef struct {
+    int32_t nsub, nchan, nbin;
+    const void* data;          /* [nsub][nchan][nbin] */
+    int32_t data_dtype;        /* PP_F64 | PP_F32 */
+    int32_t data_on_device;    /* data is a device pointer */
+    const int32_t* model_slot; /* [nsub] or NULL (= slot 0 for all) */
+    const double* freqs;       /* [nsub][nchan] or [nchan] if freqs_stride==0 */
+    int64_t freqs_stride;      /* 0 or nchan */
+    const double* errs;        /* [nsub][nchan] time-domain sigma, or NULL:
+                                  measured per channel as get_noise_PS
+                                  (pplib.py:2227-2247) */
+    const uint8_t* chan_mask;  /* [nsub][nchan], 1 = fit this channel, or NULL */
+    const double* P;           /* [nsub] spin period [s] */
+    const double* init_params; /* [nsub][5] phi, DM, GM, tau|log10 tau, alpha */
+    const double* nu_fits;     /* [nsub][3] or NULL; NaN = mean(freqs) */
+    const double* nu_outs;     /* [nsub][3] or NULL; NaN = zero-covariance */
+    int32_t fit_flags[5];
+    int32_t log10_tau;
+    int32_t option;            /* get_nu_zeros option (pptoaslib.py:734) */
+    int32_t is_toa;
+} pp_fit_in;
+
+typedef struct {
+    double* params;       /* [nsub][5]  phi(nu_out), DM, GM, tau(nu_out), alpha */
+    double* param_errs;   /* [nsub][5]  0 where not fitted */
+    double* nu_refs;      /* [nsub][3]  nu_DM, nu_GM, nu_tau of the outputs */
+    double* cov;          /* [nsub][5][5] covariance, zero rows/cols if unfit */
+    double* chi2;         /* [nsub] */
+    double* red_chi2;     /* [nsub] */
+    double* snr;          /* [nsub] */
+    int32_t* nfeval;      /* [nsub] objective evaluations */
+    int32_t* return_code; /* [nsub] PP_RC_* */
+    double* scales;       /* [nsub][nchan] or NULL */
+    double* scale_errs;   /* [nsub][nchan] or NULL */
+    double* channel_snrs; /* [nsub][nchan] or NULL */
+    double* obj_f;        /* [nsub]      objective at init_params, or NULL */
+    double* obj_grad;     /* [nsub][5]   its gradient, or NULL */
+    double* obj_hess;     /* [nsub][25]  its Hessian, or NULL */
+    double* duration;     /* [1] seconds of device time for the whole call */
+} pp_fit_out;
+
+/* Fit every subint of the batch: rFFT, cross-spectrum, trust-region Newton
+ * solve, zero-covariance frequencies, errors, S/N, chi2.  One call replaces
+ * nsub calls of fit_portrait_full (pptoaslib.py:928-1096), i.e. the body of
+ * the per-subint loop of GetTOAs.get_TOAs (pptoas.py:344-489).
+ * max_iter == 0 only evaluates the objective at init_params (obj_* outputs). */
+int pp_fit_portrait_batch(pp_ctx* ctx, const pp_fit_in* in, pp_fit_out* out);
+
+/* ---- building blocks exported for parity tests --------------------------- */
+/* rFFT of nrows real rows of length nbin (host pointers); out holds
+ * nrows*(nbin/2+1) interleaved (re,im) doubles.  numpy.fft.rfft of
+ * pptoaslib.py:976-978. */
+int pp_rfft_rows(pp_ctx* ctx, const void* rows, int dtype, int nrows, int nbin,
+                 double* out);
+
+/* 1-D FFTFIT of nprof (data, model) profile pairs: 7 doubles per pair
+ * (phase, phase_err, scale, scale_err, snr, red_chi2, duration).
+ * fit_phase_shift (pplib.py:2054-2100).  noise[i] < 0 or NaN = measure it. */
+int pp_fit_phase_shift_batch(pp_ctx* ctx, const double* data,
+                             const double* model, const double* noise,
+                             int nprof, int nbin, double lo, double hi, int Ns,
+                             double* out7);
+
+/* ---- synthetic portraits generated on the device ------------------------- */
+/* Fill dst[nsub][nchan][nbin] (device pointer, dtype) with
+ *   gain[i][n] * rotate(model slot, -phi_i, -DM_i, -GM_i) + N(0, sigma)
+ * using a counter-based RNG keyed on (seed, first_subint + i, channel, bin).
+ * inj is host [nsub][3] (phi, DM, GM injected, reference frequency infinity). */
+int pp_synth_portraits(pp_ctx* ctx, int slot, void* dst, int dtype, int nsub,
+                       const double* freqs, const double* P, const double* inj,
+                       double sigma, uint64_t seed, int64_t first_subint);
+
+/* ---- measurement --------------------------------------------------------- */
+/* Accumulated HIP-event time per kernel family since the last reset (only
+ * while option "profile" = 1): names[i] points to a static string.
+ * Returns the number of families written (<= cap). */
+int pp_kernel_times(pp_ctx* ctx, int cap, const char** names, double* seconds,
+                    int64_t* launches);
+int pp_kernel_times_reset(pp_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PP_TOAS_H */

@@ -1,0 +1,96 @@
+// Shared device helpers for the wideband-TOA kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pp {
+
+// reference pplib.py:48,51: "traditional" dispersion constant, bit-identical
+// to Python's 0.000241**-1 (= 4149.377593360996)
+#define PP_DCONST 4149.377593360996
+#define PP_TWO_PI 6.283185307179586476925286766559
+#define PP_LN10 2.302585092994045684017991454684
+
+typedef double2 cplx;
+
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+    return make_double2(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x));
+}
+// a * conj(b)
+__device__ __forceinline__ cplx cmulc(cplx a, cplx b) {
+    return make_double2(fma(a.x, b.x, a.y * b.y), fma(a.y, b.x, -a.x * b.y));
+}
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+// multiply by -i
+__device__ __forceinline__ cplx cmul_mi(cplx a) { return make_double2(a.y, -a.x); }
+__device__ __forceinline__ double cnorm(cplx a) { return fma(a.x, a.x, a.y * a.y); }
+
+// exp(2 pi i k phi) with the product reduced modulo 1 before the sincos:
+// k*phi is formed exactly (fma residual), so large non-dedispersed phase
+// shifts do not lose the fraction.
+__device__ __forceinline__ cplx unit_phasor(double k, double phi) {
+    double pfrac = phi - rint(phi);          // exact
+    double prod = k * pfrac;
+    double err = fma(k, pfrac, -prod);       // exact residual of the product
+    double r = (prod - rint(prod)) + err;
+    double s, c;
+    sincospi(2.0 * r, &s, &c);
+    return make_double2(c, s);
+}
+
+// sum over the lanes of an aligned group of W lanes (W = 2^n <= 64)
+template <int W>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int W>
+__device__ __forceinline__ double group_max(double v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum of NV values held by every thread; result valid in all
+// threads.  scratch must hold (blockDim.x/64)*NV doubles.
+template <int NV>
+__device__ inline void block_sum(double (&v)[NV], double* scratch) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = group_sum<64>(v[i]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) scratch[wid * NV + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += scratch[w * NV + i];
+        v[i] = s;
+    }
+}
+
+// ---- per-subint solver state (device resident) ---------------------------
+struct SubState {
+    double x[5];       // accepted parameters (at the fit reference frequencies)
+    double xe[5];      // parameters the next evaluation is made at
+    double f;          // objective at x
+    double g[5];
+    double H[25];
+    double f0, g0[5], H0[25];   // objective at init_params (parity hooks)
+    double radius;
+    double pred_red;   // predicted reduction of the pending proposal
+    int hits_boundary;
+    int iter, nfev, status, done, cur;  // cur: csum buffer of the accepted point
+};
+
+// number of per-subint accumulators of one evaluation: f, g[5], H upper[15]
+#define PP_NACC 21
+// raw per-channel sums kept for the post-fit stage
+#define PP_NCS 9   // A0 A1 A2 T1 T2 A1T S0 S1 S2
+
+}  // namespace pp

@@ -1,0 +1,964 @@
+// HIP kernels of the wideband-TOA fit (gfx950).  Included by pp_toas.hip.
+//
+//   k_model_fft   rFFT of template rows -> m_nk (k = 1..M), sum_k |m_nk|^2
+//   k_model_kcut  last harmonic whose |m_nk| exceeds eps * max_k |m_nk|
+//   k_xspec       rFFT of data rows, X_nk = d_nk conj(m_nk), sum_k |d_nk|^2,
+//                 power-spectrum noise estimate        (pptoaslib.py:976-985)
+//   k_prep        per-channel weights 1/sigma_F^2, S_d   (pptoaslib.py:980-985)
+//   k_eval        chi^2 surface evaluator: per-channel Fourier sums by phasor
+//                 recurrence, reduced to f, grad f, Hess f (pptoaslib.py:525-643)
+//   k_step        trust-region Newton step per subint    (pptoaslib.py:1001-1014)
+//   k_finalize    zero-covariance frequencies, output transform, covariance
+//                 with amplitudes, S/N, chi^2            (pptoaslib.py:1040-1096)
+#pragma once
+#include "pp_fft.h"
+
+namespace pp {
+
+// --------------------------------------------------------------------------
+// argument blocks (passed by value)
+// --------------------------------------------------------------------------
+struct ModelFftArgs {
+    const void* port;   // [nchan][B]
+    cplx* mft;          // [nchan][M]   harmonics 1..M
+    double* msum;       // [nchan] sum_k |m|^2
+    double* mmax;       // [nchan] max_k |m|^2
+    const cplx* twB;
+    int nchan;
+};
+
+struct XspecArgs {
+    const void* data;         // [nsub][nchan][B]
+    const cplx* const* mft;   // [nslot] device table of model FT base pointers
+    const int* slot;          // [nsub] or nullptr
+    cplx* X;                  // [nsub][nchan][Kt]
+    double* sdraw;            // [nsub][nchan] sum_{k>=1} |d|^2
+    double* noise;            // [nsub][nchan] get_noise_PS estimate
+    const cplx* twB;
+    int nsub, nchan, Kt;
+};
+
+struct FitArgs {
+    int nsub, nchan, nbin, M, Kt;
+    int flags[5];
+    int log10_tau, option, is_toa, max_iter, scat;
+    const cplx* X;
+    const cplx* const* mft;
+    const double* const* msum;
+    const int* slot;
+    const double* freqs; long long freqs_stride;
+    const double* wts;        // [nsub][nchan] 1/(sigma^2 B/2), 0 = masked
+    const double* sdraw;
+    const double* P;          // [nsub]
+    const double* nu_fit;     // [nsub][3]
+    const double* nu_out;     // [nsub][3] NaN = zero-covariance
+    const double* x0;         // [nsub][5]
+    SubState* st;
+    double* csum;             // [2][nsub][nchan][ncs]
+    int ncs;                  // 3 (no scattering) or 9
+    double* partial;          // [nsub][nchunk][PP_NACC]
+    int nchunk, cpc;          // channels per chunk
+    int* nactive;
+    // outputs (device)
+    double* o_params; double* o_errs; double* o_nu; double* o_cov;
+    double* o_chi2; double* o_rchi2; double* o_snr; int* o_nfev; int* o_rc;
+    double* o_scales; double* o_scale_errs; double* o_csnr;
+    double* o_f0; double* o_g0; double* o_H0;
+};
+
+// --------------------------------------------------------------------------
+// model rFFT
+// --------------------------------------------------------------------------
+template <int M, typename Tin>
+__global__ __launch_bounds__(FftPlan<M>::T) void k_model_fft(ModelFftArgs a) {
+    constexpr int T = FftPlan<M>::T;
+    __shared__ cplx lds[FftPlan<M>::LDS_ELEMS];
+    __shared__ double red[2 * (T / 64) + 2];
+    const int tid = threadIdx.x;
+    for (int n = blockIdx.x; n < a.nchan; n += gridDim.x) {
+        const Tin* grow = reinterpret_cast<const Tin*>(a.port) + (size_t)n * (2 * M);
+        fft_row<M, Tin>(lds, grow, a.twB, tid);
+        double s = 0.0, mx = 0.0;
+        for (int k = 1 + tid; k <= M; k += T) {
+            const cplx d = rfft_harmonic<M>(lds, a.twB, k);
+            a.mft[(size_t)n * M + (k - 1)] = d;
+            const double p = cnorm(d);
+            s += p;
+            mx = fmax(mx, p);
+        }
+        s = group_sum<64>(s);
+        mx = group_max<64>(mx);
+        if (T > 64) {
+            if ((tid & 63) == 0) { red[2 * (tid >> 6)] = s; red[2 * (tid >> 6) + 1] = mx; }
+            __syncthreads();
+            if (tid == 0) {
+                s = 0.0; mx = 0.0;
+                for (int w = 0; w < T / 64; ++w) { s += red[2 * w]; mx = fmax(mx, red[2 * w + 1]); }
+            }
+        }
+        if (tid == 0) { a.msum[n] = s; a.mmax[n] = mx; }
+        __syncthreads();
+    }
+}
+
+// kcut = max over channels of the last k (1-based) with |m_nk|^2 > eps2*max
+__global__ void k_model_kcut(const cplx* mft, const double* mmax, int nchan, int M, double eps2,
+                             int* kcut) {
+    const int n = blockIdx.x;
+    const double thr = eps2 * mmax[n];
+    int last = 0;
+    for (int k = 1 + threadIdx.x; k <= M; k += blockDim.x)
+        if (cnorm(mft[(size_t)n * M + k - 1]) > thr) last = k;
+    for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(kcut, last);
+}
+
+// --------------------------------------------------------------------------
+// data rFFT + cross-spectrum.  Rows are visited channel-major (row = n*nsub+i)
+// so every workgroup in flight shares a handful of model rows (L2-resident).
+// --------------------------------------------------------------------------
+template <int M, typename Tin>
+__global__ __launch_bounds__(FftPlan<M>::T) void k_xspec(XspecArgs a) {
+    constexpr int T = FftPlan<M>::T;
+    __shared__ cplx lds[FftPlan<M>::LDS_ELEMS];
+    __shared__ double red[2 * (T / 64) + 2];
+    const int tid = threadIdx.x;
+    const long long nrows = (long long)a.nsub * a.nchan;
+    const int H = M + 1;
+    const int kc = (int)(0.75 * H);   // get_noise_PS: int((1 - 1/4) * len(pows))
+    for (long long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int n = (int)(row / a.nsub), i = (int)(row % a.nsub);
+        const size_t rc = (size_t)i * a.nchan + n;
+        const Tin* grow = reinterpret_cast<const Tin*>(a.data) + rc * (2 * M);
+        fft_row<M, Tin>(lds, grow, a.twB, tid);
+        const cplx* mrow = a.mft[a.slot ? a.slot[i] : 0] + (size_t)n * M;
+        cplx* xrow = a.X + rc * a.Kt;
+        double sd = 0.0, tail = 0.0;
+        for (int k = 1 + tid; k <= M; k += T) {
+            const cplx d = rfft_harmonic<M>(lds, a.twB, k);
+            const double p = cnorm(d);
+            sd += p;
+            if (k >= kc) tail += p;
+            if (k <= a.Kt) xrow[k - 1] = cmulc(d, mrow[k - 1]);
+        }
+        sd = group_sum<64>(sd);
+        tail = group_sum<64>(tail);
+        if (T > 64) {
+            if ((tid & 63) == 0) { red[2 * (tid >> 6)] = sd; red[2 * (tid >> 6) + 1] = tail; }
+            __syncthreads();
+            if (tid == 0) {
+                sd = 0.0; tail = 0.0;
+                for (int w = 0; w < T / 64; ++w) { sd += red[2 * w]; tail += red[2 * w + 1]; }
+            }
+        }
+        if (tid == 0) {
+            a.sdraw[rc] = sd;
+            a.noise[rc] = sqrt(tail / (2.0 * M) / (double)(H - kc));
+        }
+        __syncthreads();
+    }
+}
+
+// plain rFFT of rows (parity hook): out[row][0..M] complex
+template <int M, typename Tin>
+__global__ __launch_bounds__(FftPlan<M>::T) void k_rfft_rows(const void* in, cplx* out, const cplx* twB,
+                                                             int nrows) {
+    constexpr int T = FftPlan<M>::T;
+    __shared__ cplx lds[FftPlan<M>::LDS_ELEMS];
+    const int tid = threadIdx.x;
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const Tin* grow = reinterpret_cast<const Tin*>(in) + (size_t)r * (2 * M);
+        fft_row<M, Tin>(lds, grow, twB, tid);
+        for (int k = 1 + tid; k <= M; k += T) out[(size_t)r * (M + 1) + k] = rfft_harmonic<M>(lds, twB, k);
+        if (tid == 0) {
+            const cplx z0 = lds[0];
+            out[(size_t)r * (M + 1)] = make_double2(z0.x + z0.y, 0.0);
+        }
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------
+// weights, solver state
+// --------------------------------------------------------------------------
+// wts = mask / (errs^2 * B/2); errs == nullptr -> measured noise
+__global__ void k_prep(int nsub, int nchan, int nbin, const double* errs, const double* noise,
+                       const unsigned char* mask, double* wts) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)nsub * nchan) return;
+    const double e = errs ? errs[idx] : noise[idx];
+    const double w = 1.0 / (e * e * (0.5 * nbin));
+    wts[idx] = (mask && !mask[idx]) ? 0.0 : w;
+}
+
+__global__ void k_init_state(FitArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.nsub) return;
+    SubState& s = a.st[i];
+    for (int j = 0; j < 5; ++j) { s.x[j] = a.x0[i * 5 + j]; s.xe[j] = s.x[j]; s.g[j] = 0.0; }
+    for (int j = 0; j < 25; ++j) s.H[j] = 0.0;
+    s.f = 0.0;
+    s.radius = 1.0;          // scipy initial_trust_radius
+    s.pred_red = 0.0;
+    s.hits_boundary = 0;
+    s.iter = 0; s.nfev = 0; s.status = PP_RC_MAXITER; s.done = 0; s.cur = 1;
+    if (i == 0) *a.nactive = a.nsub;
+}
+
+// per-channel geometry shared by evaluator and finaliser
+struct ChanGeom {
+    double p1, p2;               // d phi_n / d DM, / d GM
+    double taun, q1, q2, q11, q12, q22, lnf;
+};
+
+__device__ __forceinline__ void chan_geom(double nu, double P, double nuDM, double nuGM, double nutau,
+                                          double tau, double alpha, int log10_tau, bool scat_on,
+                                          ChanGeom& c) {
+    const double a2 = 1.0 / (nu * nu);
+    const double iDM = (nuDM == INFINITY) ? 0.0 : 1.0 / (nuDM * nuDM);
+    const double iGM = (nuGM == INFINITY) ? 0.0 : 1.0 / (nuGM * nuGM * nuGM * nuGM);
+    c.p1 = PP_DCONST * (a2 - iDM) / P;
+    c.p2 = PP_DCONST * PP_DCONST * (a2 * a2 - iGM) / P;
+    const double r = nu / nutau;
+    c.lnf = log(r);
+    c.taun = tau * pow(r, alpha);
+    if (!log10_tau) {
+        c.q1 = scat_on ? c.taun / tau : 0.0;
+        c.q2 = c.lnf * c.taun;
+        c.q11 = 0.0;
+        c.q12 = scat_on ? c.q2 / tau : 0.0;
+    } else {
+        c.q1 = PP_LN10 * c.taun;
+        c.q2 = c.lnf * c.taun;
+        c.q11 = PP_LN10 * c.q1;
+        c.q12 = PP_LN10 * c.q2;
+    }
+    c.q22 = c.lnf * c.q2;
+}
+
+// local (phi_n, tau_n) derivatives of F_n = -C^2/S from weighted sums
+struct Local {
+    double F, Gp, Gt, Lpp, Lpt, Ltt;
+};
+__device__ __forceinline__ Local local_terms(const double* s /*9 raw sums*/, double w) {
+    const double A0 = s[0], A1 = s[1], A2 = s[2], T1 = s[3], T2 = s[4], A1T = s[5];
+    const double S0 = s[6], S1 = s[7], S2 = s[8];
+    const double iS = 1.0 / S0;
+    const double r = A0 * iS;          // = C/S (weights cancel)
+    Local L;
+    L.F = -w * A0 * r;
+    L.Gp = -2.0 * w * r * A1;
+    L.Gt = -w * (2.0 * r * T1 - r * r * S1);
+    L.Lpp = -2.0 * w * (A1 * A1 * iS + r * A2);
+    L.Lpt = -2.0 * w * (r * A1T + A1 * T1 * iS - r * A1 * S1 * iS);
+    L.Ltt = -2.0 * w * (r * T2 - 0.5 * r * r * S2 + T1 * T1 * iS + r * r * S1 * S1 * iS -
+                        2.0 * r * T1 * S1 * iS);
+    return L;
+}
+
+// --------------------------------------------------------------------------
+// chi^2 evaluator.  grid = (nchunk, nsub), 256 threads; 16 lanes per channel.
+// Each lane owns harmonics k = l+1, l+17, ... and advances its phasor by
+// e^{2 pi i 16 phi_n} (taken from lane 15's start phasor, k = 16).
+// --------------------------------------------------------------------------
+template <bool SCAT>
+__global__ __launch_bounds__(256) void k_eval(FitArgs a) {
+    constexpr int LPC = 16;
+    const int i = blockIdx.y, chunk = blockIdx.x;
+    SubState& st = a.st[i];
+    if (st.done) return;
+    __shared__ double red[(256 / LPC) * PP_NACC];
+    const int tid = threadIdx.x, g = tid / LPC, l = tid % LPC;
+    const double phi = st.xe[0], DM = st.xe[1], GM = st.xe[2], alpha = st.xe[4];
+    const double tau = a.log10_tau ? pow(10.0, st.xe[3]) : st.xe[3];
+    const bool scat_on = SCAT && (tau != 0.0);
+    const double P = a.P[i];
+    const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1], nutau = a.nu_fit[i * 3 + 2];
+    const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
+    const double* wts = a.wts + (size_t)i * a.nchan;
+    const int slot = a.slot ? a.slot[i] : 0;
+    const double* msum = a.msum[slot];
+    const cplx* mft = a.mft[slot];
+    const int trial = 1 - st.cur;
+    double* csum = a.csum + ((size_t)trial * a.nsub + i) * a.nchan * a.ncs;
+    double acc[PP_NACC];
+#pragma unroll
+    for (int j = 0; j < PP_NACC; ++j) acc[j] = 0.0;
+    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan);
+    for (int n = n0 + g; n < n1; n += 256 / LPC) {
+        const double w = wts[n];
+        ChanGeom cg;
+        chan_geom(freqs[n], P, nuDM, nuGM, nutau, tau, alpha, a.log10_tau, scat_on, cg);
+        // reference order of operations: phi + Dconst*DM*(f^-2 - nu^-2)/P + ...
+        const double phin = phi + DM * cg.p1 + GM * cg.p2;
+        cplx e = unit_phasor((double)(l + 1), phin);
+        const int src = ((tid & 63) & ~(LPC - 1)) | (LPC - 1);
+        const cplx wst = make_double2(__shfl(e.x, src, 64), __shfl(e.y, src, 64));
+        const cplx* xrow = a.X + ((size_t)i * a.nchan + n) * a.Kt;
+        double s0 = 0, s1 = 0, s2 = 0, t1 = 0, t2 = 0, a1t = 0, S0 = 0, S1 = 0, S2 = 0;
+        double k = (double)(l + 1);
+        if (w != 0.0) {
+            for (int j = l; j < a.Kt; j += LPC) {
+                const cplx x = xrow[j];
+                const cplx z = cmul(x, e);
+                if (!SCAT) {
+                    s0 += z.x;
+                    s1 = fma(k, z.y, s1);
+                    s2 = fma(k * k, z.x, s2);
+                } else {
+                    const double kap = PP_TWO_PI * k, u = kap * cg.taun;
+                    const double D = 1.0 / fma(u, u, 1.0);
+                    const cplx b = make_double2(D, u * D);      // conj(B)
+                    const cplx zb = cmul(z, b);
+                    s0 += zb.x;
+                    s1 = fma(kap, zb.y, s1);                    // A1 = -sum kap Im(zb)
+                    s2 = fma(kap * kap, zb.x, s2);              // A2 = -sum kap^2 Re(zb)
+                    const double Mk = cnorm(mft[(size_t)n * a.M + j]);
+                    S0 = fma(D, Mk, S0);
+                    if (scat_on) {
+                        const cplx zb2 = cmul(zb, b);
+                        const cplx zb3 = cmul(zb2, b);
+                        t1 = fma(kap, zb2.y, t1);               // T1 = -sum kap Im(z b^2)
+                        a1t = fma(kap * kap, zb2.x, a1t);       // A1T = -sum kap^2 Re(z b^2)
+                        t2 = fma(kap * kap, zb3.x, t2);         // T2 = -2 sum kap^2 Re(z b^3)
+                        const double D2 = D * D;
+                        S1 = fma(kap * u * D2, Mk, S1);         // S1 = -2 sum kap u D^2 M
+                        S2 = fma(kap * kap * D2 * fma(4.0 * u * u, D, -1.0), Mk, S2);  // *2
+                    }
+                }
+                e = cmul(e, wst);
+                k += (double)LPC;
+            }
+        }
+        double cs[PP_NCS];
+        if (!SCAT) {
+            cs[0] = group_sum<LPC>(s0);
+            cs[1] = -PP_TWO_PI * group_sum<LPC>(s1);
+            cs[2] = -PP_TWO_PI * PP_TWO_PI * group_sum<LPC>(s2);
+            cs[3] = cs[4] = cs[5] = 0.0;
+            cs[6] = msum[n];
+            cs[7] = cs[8] = 0.0;
+        } else {
+            cs[0] = group_sum<LPC>(s0);
+            cs[1] = -group_sum<LPC>(s1);
+            cs[2] = -group_sum<LPC>(s2);
+            cs[3] = -group_sum<LPC>(t1);
+            cs[4] = -2.0 * group_sum<LPC>(t2);
+            cs[5] = -group_sum<LPC>(a1t);
+            cs[6] = group_sum<LPC>(S0);
+            cs[7] = -2.0 * group_sum<LPC>(S1);
+            cs[8] = 2.0 * group_sum<LPC>(S2);
+        }
+        if (l == 0) {
+            double* co = csum + (size_t)n * a.ncs;
+            if (a.ncs == 3) { co[0] = cs[0]; co[1] = cs[1]; co[2] = cs[2]; }
+            else {
+#pragma unroll
+                for (int j = 0; j < PP_NCS; ++j) co[j] = cs[j];
+            }
+            if (w != 0.0) {
+                const Local L = local_terms(cs, w);
+                const double p1 = cg.p1, p2 = cg.p2;
+                acc[0] += L.F;
+                acc[1] += L.Gp; acc[2] += L.Gp * p1; acc[3] += L.Gp * p2;
+                acc[4] += L.Gt * cg.q1; acc[5] += L.Gt * cg.q2;
+                acc[6] += L.Lpp; acc[7] += L.Lpp * p1; acc[8] += L.Lpp * p2;
+                acc[9] += L.Lpt * cg.q1; acc[10] += L.Lpt * cg.q2;
+                acc[11] += L.Lpp * p1 * p1; acc[12] += L.Lpp * p1 * p2;
+                acc[13] += L.Lpt * p1 * cg.q1; acc[14] += L.Lpt * p1 * cg.q2;
+                acc[15] += L.Lpp * p2 * p2;
+                acc[16] += L.Lpt * p2 * cg.q1; acc[17] += L.Lpt * p2 * cg.q2;
+                acc[18] += L.Ltt * cg.q1 * cg.q1 + L.Gt * cg.q11;
+                acc[19] += L.Ltt * cg.q1 * cg.q2 + L.Gt * cg.q12;
+                acc[20] += L.Ltt * cg.q2 * cg.q2 + L.Gt * cg.q22;
+            }
+        }
+    }
+    if (l == 0) {
+#pragma unroll
+        for (int j = 0; j < PP_NACC; ++j) red[g * PP_NACC + j] = acc[j];
+    }
+    __syncthreads();
+    if (tid < PP_NACC) {
+        double s = 0.0;
+        for (int gg = 0; gg < 256 / LPC; ++gg) s += red[gg * PP_NACC + tid];
+        a.partial[((size_t)i * a.nchunk + chunk) * PP_NACC + tid] = s;
+    }
+}
+
+// --------------------------------------------------------------------------
+// small dense linear algebra on the fit subspace (n <= 5), one thread
+// --------------------------------------------------------------------------
+__device__ inline bool chol_solve(int n, const double* A, const double* b, double* x) {
+    double Lm[25];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i * n + j];
+            for (int k = 0; k < j; ++k) s -= Lm[i * n + k] * Lm[j * n + k];
+            if (i == j) {
+                if (!(s > 0.0)) return false;
+                Lm[i * n + i] = sqrt(s);
+            } else Lm[i * n + j] = s / Lm[j * n + j];
+        }
+    double y[5];
+    for (int i = 0; i < n; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= Lm[i * n + k] * y[k];
+        y[i] = s / Lm[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = y[i];
+        for (int k = i + 1; k < n; ++k) s -= Lm[k * n + i] * x[k];
+        x[i] = s / Lm[i * n + i];
+    }
+    return true;
+}
+
+// in-place Gauss-Jordan inverse with partial pivoting; false if singular
+__device__ inline bool mat_inverse(int n, double* A) {
+    double inv[25];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) inv[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int c = 0; c < n; ++c) {
+        int piv = c;
+        double best = fabs(A[c * n + c]);
+        for (int r = c + 1; r < n; ++r)
+            if (fabs(A[r * n + c]) > best) { best = fabs(A[r * n + c]); piv = r; }
+        if (!(best > 0.0) || !isfinite(best)) return false;
+        if (piv != c)
+            for (int j = 0; j < n; ++j) {
+                double t = A[c * n + j]; A[c * n + j] = A[piv * n + j]; A[piv * n + j] = t;
+                t = inv[c * n + j]; inv[c * n + j] = inv[piv * n + j]; inv[piv * n + j] = t;
+            }
+        const double d = 1.0 / A[c * n + c];
+        for (int j = 0; j < n; ++j) { A[c * n + j] *= d; inv[c * n + j] *= d; }
+        for (int r = 0; r < n; ++r)
+            if (r != c) {
+                const double f = A[r * n + c];
+                if (f != 0.0)
+                    for (int j = 0; j < n; ++j) { A[r * n + j] -= f * A[c * n + j]; inv[r * n + j] -= f * inv[c * n + j]; }
+            }
+    }
+    for (int j = 0; j < n * n; ++j) A[j] = inv[j];
+    return true;
+}
+
+__device__ inline double vdot(int n, const double* a, const double* b) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+}
+
+// trust-region subproblem: Newton step if H is positive definite and the step
+// is inside the region, else Steihaug conjugate gradients to the boundary
+// (scipy/optimize/_trustregion_ncg.py is what the reference drives).
+__device__ inline void tr_subproblem(int n, const double* g, const double* H, double radius, double* p,
+                                     int* hits) {
+    *hits = 0;
+    double mg[5];
+    for (int i = 0; i < n; ++i) mg[i] = -g[i];
+    if (chol_solve(n, H, mg, p)) {
+        if (sqrt(vdot(n, p, p)) < radius) return;
+    }
+    double z[5] = {0, 0, 0, 0, 0}, r[5], d[5], Bd[5];
+    for (int i = 0; i < n; ++i) { r[i] = g[i]; d[i] = -g[i]; }
+    const double gnorm = sqrt(vdot(n, g, g));
+    const double tol = 1e-14 * gnorm;
+    for (int it = 0; it < 4 * n + 4; ++it) {
+        for (int i = 0; i < n; ++i) Bd[i] = vdot(n, H + i * n, d);
+        const double dBd = vdot(n, d, Bd);
+        const double dd = vdot(n, d, d), zd = vdot(n, z, d), zz = vdot(n, z, z);
+        // intersections of z + t d with the boundary
+        const double disc = sqrt(fmax(zd * zd - dd * (zz - radius * radius), 0.0));
+        const double ta = (-zd - disc) / dd, tb = (-zd + disc) / dd;
+        if (dBd <= 0.0) {
+            double pa[5], pb[5], Hp[5];
+            for (int i = 0; i < n; ++i) { pa[i] = z[i] + ta * d[i]; pb[i] = z[i] + tb * d[i]; }
+            for (int i = 0; i < n; ++i) Hp[i] = vdot(n, H + i * n, pa);
+            const double ma = vdot(n, g, pa) + 0.5 * vdot(n, pa, Hp);
+            for (int i = 0; i < n; ++i) Hp[i] = vdot(n, H + i * n, pb);
+            const double mb = vdot(n, g, pb) + 0.5 * vdot(n, pb, Hp);
+            for (int i = 0; i < n; ++i) p[i] = (ma < mb) ? pa[i] : pb[i];
+            *hits = 1;
+            return;
+        }
+        const double rr = vdot(n, r, r), al = rr / dBd;
+        double zn[5];
+        for (int i = 0; i < n; ++i) zn[i] = z[i] + al * d[i];
+        if (sqrt(vdot(n, zn, zn)) >= radius) {
+            for (int i = 0; i < n; ++i) p[i] = z[i] + tb * d[i];
+            *hits = 1;
+            return;
+        }
+        double rn2 = 0.0;
+        for (int i = 0; i < n; ++i) { r[i] += al * Bd[i]; rn2 += r[i] * r[i]; }
+        for (int i = 0; i < n; ++i) z[i] = zn[i];
+        if (sqrt(rn2) <= tol) break;
+        const double be = rn2 / rr;
+        for (int i = 0; i < n; ++i) d[i] = -r[i] + be * d[i];
+    }
+    for (int i = 0; i < n; ++i) p[i] = z[i];
+}
+
+// unpack the 21 accumulators into g[5], H[25] with the fit flags applied
+// (pptoaslib.py:573, 629-630)
+__device__ inline void unpack_acc(const double* acc, const int* flags, double& f, double* g, double* H) {
+    f = acc[0];
+    for (int j = 0; j < 5; ++j) g[j] = flags[j] ? acc[1 + j] : 0.0;
+    int c = 6;
+    for (int i = 0; i < 5; ++i)
+        for (int j = i; j < 5; ++j) {
+            const double v = (flags[i] && flags[j]) ? acc[c] : 0.0;
+            H[i * 5 + j] = v;
+            H[j * 5 + i] = v;
+            ++c;
+        }
+}
+
+// one trust-region iteration per subint (64 threads, lane 0 decides)
+__global__ __launch_bounds__(64) void k_step(FitArgs a) {
+    const int i = blockIdx.x, tid = threadIdx.x;
+    SubState& s = a.st[i];
+    if (s.done) return;
+    __shared__ double acc[PP_NACC];
+    if (tid < PP_NACC) {
+        double v = 0.0;
+        for (int c = 0; c < a.nchunk; ++c) v += a.partial[((size_t)i * a.nchunk + c) * PP_NACC + tid];
+        acc[tid] = v;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    double f, g[5], H[25];
+    unpack_acc(acc, a.flags, f, g, H);
+    bool finite = isfinite(f);
+    for (int j = 0; j < 5; ++j) finite = finite && isfinite(g[j]);
+    for (int j = 0; j < 25; ++j) finite = finite && isfinite(H[j]);
+    const bool first = (s.nfev == 0);
+    s.nfev += 1;
+    bool done = false;
+    if (first) {
+        s.f = f; s.f0 = f;
+        for (int j = 0; j < 5; ++j) { s.g[j] = g[j]; s.g0[j] = g[j]; }
+        for (int j = 0; j < 25; ++j) { s.H[j] = H[j]; s.H0[j] = H[j]; }
+        s.cur = 1 - s.cur;
+        if (!finite) { s.status = PP_RC_NAN; done = true; }
+        if (a.max_iter <= 0) { s.status = PP_RC_MAXITER; done = true; }
+    } else {
+        const double actual = s.f - f;
+        const double rho = finite ? actual / s.pred_red : -1.0;
+        if (rho < 0.25) s.radius *= 0.25;
+        else if (rho > 0.75 && s.hits_boundary) s.radius = fmin(2.0 * s.radius, 1000.0);
+        if (rho > 0.15) {
+            for (int j = 0; j < 5; ++j) { s.x[j] = s.xe[j]; s.g[j] = g[j]; }
+            for (int j = 0; j < 25; ++j) s.H[j] = H[j];
+            s.f = f;
+            s.cur = 1 - s.cur;
+        }
+        s.iter += 1;
+        if (s.iter >= a.max_iter) { s.status = PP_RC_MAXITER; done = true; }
+        if (!(s.radius > 1e-300)) { s.status = PP_RC_NAN; done = true; }
+    }
+    if (!done) {
+        int idx[5], n = 0;
+        for (int j = 0; j < 5; ++j) if (a.flags[j]) idx[n++] = j;
+        double gs[5], Hs[25], p[5];
+        for (int r = 0; r < n; ++r) {
+            gs[r] = s.g[idx[r]];
+            for (int c = 0; c < n; ++c) Hs[r * n + c] = s.H[idx[r] * 5 + idx[c]];
+        }
+        int hits = 0;
+        tr_subproblem(n, gs, Hs, s.radius, p, &hits);
+        double Hp[5];
+        for (int r = 0; r < n; ++r) Hp[r] = vdot(n, Hs + r * n, p);
+        const double pred = -(vdot(n, gs, p) + 0.5 * vdot(n, p, Hp));
+        // scipy: predicted_reduction <= 0 -> status 2 (the reference's normal exit)
+        const double fpred = s.f - pred;     // what scipy compares: m(p) vs m(0)
+        if (!(pred > 0.0) || !(fpred < s.f)) { s.status = PP_RC_STALL; done = true; }
+        else {
+            for (int j = 0; j < 5; ++j) s.xe[j] = s.x[j];
+            for (int r = 0; r < n; ++r) s.xe[idx[r]] = s.x[idx[r]] + p[r];
+            s.pred_red = pred;
+            s.hits_boundary = hits;
+        }
+    }
+    if (done) {
+        s.done = 1;
+        atomicSub(a.nactive, 1);
+    }
+}
+
+// --------------------------------------------------------------------------
+// real roots of a real polynomial (degree <= 6) by Aberth-Ehrlich iteration;
+// returns the positive real root (after an optional sqrt) closest to target,
+// NaN if none (reference: np.roots + selection, pptoaslib.py:791-794, 859-863)
+// --------------------------------------------------------------------------
+__device__ inline double pick_poly_root(const double* cin, int deg, double target, bool take_sqrt) {
+    // strip leading zeros
+    double c[7];
+    int n = deg, off = 0;
+    while (n > 0 && cin[off] == 0.0) { ++off; --n; }
+    while (n > 0 && cin[off + n] == 0.0) --n;   // roots at zero are never selected
+    for (int j = 0; j <= n; ++j) c[j] = cin[off + j] / cin[off];
+    if (n <= 0) return NAN;
+    // Cauchy bound for the starting circle
+    double rad = 0.0;
+    for (int j = 1; j <= n; ++j) rad = fmax(rad, fabs(c[j]));
+    rad = 1.0 + rad;
+    double zr[6], zi[6];
+    for (int j = 0; j < n; ++j) {
+        double s, co;
+        sincos(PP_TWO_PI * j / n + 0.4, &s, &co);
+        zr[j] = 0.5 * rad * co; zi[j] = 0.5 * rad * s;
+    }
+    for (int it = 0; it < 200; ++it) {
+        double maxstep = 0.0;
+        for (int j = 0; j < n; ++j) {
+            // p(z), p'(z) by Horner
+            double pr = 1.0, pi = 0.0, dr = 0.0, di = 0.0;
+            for (int m = 1; m <= n; ++m) {
+                const double ndr = dr * zr[j] - di * zi[j] + pr, ndi = dr * zi[j] + di * zr[j] + pi;
+                dr = ndr; di = ndi;
+                const double npr = pr * zr[j] - pi * zi[j] + c[m], npi = pr * zi[j] + pi * zr[j];
+                pr = npr; pi = npi;
+            }
+            const double dn = dr * dr + di * di;
+            if (dn == 0.0) continue;
+            // w = p/p'
+            double wr = (pr * dr + pi * di) / dn, wi = (pi * dr - pr * di) / dn;
+            double sr = 0.0, si = 0.0;
+            for (int m = 0; m < n; ++m)
+                if (m != j) {
+                    const double er = zr[j] - zr[m], ei = zi[j] - zi[m], en = er * er + ei * ei;
+                    if (en > 0.0) { sr += er / en; si -= ei / en; }
+                }
+            // step = w / (1 - w*s)
+            const double qr = 1.0 - (wr * sr - wi * si), qi = -(wr * si + wi * sr), qn = qr * qr + qi * qi;
+            const double stx = (wr * qr + wi * qi) / qn, sty = (wi * qr - wr * qi) / qn;
+            zr[j] -= stx; zi[j] -= sty;
+            maxstep = fmax(maxstep, (fabs(stx) + fabs(sty)) / (fabs(zr[j]) + fabs(zi[j]) + 1e-300));
+        }
+        if (maxstep < 1e-16) break;
+    }
+    double best = NAN, bestd = INFINITY;
+    for (int j = 0; j < n; ++j) {
+        if (fabs(zi[j]) > 1e-9 * fabs(zr[j]) || !(zr[j] > 0.0)) continue;
+        // polish the real root with Newton on the real polynomial
+        double x = zr[j];
+        for (int it = 0; it < 4; ++it) {
+            double pv = 1.0, dv = 0.0;
+            for (int m = 1; m <= n; ++m) { dv = dv * x + pv; pv = pv * x + c[m]; }
+            if (dv != 0.0) x -= pv / dv;
+        }
+        if (!(x > 0.0)) continue;
+        const double v = take_sqrt ? sqrt(x) : x;
+        if (fabs(target - v) < bestd) { bestd = fabs(target - v); best = v; }
+    }
+    return best;
+}
+
+// --------------------------------------------------------------------------
+// post-fit stage: one 256-thread block per subint
+// --------------------------------------------------------------------------
+__device__ __forceinline__ double py_wrap_half(double x) {
+    // reference pptoaslib.py:1056-1057
+    if (fabs(x) >= 0.5) { x = fmod(x, 1.0); if (x < 0.0) x += 1.0; }
+    if (x >= 0.5) x -= 1.0;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_finalize(FitArgs a) {
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const SubState& s = a.st[i];
+    __shared__ double scratch[4 * 32];
+    __shared__ double sh[64];
+    const double P = a.P[i];
+    const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
+    const double* wts = a.wts + (size_t)i * a.nchan;
+    const double* csum = a.csum + ((size_t)s.cur * a.nsub + i) * a.nchan * a.ncs;
+    const int slot = a.slot ? a.slot[i] : 0;
+    const double* msum = a.msum[slot];
+    const int* fl = a.flags;
+    const double phi = s.x[0], DM = s.x[1], GM = s.x[2], alpha = s.x[4];
+    const double taup = s.x[3];
+    const double tau = a.log10_tau ? pow(10.0, taup) : taup;
+    const bool scat_on = a.scat && (tau != 0.0);
+    const double nfDM = a.nu_fit[i * 3], nfGM = a.nu_fit[i * 3 + 1], nftau = a.nu_fit[i * 3 + 2];
+    double noDM = a.nu_out ? a.nu_out[i * 3] : NAN, noGM = a.nu_out ? a.nu_out[i * 3 + 1] : NAN,
+           notau = a.nu_out ? a.nu_out[i * 3 + 2] : NAN;
+    auto load_cs = [&](int n, double* cs) {
+        if (a.ncs == 3) {
+            cs[0] = csum[(size_t)n * 3]; cs[1] = csum[(size_t)n * 3 + 1]; cs[2] = csum[(size_t)n * 3 + 2];
+            cs[3] = cs[4] = cs[5] = 0.0; cs[6] = msum[n]; cs[7] = cs[8] = 0.0;
+        } else {
+            for (int j = 0; j < PP_NCS; ++j) cs[j] = csum[(size_t)n * PP_NCS + j];
+        }
+    };
+    // ---- pass 0: Sd, mean frequency, used channels -------------------------
+    double v3[3] = {0.0, 0.0, 0.0};
+    for (int n = tid; n < a.nchan; n += 256) {
+        const double w = wts[n];
+        if (w != 0.0) { v3[0] += w * a.sdraw[(size_t)i * a.nchan + n]; v3[1] += freqs[n]; v3[2] += 1.0; }
+    }
+    block_sum<3>(v3, scratch);
+    const double Sd = v3[0], nused = v3[2], fmean = v3[1] / v3[2];
+    int pat = 0;
+    for (int j = 0; j < 5; ++j) pat = pat * 2 + (fl[j] ? 1 : 0);
+    if (pat == 0x1F) pat = 0x1B;  // [1,1,1,1,1] is approximated by [1,1,0,1,1] (:893-901)
+    // effective flags of the Hessian used for nu_zero
+    int efl[5];
+    for (int j = 0; j < 5; ++j) efl[j] = fl[j];
+    if ((fl[0] && fl[1] && fl[2] && fl[3] && fl[4])) efl[2] = 0;
+    const bool need_zero = isnan(noDM) || isnan(noGM) || isnan(notau);
+    double nzDM = nfDM, nzGM = nfGM, nztau = nftau;
+    if (need_zero) {
+        // sums over channels of local terms times powers of frequency
+        // v[0..]: see per-pattern use below
+        double v[20];
+        for (int j = 0; j < 20; ++j) v[j] = 0.0;
+        for (int n = tid; n < a.nchan; n += 256) {
+            const double w = wts[n];
+            if (w == 0.0) continue;
+            double cs[PP_NCS];
+            load_cs(n, cs);
+            const Local L = local_terms(cs, w);
+            ChanGeom cg;
+            const double nu = freqs[n];
+            chan_geom(nu, P, nfDM, nfGM, nftau, tau, alpha, a.log10_tau, scat_on, cg);
+            const double a2 = 1.0 / (nu * nu), a4 = a2 * a2, lf = log(nu);
+            const double h = L.Lpp;
+            const double q2p = cg.taun;                                  // q2 / lnf
+            const double q12p = a.log10_tau ? PP_LN10 * cg.taun : (scat_on ? cg.taun / tau : 0.0);
+            const double Htt = L.Ltt * cg.q1 * cg.q1 + L.Gt * cg.q11;   // H[3][3]
+            const double Hta = L.Ltt * cg.q1 * cg.q2 + L.Gt * cg.q12;   // H[3][4]
+            const double Haa = L.Ltt * cg.q2 * cg.q2 + L.Gt * cg.q22;   // H[4][4]
+            const double Hta_l = L.Ltt * cg.q1 * q2p + L.Gt * q12p;     // H[3][4]/lnf
+            switch (pat) {
+            case 0x18:  // [1,1,0,0,0]
+                v[0] += a2 * h; v[1] += h; break;
+            case 0x14:  // [1,0,1,0,0]
+                v[0] += a4 * h; v[1] += h; break;
+            case 0x03:  // [0,0,0,1,1]
+                v[0] += lf * Hta_l; v[1] += Hta_l; break;
+            case 0x1A: {  // [1,1,0,1,0]
+                const double H23 = L.Lpt * cg.q1;
+                v[0] += H23;            // H13 = sum Lpt q1
+                v[1] += Htt;            // H33
+                v[2] += a2 * H23; v[3] += a2 * h; v[4] += h;
+                break; }
+            case 0x1C: {  // [1,1,1,0,0]
+                const double pj = (a.option == 1) ? cg.p1 : cg.p2;
+                v[0] += h * a4; v[1] += h;               // A, B
+                v[2] += h * pj * a2; v[3] += h * pj;     // C, D
+                v[4] += h * pj * a4;                      // E  (F = D)
+                v[5] += h * a2;                           // G  (H = B)
+                break; }
+            case 0x1B: {  // [1,1,0,1,1]
+                const double H23 = L.Lpt * cg.q1, H24 = L.Lpt * cg.q2;
+                const double H41 = L.Lpt * q2p, H42 = L.Lpt * cg.p1 * q2p, H43 = Hta_l;
+                v[0] += h; v[1] += h * cg.p1 * cg.p1; v[2] += Htt; v[3] += Haa;   // H11 H22 H33 H44
+                v[4] += h * cg.p1; v[5] += H23; v[6] += H24;                         // H12 H13 H14
+                v[7] += H23 * cg.p1; v[8] += H24 * cg.p1; v[9] += Hta;               // H23 H24 H34
+                v[10] += a2 * h; v[11] += a2 * H23; v[12] += a2 * H24;
+                v[13] += lf * H41; v[14] += lf * H42; v[15] += lf * H43;
+                v[16] += H41; v[17] += H42; v[18] += H43;
+                break; }
+            case 0x1E: {  // [1,1,1,1,0]
+                const double k1 = PP_DCONST / P, k2 = PP_DCONST * PP_DCONST / P;
+                const double Hpt = L.Lpt * cg.q1;
+                v[0] += Hpt; v[1] += Htt;     // H14, H44
+                if (a.option == 0) {
+                    const double H21 = h * k1, H23 = h * cg.p2 * k1, H24 = Hpt * k1;
+                    const double H31 = h * k2, H33 = h * cg.p2 * k2, H34 = Hpt * k2;
+                    v[2] += a4 * H34; v[3] += H34; v[4] += a2 * H21; v[5] += H21;
+                    v[6] += a4 * H31; v[7] += H31; v[8] += a2 * H23; v[9] += H23;
+                    v[10] += a4 * H33; v[11] += H33; v[12] += a2 * H24; v[13] += H24;
+                } else {
+                    const double H21 = h * k1, H22 = h * cg.p1 * k1, H24 = Hpt * k1;
+                    const double H31 = h * k2, H32 = h * cg.p1 * k2, H34 = Hpt * k2;
+                    v[2] += a2 * H24; v[3] += H24; v[4] += a4 * H31; v[5] += H31;
+                    v[6] += a2 * H21; v[7] += H21; v[8] += a4 * H32; v[9] += H32;
+                    v[10] += a2 * H22; v[11] += H22; v[12] += a4 * H34; v[13] += H34;
+                }
+                break; }
+            default: break;
+            }
+        }
+        block_sum<20>(v, scratch);
+        switch (pat) {
+        case 0x18: nzDM = 1.0 / sqrt(v[0] / v[1]); break;
+        case 0x14: nzGM = pow(v[0] / v[1], -0.25); break;
+        case 0x03: nztau = exp(v[0] / v[1]); break;
+        case 0x1A: {
+            const double numer = v[0] * v[2] - v[1] * v[3], denom = v[0] * v[0] - v[1] * v[4];
+            nzDM = 1.0 / sqrt(numer / denom);
+            break; }
+        case 0x1C:
+            if (a.option == 0 || a.option == 1) {
+                const double A = v[0], B = v[1], C = v[2], D = v[3], E = v[4], F = v[3], G = v[5], Hh = v[1];
+                // coefficients of nu^6, nu^4, nu^2, 1 -> cubic in y = nu^2
+                double co[4] = {A * C - E * G, E * Hh - A * D, F * G - B * C, B * D - F * Hh};
+                if (tid == 0) sh[0] = pick_poly_root(co, 3, fmean, true);
+                __syncthreads();
+                nzDM = nzGM = sh[0];
+                __syncthreads();
+            }
+            break;
+        case 0x1B: {
+            const double H11 = v[0], H22 = v[1], H33 = v[2], H44 = v[3], H12 = v[4], H13 = v[5], H14 = v[6];
+            const double H23 = v[7], H34 = v[9];
+            const double c1 = H34 * H34 - H33 * H44, c2 = H13 * H44 - H14 * H34, c3 = H14 * H33 - H13 * H34;
+            nzDM = 1.0 / sqrt((c1 * v[10] + c2 * v[11] + c3 * v[12]) / (c1 * v[0] + c2 * v[5] + c3 * v[6]));
+            const double e1 = H13 * H22 - H12 * H23, e2 = H11 * H23 - H12 * H13, e3 = H12 * H12 - H11 * H22;
+            nztau = exp((e1 * v[13] + e2 * v[14] + e3 * v[15]) / (e1 * v[16] + e2 * v[17] + e3 * v[18]));
+            break; }
+        case 0x1E:
+            if (a.option == 0 || a.option == 1) {
+                const double H14 = v[0], H44 = v[1];
+                const double A = v[2], aa = v[3], B = v[4], b = v[5], C = v[6], c = v[7], D = v[8], d = v[9];
+                const double E = v[10], e = v[11], F = v[12], f = v[13];
+                double co[6];
+                int deg;
+                if (a.option == 0) {
+                    co[0] = A * A * B + H44 * C * D + H14 * E * F - H44 * B * E - A * C * F - H14 * A * D;
+                    co[1] = -A * A * b - H44 * C * d - H14 * E * f + H44 * b * E + A * C * f + H14 * A * d;
+                    co[2] = -2 * A * aa * B - H44 * c * D - H14 * e * F + H44 * B * e + (A * c + aa * C) * F + H14 * aa * D;
+                    co[3] = 2 * A * aa * b + H44 * c * d + H14 * e * f - H44 * b * e - (A * c + aa * C) * f - H14 * aa * d;
+                    co[4] = aa * aa * B - aa * c * F;
+                    co[5] = -aa * aa * b + aa * c * f;
+                    deg = 5;
+                } else {
+                    co[0] = A * A * B + H44 * C * D + H14 * E * F - H44 * B * E - A * C * F - H14 * A * D;
+                    co[1] = -2 * A * aa * B - H44 * c * D - H14 * e * F + H44 * B * e + (A * c + aa * C) * F + H14 * aa * D;
+                    co[2] = -(A * A * b - aa * aa * B) - H44 * C * d - H14 * E * f + H44 * b * E + (A * C * f - aa * c * F) + H14 * A * d;
+                    co[3] = 2 * A * aa * b + H44 * c * d + H14 * e * f - H44 * b * e - (A * c + aa * C) * f - H14 * aa * d;
+                    co[4] = -aa * aa * b + aa * c * f;
+                    deg = 4;
+                }
+                if (tid == 0) sh[0] = pick_poly_root(co, deg, fmean, true);
+                __syncthreads();
+                nzDM = nzGM = sh[0];
+                __syncthreads();
+            }
+            break;
+        default: break;
+        }
+    }
+    if (isnan(noDM)) noDM = nzDM;
+    if (isnan(noGM)) noGM = nzGM;
+    if (isnan(notau)) notau = nztau;
+    if (a.is_toa) {  // pptoaslib.py:1048-1050
+        if (fl[1]) noGM = noDM;
+        else if (fl[2]) noDM = noGM;
+    }
+    const double k1 = PP_DCONST / P, k2 = PP_DCONST * PP_DCONST / P;
+    const double inv2 = (nfDM == INFINITY) ? 0.0 : 1.0 / (nfDM * nfDM);
+    const double inv4 = (nfGM == INFINITY) ? 0.0 : 1.0 / (nfGM * nfGM * nfGM * nfGM);
+    const double phi_inf = phi + PP_DCONST * DM * (0.0 - inv2) / P + PP_DCONST * PP_DCONST * GM * (0.0 - inv4) / P;
+    const double phi_out = py_wrap_half(phi_inf + k1 * DM / (noDM * noDM) + k2 * GM / (noGM * noGM * noGM * noGM));
+    const double tau_out = tau * pow(notau / nftau, alpha);
+    // ---- covariance with the amplitude parameters at the output references --
+    // A_ij (15 upper) + Schur correction sum_n U_i U_j/(2 S_n) (15) -> 30 sums,
+    // then snr^2
+    double m[31];
+    for (int j = 0; j < 31; ++j) m[j] = 0.0;
+    for (int n = tid; n < a.nchan; n += 256) {
+        const double w = wts[n];
+        if (w == 0.0) continue;
+        double cs[PP_NCS];
+        load_cs(n, cs);
+        ChanGeom cg;
+        chan_geom(freqs[n], P, noDM, noGM, notau, tau_out, alpha, a.log10_tau, scat_on, cg);
+        const double A0 = cs[0], A1 = cs[1], A2 = cs[2], T1 = cs[3], T2 = cs[4], A1T = cs[5];
+        const double S0 = cs[6], S1 = cs[7], S2 = cs[8];
+        const double r = A0 / S0;                     // scale a_n
+        // reduced local second derivatives (pptoaslib.py:694-697)
+        const double Lpp = -2.0 * w * r * A2, Lpt = -2.0 * w * r * A1T;
+        const double Ltt = -2.0 * w * (r * T2 - 0.5 * r * r * S2);
+        const double Gt = -2.0 * w * (r * T1 - 0.5 * r * r * S1);
+        const double J[5] = {1.0, cg.p1, cg.p2, cg.q1, cg.q2};
+        // cross terms with a_n (pptoaslib.py:690): U = -2 (dC - a dS)
+        const double up = -2.0 * w * A1, ut = -2.0 * w * (T1 - r * S1);
+        const double U[5] = {up, up * cg.p1, up * cg.p2, ut * cg.q1, ut * cg.q2};
+        const double cinv = 1.0 / (2.0 * w * S0);
+        int c = 0;
+        for (int ii = 0; ii < 5; ++ii)
+            for (int jj = ii; jj < 5; ++jj) {
+                double hij;
+                if (jj < 3) hij = Lpp * J[ii] * J[jj];
+                else if (ii < 3) hij = Lpt * J[ii] * J[jj];
+                else hij = Ltt * J[ii] * J[jj] + Gt * (ii == 3 ? (jj == 3 ? cg.q11 : cg.q12) : cg.q22);
+                m[c] += hij;
+                m[15 + c] += U[ii] * U[jj] * cinv;
+                ++c;
+            }
+        m[30] += w * A0 * r;      // (a_n sqrt(S_n))^2 = w A0^2/S0
+    }
+    block_sum<31>(m, scratch);
+    int idx[5], nfit = 0;
+    for (int j = 0; j < 5; ++j) if (fl[j]) idx[nfit++] = j;
+    // X = inv(Afit - U Cinv U^T)   (every thread computes the same small matrix)
+    double Xm[25], full[25];
+    {
+        int c = 0;
+        for (int ii = 0; ii < 5; ++ii)
+            for (int jj = ii; jj < 5; ++jj) {
+                const double vv = (fl[ii] && fl[jj]) ? (m[c] - m[15 + c]) : 0.0;
+                full[ii * 5 + jj] = vv; full[jj * 5 + ii] = vv;
+                ++c;
+            }
+        for (int r = 0; r < nfit; ++r)
+            for (int c2 = 0; c2 < nfit; ++c2) Xm[r * nfit + c2] = full[idx[r] * 5 + idx[c2]];
+    }
+    const bool inv_ok = mat_inverse(nfit, Xm);
+    // ---- per-channel outputs -------------------------------------------------
+    for (int n = tid; n < a.nchan; n += 256) {
+        const double w = wts[n];
+        double sc = 0.0, se = 0.0, sn = 0.0;
+        if (w != 0.0) {
+            double cs[PP_NCS];
+            load_cs(n, cs);
+            ChanGeom cg;
+            chan_geom(freqs[n], P, noDM, noGM, notau, tau_out, alpha, a.log10_tau, scat_on, cg);
+            const double r = cs[0] / cs[6];
+            const double up = -2.0 * w * cs[1], ut = -2.0 * w * (cs[3] - r * cs[7]);
+            const double U[5] = {up, up * cg.p1, up * cg.p2, ut * cg.q1, ut * cg.q2};
+            const double cinv = 1.0 / (2.0 * w * cs[6]);
+            double uXu = 0.0;
+            for (int r1 = 0; r1 < nfit; ++r1)
+                for (int c1 = 0; c1 < nfit; ++c1) uXu += U[idx[r1]] * Xm[r1 * nfit + c1] * U[idx[c1]];
+            sc = r;
+            se = sqrt(2.0 * (cinv + cinv * cinv * uXu));
+            sn = r * sqrt(w * cs[6]);
+        }
+        if (a.o_scales) a.o_scales[(size_t)i * a.nchan + n] = sc;
+        if (a.o_scale_errs) a.o_scale_errs[(size_t)i * a.nchan + n] = se;
+        if (a.o_csnr) a.o_csnr[(size_t)i * a.nchan + n] = sn;
+    }
+    if (tid == 0) {
+        double* op = a.o_params + (size_t)i * 5;
+        op[0] = phi_out; op[1] = DM; op[2] = GM;
+        op[3] = a.log10_tau ? log10(tau_out) : tau_out;
+        op[4] = alpha;
+        double* oe = a.o_errs + (size_t)i * 5;
+        double* oc = a.o_cov + (size_t)i * 25;
+        for (int j = 0; j < 5; ++j) oe[j] = 0.0;
+        for (int j = 0; j < 25; ++j) oc[j] = 0.0;
+        for (int r = 0; r < nfit; ++r) {
+            for (int c = 0; c < nfit; ++c) oc[idx[r] * 5 + idx[c]] = inv_ok ? 2.0 * Xm[r * nfit + c] : NAN;
+            oe[idx[r]] = inv_ok ? sqrt(2.0 * Xm[r * nfit + r]) : NAN;
+        }
+        a.o_nu[(size_t)i * 3] = noDM; a.o_nu[(size_t)i * 3 + 1] = noGM; a.o_nu[(size_t)i * 3 + 2] = notau;
+        const double chi2 = Sd + s.f;
+        const double dof = nused * a.nbin - (nfit + nused);
+        a.o_chi2[i] = chi2;
+        a.o_rchi2[i] = chi2 / dof;
+        a.o_snr[i] = sqrt(m[30]);
+        a.o_nfev[i] = s.nfev;
+        a.o_rc[i] = s.status;
+        if (a.o_f0) a.o_f0[i] = s.f0;
+        if (a.o_g0) for (int j = 0; j < 5; ++j) a.o_g0[(size_t)i * 5 + j] = s.g0[j];
+        if (a.o_H0) for (int j = 0; j < 25; ++j) a.o_H0[(size_t)i * 25 + j] = s.H0[j];
+    }
+}
+
+}  // namespace pp

@@ -1,0 +1,589 @@
+// libpptoas_hip.so -- host side of the C ABI declared in include/pp_toas.h.
+// Pure HIP runtime (no torch, no vendor FFT/BLAS); gfx950 only.
+#include "../../include/pp_toas.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "pp_kernels.h"
+#include "pp_extra.h"
+
+using namespace pp;
+
+// --------------------------------------------------------------------------
+// errors
+// --------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? PP_ENOMEM : PP_EHIP, "%s: %s (%s:%d)",   \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                   \
+    } while (0)
+
+// --------------------------------------------------------------------------
+// context
+// --------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return PP_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(PP_ENOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+        }
+        cap = bytes;
+        return PP_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct ModelSlot {
+    bool set = false;
+    int nchan = 0, nbin = 0, Kt = 0;
+    DevBuf mft, msum, mmax;
+};
+
+enum KernelFamily { KF_MODEL = 0, KF_XSPEC, KF_PREP, KF_EVAL, KF_STEP, KF_FINAL, KF_SYNTH, KF_FPS, KF_COUNT };
+static const char* kFamilyNames[KF_COUNT] = {"model_fft", "xspec", "prep", "eval", "step", "finalize",
+                                            "synth", "fit_phase_shift"};
+
+struct pp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::map<int, DevBuf> twiddles;   // by nbin
+    ModelSlot slots[PP_MAX_SLOTS];
+    DevBuf mft_table, msum_table;     // device arrays of slot base pointers
+    // work buffers
+    DevBuf data, X, sdraw, noise, wts, freqs, errs, mask, P, x0, nufit, nuout, slot, state, csum, partial;
+    DevBuf o_params, o_errs, o_nu, o_cov, o_chi2, o_rchi2, o_snr, o_nfev, o_rc, o_scales, o_serrs, o_csnr,
+        o_f0, o_g0, o_H0, misc;
+    int* nactive_h = nullptr;   // pinned
+    // options
+    double harm_eps = 8.8817841970012523e-16;  // 2^-50
+    int max_iter = 64;
+    int profile = 0;
+    int check_every = 1;
+    double max_work_bytes = 96e9;
+    // profiling
+    struct Span { int fam; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    double fam_sec[KF_COUNT] = {0};
+    long long fam_n[KF_COUNT] = {0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct Prof {
+    pp_ctx* c; int fam; hipEvent_t a = nullptr, b = nullptr;
+    Prof(pp_ctx* c_, int fam_) : c(c_), fam(fam_) {
+        if (c->profile) {
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, c->stream);
+        }
+    }
+    ~Prof() {
+        if (c->profile) {
+            (void)hipEventRecord(b, c->stream);
+            c->spans.push_back({fam, a, b});
+        }
+    }
+};
+
+static void resolve_spans(pp_ctx* c) {
+    for (auto& s : c->spans) {
+        float ms = 0.f;
+        if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            c->fam_sec[s.fam] += 1e-3 * ms;
+            c->fam_n[s.fam] += 1;
+        }
+        (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
+    }
+    c->spans.clear();
+}
+
+extern "C" int pp_abi_version(void) { return PP_ABI_VERSION; }
+extern "C" const char* pp_last_error(void) { return g_err.c_str(); }
+
+extern "C" int pp_create(int device_id, pp_ctx** out) {
+    if (!out) return fail(PP_EINVAL, "pp_create: out is NULL");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(PP_EINVAL, "pp_create: device %d of %d", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    pp_ctx* c = new pp_ctx();
+    c->device = device_id;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipHostMalloc((void**)&c->nactive_h, sizeof(int) * 4, hipHostMallocDefault));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    int rc = c->mft_table.reserve(sizeof(void*) * PP_MAX_SLOTS);
+    if (rc) return rc;
+    rc = c->msum_table.reserve(sizeof(void*) * PP_MAX_SLOTS);
+    if (rc) return rc;
+    HIP_TRY(hipMemset(c->mft_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
+    HIP_TRY(hipMemset(c->msum_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
+    *out = c;
+    return PP_OK;
+}
+
+extern "C" int pp_destroy(pp_ctx* c) {
+    if (!c) return PP_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    resolve_spans(c);
+    for (auto& kv : c->twiddles) kv.second.release();
+    for (auto& s : c->slots) { s.mft.release(); s.msum.release(); s.mmax.release(); }
+    DevBuf* bufs[] = {&c->mft_table, &c->msum_table, &c->data, &c->X, &c->sdraw, &c->noise, &c->wts, &c->freqs,
+                      &c->errs, &c->mask, &c->P, &c->x0, &c->nufit, &c->nuout, &c->slot, &c->state, &c->csum,
+                      &c->partial, &c->o_params, &c->o_errs, &c->o_nu, &c->o_cov, &c->o_chi2, &c->o_rchi2,
+                      &c->o_snr, &c->o_nfev, &c->o_rc, &c->o_scales, &c->o_serrs, &c->o_csnr, &c->o_f0, &c->o_g0,
+                      &c->o_H0, &c->misc};
+    for (DevBuf* b : bufs) b->release();
+    if (c->nactive_h) (void)hipHostFree(c->nactive_h);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PP_OK;
+}
+
+extern "C" int pp_synchronize(pp_ctx* c) {
+    if (!c) return fail(PP_EINVAL, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PP_OK;
+}
+
+extern "C" void* pp_stream(pp_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+extern "C" int pp_set_option(pp_ctx* c, const char* name, double value) {
+    if (!c || !name) return fail(PP_EINVAL, "pp_set_option: null argument");
+    std::string n(name);
+    if (n == "harm_eps") c->harm_eps = value;
+    else if (n == "max_iter") c->max_iter = (int)value;
+    else if (n == "profile") c->profile = (int)value;
+    else if (n == "check_every") c->check_every = std::max(1, (int)value);
+    else if (n == "max_work_bytes") c->max_work_bytes = value;
+    else return fail(PP_EINVAL, "pp_set_option: unknown option '%s'", name);
+    return PP_OK;
+}
+
+extern "C" int pp_kernel_times(pp_ctx* c, int cap, const char** names, double* seconds, int64_t* launches) {
+    if (!c) return fail(PP_EINVAL, "null context");
+    (void)hipStreamSynchronize(c->stream);
+    resolve_spans(c);
+    int n = std::min(cap, (int)KF_COUNT);
+    for (int i = 0; i < n; ++i) {
+        if (names) names[i] = kFamilyNames[i];
+        if (seconds) seconds[i] = c->fam_sec[i];
+        if (launches) launches[i] = c->fam_n[i];
+    }
+    return n;
+}
+
+extern "C" int pp_kernel_times_reset(pp_ctx* c) {
+    if (!c) return fail(PP_EINVAL, "null context");
+    (void)hipStreamSynchronize(c->stream);
+    resolve_spans(c);
+    for (int i = 0; i < KF_COUNT; ++i) { c->fam_sec[i] = 0; c->fam_n[i] = 0; }
+    return PP_OK;
+}
+
+// --------------------------------------------------------------------------
+// twiddles: W_B^k = exp(-2 pi i k / B), k = 0..B/2, correctly rounded
+// --------------------------------------------------------------------------
+static int get_twiddles(pp_ctx* c, int nbin, const cplx** out) {
+    auto it = c->twiddles.find(nbin);
+    if (it != c->twiddles.end()) { *out = it->second.as<cplx>(); return PP_OK; }
+    const int M = nbin / 2;
+    std::vector<double> h(2 * (size_t)(M + 1));
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (int k = 0; k <= M; ++k) {
+        // octant symmetry keeps the argument in [0, pi/4] for full accuracy
+        long double ang = two_pi * (long double)k / (long double)nbin;
+        h[2 * k] = (double)cosl(ang);
+        h[2 * k + 1] = (double)(-sinl(ang));
+    }
+    h[0] = 1.0; h[1] = 0.0;
+    if (M % 2 == 0) { h[2 * (M / 2)] = 0.0; h[2 * (M / 2) + 1] = -1.0; }
+    h[2 * M] = -1.0; h[2 * M + 1] = 0.0;
+    DevBuf b;
+    int rc = b.reserve(h.size() * sizeof(double));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(b.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->twiddles[nbin] = b;
+    *out = b.as<cplx>();
+    return PP_OK;
+}
+
+static bool nbin_ok(int nbin) { return nbin >= 32 && nbin <= 8192 && (nbin & (nbin - 1)) == 0; }
+
+static int fft_grid(int T, long long nrows) {
+    // persistent workgroups: enough to fill 256 CUs at the LDS-limited residency
+    long long g = 256LL * (T == 64 ? 8 : (T == 128 ? 4 : 2));
+    return (int)std::max(1LL, std::min(nrows, g));
+}
+
+// dispatch a templated kernel on (M, dtype)
+#define PP_DISPATCH_M(M_, BODY)        \
+    switch (M_) {                      \
+        case 16: { constexpr int MM = 16; BODY; break; }     \
+        case 32: { constexpr int MM = 32; BODY; break; }     \
+        case 64: { constexpr int MM = 64; BODY; break; }     \
+        case 128: { constexpr int MM = 128; BODY; break; }   \
+        case 256: { constexpr int MM = 256; BODY; break; }   \
+        case 512: { constexpr int MM = 512; BODY; break; }   \
+        case 1024: { constexpr int MM = 1024; BODY; break; } \
+        case 2048: { constexpr int MM = 2048; BODY; break; } \
+        case 4096: { constexpr int MM = 4096; BODY; break; } \
+        default: return fail(PP_EINVAL, "unsupported nbin %d", 2 * (M_)); \
+    }
+
+// --------------------------------------------------------------------------
+// model
+// --------------------------------------------------------------------------
+extern "C" int pp_model_set(pp_ctx* c, int slot, const void* portrait, int dtype, int on_device, int nchan,
+                            int nbin) {
+    if (!c || !portrait) return fail(PP_EINVAL, "pp_model_set: null argument");
+    if (slot < 0 || slot >= PP_MAX_SLOTS) return fail(PP_EINVAL, "pp_model_set: slot %d", slot);
+    if (!nbin_ok(nbin)) return fail(PP_EINVAL, "pp_model_set: nbin %d must be a power of two in [32,8192]", nbin);
+    if (nchan < 1) return fail(PP_EINVAL, "pp_model_set: nchan %d", nchan);
+    if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_model_set: dtype %d", dtype);
+    HIP_TRY(hipSetDevice(c->device));
+    const int M = nbin / 2;
+    const size_t esz = dtype == PP_F64 ? 8 : 4;
+    ModelSlot& s = c->slots[slot];
+    int rc;
+    if ((rc = s.mft.reserve((size_t)nchan * M * sizeof(cplx)))) return rc;
+    if ((rc = s.msum.reserve((size_t)nchan * sizeof(double)))) return rc;
+    if ((rc = s.mmax.reserve((size_t)nchan * sizeof(double)))) return rc;
+    const void* dport = portrait;
+    if (!on_device) {
+        if ((rc = c->data.reserve((size_t)nchan * nbin * esz))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->data.p, portrait, (size_t)nchan * nbin * esz, hipMemcpyHostToDevice, c->stream));
+        dport = c->data.p;
+    }
+    const cplx* tw = nullptr;
+    if ((rc = get_twiddles(c, nbin, &tw))) return rc;
+    ModelFftArgs a{dport, s.mft.as<cplx>(), s.msum.as<double>(), s.mmax.as<double>(), tw, nchan};
+    {
+        Prof pr(c, KF_MODEL);
+        PP_DISPATCH_M(M, {
+            const int T = FftPlan<MM>::T;
+            if (dtype == PP_F64) hipLaunchKernelGGL((k_model_fft<MM, double>), dim3(fft_grid(T, nchan)), dim3(T), 0, c->stream, a);
+            else hipLaunchKernelGGL((k_model_fft<MM, float>), dim3(fft_grid(T, nchan)), dim3(T), 0, c->stream, a);
+        });
+    }
+    HIP_TRY(hipGetLastError());
+    // harmonic truncation
+    int Kt = M;
+    if (c->harm_eps > 0.0) {
+        if ((rc = c->misc.reserve(256))) return rc;
+        HIP_TRY(hipMemsetAsync(c->misc.p, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_model_kcut, dim3(nchan), dim3(64), 0, c->stream, s.mft.as<cplx>(), s.mmax.as<double>(),
+                           nchan, M, c->harm_eps * c->harm_eps, c->misc.as<int>());
+        HIP_TRY(hipGetLastError());
+        int kcut = 0;
+        HIP_TRY(hipMemcpyAsync(&kcut, c->misc.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        Kt = std::min(M, std::max(32, ((kcut + 31) / 32) * 32));
+    } else {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    s.set = true; s.nchan = nchan; s.nbin = nbin; s.Kt = Kt;
+    void* pm = s.mft.p;
+    void* ps = s.msum.p;
+    HIP_TRY(hipMemcpy((char*)c->mft_table.p + sizeof(void*) * slot, &pm, sizeof(void*), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy((char*)c->msum_table.p + sizeof(void*) * slot, &ps, sizeof(void*), hipMemcpyHostToDevice));
+    return PP_OK;
+}
+
+extern "C" int pp_model_nharm(pp_ctx* c, int slot) {
+    if (!c || slot < 0 || slot >= PP_MAX_SLOTS || !c->slots[slot].set) return fail(PP_ESTATE, "slot not set");
+    return c->slots[slot].Kt;
+}
+
+// --------------------------------------------------------------------------
+// rFFT parity hook
+// --------------------------------------------------------------------------
+extern "C" int pp_rfft_rows(pp_ctx* c, const void* rows, int dtype, int nrows, int nbin, double* out) {
+    if (!c || !rows || !out) return fail(PP_EINVAL, "pp_rfft_rows: null argument");
+    if (!nbin_ok(nbin) || nrows < 1) return fail(PP_EINVAL, "pp_rfft_rows: bad shape %d x %d", nrows, nbin);
+    HIP_TRY(hipSetDevice(c->device));
+    const int M = nbin / 2;
+    const size_t esz = dtype == PP_F64 ? 8 : 4;
+    int rc;
+    if ((rc = c->data.reserve((size_t)nrows * nbin * esz))) return rc;
+    if ((rc = c->X.reserve((size_t)nrows * (M + 1) * sizeof(cplx)))) return rc;
+    const cplx* tw = nullptr;
+    if ((rc = get_twiddles(c, nbin, &tw))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->data.p, rows, (size_t)nrows * nbin * esz, hipMemcpyHostToDevice, c->stream));
+    PP_DISPATCH_M(M, {
+        const int T = FftPlan<MM>::T;
+        if (dtype == PP_F64) hipLaunchKernelGGL((k_rfft_rows<MM, double>), dim3(fft_grid(T, nrows)), dim3(T), 0, c->stream, (const void*)c->data.p, c->X.as<cplx>(), tw, nrows);
+        else hipLaunchKernelGGL((k_rfft_rows<MM, float>), dim3(fft_grid(T, nrows)), dim3(T), 0, c->stream, (const void*)c->data.p, c->X.as<cplx>(), tw, nrows);
+    });
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->X.p, (size_t)nrows * (M + 1) * sizeof(cplx), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PP_OK;
+}
+
+// --------------------------------------------------------------------------
+// the batched fit
+// --------------------------------------------------------------------------
+static int upload(pp_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+    int rc = b.reserve(bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return PP_OK;
+}
+
+static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, int ns, int Kt, bool scat,
+                     const std::vector<double>& nufit_h, const std::vector<double>& nuout_h) {
+    const int C = in->nchan, B = in->nbin, M = B / 2;
+    const size_t esz = in->data_dtype == PP_F64 ? 8 : 4;
+    int rc;
+    const cplx* tw = nullptr;
+    if ((rc = get_twiddles(c, B, &tw))) return rc;
+    // ---- inputs ----
+    const void* ddata;
+    const size_t sub_elems = (size_t)C * B;
+    if (in->data_on_device) {
+        ddata = (const char*)in->data + (size_t)s0 * sub_elems * esz;
+    } else {
+        if ((rc = upload(c, c->data, (const char*)in->data + (size_t)s0 * sub_elems * esz, (size_t)ns * sub_elems * esz))) return rc;
+        ddata = c->data.p;
+    }
+    const size_t nc = (size_t)ns * C;
+    if (in->freqs_stride) { if ((rc = upload(c, c->freqs, in->freqs + (size_t)s0 * C, nc * 8))) return rc; }
+    else { if ((rc = upload(c, c->freqs, in->freqs, (size_t)C * 8))) return rc; }
+    if (in->errs) if ((rc = upload(c, c->errs, in->errs + (size_t)s0 * C, nc * 8))) return rc;
+    if (in->chan_mask) if ((rc = upload(c, c->mask, in->chan_mask + (size_t)s0 * C, nc))) return rc;
+    if ((rc = upload(c, c->P, in->P + s0, (size_t)ns * 8))) return rc;
+    if ((rc = upload(c, c->x0, in->init_params + (size_t)s0 * 5, (size_t)ns * 40))) return rc;
+    if ((rc = upload(c, c->nufit, nufit_h.data() + (size_t)s0 * 3, (size_t)ns * 24))) return rc;
+    if ((rc = upload(c, c->nuout, nuout_h.data() + (size_t)s0 * 3, (size_t)ns * 24))) return rc;
+    if (in->model_slot) if ((rc = upload(c, c->slot, in->model_slot + s0, (size_t)ns * 4))) return rc;
+    // ---- work ----
+    const int ncs = scat ? PP_NCS : 3;
+    int nchunk = std::min(std::max(1, C / 64), std::max(1, (4096 + ns - 1) / ns));
+    int cpc = (C + nchunk - 1) / nchunk;
+    cpc = ((cpc + 15) / 16) * 16;
+    nchunk = (C + cpc - 1) / cpc;
+    if ((rc = c->X.reserve(nc * Kt * sizeof(cplx)))) return rc;
+    if ((rc = c->sdraw.reserve(nc * 8))) return rc;
+    if ((rc = c->noise.reserve(nc * 8))) return rc;
+    if ((rc = c->wts.reserve(nc * 8))) return rc;
+    if ((rc = c->state.reserve((size_t)ns * sizeof(SubState)))) return rc;
+    if ((rc = c->csum.reserve(2 * nc * ncs * 8))) return rc;
+    if ((rc = c->partial.reserve((size_t)ns * nchunk * PP_NACC * 8))) return rc;
+    if ((rc = c->misc.reserve(256))) return rc;
+    if ((rc = c->o_params.reserve((size_t)ns * 40))) return rc;
+    if ((rc = c->o_errs.reserve((size_t)ns * 40))) return rc;
+    if ((rc = c->o_nu.reserve((size_t)ns * 24))) return rc;
+    if ((rc = c->o_cov.reserve((size_t)ns * 200))) return rc;
+    if ((rc = c->o_chi2.reserve((size_t)ns * 8))) return rc;
+    if ((rc = c->o_rchi2.reserve((size_t)ns * 8))) return rc;
+    if ((rc = c->o_snr.reserve((size_t)ns * 8))) return rc;
+    if ((rc = c->o_nfev.reserve((size_t)ns * 4))) return rc;
+    if ((rc = c->o_rc.reserve((size_t)ns * 4))) return rc;
+    if ((rc = c->o_f0.reserve((size_t)ns * 8))) return rc;
+    if ((rc = c->o_g0.reserve((size_t)ns * 40))) return rc;
+    if ((rc = c->o_H0.reserve((size_t)ns * 200))) return rc;
+    if (out->scales) if ((rc = c->o_scales.reserve(nc * 8))) return rc;
+    if (out->scale_errs) if ((rc = c->o_serrs.reserve(nc * 8))) return rc;
+    if (out->channel_snrs) if ((rc = c->o_csnr.reserve(nc * 8))) return rc;
+
+    // ---- rFFT + cross-spectrum ----
+    XspecArgs xa{ddata, (const cplx* const*)c->mft_table.p, in->model_slot ? c->slot.as<int>() : nullptr,
+                 c->X.as<cplx>(), c->sdraw.as<double>(), c->noise.as<double>(), tw, ns, C, Kt};
+    {
+        Prof pr(c, KF_XSPEC);
+        PP_DISPATCH_M(M, {
+            const int T = FftPlan<MM>::T;
+            const int grid = fft_grid(T, (long long)ns * C);
+            if (in->data_dtype == PP_F64) hipLaunchKernelGGL((k_xspec<MM, double>), dim3(grid), dim3(T), 0, c->stream, xa);
+            else hipLaunchKernelGGL((k_xspec<MM, float>), dim3(grid), dim3(T), 0, c->stream, xa);
+        });
+    }
+    HIP_TRY(hipGetLastError());
+    {
+        Prof pr(c, KF_PREP);
+        hipLaunchKernelGGL(k_prep, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, ns, C, B,
+                           in->errs ? c->errs.as<double>() : (const double*)nullptr, c->noise.as<double>(),
+                           in->chan_mask ? c->mask.as<unsigned char>() : (const unsigned char*)nullptr,
+                           c->wts.as<double>());
+    }
+    HIP_TRY(hipGetLastError());
+    FitArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.nsub = ns; fa.nchan = C; fa.nbin = B; fa.M = M; fa.Kt = Kt;
+    for (int j = 0; j < 5; ++j) fa.flags[j] = in->fit_flags[j] ? 1 : 0;
+    fa.log10_tau = in->log10_tau ? 1 : 0; fa.option = in->option; fa.is_toa = in->is_toa ? 1 : 0;
+    fa.max_iter = c->max_iter; fa.scat = scat ? 1 : 0;
+    fa.X = c->X.as<cplx>();
+    fa.mft = (const cplx* const*)c->mft_table.p;
+    fa.msum = (const double* const*)c->msum_table.p;
+    fa.slot = in->model_slot ? c->slot.as<int>() : nullptr;
+    fa.freqs = c->freqs.as<double>(); fa.freqs_stride = in->freqs_stride ? C : 0;
+    fa.wts = c->wts.as<double>(); fa.sdraw = c->sdraw.as<double>();
+    fa.P = c->P.as<double>(); fa.nu_fit = c->nufit.as<double>(); fa.nu_out = c->nuout.as<double>();
+    fa.x0 = c->x0.as<double>(); fa.st = c->state.as<SubState>();
+    fa.csum = c->csum.as<double>(); fa.ncs = ncs;
+    fa.partial = c->partial.as<double>(); fa.nchunk = nchunk; fa.cpc = cpc;
+    fa.nactive = c->misc.as<int>();
+    fa.o_params = c->o_params.as<double>(); fa.o_errs = c->o_errs.as<double>(); fa.o_nu = c->o_nu.as<double>();
+    fa.o_cov = c->o_cov.as<double>(); fa.o_chi2 = c->o_chi2.as<double>(); fa.o_rchi2 = c->o_rchi2.as<double>();
+    fa.o_snr = c->o_snr.as<double>(); fa.o_nfev = c->o_nfev.as<int>(); fa.o_rc = c->o_rc.as<int>();
+    fa.o_scales = out->scales ? c->o_scales.as<double>() : nullptr;
+    fa.o_scale_errs = out->scale_errs ? c->o_serrs.as<double>() : nullptr;
+    fa.o_csnr = out->channel_snrs ? c->o_csnr.as<double>() : nullptr;
+    fa.o_f0 = c->o_f0.as<double>(); fa.o_g0 = c->o_g0.as<double>(); fa.o_H0 = c->o_H0.as<double>();
+
+    hipLaunchKernelGGL(k_init_state, dim3((ns + 63) / 64), dim3(64), 0, c->stream, fa);
+    HIP_TRY(hipGetLastError());
+    // ---- trust-region iterations: evaluation + step, until every subint is done
+    const int max_evals = std::max(1, c->max_iter + 1);
+    for (int it = 0; it < max_evals; ++it) {
+        {
+            Prof pr(c, KF_EVAL);
+            if (scat) hipLaunchKernelGGL(k_eval<true>, dim3(nchunk, ns), dim3(256), 0, c->stream, fa);
+            else hipLaunchKernelGGL(k_eval<false>, dim3(nchunk, ns), dim3(256), 0, c->stream, fa);
+        }
+        {
+            Prof pr(c, KF_STEP);
+            hipLaunchKernelGGL(k_step, dim3(ns), dim3(64), 0, c->stream, fa);
+        }
+        HIP_TRY(hipGetLastError());
+        if (it >= 2 && ((it - 2) % c->check_every) == 0) {
+            HIP_TRY(hipMemcpyAsync(c->nactive_h, fa.nactive, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->nactive_h[0] <= 0) break;
+        }
+    }
+    {
+        Prof pr(c, KF_FINAL);
+        hipLaunchKernelGGL(k_finalize, dim3(ns), dim3(256), 0, c->stream, fa);
+    }
+    HIP_TRY(hipGetLastError());
+    // ---- outputs ----
+#define PP_D2H(dst, buf, off, bytes) \
+    if (dst) HIP_TRY(hipMemcpyAsync((char*)(dst) + (off), (buf).p, (bytes), hipMemcpyDeviceToHost, c->stream))
+    PP_D2H(out->params, c->o_params, (size_t)s0 * 40, (size_t)ns * 40);
+    PP_D2H(out->param_errs, c->o_errs, (size_t)s0 * 40, (size_t)ns * 40);
+    PP_D2H(out->nu_refs, c->o_nu, (size_t)s0 * 24, (size_t)ns * 24);
+    PP_D2H(out->cov, c->o_cov, (size_t)s0 * 200, (size_t)ns * 200);
+    PP_D2H(out->chi2, c->o_chi2, (size_t)s0 * 8, (size_t)ns * 8);
+    PP_D2H(out->red_chi2, c->o_rchi2, (size_t)s0 * 8, (size_t)ns * 8);
+    PP_D2H(out->snr, c->o_snr, (size_t)s0 * 8, (size_t)ns * 8);
+    PP_D2H(out->nfeval, c->o_nfev, (size_t)s0 * 4, (size_t)ns * 4);
+    PP_D2H(out->return_code, c->o_rc, (size_t)s0 * 4, (size_t)ns * 4);
+    PP_D2H(out->scales, c->o_scales, (size_t)s0 * C * 8, nc * 8);
+    PP_D2H(out->scale_errs, c->o_serrs, (size_t)s0 * C * 8, nc * 8);
+    PP_D2H(out->channel_snrs, c->o_csnr, (size_t)s0 * C * 8, nc * 8);
+    PP_D2H(out->obj_f, c->o_f0, (size_t)s0 * 8, (size_t)ns * 8);
+    PP_D2H(out->obj_grad, c->o_g0, (size_t)s0 * 40, (size_t)ns * 40);
+    PP_D2H(out->obj_hess, c->o_H0, (size_t)s0 * 200, (size_t)ns * 200);
+#undef PP_D2H
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PP_OK;
+}
+
+extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out) {
+    if (!c || !in || !out) return fail(PP_EINVAL, "pp_fit_portrait_batch: null argument");
+    if (in->nsub < 1 || in->nchan < 1) return fail(PP_EINVAL, "bad batch shape %d x %d", in->nsub, in->nchan);
+    if (!nbin_ok(in->nbin)) return fail(PP_EINVAL, "nbin %d must be a power of two in [32,8192]", in->nbin);
+    if (!in->data || !in->freqs || !in->P || !in->init_params) return fail(PP_EINVAL, "missing input array");
+    if (in->data_dtype != PP_F64 && in->data_dtype != PP_F32) return fail(PP_EINVAL, "data_dtype %d", in->data_dtype);
+    if (in->freqs_stride != 0 && in->freqs_stride != in->nchan) return fail(PP_EINVAL, "freqs_stride must be 0 or nchan");
+    if (!out->params || !out->param_errs || !out->nu_refs || !out->cov || !out->chi2 || !out->red_chi2 ||
+        !out->snr || !out->nfeval || !out->return_code)
+        return fail(PP_EINVAL, "missing output array");
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = in->nsub, C = in->nchan, B = in->nbin, M = B / 2;
+    // models used by this batch
+    int Kt = 0;
+    for (int i = 0; i < N; ++i) {
+        const int sl = in->model_slot ? in->model_slot[i] : 0;
+        if (sl < 0 || sl >= PP_MAX_SLOTS || !c->slots[sl].set) return fail(PP_ESTATE, "subint %d: model slot %d not set", i, sl);
+        if (c->slots[sl].nchan != C || c->slots[sl].nbin != B)
+            return fail(PP_EINVAL, "subint %d: model slot %d is %dx%d, data is %dx%d", i, sl, c->slots[sl].nchan, c->slots[sl].nbin, C, B);
+        Kt = std::max(Kt, c->slots[sl].Kt);
+        if (!in->model_slot) break;
+    }
+    // scattering path needed? (reference builds B_nk for any tau != 0)
+    bool scat = in->fit_flags[3] || in->fit_flags[4] || in->log10_tau;
+    if (!scat)
+        for (int i = 0; i < N; ++i) if (in->init_params[(size_t)i * 5 + 3] != 0.0) { scat = true; break; }
+    if (scat) Kt = M;   // S_n(tau) needs every harmonic of the model
+    // default reference frequencies: mean of the (unmasked) channel frequencies
+    std::vector<double> nufit((size_t)N * 3), nuout((size_t)N * 3);
+    for (int i = 0; i < N; ++i) {
+        double mean = NAN;
+        for (int j = 0; j < 3; ++j) {
+            double v = in->nu_fits ? in->nu_fits[(size_t)i * 3 + j] : NAN;
+            if (std::isnan(v)) {
+                if (std::isnan(mean)) {
+                    const double* f = in->freqs + (in->freqs_stride ? (size_t)i * C : 0);
+                    const uint8_t* m = in->chan_mask ? in->chan_mask + (size_t)i * C : nullptr;
+                    double s = 0.0; long long cnt = 0;
+                    for (int n = 0; n < C; ++n) if (!m || m[n]) { s += f[n]; ++cnt; }
+                    mean = cnt ? s / (double)cnt : NAN;
+                }
+                v = mean;
+            }
+            nufit[(size_t)i * 3 + j] = v;
+            nuout[(size_t)i * 3 + j] = in->nu_outs ? in->nu_outs[(size_t)i * 3 + j] : NAN;
+        }
+    }
+    // sub-batches sized to the work-memory budget
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const double per_sub = (double)C * Kt * 16.0 + (in->data_on_device ? 0.0 : (double)C * B * (in->data_dtype == PP_F64 ? 8 : 4)) +
+                           (double)C * (8.0 * 12 + 2 * 9 * 8.0) + 4096.0;
+    double budget = std::min(c->max_work_bytes, 0.85 * ((double)free_b + (double)c->X.cap + (double)c->data.cap + (double)c->csum.cap));
+    int cap = (int)std::max(1.0, std::floor(budget / per_sub));
+    cap = std::min(cap, N);
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (int s0 = 0; s0 < N; s0 += cap) {
+        const int ns = std::min(cap, N - s0);
+        int rc = fit_chunk(c, in, out, s0, ns, Kt, scat, nufit, nuout);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    if (out->duration) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        out->duration[0] = 1e-3 * ms;
+    }
+    if (c->profile) resolve_spans(c);
+    return PP_OK;
+}
+
+#include "pp_extra_api.h"

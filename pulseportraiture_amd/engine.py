@@ -1,0 +1,252 @@
+"""Thin Python wrapper of the C ABI: one Engine = one device context.
+
+The batch entry point `Engine.fit_batch` is what reaches 10^4 fits/s; the
+reference-shaped single-subint functions in pptoaslib.py / pplib.py marshal
+into it.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FitIn, FitOut, PP_F32, PP_F64, c_double_p, c_int32_p, c_uint8_p
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise EngineError("%s failed (%d): %s" % (what, rc, _lib.last_error()))
+
+
+def _is_device_array(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda") and bool(x.is_cuda)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+def _f64(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = np.ascontiguousarray(np.broadcast_to(a, shape))
+    return a
+
+
+class Engine(object):
+    """Device context + scratch; not thread-safe (one per host thread and GPU)."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        ctx = C.c_void_p()
+        _check(self._lib.pp_create(int(device), C.byref(ctx)), "pp_create")
+        self._ctx = ctx
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.pp_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration --------------------------------------------------
+    def set_option(self, name, value):
+        _check(self._lib.pp_set_option(self._ctx, name.encode(), float(value)),
+               "pp_set_option(%s)" % name)
+
+    def synchronize(self):
+        _check(self._lib.pp_synchronize(self._ctx), "pp_synchronize")
+
+    # -- model ------------------------------------------------------------
+    def set_model(self, model, slot=0):
+        """Upload an nchan x nbin template (numpy array or CUDA tensor)."""
+        if _is_device_array(model):
+            nchan, nbin = int(model.shape[-2]), int(model.shape[-1])
+            dtype = PP_F64 if model.element_size() == 8 else PP_F32
+            ptr, on_dev, keep = model.data_ptr(), 1, model
+        else:
+            m = np.asarray(model)
+            if m.dtype != np.float32:
+                m = m.astype(np.float64, copy=False)
+            m = np.ascontiguousarray(m)
+            nchan, nbin = m.shape
+            dtype = PP_F64 if m.dtype == np.float64 else PP_F32
+            ptr, on_dev, keep = m.ctypes.data, 0, m
+        _check(self._lib.pp_model_set(self._ctx, int(slot), C.c_void_p(ptr), dtype,
+                                      on_dev, nchan, nbin), "pp_model_set")
+        del keep
+        return self._lib.pp_model_nharm(self._ctx, int(slot))
+
+    def model_nharm(self, slot=0):
+        return self._lib.pp_model_nharm(self._ctx, int(slot))
+
+    # -- the fit ------------------------------------------------------------
+    def fit_batch(self, data, freqs, P, init_params, errs=None, nu_fits=None,
+                  nu_outs=None, fit_flags=(1, 1, 0, 0, 0), log10_tau=False,
+                  option=0, is_toa=True, model_slot=None, chan_mask=None,
+                  per_channel=True, objective=False):
+        """Fit nsub subints.  data: [nsub,nchan,nbin] numpy array (f64/f32) or
+        CUDA tensor.  freqs: [nchan] or [nsub,nchan].  Returns a dict of arrays
+        (see include/pp_toas.h pp_fit_out)."""
+        if _is_device_array(data):
+            nsub, nchan, nbin = (int(s) for s in data.shape)
+            if not data.is_contiguous():
+                raise EngineError("device data must be contiguous")
+            dtype = PP_F64 if data.element_size() == 8 else PP_F32
+            dptr, on_dev, keep = data.data_ptr(), 1, data
+        else:
+            d = np.asarray(data)
+            if d.dtype != np.float32:
+                d = d.astype(np.float64, copy=False)
+            d = np.ascontiguousarray(d)
+            if d.ndim == 2:
+                d = d[None]
+            nsub, nchan, nbin = d.shape
+            dtype = PP_F64 if d.dtype == np.float64 else PP_F32
+            dptr, on_dev, keep = d.ctypes.data, 0, d
+        freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+        if freqs.ndim == 1:
+            if freqs.shape[0] != nchan:
+                raise EngineError("freqs has %d entries for %d channels" %
+                                  (freqs.shape[0], nchan))
+            fstride = 0
+        else:
+            if freqs.shape != (nsub, nchan):
+                raise EngineError("freqs shape %s != (%d, %d)" %
+                                  (freqs.shape, nsub, nchan))
+            fstride = nchan
+        P = _f64(P, (nsub,))
+        x0 = _f64(init_params, (nsub, 5))
+        errs = _f64(errs, (nsub, nchan))
+        nan3 = np.full((nsub, 3), np.nan)
+        nu_fits = nan3 if nu_fits is None else _f64(
+            [[np.nan if v is None else v for v in row] for row in
+             np.broadcast_to(np.asarray(nu_fits, dtype=object), (nsub, 3))])
+        nu_outs = nan3.copy() if nu_outs is None else _f64(
+            [[np.nan if v is None else v for v in row] for row in
+             np.broadcast_to(np.asarray(nu_outs, dtype=object), (nsub, 3))])
+        slot = None if model_slot is None else np.ascontiguousarray(
+            np.broadcast_to(model_slot, (nsub,)), dtype=np.int32)
+        mask = None if chan_mask is None else np.ascontiguousarray(
+            np.broadcast_to(chan_mask, (nsub, nchan)), dtype=np.uint8)
+
+        fin = FitIn()
+        fin.nsub, fin.nchan, fin.nbin = nsub, nchan, nbin
+        fin.data = C.c_void_p(dptr)
+        fin.data_dtype, fin.data_on_device = dtype, on_dev
+        fin.model_slot = None if slot is None else slot.ctypes.data_as(c_int32_p)
+        fin.freqs, fin.freqs_stride = _dp(freqs), fstride
+        fin.errs = _dp(errs)
+        fin.chan_mask = None if mask is None else mask.ctypes.data_as(c_uint8_p)
+        fin.P, fin.init_params = _dp(P), _dp(x0)
+        fin.nu_fits, fin.nu_outs = _dp(nu_fits), _dp(nu_outs)
+        for j in range(5):
+            fin.fit_flags[j] = 1 if fit_flags[j] else 0
+        fin.log10_tau = int(bool(log10_tau))
+        fin.option, fin.is_toa = int(option), int(bool(is_toa))
+
+        res = dict(params=np.empty((nsub, 5)), param_errs=np.empty((nsub, 5)),
+                   nu_refs=np.empty((nsub, 3)), cov=np.empty((nsub, 5, 5)),
+                   chi2=np.empty(nsub), red_chi2=np.empty(nsub), snr=np.empty(nsub),
+                   nfeval=np.empty(nsub, dtype=np.int32),
+                   return_code=np.empty(nsub, dtype=np.int32),
+                   duration=np.zeros(1))
+        if per_channel:
+            res.update(scales=np.empty((nsub, nchan)),
+                       scale_errs=np.empty((nsub, nchan)),
+                       channel_snrs=np.empty((nsub, nchan)))
+        if objective:
+            res.update(obj_f=np.empty(nsub), obj_grad=np.empty((nsub, 5)),
+                       obj_hess=np.empty((nsub, 5, 5)))
+        fout = FitOut()
+        for name, _ in FitOut._fields_:
+            arr = res.get(name)
+            if arr is None:
+                setattr(fout, name, None)
+            elif arr.dtype == np.int32:
+                setattr(fout, name, arr.ctypes.data_as(c_int32_p))
+            else:
+                setattr(fout, name, arr.ctypes.data_as(c_double_p))
+        _check(self._lib.pp_fit_portrait_batch(self._ctx, C.byref(fin),
+                                               C.byref(fout)),
+               "pp_fit_portrait_batch")
+        del keep
+        res["duration"] = float(res["duration"][0])
+        res["fit_flags"] = [1 if f else 0 for f in fit_flags]
+        return res
+
+    # -- parity hooks / measurement ---------------------------------------
+    def rfft_rows(self, rows):
+        r = np.asarray(rows)
+        if r.dtype != np.float32:
+            r = r.astype(np.float64, copy=False)
+        r = np.ascontiguousarray(r)
+        nrows, nbin = r.shape
+        out = np.empty((nrows, nbin // 2 + 1), dtype=np.complex128)
+        _check(self._lib.pp_rfft_rows(self._ctx, C.c_void_p(r.ctypes.data),
+                                      PP_F64 if r.dtype == np.float64 else PP_F32,
+                                      nrows, nbin,
+                                      out.ctypes.data_as(c_double_p)),
+               "pp_rfft_rows")
+        return out
+
+    def fit_phase_shift_batch(self, data, model, noise=None, bounds=(-0.5, 0.5),
+                              Ns=100):
+        d = _f64(np.atleast_2d(data))
+        nprof, nbin = d.shape
+        m = _f64(np.atleast_2d(model), (nprof, nbin))
+        nz = np.full(nprof, np.nan) if noise is None else _f64(
+            [np.nan if v is None else v for v in
+             np.broadcast_to(np.asarray(noise, dtype=object), (nprof,))])
+        out = np.empty((nprof, 7))
+        _check(self._lib.pp_fit_phase_shift_batch(
+            self._ctx, _dp(d), _dp(m), _dp(nz), nprof, nbin, float(bounds[0]),
+            float(bounds[1]), int(Ns), _dp(out)), "pp_fit_phase_shift_batch")
+        return out
+
+    def synth_portraits(self, dst, freqs, P, inj, sigma, seed, first_subint=0,
+                        slot=0):
+        """Fill a CUDA tensor dst[nsub,nchan,nbin] with synthetic subints."""
+        if not _is_device_array(dst):
+            raise EngineError("synth_portraits needs a CUDA tensor destination")
+        nsub = int(dst.shape[0])
+        freqs = _f64(freqs)
+        P = _f64(P, (nsub,))
+        inj = _f64(inj, (nsub, 3))
+        _check(self._lib.pp_synth_portraits(
+            self._ctx, int(slot), C.c_void_p(dst.data_ptr()),
+            PP_F64 if dst.element_size() == 8 else PP_F32, nsub, _dp(freqs),
+            _dp(P), _dp(inj), float(sigma), C.c_uint64(int(seed)),
+            C.c_int64(int(first_subint))), "pp_synth_portraits")
+
+    def kernel_times(self, reset=False):
+        n = 16
+        names = (C.c_char_p * n)()
+        secs = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        k = self._lib.pp_kernel_times(self._ctx, n, names, secs, cnt)
+        out = {names[i].decode(): (secs[i], cnt[i]) for i in range(k)}
+        if reset:
+            self._lib.pp_kernel_times_reset(self._ctx)
+        return out
+
+
+_default = {}
+
+
+def default_engine(device=0):
+    """Process-wide engine for the reference-shaped single-call API."""
+    eng = _default.get(device)
+    if eng is None:
+        eng = _default[device] = Engine(device)
+    return eng

@@ -1,0 +1,119 @@
+"""Reference-shaped entry points of pplib that sit on the wideband-TOA path.
+
+Mirrors (same names, argument meaning, result fields) of the reference's
+pplib.py for: module settings (:45-83), RCSTRINGS (:111-119), DataBunch
+(:125-136), fit_phase_shift (:2054-2100), the legacy fit_portrait (:2102-2204),
+and the small host-side helpers the callers use between fits
+(get_bin_centers :671-684, DM_delay :2577-2590, phase_transform :2592-2616,
+guess_fit_freq :2618-2632).  All array arithmetic of the fits themselves runs
+in HIP kernels through pulseportraiture_amd.engine.
+"""
+import sys
+
+import numpy as np
+
+from .engine import default_engine
+
+# ---- settings (pplib.py:45-83); Dconst must be bit-identical ---------------
+Dconst_exact = 4.148808e3
+Dconst_trad = 0.000241 ** -1
+Dconst = Dconst_trad
+scattering_alpha = -4.0
+use_get_noise = True
+default_noise_method = 'PS'
+F0_fact = 0
+wid_max = 0.25
+default_model = '000'
+binshift = 1.0
+
+# return-code strings (pplib.py:111-119); the device solver reports
+# 0 gradient-converged, 1 iteration limit, 2 stalled at rounding (the
+# reference's usual trust-ncg exit), 3 NaN/singular
+RCSTRINGS = {'-1': 'INFEASIBLE: Infeasible (low > up).',
+             '0': 'LOCALMINIMUM: Local minima reach (|pg| ~= 0).',
+             '1': 'FCONVERGED: Converged (|f_n-f_(n-1)| ~= 0.)',
+             '2': 'XCONVERGED: Converged (|x_n-x_(n-1)| ~= 0.)',
+             '3': 'MAXFUN: Max. number of function evaluations reach.',
+             '4': 'LSFAIL: Linear search failed.',
+             '5': 'CONSTANT: All lower bounds are equal to the upper bounds.',
+             '6': 'NOPROGRESS: Unable to progress.',
+             '7': 'USERABORT: User requested end of minimization.'}
+
+
+class DataBunch(dict):
+    """dict whose attributes are its keys; results stay mutable attribute-dicts
+    because callers modify them after the fit (pplib.py:125-136)."""
+
+    def __init__(self, **kwds):
+        dict.__init__(self, kwds)
+        self.__dict__ = self
+
+
+# ---- small host helpers ------------------------------------------------------
+def get_bin_centers(nbin, lo=0.0, hi=1.0):
+    lo, hi = np.double(lo), np.double(hi)
+    diff = hi - lo
+    return np.double(np.linspace(lo + diff / (nbin * 2), hi - diff / (nbin * 2),
+                                 nbin))
+
+
+def DM_delay(DM, freq, freq_ref=np.inf, P=None):
+    delay = Dconst * DM * ((freq ** -2.0) - (freq_ref ** -2.0))
+    return delay / P if P else delay
+
+
+def phase_transform(phi, DM, nu_ref1=np.inf, nu_ref2=np.inf, P=None, mod=False):
+    if P is None:
+        P, mod = 1.0, False
+    phi_prime = phi + (Dconst * DM * P ** -1 * (nu_ref2 ** -2.0 - nu_ref1 ** -2.0))
+    if mod:
+        phi_prime = np.where(abs(phi_prime) >= 0.5, phi_prime % 1, phi_prime)
+        phi_prime = np.where(phi_prime >= 0.5, phi_prime - 1.0, phi_prime)
+        if not phi_prime.shape:
+            phi_prime = np.float64(phi_prime)
+    return phi_prime
+
+
+def guess_fit_freq(freqs, SNRs=None):
+    freqs = np.asarray(freqs, dtype=np.float64)
+    nu0 = (freqs.min() + freqs.max()) * 0.5
+    if SNRs is None:
+        SNRs = np.ones(len(freqs))
+    diff = np.sum((freqs - nu0) * SNRs * freqs ** -2) / np.sum(SNRs * freqs ** -2)
+    return nu0 + diff
+
+
+# ---- 1-D FFTFIT ----------------------------------------------------------------
+def fit_phase_shift(data, model, noise=None, bounds=[-0.5, 0.5], Ns=100):
+    """Fit a phase shift between a data and a model profile on the GPU:
+    Ns-point brute grid over `bounds` (both ends included), refined to the
+    local optimum (the reference polishes with a simplex to ~1e-4)."""
+    eng = default_engine()
+    out = eng.fit_phase_shift_batch(np.asarray(data, dtype=np.float64)[None],
+                                    np.asarray(model, dtype=np.float64)[None],
+                                    noise=None if noise is None else [noise],
+                                    bounds=bounds, Ns=Ns)[0]
+    return DataBunch(phase=out[0], phase_err=out[1], scale=out[2],
+                     scale_err=out[3], snr=out[4], red_chi2=out[5],
+                     duration=out[6])
+
+
+# ---- legacy 2-parameter fit ------------------------------------------------------
+def fit_portrait(data, model, init_params, P, freqs, nu_fit=None, nu_out=None,
+                 errs=None, bounds=[(None, None), (None, None)], id=None,
+                 quiet=True):
+    """(phase, DM) fit with the legacy result fields; runs the same device
+    engine as fit_portrait_full with fit_flags = [1,1,0,0,0] (the reference's
+    TNC minimiser is not reproduced: both converge to the same optimum)."""
+    from .pptoaslib import fit_portrait_full
+    x0 = [init_params[0], init_params[1], 0.0, 0.0, 0.0]
+    r = fit_portrait_full(data, model, x0, P, freqs, [nu_fit] * 3, [nu_out] * 3,
+                          errs, [1, 1, 0, 0, 0], log10_tau=False, sub_id=id,
+                          is_toa=True, quiet=quiet)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        scale_errs = np.abs(r.scales / r.channel_snrs)   # (p_n/sigma_n^2)^-1/2
+    return DataBunch(phase=r.phi, phase_err=r.phi_err, DM=r.DM, DM_err=r.DM_err,
+                     scales=r.scales, scale_errs=scale_errs, nu_ref=r.nu_DM,
+                     covariance=r.covariance_matrix[0, 1], chi2=r.chi2,
+                     red_chi2=r.red_chi2, snr=r.snr, duration=r.duration,
+                     nfeval=r.nfeval, return_code=r.return_code)

@@ -1,0 +1,81 @@
+"""Reference-shaped wideband fit: `fit_portrait_full` (pptoaslib.py:928-1096)
+and its batched form.  The arithmetic (rFFT, cross-spectrum, chi^2 surface,
+trust-region solve, zero-covariance frequencies, covariance with amplitudes)
+runs in the HIP kernels of csrc/ via the C ABI."""
+import sys
+
+import numpy as np
+
+from .engine import default_engine
+from .pplib import DataBunch, Dconst, RCSTRINGS  # noqa: F401
+
+_METHODS = ('trust-ncg', 'Newton-CG', 'TNC')
+
+
+def _bunch(res, i, fit_flags):
+    ifit = np.where(fit_flags)[0]
+    p, e = res["params"][i], res["param_errs"][i]
+    cov = res["cov"][i][np.ix_(ifit, ifit)]
+    return DataBunch(
+        params=list(p), param_errs=e.copy(), phi=p[0], phi_err=e[0], DM=p[1],
+        DM_err=e[1], GM=p[2], GM_err=e[2], tau=p[3], tau_err=e[3], alpha=p[4],
+        alpha_err=e[4], scales=res["scales"][i].copy(),
+        scale_errs=res["scale_errs"][i].copy(), nu_DM=res["nu_refs"][i, 0],
+        nu_GM=res["nu_refs"][i, 1], nu_tau=res["nu_refs"][i, 2],
+        covariance_matrix=cov, chi2=res["chi2"][i], red_chi2=res["red_chi2"][i],
+        snr=res["snr"][i], channel_snrs=res["channel_snrs"][i].copy(),
+        duration=res["duration"], nfeval=int(res["nfeval"][i]),
+        return_code=int(res["return_code"][i]))
+
+
+def fit_portrait_full(data_port, model_port, init_params, P, freqs,
+                      nu_fits=[None, None, None], nu_outs=[None, None, None],
+                      errs=None, fit_flags=[1, 1, 1, 1, 1],
+                      bounds=[(None, None), (None, None), (None, None),
+                              (None, None), (None, None)], log10_tau=True,
+                      option=0, sub_id=None, method='trust-ncg', is_toa=True,
+                      quiet=True):
+    """Fit phase, DM, GM, tau and alpha between a data and a model portrait.
+
+    Same arguments and result fields as the reference.  `method` selects
+    nothing on the device (one trust-region Newton solver serves the three
+    reference method names; `bounds` are not applied); an unknown method exits
+    like the reference does (pptoaslib.py:1008-1010)."""
+    if method not in _METHODS:
+        print("Method '%s' is not implemented." % method)
+        sys.exit()
+    eng = default_engine()
+    flags = [1 if f else 0 for f in fit_flags]
+    eng.set_model(model_port, slot=0)
+    data = np.asarray(data_port)
+    res = eng.fit_batch(data[None] if data.ndim == 2 else data, freqs, P,
+                        init_params, errs=errs, nu_fits=[list(nu_fits)],
+                        nu_outs=[list(nu_outs)], fit_flags=flags,
+                        log10_tau=log10_tau, option=option, is_toa=is_toa)
+    r = _bunch(res, 0, flags)
+    if r.return_code not in (0, 1, 2, 4):
+        rcs = "NaN or singular objective"
+        if sub_id is not None:
+            ii = sub_id[::-1].index("_")
+            sys.stderr.write("Fit 'failed' with return code %d: %s -- %s subint %s\n"
+                             % (r.return_code, rcs, sub_id[:-ii - 1], sub_id[-ii:]))
+        else:
+            sys.stderr.write("Fit 'failed' with return code %d -- %s" %
+                             (r.return_code, rcs))
+    return r
+
+
+def fit_portrait_full_batch(data_ports, model_port, init_params, Ps, freqs,
+                            nu_fits=None, nu_outs=None, errs=None,
+                            fit_flags=[1, 1, 0, 0, 0], log10_tau=False, option=0,
+                            is_toa=True, chan_mask=None, model_slot=None,
+                            engine=None):
+    """Batched form: data_ports[nsub,nchan,nbin] against one model (or several
+    pre-loaded slots); returns the dict of result arrays of Engine.fit_batch."""
+    eng = engine or default_engine()
+    if model_port is not None:
+        eng.set_model(model_port, slot=0)
+    return eng.fit_batch(data_ports, freqs, Ps, init_params, errs=errs,
+                         nu_fits=nu_fits, nu_outs=nu_outs, fit_flags=fit_flags,
+                         log10_tau=log10_tau, option=option, is_toa=is_toa,
+                         chan_mask=chan_mask, model_slot=model_slot)

@@ -1,0 +1,189 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors
+of the true reference and against the CPU oracle on the same inputs.
+
+Bars (BASELINE.json north_star): |dphi| < 1e-9 rot, |dDM| < 1e-6 pc cm^-3."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+FPF = sorted(os.path.basename(p)[:-4] for p in
+             glob.glob(os.path.join(GOLDEN, "fpf_64x256_*.npz")) +
+             glob.glob(os.path.join(GOLDEN, "fpf_128x512_*.npz")))
+PHI_BAR, DM_BAR = 1e-9, 1e-6
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from pulseportraiture_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def _dphi(a, b):
+    d = abs(a - b)
+    return min(d, abs(d - 1.0))
+
+
+@pytest.mark.parametrize("nbin", [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_rfft_rows(eng, nbin, dtype):
+    rng = np.random.default_rng(nbin)
+    x = rng.normal(size=(7, nbin)).astype(dtype)
+    got = eng.rfft_rows(x)
+    ref = np.fft.rfft(x.astype(np.float64), axis=-1)
+    scale = np.abs(ref).max()
+    # f64 arithmetic throughout: agreement at a few ulp * log2(nbin)
+    assert np.abs(got - ref).max() < 2e-15 * np.log2(nbin) * scale
+
+
+@pytest.mark.parametrize("name", FPF)
+def test_objective_at_fixed_points(eng, name):
+    g = _load(name)
+    eng.set_option("max_iter", 0)
+    try:
+        eng.set_model(g["model"])
+        for i, p in enumerate(g["obj_points"]):
+            r = eng.fit_batch(g["data"][None], g["freqs"], float(g["P"]), p,
+                              errs=g["errs"], nu_fits=[list(g["nu_fits"])],
+                              fit_flags=list(g["fit_flags"]),
+                              log10_tau=bool(g["log10_tau"]), objective=True)
+            np.testing.assert_allclose(r["obj_f"][0], g["obj_f"][i], rtol=1e-12)
+            gs = np.abs(g["obj_grad"][i]).max() + 1e-300
+            np.testing.assert_allclose(r["obj_grad"][0], g["obj_grad"][i],
+                                       rtol=1e-8, atol=1e-11 * gs)
+            hs = np.abs(g["obj_hess"][i]).max()
+            np.testing.assert_allclose(r["obj_hess"][0], g["obj_hess"][i],
+                                       rtol=1e-8, atol=1e-11 * hs)
+    finally:
+        eng.set_option("max_iter", 64)
+
+
+@pytest.mark.parametrize("name", FPF)
+def test_fit_matches_reference_golden(name):
+    from pulseportraiture_amd.pptoaslib import fit_portrait_full
+    g = _load(name)
+    nu_outs = [None if np.isnan(v) else float(v) for v in g["nu_outs"]]
+    r = fit_portrait_full(g["data"], g["model"], g["init_params"], float(g["P"]),
+                          g["freqs"], list(g["nu_fits"]), nu_outs, g["errs"],
+                          list(g["fit_flags"]), log10_tau=bool(g["log10_tau"]))
+    assert _dphi(r.phi, float(g["out_phi"])) < PHI_BAR
+    assert abs(r.DM - float(g["out_DM"])) < DM_BAR
+    scat = bool(g["fit_flags"][2] or g["fit_flags"][3] or g["fit_flags"][4])
+    rt = 2e-5 if scat else 1e-8
+    np.testing.assert_allclose(r.params, g["out_params"], rtol=rt, atol=1e-9)
+    np.testing.assert_allclose(r.param_errs, g["out_param_errs"], rtol=1e-5)
+    np.testing.assert_allclose([r.nu_DM, r.nu_GM, r.nu_tau],
+                               [g["out_nu_DM"], g["out_nu_GM"], g["out_nu_tau"]],
+                               rtol=1e-5 if scat else 1e-9)
+    np.testing.assert_allclose(r.scales, g["out_scales"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(r.scale_errs, g["out_scale_errs"], rtol=1e-6)
+    np.testing.assert_allclose(r.channel_snrs, g["out_channel_snrs"], rtol=1e-6,
+                               atol=1e-7)
+    cov = g["out_covariance_matrix"]
+    cs = np.sqrt(np.outer(np.diag(cov), np.diag(cov)))
+    assert np.all(np.abs(r.covariance_matrix - cov) <= 1e-4 * np.abs(cov) +
+                  1e-7 * cs)
+    np.testing.assert_allclose(r.chi2, g["out_chi2"], rtol=1e-10)
+    np.testing.assert_allclose(r.red_chi2, g["out_red_chi2"], rtol=1e-10)
+    np.testing.assert_allclose(r.snr, g["out_snr"], rtol=1e-8)
+    assert r.return_code in (0, 2)
+
+
+def test_harmonic_truncation_is_parity_safe(eng):
+    """Dropping the model's negligible trailing harmonics (option harm_eps)
+    must not move the answer: compare against the untruncated run."""
+    g = _load("fpf_128x512_phiDM_scint")
+    kw = dict(errs=g["errs"], nu_fits=[list(g["nu_fits"])], fit_flags=[1, 1, 0, 0, 0])
+    eng.set_option("harm_eps", 0.0)
+    k_full = eng.set_model(g["model"])
+    full = eng.fit_batch(g["data"][None], g["freqs"], float(g["P"]),
+                         g["init_params"], **kw)
+    eng.set_option("harm_eps", 2.0 ** -50)
+    k_cut = eng.set_model(g["model"])
+    cut = eng.fit_batch(g["data"][None], g["freqs"], float(g["P"]),
+                        g["init_params"], **kw)
+    assert k_full == 256 and k_cut < k_full
+    assert abs(full["params"][0, 0] - cut["params"][0, 0]) < 1e-13
+    assert abs(full["params"][0, 1] - cut["params"][0, 1]) < 1e-12
+    np.testing.assert_allclose(cut["param_errs"], full["param_errs"], rtol=1e-10)
+
+
+def test_batch_with_ragged_inputs_matches_oracle(eng):
+    """Several subints in one call with different periods, frequencies, guesses
+    and channel masks; each must match the oracle run on its own (sliced)
+    arrays -- the per-subint ok_ichans of pptoas.py:384-397."""
+    from oracle import pptoas_oracle as orc
+    from tests.synth_host import make_inputs, caller_guess, model_portrait
+    C, B, N = 32, 128, 5
+    freqs0, model = model_portrait(C, B)
+    eng.set_model(model)
+    rng = np.random.default_rng(5)
+    data, fr, P, x0, mask, nuf = [], [], [], [], [], []
+    for i in range(N):
+        inp = make_inputs(C, B, 900 + i, model=model, DM0=3.0 * i)
+        gss = caller_guess(inp)
+        m = np.ones(C, dtype=np.uint8)
+        if i % 2:
+            m[rng.choice(C, size=5, replace=False)] = 0
+        data.append(inp["data"]); fr.append(inp["freqs"]); P.append(inp["P"])
+        x0.append(gss["init_params"]); mask.append(m); nuf.append([gss["nu_fit"]] * 3)
+    errs = np.full((N, C), 0.05)
+    res = eng.fit_batch(np.array(data), np.array(fr), np.array(P), np.array(x0),
+                        errs=errs, nu_fits=nuf, fit_flags=[1, 1, 0, 0, 0],
+                        chan_mask=np.array(mask))
+    for i in range(N):
+        ok = mask[i].astype(bool)
+        o = orc.fit_portrait_full(data[i][ok], model[ok], x0[i], P[i], fr[i][ok],
+                                  nuf[i], [None] * 3, errs[i][ok], [1, 1, 0, 0, 0],
+                                  log10_tau=False)
+        assert _dphi(res["params"][i, 0], o.phi) < PHI_BAR
+        assert abs(res["params"][i, 1] - o.DM) < DM_BAR
+        np.testing.assert_allclose(res["param_errs"][i, :2], o.param_errs[:2],
+                                   rtol=1e-6)
+        np.testing.assert_allclose(res["nu_refs"][i, 0], o.nu_DM, rtol=1e-9)
+        np.testing.assert_allclose(res["red_chi2"][i], o.red_chi2, rtol=1e-9)
+        np.testing.assert_allclose(res["scales"][i][ok], o.scales, rtol=1e-6)
+        assert np.all(res["scales"][i][~ok] == 0.0)
+
+
+def test_measured_noise_when_errs_is_none(eng):
+    from oracle import pptoas_oracle as orc
+    g = _load("fpf_64x256_phiDM")
+    eng.set_model(g["model"])
+    r = eng.fit_batch(g["data"][None], g["freqs"], float(g["P"]), g["init_params"],
+                      errs=None, nu_fits=[list(g["nu_fits"])],
+                      fit_flags=[1, 1, 0, 0, 0])
+    o = orc.fit_portrait_full(g["data"], g["model"], g["init_params"],
+                              float(g["P"]), g["freqs"], list(g["nu_fits"]),
+                              [None] * 3, None, [1, 1, 0, 0, 0], log10_tau=False)
+    assert _dphi(r["params"][0, 0], o.phi) < PHI_BAR
+    assert abs(r["params"][0, 1] - o.DM) < DM_BAR
+    np.testing.assert_allclose(r["red_chi2"][0], o.red_chi2, rtol=1e-9)
+
+
+def test_float32_portraits(eng):
+    """f32-resident data (PSRFITS amplitudes are single precision on disk) is
+    promoted to f64 in the FFT; compare with the oracle fed the same values."""
+    from oracle import pptoas_oracle as orc
+    g = _load("fpf_64x256_phiDM_dm0")
+    d32 = g["data"].astype(np.float32)
+    eng.set_model(g["model"])
+    r = eng.fit_batch(d32[None], g["freqs"], float(g["P"]), g["init_params"],
+                      errs=g["errs"], nu_fits=[list(g["nu_fits"])],
+                      fit_flags=[1, 1, 0, 0, 0])
+    o = orc.fit_portrait_full(d32.astype(np.float64), g["model"], g["init_params"],
+                              float(g["P"]), g["freqs"], list(g["nu_fits"]),
+                              [None] * 3, g["errs"], [1, 1, 0, 0, 0],
+                              log10_tau=False)
+    assert _dphi(r["params"][0, 0], o.phi) < PHI_BAR
+    assert abs(r["params"][0, 1] - o.DM) < DM_BAR
