@@ -1,6 +1,209 @@
-// Kernels beside the main fit: 1-D FFTFIT (fit_phase_shift) and the
-// on-device synthetic portrait generator.
+// Kernels beside the main fit: 1-D FFTFIT (fit_phase_shift, pplib.py:2054-2100)
+// and the on-device synthetic portrait generator.
 #pragma once
 #include "pp_kernels.h"
+
 namespace pp {
+
+// --------------------------------------------------------------------------
+// counter-based RNG: Philox4x32-10 (Salmon et al. 2011), keyed on the seed,
+// counter = (bin pair, channel, subint lo, subint hi)
+// --------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// two independent N(0,1) deviates for (subint, channel, bin pair)
+__device__ __forceinline__ void normal_pair(uint64_t seed, int64_t sub, int chan, int pair, double& z0, double& z1) {
+    uint32_t c[4] = {(uint32_t)pair, (uint32_t)chan, (uint32_t)((uint64_t)sub & 0xffffffffu),
+                     (uint32_t)((uint64_t)sub >> 32)};
+    philox4x32_10(c, (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32));
+    const uint64_t a = ((uint64_t)c[0] << 32) | c[1], b = ((uint64_t)c[2] << 32) | c[3];
+    const double u1 = ((double)(a >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    const double u2 = ((double)(b >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    const double r = sqrt(-2.0 * log(u1));
+    double s, co;
+    sincospi(2.0 * u2, &s, &co);
+    z0 = r * co;
+    z1 = r * s;
+}
+
+struct SynthArgs {
+    const cplx* mft;      // [nchan][M] harmonics 1..M of the model slot
+    const double* mdc;    // [nchan] DC harmonic (real)
+    void* dst;            // [nsub][nchan][B]
+    const double* freqs;  // [nchan]
+    const double* P;      // [nsub]
+    const double* inj;    // [nsub][3] phi, DM, GM (reference frequency infinity)
+    const cplx* twB;
+    double sigma;
+    uint64_t seed;
+    int64_t first_subint;
+    int nsub, nchan;
+};
+
+// dst = irfft(m_k e^{2 pi i k phi_n}) + sigma N(0,1); phi_n = -(phi + DM and GM
+// delays): data "delayed by" the injected values (pptoaslib.py:52-81, 57-58)
+template <int M, typename Tout>
+__global__ __launch_bounds__(FftPlan<M>::T) void k_synth(SynthArgs a) {
+    constexpr int T = FftPlan<M>::T;
+    constexpr int PL = FftPlan<M>::PADLOG;
+    __shared__ cplx lds[FftPlan<M>::LDS_ELEMS];
+    __shared__ cplx zin[M];
+    const int tid = threadIdx.x;
+    const long long nrows = (long long)a.nsub * a.nchan;
+    for (long long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int i = (int)(row / a.nchan), n = (int)(row % a.nchan);
+        const double nu = a.freqs[n], P = a.P[i];
+        const double a2 = 1.0 / (nu * nu);
+        const double phin = -(a.inj[i * 3] + PP_DCONST * a.inj[i * 3 + 1] * a2 / P +
+                              PP_DCONST * PP_DCONST * a.inj[i * 3 + 2] * a2 * a2 / P);
+        const cplx* mrow = a.mft + (size_t)n * M;
+        const double yM = cmul(mrow[M - 1], unit_phasor((double)M, phin)).x;   // Nyquist: real part
+        for (int k = tid; k < M; k += T) {
+            cplx yk, ym;
+            if (k == 0) { yk = make_double2(a.mdc[n], 0.0); ym = make_double2(yM, 0.0); }
+            else {
+                yk = cmul(mrow[k - 1], unit_phasor((double)k, phin));
+                ym = cmul(mrow[M - k - 1], unit_phasor((double)(M - k), phin));
+            }
+            ym.y = -ym.y;
+            const cplx ev = make_double2(0.5 * (yk.x + ym.x), 0.5 * (yk.y + ym.y));
+            cplx od = make_double2(0.5 * (yk.x - ym.x), 0.5 * (yk.y - ym.y));
+            cplx w = a.twB[k];
+            w.y = -w.y;
+            od = cmul(od, w);
+            // Z = ev + i od ; store conj(Z)
+            zin[k] = make_double2(ev.x - od.y, -(ev.y + od.x));
+        }
+        __syncthreads();
+        fft_row<M, cplx>(lds, zin, a.twB, tid);
+        Tout* out = reinterpret_cast<Tout*>(a.dst) + (size_t)row * (2 * M);
+        const double inv = 1.0 / (double)M;
+        for (int j = tid; j < M; j += T) {
+            const cplx r = lds[lds_pad<PL>(j)];
+            double z0, z1;
+            normal_pair(a.seed, a.first_subint + i, n, j, z0, z1);
+            const double x0 = r.x * inv + a.sigma * z0, x1 = -r.y * inv + a.sigma * z1;
+            if (sizeof(Tout) == 8) reinterpret_cast<double2*>(out)[j] = make_double2(x0, x1);
+            else reinterpret_cast<float2*>(out)[j] = make_float2((float)x0, (float)x1);
+        }
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------
+// 1-D FFTFIT.  spec[2*i] = rfft(data_i), spec[2*i+1] = rfft(model_i), each
+// M+1 complex.  One 256-thread block per pair.
+// --------------------------------------------------------------------------
+struct FpsArgs {
+    const cplx* spec;
+    const double* noise;   // [nprof] time-domain sigma, NaN/<0 = measure
+    double* out7;          // [nprof][7]
+    double lo, hi;
+    int Ns, M, nprof;
+};
+
+// sum_k X_k e^{2 pi i k phi} weighted by (1, k, k^2): returns Re-sum, k*Im-sum,
+// k^2*Re-sum over this thread's strided harmonics
+__device__ __forceinline__ void fps_sums(const cplx* X, int M, double phi, int tid, int nt, double& s0,
+                                         double& s1, double& s2) {
+    s0 = s1 = s2 = 0.0;
+    if (tid >= M) return;
+    cplx e = unit_phasor((double)(tid + 1), phi);
+    const cplx w = unit_phasor((double)nt, phi);
+    for (int j = tid; j < M; j += nt) {
+        const cplx z = cmul(X[j], e);
+        const double k = (double)(j + 1);
+        s0 += z.x;
+        s1 = fma(k, z.y, s1);
+        s2 = fma(k * k, z.x, s2);
+        e = cmul(e, w);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
+    const int i = blockIdx.x, tid = threadIdx.x, M = a.M;
+    __shared__ double scratch[4 * 4];
+    __shared__ double gridf[1024];
+    __shared__ double sh[8];
+    const cplx* d = a.spec + (size_t)(2 * i) * (M + 1);
+    const cplx* m = a.spec + (size_t)(2 * i + 1) * (M + 1);
+    cplx* X = xwork + (size_t)i * M;
+    const int H = M + 1, kc = (int)(0.75 * H);
+    double v[3] = {0.0, 0.0, 0.0};   // sum |d|^2, sum |m|^2, tail of |d|^2
+    for (int k = 1 + tid; k <= M; k += 256) {
+        const cplx dk = d[k], mk = m[k];
+        X[k - 1] = cmulc(dk, mk);
+        const double pd = cnorm(dk);
+        v[0] += pd; v[1] += cnorm(mk);
+        if (k >= kc) v[2] += pd;
+    }
+    block_sum<3>(v, scratch);
+    __syncthreads();
+    const double B = 2.0 * M;
+    double sig = a.noise ? a.noise[i] : NAN;
+    if (!(sig >= 0.0)) sig = sqrt(v[2] / B / (double)(H - kc));   // get_noise_PS
+    const double err2 = sig * sig * (0.5 * B);
+    const double dd = v[0] / err2, pp_ = v[1] / err2;
+    // brute grid, both ends included (scipy.optimize.brute with complex(Ns))
+    const int Ns = min(a.Ns, 1024);
+    for (int j = tid; j < Ns; j += 256) {
+        const double phi = (Ns > 1) ? a.lo + (a.hi - a.lo) * (double)j / (double)(Ns - 1) : a.lo;
+        double s0, s1, s2;
+        fps_sums(X, M, phi, 0, 1, s0, s1, s2);
+        gridf[j] = -s0 / err2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int best = 0;
+        for (int j = 1; j < Ns; ++j) if (gridf[j] < gridf[best]) best = j;
+        sh[0] = (Ns > 1) ? a.lo + (a.hi - a.lo) * (double)best / (double)(Ns - 1) : a.lo;
+    }
+    __syncthreads();
+    // polish: safeguarded Newton on f(phi) = -Re sum X e / err2 inside +-1 grid step
+    const double h = (Ns > 1) ? (a.hi - a.lo) / (double)(Ns - 1) : 0.5;
+    double phi = sh[0], lo = phi - h, hi = phi + h;
+    double f = 0.0, f2 = 0.0;
+    for (int it = 0; it < 60; ++it) {
+        double s[3];
+        fps_sums(X, M, phi, tid, 256, s[0], s[1], s[2]);
+        block_sum<3>(s, scratch);
+        __syncthreads();
+        f = -s[0] / err2;
+        const double f1 = PP_TWO_PI * s[1] / err2;                   // df/dphi
+        f2 = PP_TWO_PI * PP_TWO_PI * s[2] / err2;                     // d2f/dphi2
+        if (f1 > 0.0) hi = phi; else lo = phi;
+        double nxt = (f2 > 0.0) ? phi - f1 / f2 : 0.5 * (lo + hi);
+        if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);
+        const double step = fabs(nxt - phi);
+        phi = nxt;
+        if (step < 1e-15) break;
+    }
+    // value and curvature at the final phase
+    double s[3];
+    fps_sums(X, M, phi, tid, 256, s[0], s[1], s[2]);
+    block_sum<3>(s, scratch);
+    f = -s[0] / err2;
+    f2 = PP_TWO_PI * PP_TWO_PI * s[2] / err2;
+    if (tid == 0) {
+        const double scale = -f / pp_;
+        double* o = a.out7 + (size_t)i * 7;
+        o[0] = phi;
+        o[1] = 1.0 / sqrt(scale * f2);
+        o[2] = scale;
+        o[3] = 1.0 / sqrt(pp_);
+        o[4] = sqrt(scale * scale * pp_);
+        o[5] = (dd - f * f / pp_) / (B - 2.0);
+        o[6] = 0.0;
+    }
+}
+
 }  // namespace pp

@@ -1,10 +1,78 @@
 // host entry points for pp_extra.h (included at the end of pp_toas.hip)
+
 extern "C" int pp_fit_phase_shift_batch(pp_ctx* c, const double* data, const double* model, const double* noise,
                                         int nprof, int nbin, double lo, double hi, int Ns, double* out7) {
-    return fail(PP_ESTATE, "pp_fit_phase_shift_batch: not built yet");
+    if (!c || !data || !model || !out7) return fail(PP_EINVAL, "pp_fit_phase_shift_batch: null argument");
+    if (!nbin_ok(nbin) || nprof < 1) return fail(PP_EINVAL, "pp_fit_phase_shift_batch: bad shape %d x %d", nprof, nbin);
+    if (Ns < 1 || Ns > 1024) return fail(PP_EINVAL, "pp_fit_phase_shift_batch: Ns %d not in [1,1024]", Ns);
+    HIP_TRY(hipSetDevice(c->device));
+    const int M = nbin / 2;
+    int rc;
+    // interleave rows: data_i, model_i
+    const size_t rowb = (size_t)nbin * 8;
+    if ((rc = c->data.reserve(2 * (size_t)nprof * rowb))) return rc;
+    HIP_TRY(hipMemcpy2DAsync(c->data.p, 2 * rowb, data, rowb, rowb, nprof, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpy2DAsync((char*)c->data.p + rowb, 2 * rowb, model, rowb, rowb, nprof, hipMemcpyHostToDevice, c->stream));
+    if ((rc = c->X.reserve((size_t)nprof * (2 * (size_t)(M + 1) + M) * sizeof(cplx)))) return rc;
+    if ((rc = c->o_params.reserve((size_t)nprof * 56))) return rc;
+    const cplx* tw = nullptr;
+    if ((rc = get_twiddles(c, nbin, &tw))) return rc;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    cplx* spec = c->X.as<cplx>();
+    cplx* xwork = spec + 2 * (size_t)nprof * (M + 1);
+    {
+        Prof pr(c, KF_FPS);
+        PP_DISPATCH_M(M, {
+            const int T = FftPlan<MM>::T;
+            hipLaunchKernelGGL((k_rfft_rows<MM, double>), dim3(fft_grid(T, 2 * nprof)), dim3(T), 0, c->stream,
+                               (const void*)c->data.p, spec, tw, 2 * nprof);
+        });
+        const double* dnoise = nullptr;
+        if (noise) {
+            if ((rc = upload(c, c->errs, noise, (size_t)nprof * 8))) return rc;
+            dnoise = c->errs.as<double>();
+        }
+        FpsArgs fa{spec, dnoise, c->o_params.as<double>(), lo, hi, Ns, M, nprof};
+        hipLaunchKernelGGL(k_fps, dim3(nprof), dim3(256), 0, c->stream, fa, xwork);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipMemcpyAsync(out7, c->o_params.p, (size_t)nprof * 56, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    for (int i = 0; i < nprof; ++i) out7[(size_t)i * 7 + 6] = 1e-3 * ms / nprof;
+    return PP_OK;
 }
+
 extern "C" int pp_synth_portraits(pp_ctx* c, int slot, void* dst, int dtype, int nsub, const double* freqs,
                                   const double* P, const double* inj, double sigma, uint64_t seed,
                                   int64_t first_subint) {
-    return fail(PP_ESTATE, "pp_synth_portraits: not built yet");
+    if (!c || !dst || !freqs || !P || !inj) return fail(PP_EINVAL, "pp_synth_portraits: null argument");
+    if (slot < 0 || slot >= PP_MAX_SLOTS || !c->slots[slot].set) return fail(PP_ESTATE, "pp_synth_portraits: slot %d not set", slot);
+    if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_synth_portraits: dtype %d", dtype);
+    if (nsub < 1) return fail(PP_EINVAL, "pp_synth_portraits: nsub %d", nsub);
+    HIP_TRY(hipSetDevice(c->device));
+    ModelSlot& s = c->slots[slot];
+    const int C = s.nchan, B = s.nbin, M = B / 2;
+    int rc;
+    if ((rc = upload(c, c->freqs, freqs, (size_t)C * 8))) return rc;
+    if ((rc = upload(c, c->P, P, (size_t)nsub * 8))) return rc;
+    if ((rc = upload(c, c->x0, inj, (size_t)nsub * 24))) return rc;
+    const cplx* tw = nullptr;
+    if ((rc = get_twiddles(c, B, &tw))) return rc;
+    SynthArgs a{s.mft.as<cplx>(), s.mdc.as<double>(), dst, c->freqs.as<double>(), c->P.as<double>(),
+                c->x0.as<double>(), tw, sigma, seed, first_subint, nsub, C};
+    {
+        Prof pr(c, KF_SYNTH);
+        PP_DISPATCH_M(M, {
+            const int T = FftPlan<MM>::T;
+            const int grid = fft_grid(T, (long long)nsub * C);
+            if (dtype == PP_F64) hipLaunchKernelGGL((k_synth<MM, double>), dim3(grid), dim3(T), 0, c->stream, a);
+            else hipLaunchKernelGGL((k_synth<MM, float>), dim3(grid), dim3(T), 0, c->stream, a);
+        });
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PP_OK;
 }

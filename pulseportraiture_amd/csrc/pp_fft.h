@@ -97,6 +97,8 @@ __device__ __forceinline__ int lds_pad(int i) { return i + (i >> PADLOG); }
 __device__ __forceinline__ cplx load_pair(const double* row, int idx) {
     return *reinterpret_cast<const double2*>(row + 2 * idx);
 }
+// first-stage input already complex (e.g. staged in LDS by the generator)
+__device__ __forceinline__ cplx load_pair(const cplx* row, int idx) { return row[idx]; }
 __device__ __forceinline__ cplx load_pair(const float* row, int idx) {
     float2 v = *reinterpret_cast<const float2*>(row + 2 * idx);
     return make_double2((double)v.x, (double)v.y);

@@ -23,6 +23,7 @@ struct ModelFftArgs {
     cplx* mft;          // [nchan][M]   harmonics 1..M
     double* msum;       // [nchan] sum_k |m|^2
     double* mmax;       // [nchan] max_k |m|^2
+    double* mdc;        // [nchan] DC harmonic (kept for the synthetic generator only)
     const cplx* twB;
     int nchan;
 };
@@ -96,7 +97,11 @@ __global__ __launch_bounds__(FftPlan<M>::T) void k_model_fft(ModelFftArgs a) {
                 for (int w = 0; w < T / 64; ++w) { s += red[2 * w]; mx = fmax(mx, red[2 * w + 1]); }
             }
         }
-        if (tid == 0) { a.msum[n] = s; a.mmax[n] = mx; }
+        if (tid == 0) {
+            a.msum[n] = s; a.mmax[n] = mx;
+            const cplx z0 = lds[0];
+            a.mdc[n] = z0.x + z0.y;
+        }
         __syncthreads();
     }
 }

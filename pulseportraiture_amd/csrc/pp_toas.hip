@@ -66,7 +66,7 @@ struct DevBuf {
 struct ModelSlot {
     bool set = false;
     int nchan = 0, nbin = 0, Kt = 0;
-    DevBuf mft, msum, mmax;
+    DevBuf mft, msum, mmax, mdc;
 };
 
 enum KernelFamily { KF_MODEL = 0, KF_XSPEC, KF_PREP, KF_EVAL, KF_STEP, KF_FINAL, KF_SYNTH, KF_FPS, KF_COUNT };
@@ -157,7 +157,7 @@ extern "C" int pp_destroy(pp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     resolve_spans(c);
     for (auto& kv : c->twiddles) kv.second.release();
-    for (auto& s : c->slots) { s.mft.release(); s.msum.release(); s.mmax.release(); }
+    for (auto& s : c->slots) { s.mft.release(); s.msum.release(); s.mmax.release(); s.mdc.release(); }
     DevBuf* bufs[] = {&c->mft_table, &c->msum_table, &c->data, &c->X, &c->sdraw, &c->noise, &c->wts, &c->freqs,
                       &c->errs, &c->mask, &c->P, &c->x0, &c->nufit, &c->nuout, &c->slot, &c->state, &c->csum,
                       &c->partial, &c->o_params, &c->o_errs, &c->o_nu, &c->o_cov, &c->o_chi2, &c->o_rchi2,
@@ -281,6 +281,7 @@ extern "C" int pp_model_set(pp_ctx* c, int slot, const void* portrait, int dtype
     if ((rc = s.mft.reserve((size_t)nchan * M * sizeof(cplx)))) return rc;
     if ((rc = s.msum.reserve((size_t)nchan * sizeof(double)))) return rc;
     if ((rc = s.mmax.reserve((size_t)nchan * sizeof(double)))) return rc;
+    if ((rc = s.mdc.reserve((size_t)nchan * sizeof(double)))) return rc;
     const void* dport = portrait;
     if (!on_device) {
         if ((rc = c->data.reserve((size_t)nchan * nbin * esz))) return rc;
@@ -289,7 +290,7 @@ extern "C" int pp_model_set(pp_ctx* c, int slot, const void* portrait, int dtype
     }
     const cplx* tw = nullptr;
     if ((rc = get_twiddles(c, nbin, &tw))) return rc;
-    ModelFftArgs a{dport, s.mft.as<cplx>(), s.msum.as<double>(), s.mmax.as<double>(), tw, nchan};
+    ModelFftArgs a{dport, s.mft.as<cplx>(), s.msum.as<double>(), s.mmax.as<double>(), s.mdc.as<double>(), tw, nchan};
     {
         Prof pr(c, KF_MODEL);
         PP_DISPATCH_M(M, {

@@ -83,3 +83,46 @@ def caller_guess(inp, fit_scat=False, log10_tau=True, tau_guess_rot=None,
                                     mod=True)
     return dict(nu_fit=nu_fit, init_params=np.array(
         [phi_guess, DM_guess, 0.0, tau_guess, a_guess]))
+
+
+# ---- host restatement of the device generator (csrc/pp_extra.h k_synth) ----
+def _philox4x32_10(c0, c1, c2, c3, k0, k1):
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    mask = np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = (np.asarray(v, dtype=np.uint64) for v in (c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & mask, (k1 + np.uint64(0xBB67AE85)) & mask
+    return c0, c1, c2, c3
+
+
+def philox_normal_pairs(seed, sub, chan, npair):
+    """N(0,1) pairs for bins (2j, 2j+1), j < npair, of (subint, channel)."""
+    j = np.arange(npair, dtype=np.uint64)
+    ones = np.ones(npair, dtype=np.uint64)
+    c = _philox4x32_10(j, ones * np.uint64(chan), ones * np.uint64(sub & 0xFFFFFFFF),
+                       ones * np.uint64(sub >> 32), seed & 0xFFFFFFFF, seed >> 32)
+    a = (c[0] << np.uint64(32)) | c[1]
+    b = (c[2] << np.uint64(32)) | c[3]
+    u1 = ((a >> np.uint64(11)).astype(np.float64) + 0.5) / 9007199254740992.0
+    u2 = ((b >> np.uint64(11)).astype(np.float64) + 0.5) / 9007199254740992.0
+    r = np.sqrt(-2.0 * np.log(u1))
+    return r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)
+
+
+def device_recipe_host(model, freqs, P, inj, sigma, seed, first_subint):
+    """data[i] = rotate(model, -phi, -DM, -GM; nu_ref = inf) + sigma N(0,1)."""
+    C, B = model.shape
+    out = np.empty((len(P), C, B))
+    for i in range(len(P)):
+        port = orc.rotate_portrait_full(model, -inj[i, 0], -inj[i, 1], -inj[i, 2],
+                                        freqs, np.inf, np.inf, P[i])
+        for n in range(C):
+            z0, z1 = philox_normal_pairs(seed, first_subint + i, n, B // 2)
+            port[n, 0::2] += sigma * z0
+            port[n, 1::2] += sigma * z1
+        out[i] = port
+    return out

@@ -1,0 +1,70 @@
+"""N>1 path on CPU: contiguous subint shards and the single gather of result
+records, world_size 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from pulseportraiture_amd import dist as ppdist
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 8, 100000, 12501):
+        for world in (1, 2, 3, 8):
+            spans = [ppdist.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a0, a1), (b0, b1) in zip(spans[:-1], spans[1:]):
+                assert a1 == b0
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _fake_result(lo, hi):
+    n = hi - lo
+    idx = np.arange(lo, hi, dtype=np.float64)
+    return dict(params=np.outer(idx, [1, 2, 3, 4, 5.0]),
+                param_errs=np.outer(idx, [0.1, 0.2, 0.3, 0.4, 0.5]),
+                nu_refs=np.outer(idx, [10, 20, 30.0]), chi2=idx * 7, red_chi2=idx / 3,
+                snr=idx + 0.5, nfeval=np.full(n, 4, dtype=np.int32),
+                return_code=np.full(n, 2, dtype=np.int32))
+
+
+def _worker(rank, world, port, n, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        counts = [b - a for a, b in (ppdist.shard_range(n, r, world) for r in range(world))]
+        lo, hi = ppdist.shard_range(n, rank, world)
+        rec = ppdist.pack_records(_fake_result(lo, hi))
+        out = ppdist.gather_records(rec, counts=counts)
+        if rank == 0:
+            q.put(out)
+        else:
+            assert out is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gather_records_world2_gloo():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n, world = 11, 2            # ragged: 6 + 5
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=90)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = ppdist.pack_records(_fake_result(0, n))
+    np.testing.assert_array_equal(out, want)
+    f = ppdist.unpack_records(out)
+    np.testing.assert_array_equal(f["DM"], np.arange(n) * 2.0)
+    assert set(f) == set(ppdist.RECORD_FIELDS)

@@ -1,0 +1,57 @@
+"""Host-side logic of the product that needs no GPU: .gmodel portraits, the
+result container, helper formulas, and the generator's RNG known answers."""
+import os
+
+import numpy as np
+
+from pulseportraiture_amd import gmodel, pplib
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_gmodel_portrait_matches_reference():
+    g = np.load(os.path.join(GOLDEN, "helpers_64x256.npz"))
+    m = gmodel.gaussian_portrait(gmodel.parse_gmodel(gmodel.EXAMPLE_GMODEL),
+                                 g["freqs"], 256, gmodel.EXAMPLE_PERIOD)
+    np.testing.assert_allclose(m, g["model"], rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(gmodel.gaussian_components(256, 0.9961, 0.031),
+                               g["gp"], rtol=1e-14, atol=1e-300)
+    np.testing.assert_allclose(gmodel.gaussian_components(256, 1.23, 0.11),
+                               g["gp2"], rtol=1e-14, atol=1e-300)
+    file_model = gmodel.read_gmodel(os.path.join(GOLDEN, "example.gmodel"))
+    np.testing.assert_array_equal(file_model["params"],
+                                  gmodel.parse_gmodel(gmodel.EXAMPLE_GMODEL)["params"])
+    assert np.all(gmodel.gaussian_components(64, 0.3, 0.0) == 0.0)
+
+
+def test_helpers_match_reference():
+    g = np.load(os.path.join(GOLDEN, "helpers_64x256.npz"))
+    P = gmodel.EXAMPLE_PERIOD
+    assert pplib.Dconst == 0.000241 ** -1 == 4149.377593360996
+    np.testing.assert_array_equal(pplib.get_bin_centers(256), g["phases"])
+    assert pplib.guess_fit_freq(g["freqs"]) == float(g["nu_fit"])
+    np.testing.assert_allclose(pplib.guess_fit_freq(g["freqs"], np.linspace(1, 3, 64)),
+                               g["nu_fit_snr"], rtol=1e-15)
+    np.testing.assert_allclose(pplib.phase_transform(0.3, 34.5, 1500.0, 1200.0, P, True),
+                               g["phase_tr"], rtol=1e-14)
+
+
+def test_databunch_is_a_mutable_attribute_dict():
+    r = pplib.DataBunch(phi=0.1, DM=3.0)
+    r.TOA = 5
+    r.DM *= 2
+    assert r["TOA"] == 5 and r["DM"] == 6.0 and set(r) == {"phi", "DM", "TOA"}
+
+
+def test_philox_known_answers():
+    """Random123 known-answer vectors for Philox4x32-10 (the device generator's
+    RNG, restated on the host in tests/synth_host.py)."""
+    from tests.synth_host import _philox4x32_10, philox_normal_pairs
+    c = _philox4x32_10([0], [0], [0], [0], 0, 0)
+    assert [int(v[0]) for v in c] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    m = 0xffffffff
+    c = _philox4x32_10([m], [m], [m], [m], m, m)
+    assert [int(v[0]) for v in c] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    z0, z1 = philox_normal_pairs(20260101, 7, 3, 50000)
+    assert abs(z0.mean()) < 0.02 and abs(z0.std() - 1) < 0.02
+    assert abs(z1.mean()) < 0.02 and abs(np.corrcoef(z0, z1)[0, 1]) < 0.02
