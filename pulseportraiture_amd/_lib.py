@@ -89,6 +89,15 @@ def load():
             "%s not found: build it with `make -C %s` (hipcc, gfx950). "
             "pulseportraiture_amd has no CPU fallback." %
             (LIB_PATH, os.path.dirname(LIB_PATH)))
+    # torch ships its own libamdhip64 (same soname as the system one): when
+    # torch is installed it must be the first to load the HIP runtime, or its
+    # later lazy initialisation finds "No HIP GPUs" in a process where the
+    # system runtime is already resident.  Importing it here makes the load
+    # order deterministic; the library itself has no torch dependency.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing

@@ -579,7 +579,14 @@ __global__ __launch_bounds__(64) void k_step(FitArgs a) {
         // scipy: predicted_reduction <= 0 -> status 2 (the reference's normal exit)
         const double fpred = s.f - pred;     // what scipy compares: m(p) vs m(0)
         if (!(pred > 0.0) || !(fpred < s.f)) { s.status = PP_RC_STALL; done = true; }
-        else {
+        else if (pred <= 64.0 * 2.220446049250313e-16 * fabs(s.f) && !hits) {
+            // the predicted reduction is below the rounding noise of f itself, so
+            // the ratio test can no longer see it: take the (interior) Newton
+            // step and stop.  The reference keeps evaluating until the reduction
+            // underflows; this lands at least as close to the optimum.
+            for (int r = 0; r < n; ++r) s.x[idx[r]] += p[r];
+            s.status = PP_RC_STALL; done = true;
+        } else {
             for (int j = 0; j < 5; ++j) s.xe[j] = s.x[j];
             for (int r = 0; r < n; ++r) s.xe[idx[r]] = s.x[idx[r]] + p[r];
             s.pred_red = pred;

@@ -76,9 +76,14 @@ def test_fit_matches_reference_golden(name):
     r = fit_portrait_full(g["data"], g["model"], g["init_params"], float(g["P"]),
                           g["freqs"], list(g["nu_fits"]), nu_outs, g["errs"],
                           list(g["fit_flags"]), log10_tau=bool(g["log10_tau"]))
-    assert _dphi(r.phi, float(g["out_phi"])) < PHI_BAR
-    assert abs(r.DM - float(g["out_DM"])) < DM_BAR
     scat = bool(g["fit_flags"][2] or g["fit_flags"][3] or g["fit_flags"][4])
+    # phase+DM: the reference converges to rounding -> the 1e-9 bar applies to
+    # its raw answer.  With GM / scattering its trust-ncg exit leaves it up to
+    # ~1.5e-9 from the optimum (its own scatter is 2-5e-10); the
+    # 1e-9 bar is then checked against the reference answer polished by its own
+    # remaining Newton step (test_scattering_fits_match_polished_reference).
+    assert _dphi(r.phi, float(g["out_phi"])) < (5e-9 if scat else PHI_BAR)
+    assert abs(r.DM - float(g["out_DM"])) < DM_BAR
     if not scat:
         np.testing.assert_allclose(r.params, g["out_params"], rtol=1e-8, atol=1e-9)
     else:
@@ -136,10 +141,50 @@ def test_converged_at_least_as_tightly_as_reference(name):
     assert mine <= max(ref, 1e-12 * abs(float(g["out_chi2"])))
 
 
+@pytest.mark.parametrize("name", ["fpf_64x256_phiDMGM", "fpf_64x256_scat",
+                                  "fpf_64x256_phiDMtau", "fpf_64x256_scat_lin",
+                                  "fpf_64x256_all5"])
+def test_scattering_fits_match_polished_reference(name):
+    """1e-9 / 1e-6 bars for the GM and scattering fits, measured against the
+    reference's answer after ONE exact Newton step of the oracle's objective from
+    it (what the reference would return had it converged), in the reference's
+    own output parametrisation (nu_outs fixed to the golden values)."""
+    from oracle import pptoas_oracle as orc
+    from pulseportraiture_amd.pptoaslib import fit_portrait_full
+    g = _load(name)
+    flags, l10 = list(g["fit_flags"]), bool(g["log10_tau"])
+    nus = [float(g["out_nu_DM"]), float(g["out_nu_GM"]), float(g["out_nu_tau"])]
+    r = fit_portrait_full(g["data"], g["model"], g["init_params"], float(g["P"]),
+                          g["freqs"], list(g["nu_fits"]), nus, g["errs"], flags,
+                          log10_tau=l10)
+    B = g["data"].shape[1]
+    dFT = np.fft.rfft(g["data"], axis=-1); dFT[:, 0] = 0
+    mFT = np.fft.rfft(g["model"], axis=-1); mFT[:, 0] = 0
+    a = (dFT, mFT, g["errs"] * np.sqrt(B / 2.0), float(g["P"]), g["freqs"], nus[0],
+         nus[1], nus[2], flags, l10)
+    x = g["out_params"].copy()
+    i = np.where(flags)[0]
+    for _ in range(2):
+        gr = orc.fit_portrait_full_function_deriv(x, *a)
+        hs = orc.fit_portrait_full_function_2deriv(x, *a)
+        x[i] -= np.linalg.solve(hs[np.ix_(i, i)], gr[i])
+    assert _dphi(r.phi, x[0]) < PHI_BAR
+    assert abs(r.DM - x[1]) < DM_BAR
+    tol = np.maximum(1e-5 * g["out_param_errs"], 1e-10)
+    assert np.all(np.abs(np.asarray(r.params) - x)[2:] <= tol[2:])
+
+
 def test_harmonic_truncation_is_parity_safe(eng):
     """Dropping the model's negligible trailing harmonics (option harm_eps)
     must not move the answer: compare against the untruncated run."""
-    g = _load("fpf_128x512_phiDM_scint")
+    from tests.synth_host import make_inputs, caller_guess, model_portrait
+    C, B = 16, 2048
+    freqs, model = model_portrait(C, B)
+    inp = make_inputs(C, B, 77, model=model, DM0=34.56789)
+    gss = caller_guess(inp)
+    g = dict(data=inp["data"], model=model, freqs=freqs, P=inp["P"],
+             init_params=gss["init_params"], errs=inp["errs"],
+             nu_fits=[gss["nu_fit"]] * 3)
     kw = dict(errs=g["errs"], nu_fits=[list(g["nu_fits"])], fit_flags=[1, 1, 0, 0, 0])
     eng.set_option("harm_eps", 0.0)
     k_full = eng.set_model(g["model"])
@@ -149,7 +194,7 @@ def test_harmonic_truncation_is_parity_safe(eng):
     k_cut = eng.set_model(g["model"])
     cut = eng.fit_batch(g["data"][None], g["freqs"], float(g["P"]),
                         g["init_params"], **kw)
-    assert k_full == 256 and k_cut < k_full
+    assert k_full == B // 2 and k_cut < k_full
     assert abs(full["params"][0, 0] - cut["params"][0, 0]) < 1e-13
     assert abs(full["params"][0, 1] - cut["params"][0, 1]) < 1e-12
     np.testing.assert_allclose(cut["param_errs"], full["param_errs"], rtol=1e-10)
@@ -236,7 +281,7 @@ def test_fit_phase_shift_matches_reference_rows():
         shift, noise = row[0], (None if np.isnan(row[1]) else row[1])
         d = orc.rotate_data(g["prof"], -shift)
         r = fit_phase_shift(d, g["model_prof"], noise=noise, Ns=100)
-        assert abs(r.phase - row[2]) < 1e-4
+        assert _dphi(r.phase, row[2]) < 1e-4   # grid ends -0.5 and 0.5 tie
         np.testing.assert_allclose([r.phase_err, r.scale, r.scale_err, r.snr,
                                     r.red_chi2], row[3:], rtol=2e-4)
         # and it is the exact local optimum of the oracle's objective
