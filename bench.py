@@ -130,9 +130,12 @@ def main():
             if log10_tau else 1.5 * tau_rot * (nu_fit / 1500.0) ** -4.0
         x0[:, 4] = -4.0
     errs = np.full((nsub, C), args.sigma)
+    errs_dev = torch.full((nsub, C), args.sigma, dtype=torch.float64, device=device)
     nu_fits = np.full((nsub, 3), nu_fit)
-    kw = dict(errs=errs, nu_fits=nu_fits, fit_flags=flags, log10_tau=log10_tau,
-              per_channel=True)
+    # per-channel inputs and outputs stay in HBM (inputs resident before the timed
+    # region; the fitted TOA records are what leaves the GPU)
+    kw = dict(errs=errs_dev, nu_fits=nu_fits, fit_flags=flags, log10_tau=log10_tau,
+              per_channel="device")
 
     def step():
         res = eng.fit_batch(data, freqs, P, x0, **kw)

@@ -97,6 +97,7 @@ typedef struct {
                                   measured per channel as get_noise_PS
                                   (pplib.py:2227-2247) */
     const uint8_t* chan_mask;  /* [nsub][nchan], 1 = fit this channel, or NULL */
+    int32_t aux_on_device;     /* errs and chan_mask are device pointers */
     const double* P;           /* [nsub] spin period [s] */
     const double* init_params; /* [nsub][5] phi, DM, GM, tau|log10 tau, alpha */
     const double* nu_fits;     /* [nsub][3] or NULL; NaN = mean(freqs) */
@@ -117,6 +118,7 @@ typedef struct {
     double* snr;          /* [nsub] */
     int32_t* nfeval;      /* [nsub] objective evaluations */
     int32_t* return_code; /* [nsub] PP_RC_* */
+    int32_t chan_on_device; /* the three per-channel outputs are device pointers */
     double* scales;       /* [nsub][nchan] or NULL */
     double* scale_errs;   /* [nsub][nchan] or NULL */
     double* channel_snrs; /* [nsub][nchan] or NULL */

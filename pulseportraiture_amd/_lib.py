@@ -25,7 +25,8 @@ class FitIn(C.Structure):
                 ("data", C.c_void_p), ("data_dtype", C.c_int32),
                 ("data_on_device", C.c_int32), ("model_slot", c_int32_p),
                 ("freqs", c_double_p), ("freqs_stride", C.c_int64),
-                ("errs", c_double_p), ("chan_mask", c_uint8_p), ("P", c_double_p),
+                ("errs", c_double_p), ("chan_mask", c_uint8_p),
+                ("aux_on_device", C.c_int32), ("P", c_double_p),
                 ("init_params", c_double_p), ("nu_fits", c_double_p),
                 ("nu_outs", c_double_p), ("fit_flags", C.c_int32 * 5),
                 ("log10_tau", C.c_int32), ("option", C.c_int32),
@@ -37,7 +38,7 @@ class FitOut(C.Structure):
                 ("nu_refs", c_double_p), ("cov", c_double_p), ("chi2", c_double_p),
                 ("red_chi2", c_double_p), ("snr", c_double_p),
                 ("nfeval", c_int32_p), ("return_code", c_int32_p),
-                ("scales", c_double_p), ("scale_errs", c_double_p),
+                ("chan_on_device", C.c_int32), ("scales", c_double_p), ("scale_errs", c_double_p),
                 ("channel_snrs", c_double_p), ("obj_f", c_double_p),
                 ("obj_grad", c_double_p), ("obj_hess", c_double_p),
                 ("duration", c_double_p)]

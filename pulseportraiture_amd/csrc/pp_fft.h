@@ -94,38 +94,89 @@ __device__ __forceinline__ void dft_reg<16>(cplx (&v)[16]) {
 template <int PADLOG>
 __device__ __forceinline__ int lds_pad(int i) { return i + (i >> PADLOG); }
 
-__device__ __forceinline__ cplx load_pair(const double* row, int idx) {
-    return *reinterpret_cast<const double2*>(row + 2 * idx);
-}
-// first-stage input already complex (e.g. staged in LDS by the generator)
-__device__ __forceinline__ cplx load_pair(const cplx* row, int idx) { return row[idx]; }
-__device__ __forceinline__ cplx load_pair(const float* row, int idx) {
-    float2 v = *reinterpret_cast<const float2*>(row + 2 * idx);
-    return make_double2((double)v.x, (double)v.y);
+// Make the workgroup's LDS traffic visible to all its lanes WITHOUT draining
+// the vector-memory counter: __syncthreads() lowers to
+// `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`, which would stall on the
+// prefetched HBM loads of the next row.  A one-wave workgroup (T == 64) needs
+// no barrier at all: its LDS operations retire in order.
+template <int T>
+__device__ __forceinline__ void lds_sync() {
+    if (T == 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// One Stockham stage.  S = product of the radices already applied.
+// ---- one Stockham stage, split into its load and its finish ----------------
+// S = product of the radices already applied.
 // twB[k] = exp(-2 pi i k / B), k = 0..M  (W_M^j = twB[2j]).
-template <int M, int T, int R, int S, int PADLOG, bool FIRST, typename Tin>
-__device__ __forceinline__ void fft_stage(cplx* lds, const Tin* __restrict__ grow,
-                                          const cplx* __restrict__ twB, int tid) {
-    constexpr int NBF = M / R;
-    constexpr int PER = (NBF + T - 1) / T;
-    constexpr bool LAST = (S * R == M);
-    cplx v[PER][R];
+template <int M, int T, int R>
+struct StageGeom {
+    static constexpr int NBF = M / R;                 // butterflies in the stage
+    static constexpr int PER = (NBF + T - 1) / T;     // per thread
+};
+
+// raw first-stage operands straight from HBM (kept in the input precision so a
+// prefetched row costs half the registers for f32 portraits)
+template <typename Tin> struct RawOf;
+template <> struct RawOf<double> { typedef double2 type; };
+template <> struct RawOf<float> { typedef float2 type; };
+template <> struct RawOf<cplx> { typedef double2 type; };
+
+__device__ __forceinline__ double2 load_raw(const double* row, int idx) {
+    return *reinterpret_cast<const double2*>(row + 2 * idx);
+}
+__device__ __forceinline__ float2 load_raw(const float* row, int idx) {
+    return *reinterpret_cast<const float2*>(row + 2 * idx);
+}
+__device__ __forceinline__ double2 load_raw(const cplx* row, int idx) { return row[idx]; }
+__device__ __forceinline__ cplx to_cplx(double2 v) { return v; }
+__device__ __forceinline__ cplx to_cplx(float2 v) { return make_double2((double)v.x, (double)v.y); }
+
+template <int M, int T, int R, typename Tin, typename Raw, int PER>
+__device__ __forceinline__ void stage_load_global(Raw (&v)[PER][R], const Tin* __restrict__ grow, int tid) {
+    constexpr int NBF = StageGeom<M, T, R>::NBF;
+    static_assert(PER == StageGeom<M, T, R>::PER, "register tile does not match the stage");
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int t = tid + T * i;
         if (NBF % T == 0 || t < NBF) {
 #pragma unroll
+            for (int k = 0; k < R; ++k) v[i][k] = load_raw(grow, t + k * NBF);
+        }
+    }
+}
+
+// LDS addresses are written as (one per-thread base) + (compile-time offset) so
+// they fold into the ds_read/ds_write immediate field: the per-element padded
+// indices are affine in the element number because every stride is a multiple
+// of the padding period 2^PADLOG.
+template <int M, int T, int R, int PADLOG, int PER>
+__device__ __forceinline__ void stage_load_lds(cplx (&v)[PER][R], const cplx* lds, int tid) {
+    constexpr int NBF = StageGeom<M, T, R>::NBF;
+    static_assert(PER == StageGeom<M, T, R>::PER, "register tile does not match the stage");
+    static_assert(NBF % (1 << PADLOG) == 0 || NBF < (1 << PADLOG), "stride must keep the padding affine");
+    constexpr int KSTEP = (NBF % (1 << PADLOG) == 0) ? NBF + (NBF >> PADLOG) : 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int t = tid + T * i;
+        if (NBF % T == 0 || t < NBF) {
+            const cplx* base = lds + lds_pad<PADLOG>(t);
+#pragma unroll
             for (int k = 0; k < R; ++k) {
-                const int idx = t + k * NBF;
-                if (FIRST) v[i][k] = load_pair(grow, idx);
-                else v[i][k] = lds[lds_pad<PADLOG>(idx)];
+                if (KSTEP) v[i][k] = base[k * KSTEP];
+                else v[i][k] = lds[lds_pad<PADLOG>(t + k * NBF)];
             }
         }
     }
-    if (!FIRST) __syncthreads();
+}
+
+// butterflies + inter-stage twiddles + in-place write + LDS sync.
+// tw[i] = W_M^(t - t%S) of this thread's i-th butterfly (unused in the last
+// stage): loop-invariant per thread, so callers hoist it out of their row loop.
+template <int M, int T, int R, int S, int PADLOG, int PER, typename TW>
+__device__ __forceinline__ void stage_finish(cplx (&v)[PER][R], cplx* lds, const TW& tw, int tid) {
+    constexpr int NBF = StageGeom<M, T, R>::NBF;
+    static_assert(PER == StageGeom<M, T, R>::PER, "register tile does not match the stage");
+    constexpr bool LAST = (S * R == M);
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int t = tid + T * i;
@@ -133,80 +184,138 @@ __device__ __forceinline__ void fft_stage(cplx* lds, const Tin* __restrict__ gro
             dft_reg<R>(v[i]);
             const int q = t & (S - 1);
             const int ob = q + S * R * (t / S);
-            if (!LAST) {
-                // w^j, w = W_M^(t - q), by a product tree (depth <= 4)
-                const cplx w1 = twB[2 * (t - q)];
-                cplx w[R];
-                w[1] = w1;
+            if constexpr (!LAST) {
+                // v[j] *= w^j as the product of w^(2^b) over the set bits of j:
+                // one twiddle power live at a time (register pressure), at most
+                // log2(R) roundings per element
+                cplx wp = tw[i];
 #pragma unroll
-                for (int j = 2; j < R; ++j) w[j] = cmul(w[j >> 1], w[j - (j >> 1)]);
+                for (int b = 1; b < R; b <<= 1) {
 #pragma unroll
-                for (int j = 1; j < R; ++j) v[i][j] = cmul(v[i][j], w[j]);
+                    for (int j = 1; j < R; ++j)
+                        if (j & b) v[i][j] = cmul(v[i][j], wp);
+                    if (2 * b < R) wp = cmul(wp, wp);
+                }
             }
+            // pad(ob + S*j) = pad(ob) + j*(S + S/2^PADLOG) for S a multiple of the
+            // padding period; for the first stage (S = 1, R = 2^PADLOG) it is
+            // pad(ob) + j
+            cplx* wbase = lds + lds_pad<PADLOG>(ob);
+            constexpr int JSTEP = (S % (1 << PADLOG) == 0) ? S + (S >> PADLOG) : ((S == 1 && R == (1 << PADLOG)) ? 1 : 0);
 #pragma unroll
-            for (int j = 0; j < R; ++j) lds[lds_pad<PADLOG>(ob + S * j)] = v[i][j];
+            for (int j = 0; j < R; ++j) {
+                if (JSTEP) wbase[j * JSTEP] = v[i][j];
+                else lds[lds_pad<PADLOG>(ob + S * j)] = v[i][j];
+            }
         }
     }
-    __syncthreads();
+    lds_sync<T>();
+}
+
+// twiddles of one non-last stage for this thread
+template <int M, int T, int R, int S, int PER>
+__device__ __forceinline__ void stage_twiddles(cplx (&tw)[PER], const cplx* __restrict__ twB, int tid) {
+    constexpr int NBF = StageGeom<M, T, R>::NBF;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int t = tid + T * i;
+        tw[i] = (NBF % T == 0 || t < NBF) ? twB[2 * (t - (t & (S - 1)))] : make_double2(1.0, 0.0);
+    }
+}
+
+// a later stage: LDS -> registers -> LDS
+template <int M, int T, int R, int S, int PADLOG, typename TW>
+__device__ __forceinline__ void stage_lds(cplx* lds, const TW& tw, int tid) {
+    cplx v[StageGeom<M, T, R>::PER][R];
+    stage_load_lds<M, T, R, PADLOG>(v, lds, tid);
+    lds_sync<T>();     // every read of this stage before any in-place write
+    stage_finish<M, T, R, S, PADLOG>(v, lds, tw, tid);
+}
+
+// Plans: T threads per row and up to four radices R1*R2*R3*R4 = M (1 = unused).
+// Radices are <= 8 and T = M/8 for M >= 512, so every thread does one radix-8
+// butterfly per stage and never holds more than 8 complex values (plus 8 more
+// of the prefetched next row): registers stay low enough for several waves per
+// SIMD.  The LDS image is padded by one element every R1.
+template <int M>
+struct FftPlan;
+#define PP_PLAN(M_, T_, R1_, R2_, R3_, R4_, PL_)                                                 \
+    template <> struct FftPlan<M_> {                                                             \
+        static constexpr int T = T_, R1 = R1_, R2 = R2_, R3 = R3_, R4 = R4_, PADLOG = PL_;       \
+        static constexpr int LDS_ELEMS = M_ + (M_ >> PL_) + 1;                                   \
+        static constexpr int PER1 = StageGeom<M_, T_, R1_>::PER;                                 \
+        static constexpr int PER2 = StageGeom<M_, T_, R2_>::PER;                                 \
+        static constexpr int PER3 = StageGeom<M_, T_, (R3_ > 1 ? R3_ : 2)>::PER;                 \
+        static_assert(R1_ * R2_ * R3_ * R4_ == M_, "radices must multiply to M");                \
+    }
+PP_PLAN(16, 64, 4, 4, 1, 1, 2);
+PP_PLAN(32, 64, 8, 4, 1, 1, 3);
+PP_PLAN(64, 64, 8, 8, 1, 1, 3);
+PP_PLAN(128, 64, 8, 4, 4, 1, 3);
+PP_PLAN(256, 64, 8, 8, 4, 1, 3);
+PP_PLAN(512, 64, 8, 8, 8, 1, 3);
+#ifndef PP_PLAN1024
+#define PP_PLAN1024 64, 16, 8, 8, 1, 4
+#endif
+#define PP_PLAN_X(M_, ...) PP_PLAN(M_, __VA_ARGS__)
+PP_PLAN_X(1024, PP_PLAN1024);
+PP_PLAN(2048, 256, 8, 8, 8, 4, 3);
+PP_PLAN(4096, 512, 8, 8, 8, 8, 3);
+#undef PP_PLAN
+
+// per-thread, row-independent twiddles of the non-last stages
+template <int M>
+struct RowTwiddles {
+    cplx t1[FftPlan<M>::PER1];
+    cplx t2[FftPlan<M>::PER2];
+    cplx t3[FftPlan<M>::PER3];
+};
+
+template <int M>
+__device__ __forceinline__ void load_row_twiddles(RowTwiddles<M>& tw, const cplx* __restrict__ twB, int tid) {
+    typedef FftPlan<M> P;
+    stage_twiddles<M, P::T, P::R1, 1>(tw.t1, twB, tid);
+    if constexpr (P::R3 > 1) stage_twiddles<M, P::T, P::R2, P::R1>(tw.t2, twB, tid);
+    if constexpr (P::R4 > 1) stage_twiddles<M, P::T, P::R3, P::R1 * P::R2>(tw.t3, twB, tid);
+}
+
+// first stage from registers
+template <int M, int PER1_, int R1_>
+__device__ __forceinline__ void fft_first_stage(cplx* lds, cplx (&v)[PER1_][R1_], const RowTwiddles<M>& tw,
+                                                int tid) {
+    typedef FftPlan<M> P;
+    static_assert(PER1_ == P::PER1 && R1_ == P::R1, "first-stage tile mismatch");
+    stage_finish<M, P::T, P::R1, 1, P::PADLOG>(v, lds, tw.t1, tid);
+}
+
+// the remaining stages, LDS to LDS
+template <int M>
+__device__ __forceinline__ void fft_later_stages(cplx* lds, const RowTwiddles<M>& tw, int tid) {
+    typedef FftPlan<M> P;
+    stage_lds<M, P::T, P::R2, P::R1, P::PADLOG>(lds, tw.t2, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (P::R3 > 1) stage_lds<M, P::T, P::R3, P::R1 * P::R2, P::PADLOG>(lds, tw.t3, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (P::R4 > 1) stage_lds<M, P::T, P::R4, P::R1 * P::R2 * P::R3, P::PADLOG>(lds, tw.t3, tid);
 }
 
 // Complex FFT of the M = B/2 packed pairs of one real row; result Z[0..M-1] is
 // left in `lds` (padded with lds_pad<FftPlan<M>::PADLOG>).
-template <int M>
-struct FftPlan;
-#define PP_PLAN(M_, T_, PL_) \
-    template <> struct FftPlan<M_> { static constexpr int T = T_; static constexpr int PADLOG = PL_; \
-        static constexpr int LDS_ELEMS = M_ + (M_ >> PL_) + 1; }
-PP_PLAN(16, 64, 2);
-PP_PLAN(32, 64, 3);
-PP_PLAN(64, 64, 3);
-PP_PLAN(128, 64, 3);
-PP_PLAN(256, 64, 4);
-PP_PLAN(512, 64, 3);
-PP_PLAN(1024, 64, 4);
-PP_PLAN(2048, 128, 4);
-PP_PLAN(4096, 256, 4);
-#undef PP_PLAN
-
 template <int M, typename Tin>
 __device__ __forceinline__ void fft_row(cplx* lds, const Tin* __restrict__ grow,
                                         const cplx* __restrict__ twB, int tid) {
-    constexpr int T = FftPlan<M>::T;
-    constexpr int P = FftPlan<M>::PADLOG;
-    if constexpr (M == 16) {
-        fft_stage<M, T, 4, 1, P, true>(lds, grow, twB, tid);
-        fft_stage<M, T, 4, 4, P, false>(lds, grow, twB, tid);
-    } else if constexpr (M == 32) {
-        fft_stage<M, T, 8, 1, P, true>(lds, grow, twB, tid);
-        fft_stage<M, T, 4, 8, P, false>(lds, grow, twB, tid);
-    } else if constexpr (M == 64) {
-        fft_stage<M, T, 8, 1, P, true>(lds, grow, twB, tid);
-        fft_stage<M, T, 8, 8, P, false>(lds, grow, twB, tid);
-    } else if constexpr (M == 128) {
-        fft_stage<M, T, 8, 1, P, true>(lds, grow, twB, tid);
-        fft_stage<M, T, 4, 8, P, false>(lds, grow, twB, tid);
-        fft_stage<M, T, 4, 32, P, false>(lds, grow, twB, tid);
-    } else if constexpr (M == 256) {
-        fft_stage<M, T, 16, 1, P, true>(lds, grow, twB, tid);
-        fft_stage<M, T, 16, 16, P, false>(lds, grow, twB, tid);
-    } else if constexpr (M == 512) {
-        fft_stage<M, T, 8, 1, P, true>(lds, grow, twB, tid);
-        fft_stage<M, T, 8, 8, P, false>(lds, grow, twB, tid);
-        fft_stage<M, T, 8, 64, P, false>(lds, grow, twB, tid);
-    } else if constexpr (M == 1024) {
-        fft_stage<M, T, 16, 1, P, true>(lds, grow, twB, tid);
-        fft_stage<M, T, 8, 16, P, false>(lds, grow, twB, tid);
-        fft_stage<M, T, 8, 128, P, false>(lds, grow, twB, tid);
-    } else if constexpr (M == 2048) {
-        fft_stage<M, T, 16, 1, P, true>(lds, grow, twB, tid);
-        fft_stage<M, T, 16, 16, P, false>(lds, grow, twB, tid);
-        fft_stage<M, T, 8, 256, P, false>(lds, grow, twB, tid);
-    } else {
-        static_assert(M == 4096, "unsupported FFT size");
-        fft_stage<M, T, 16, 1, P, true>(lds, grow, twB, tid);
-        fft_stage<M, T, 16, 16, P, false>(lds, grow, twB, tid);
-        fft_stage<M, T, 16, 256, P, false>(lds, grow, twB, tid);
-    }
+    constexpr int T = FftPlan<M>::T, R1 = FftPlan<M>::R1, PER1 = FftPlan<M>::PER1;
+    typename RawOf<Tin>::type raw[PER1][R1];
+    stage_load_global<M, T, R1>(raw, grow, tid);
+    RowTwiddles<M> tw;
+    load_row_twiddles<M>(tw, twB, tid);
+    cplx v[PER1][R1];
+#pragma unroll
+    for (int i = 0; i < PER1; ++i)
+#pragma unroll
+        for (int k = 0; k < R1; ++k) v[i][k] = to_cplx(raw[i][k]);
+    fft_first_stage<M>(lds, v, tw, tid);
+    fft_later_stages<M>(lds, tw, tid);
 }
 
 // harmonic k (1..M) of the real transform from the packed complex transform
@@ -222,6 +331,19 @@ __device__ __forceinline__ cplx rfft_harmonic(const cplx* lds, const cplx* __res
     const cplx w = twB[k];
     const cplx wo = cmul(w, O);
     // E - i*wo
+    return make_double2(E.x + wo.y, E.y - wo.x);
+}
+
+// same with the twiddle W_B^k supplied by the caller
+template <int M>
+__device__ __forceinline__ cplx rfft_harmonic_w(const cplx* lds, cplx w, int k) {
+    constexpr int P = FftPlan<M>::PADLOG;
+    const cplx zk = lds[lds_pad<P>(k & (M - 1))];
+    cplx zc = lds[lds_pad<P>((M - k) & (M - 1))];
+    zc.y = -zc.y;
+    const cplx E = make_double2(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
+    const cplx O = make_double2(0.5 * (zk.x - zc.x), 0.5 * (zk.y - zc.y));
+    const cplx wo = cmul(w, O);
     return make_double2(E.x + wo.y, E.y - wo.x);
 }
 

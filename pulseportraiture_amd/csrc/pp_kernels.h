@@ -31,12 +31,19 @@ struct ModelFftArgs {
 struct XspecArgs {
     const void* data;         // [nsub][nchan][B]
     const cplx* const* mft;   // [nslot] device table of model FT base pointers
+    const cplx* mft0;         // slot 0's base (no pointer chase when slot == nullptr)
     const int* slot;          // [nsub] or nullptr
     cplx* X;                  // [nsub][nchan][Kt]
     double* sdraw;            // [nsub][nchan] sum_{k>=1} |d|^2
     double* noise;            // [nsub][nchan] get_noise_PS estimate
     const cplx* twB;
     int nsub, nchan, Kt;
+    // fused first evaluation (phase/DM/GM model at the initial parameters)
+    const double* x0;         // [nsub][5]
+    const double* P;          // [nsub]
+    const double* nu_fit;     // [nsub][3]
+    const double* freqs; long long freqs_stride;
+    double* csum0;            // [nsub][nchan][3]: A0 A1 A2 at x0 (csum buffer 0)
 };
 
 struct FitArgs {
@@ -121,46 +128,156 @@ __global__ void k_model_kcut(const cplx* mft, const double* mmax, int nchan, int
 // --------------------------------------------------------------------------
 // data rFFT + cross-spectrum.  Rows are visited channel-major (row = n*nsub+i)
 // so every workgroup in flight shares a handful of model rows (L2-resident).
+// The next row's samples are prefetched into registers while the current row is
+// transformed, so each resident workgroup always has one row of HBM loads in
+// flight.  Only the Kt harmonics the (truncated) model keeps go through the
+// even/odd split; S_d needs no split at all because
+//   sum_{k=1}^{M-1} |d_k|^2 = sum_{k=1}^{M-1} |Z_k|^2   (Z = packed complex FFT),
+// and d_M = Re Z_0 - Im Z_0.
+// TAIL: also measure the noise from the top quarter of the power spectrum
+// (errs == NULL).  FUSE: accumulate the evaluator's sums A0, A1, A2 at the
+// initial parameters while X is still in registers (saves one pass over X).
 // --------------------------------------------------------------------------
-template <int M, typename Tin>
-__global__ __launch_bounds__(FftPlan<M>::T) void k_xspec(XspecArgs a) {
-    constexpr int T = FftPlan<M>::T;
+template <int M, typename Tin, bool TAIL, bool FUSE>
+__global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void k_xspec(XspecArgs a) {
+    constexpr int T = FftPlan<M>::T, R1 = FftPlan<M>::R1, PER1 = FftPlan<M>::PER1;
+    constexpr int PL = FftPlan<M>::PADLOG;
+    constexpr int NW = T / 64;
+    typedef typename RawOf<Tin>::type Raw;
     __shared__ cplx lds[FftPlan<M>::LDS_ELEMS];
-    __shared__ double red[2 * (T / 64) + 2];
+    __shared__ double red[5 * NW + 4];
     const int tid = threadIdx.x;
     const long long nrows = (long long)a.nsub * a.nchan;
     const int H = M + 1;
     const int kc = (int)(0.75 * H);   // get_noise_PS: int((1 - 1/4) * len(pows))
-    for (long long row = blockIdx.x; row < nrows; row += gridDim.x) {
+    Raw cur[PER1][R1];
+    RowTwiddles<M> tw;
+    load_row_twiddles<M>(tw, a.twB, tid);
+    // W_B^(tid+1) and W_B^T: split twiddles by recurrence (no loads in the loop)
+    const cplx wb0 = a.twB[min(tid + 1, M)], wbT = a.twB[min(T, M)];
+    long long row = blockIdx.x;
+    if (row < nrows) {
+        const size_t rc = (size_t)(row % a.nsub) * a.nchan + (size_t)(row / a.nsub);
+        stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rc * (2 * M), tid);
+    }
+    for (; row < nrows; row += gridDim.x) {
         const int n = (int)(row / a.nsub), i = (int)(row % a.nsub);
         const size_t rc = (size_t)i * a.nchan + n;
-        const Tin* grow = reinterpret_cast<const Tin*>(a.data) + rc * (2 * M);
-        fft_row<M, Tin>(lds, grow, a.twB, tid);
-        const cplx* mrow = a.mft[a.slot ? a.slot[i] : 0] + (size_t)n * M;
-        cplx* xrow = a.X + rc * a.Kt;
+        // Issue, BEFORE anything waits, every load of this row whose result is
+        // needed late: vector-memory results return in order, so these must be
+        // older than the prefetch of the next row or consuming them would drain it.
+        const cplx* mrow = (a.slot ? a.mft[a.slot[i]] : a.mft0) + (size_t)n * M;
+        double fP = 1.0, fnu = 1.0, fnuDM = 1.0, fnuGM = 1.0, fx0 = 0.0, fx1 = 0.0, fx2 = 0.0;
+        if (FUSE) {
+            fP = a.P[i]; fnu = a.freqs[(size_t)i * a.freqs_stride + n];
+            fnuDM = a.nu_fit[i * 3]; fnuGM = a.nu_fit[i * 3 + 1];
+            fx0 = a.x0[i * 5]; fx1 = a.x0[i * 5 + 1]; fx2 = a.x0[i * 5 + 2];
+        }
+        {
+            cplx v[PER1][R1];
+#pragma unroll
+            for (int ii = 0; ii < PER1; ++ii)
+#pragma unroll
+                for (int k = 0; k < R1; ++k) v[ii][k] = to_cplx(cur[ii][k]);
+            fft_first_stage<M>(lds, v, tw, tid);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the first stage has consumed the row: its registers now receive the
+        // NEXT row, whose HBM loads stay in flight under the rest of this one
+        const long long nrow = row + gridDim.x;
+        if (nrow < nrows) {
+            const size_t rn = (size_t)(nrow % a.nsub) * a.nchan + (size_t)(nrow / a.nsub);
+            stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fft_later_stages<M>(lds, tw, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- S_d from the packed transform ----
         double sd = 0.0, tail = 0.0;
-        for (int k = 1 + tid; k <= M; k += T) {
-            const cplx d = rfft_harmonic<M>(lds, a.twB, k);
-            const double p = cnorm(d);
-            sd += p;
-            if (k >= kc) tail += p;
-            if (k <= a.Kt) xrow[k - 1] = cmulc(d, mrow[k - 1]);
+        for (int k = tid; k < M; k += T) {
+            const cplx z = lds[lds_pad<PL>(k)];
+            if (k == 0) { const double dM = z.x - z.y; sd += dM * dM; }
+            else sd += cnorm(z);
+        }
+        if (TAIL) {
+            for (int k = kc + tid; k <= M; k += T) tail += cnorm(rfft_harmonic<M>(lds, a.twB, k));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- cross-spectrum (and the first evaluation's sums) ----
+        cplx* xrow = a.X + rc * a.Kt;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        cplx e = make_double2(1.0, 0.0), wst = make_double2(1.0, 0.0);
+        if (FUSE) {
+            const double a2 = 1.0 / (fnu * fnu);
+            const double p1 = PP_DCONST * (a2 - 1.0 / (fnuDM * fnuDM)) / fP;
+            const double p2 = PP_DCONST * PP_DCONST * (a2 * a2 - 1.0 / (fnuGM * fnuGM * fnuGM * fnuGM)) / fP;
+            const double phin = fx0 + fx1 * p1 + fx2 * p2;
+            // e^{2 pi i (tid+1) phi}: one sincos per lane (k = lane+1); lane 63
+            // holds e^{2 pi i 64 phi}, whose powers give the wave offset and the
+            // per-iteration step e^{2 pi i T phi}
+            const cplx el = unit_phasor((double)((tid & 63) + 1), phin);
+            const cplx w64 = make_double2(__shfl(el.x, 63, 64), __shfl(el.y, 63, 64));
+            e = el;
+            for (int q = 0; q < (tid >> 6); ++q) e = cmul(e, w64);
+            wst = w64;
+#pragma unroll
+            for (int q = 1; q < NW; q <<= 1) wst = cmul(wst, wst);
+        }
+        cplx wb = wb0;
+        for (int kb = 1 + tid; kb <= a.Kt; kb += 4 * T) {
+            cplx mv[4];   // four independent model loads in flight per chunk
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kb + j * T;
+                mv[j] = (k <= a.Kt) ? mrow[k - 1] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kb + j * T;
+                if (k <= a.Kt) {
+                    const cplx d = rfft_harmonic_w<M>(lds, wb, k);
+                    const cplx x = cmulc(d, mv[j]);
+                    xrow[k - 1] = x;
+                    if (FUSE) {
+                        const cplx z = cmul(x, e);
+                        const double kk = (double)k;
+                        s0 += z.x;
+                        s1 = fma(kk, z.y, s1);
+                        s2 = fma(kk * kk, z.x, s2);
+                    }
+                }
+                wb = cmul(wb, wbT);
+                if (FUSE) e = cmul(e, wst);
+            }
         }
         sd = group_sum<64>(sd);
-        tail = group_sum<64>(tail);
-        if (T > 64) {
-            if ((tid & 63) == 0) { red[2 * (tid >> 6)] = sd; red[2 * (tid >> 6) + 1] = tail; }
-            __syncthreads();
+        if (TAIL) tail = group_sum<64>(tail);
+        if (FUSE) { s0 = group_sum<64>(s0); s1 = group_sum<64>(s1); s2 = group_sum<64>(s2); }
+        if (NW > 1) {
+            if ((tid & 63) == 0) {
+                double* r = red + 5 * (tid >> 6);
+                r[0] = sd; r[1] = tail; r[2] = s0; r[3] = s1; r[4] = s2;
+            }
+            lds_sync<T>();
             if (tid == 0) {
-                sd = 0.0; tail = 0.0;
-                for (int w = 0; w < T / 64; ++w) { sd += red[2 * w]; tail += red[2 * w + 1]; }
+                sd = tail = s0 = s1 = s2 = 0.0;
+                for (int w = 0; w < NW; ++w) {
+                    sd += red[5 * w]; tail += red[5 * w + 1];
+                    s0 += red[5 * w + 2]; s1 += red[5 * w + 3]; s2 += red[5 * w + 4];
+                }
             }
         }
         if (tid == 0) {
             a.sdraw[rc] = sd;
-            a.noise[rc] = sqrt(tail / (2.0 * M) / (double)(H - kc));
+            if (TAIL) a.noise[rc] = sqrt(tail / (2.0 * M) / (double)(H - kc));
+            if (FUSE) {
+                double* co = a.csum0 + rc * 3;
+                co[0] = s0;
+                co[1] = -PP_TWO_PI * s1;
+                co[2] = -PP_TWO_PI * PP_TWO_PI * s2;
+            }
         }
-        __syncthreads();
+        lds_sync<T>();
     }
 }
 
@@ -239,6 +356,16 @@ __device__ __forceinline__ void chan_geom(double nu, double P, double nuDM, doub
         c.q12 = PP_LN10 * c.q2;
     }
     c.q22 = c.lnf * c.q2;
+}
+
+// phase-model part only (no scattering): d phi_n / d DM, d phi_n / d GM
+__device__ __forceinline__ void phase_geom(double nu, double P, double nuDM, double nuGM, double& p1,
+                                           double& p2) {
+    const double a2 = 1.0 / (nu * nu);
+    const double iDM = (nuDM == INFINITY) ? 0.0 : 1.0 / (nuDM * nuDM);
+    const double iGM = (nuGM == INFINITY) ? 0.0 : 1.0 / (nuGM * nuGM * nuGM * nuGM);
+    p1 = PP_DCONST * (a2 - iDM) / P;
+    p2 = PP_DCONST * PP_DCONST * (a2 * a2 - iGM) / P;
 }
 
 // local (phi_n, tau_n) derivatives of F_n = -C^2/S from weighted sums
@@ -382,6 +509,154 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
     if (l == 0) {
 #pragma unroll
         for (int j = 0; j < PP_NACC; ++j) red[g * PP_NACC + j] = acc[j];
+    }
+    __syncthreads();
+    if (tid < PP_NACC) {
+        double s = 0.0;
+        for (int gg = 0; gg < 256 / LPC; ++gg) s += red[gg * PP_NACC + tid];
+        a.partial[((size_t)i * a.nchunk + chunk) * PP_NACC + tid] = s;
+    }
+}
+
+// accumulate one channel's local terms into the 21 per-subint sums
+__device__ __forceinline__ void accumulate_channel(const Local& L, const ChanGeom& cg, double (&c)[PP_NACC]) {
+    const double p1 = cg.p1, p2 = cg.p2;
+    c[0] = L.F;
+    c[1] = L.Gp; c[2] = L.Gp * p1; c[3] = L.Gp * p2;
+    c[4] = L.Gt * cg.q1; c[5] = L.Gt * cg.q2;
+    c[6] = L.Lpp; c[7] = L.Lpp * p1; c[8] = L.Lpp * p2;
+    c[9] = L.Lpt * cg.q1; c[10] = L.Lpt * cg.q2;
+    c[11] = L.Lpp * p1 * p1; c[12] = L.Lpp * p1 * p2;
+    c[13] = L.Lpt * p1 * cg.q1; c[14] = L.Lpt * p1 * cg.q2;
+    c[15] = L.Lpp * p2 * p2;
+    c[16] = L.Lpt * p2 * cg.q1; c[17] = L.Lpt * p2 * cg.q2;
+    c[18] = L.Ltt * cg.q1 * cg.q1 + L.Gt * cg.q11;
+    c[19] = L.Ltt * cg.q1 * cg.q2 + L.Gt * cg.q12;
+    c[20] = L.Ltt * cg.q2 * cg.q2 + L.Gt * cg.q22;
+}
+
+// First evaluation when k_xspec already produced the per-channel sums (FUSE):
+// only the O(nchan) chain rule + reduction remains.  grid = (nchunk, nsub).
+__global__ __launch_bounds__(256) void k_accum(FitArgs a) {
+    const int i = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    SubState& st = a.st[i];
+    if (st.done) return;
+    __shared__ double scratch[4 * PP_NACC];
+    const double P = a.P[i];
+    const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1];
+    const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
+    const double* wts = a.wts + (size_t)i * a.nchan;
+    const double* msum = a.msum[a.slot ? a.slot[i] : 0];
+    const int trial = 1 - st.cur;
+    const double* csum = a.csum + ((size_t)trial * a.nsub + i) * a.nchan * a.ncs;
+    double acc[PP_NACC];
+#pragma unroll
+    for (int j = 0; j < PP_NACC; ++j) acc[j] = 0.0;
+    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan);
+    for (int n = n0 + tid; n < n1; n += 256) {
+        const double w = wts[n];
+        if (w == 0.0) continue;
+        double cs[PP_NCS];
+        cs[0] = csum[(size_t)n * 3]; cs[1] = csum[(size_t)n * 3 + 1]; cs[2] = csum[(size_t)n * 3 + 2];
+        cs[3] = cs[4] = cs[5] = 0.0; cs[6] = msum[n]; cs[7] = cs[8] = 0.0;
+        double p1, p2;
+        phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
+        const double r = cs[0] / cs[6];
+        const double F = -w * cs[0] * r, Gp = -2.0 * w * r * cs[1];
+        const double Lpp = -2.0 * w * (cs[1] * cs[1] / cs[6] + r * cs[2]);
+        acc[0] += F;
+        acc[1] += Gp; acc[2] += Gp * p1; acc[3] += Gp * p2;
+        acc[6] += Lpp; acc[7] += Lpp * p1; acc[8] += Lpp * p2;
+        acc[11] += Lpp * p1 * p1; acc[12] += Lpp * p1 * p2; acc[15] += Lpp * p2 * p2;
+    }
+    block_sum<PP_NACC>(acc, scratch);
+#pragma unroll
+    for (int j = 0; j < PP_NACC; ++j)
+        if (tid == j) a.partial[((size_t)i * a.nchunk + chunk) * PP_NACC + j] = acc[j];
+}
+
+// chi^2 evaluator without scattering (tau_n = 0): only A0, A1, A2 are needed
+// and S_n is the constant sum_k |m_nk|^2.  16 lanes per channel, four
+// independent 16-byte loads in flight per lane per iteration (Kt is a multiple
+// of 64), phasors advanced by e^{2 pi i 64 phi_n}; each lane of a group keeps
+// only two of the 21 per-subint accumulators.
+__global__ __launch_bounds__(256) void k_eval_fast(FitArgs a) {
+    constexpr int LPC = 16;
+    const int i = blockIdx.y, chunk = blockIdx.x;
+    SubState& st = a.st[i];
+    if (st.done) return;
+    __shared__ double red[(256 / LPC) * PP_NACC];
+    const int tid = threadIdx.x, g = tid / LPC, l = tid % LPC;
+    const double phi = st.xe[0], DM = st.xe[1], GM = st.xe[2];
+    const double P = a.P[i];
+    const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1];
+    const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
+    const double* wts = a.wts + (size_t)i * a.nchan;
+    const double* msum = a.msum[a.slot ? a.slot[i] : 0];
+    const int trial = 1 - st.cur;
+    double* csum = a.csum + ((size_t)trial * a.nsub + i) * a.nchan * a.ncs;
+    double accA = 0.0;
+    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan);
+    const int src = ((tid & 63) & ~(LPC - 1)) | (LPC - 1);
+    for (int n = n0 + g; n < n1; n += 256 / LPC) {
+        const double w = wts[n];
+        double p1, p2;
+        phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
+        const double phin = phi + DM * p1 + GM * p2;
+        cplx e0 = unit_phasor((double)(l + 1), phin);
+        const cplx w1 = make_double2(__shfl(e0.x, src, 64), __shfl(e0.y, src, 64));
+        const cplx w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+        const cplx* xrow = a.X + ((size_t)i * a.nchan + n) * a.Kt;
+        double s0a = 0, s1a = 0, s2a = 0, s0b = 0, s1b = 0, s2b = 0;
+        double k = (double)(l + 1);
+        if (w != 0.0) {
+#pragma unroll 1
+            for (int j = l; j < a.Kt; j += 4 * LPC) {
+                const cplx x0 = xrow[j], x1 = xrow[j + LPC], x2 = xrow[j + 2 * LPC], x3 = xrow[j + 3 * LPC];
+                const cplx e1 = cmul(e0, w1), e2 = cmul(e0, w2), e3 = cmul(e0, w3);
+                const cplx z0 = cmul(x0, e0), z1 = cmul(x1, e1), z2 = cmul(x2, e2), z3 = cmul(x3, e3);
+                const double k1 = k + LPC, k2 = k + 2 * LPC, k3 = k + 3 * LPC;
+                s0a += z0.x; s1a = fma(k, z0.y, s1a); s2a = fma(k * k, z0.x, s2a);
+                s0b += z1.x; s1b = fma(k1, z1.y, s1b); s2b = fma(k1 * k1, z1.x, s2b);
+                s0a += z2.x; s1a = fma(k2, z2.y, s1a); s2a = fma(k2 * k2, z2.x, s2a);
+                s0b += z3.x; s1b = fma(k3, z3.y, s1b); s2b = fma(k3 * k3, z3.x, s2b);
+                e0 = cmul(e0, w4);
+                k += 4.0 * LPC;
+            }
+        }
+        const double A0 = group_sum<LPC>(s0a + s0b);
+        const double A1 = -PP_TWO_PI * group_sum<LPC>(s1a + s1b);
+        const double A2 = -PP_TWO_PI * PP_TWO_PI * group_sum<LPC>(s2a + s2b);
+        if (l < 3) csum[(size_t)n * 3 + l] = (l == 0) ? A0 : (l == 1 ? A1 : A2);
+        if (w != 0.0) {
+            const double S0 = msum[n], r = A0 / S0;
+            const double F = -w * A0 * r, Gp = -2.0 * w * r * A1;
+            const double Lpp = -2.0 * w * (A1 * A1 / S0 + r * A2);
+            // the 10 non-zero accumulators, one per lane: f, g[0..2], H phi-block
+            double ca = F;
+            ca = (l == 1) ? Gp : ca;
+            ca = (l == 2) ? Gp * p1 : ca;
+            ca = (l == 3) ? Gp * p2 : ca;
+            ca = (l == 4) ? Lpp : ca;
+            ca = (l == 5) ? Lpp * p1 : ca;
+            ca = (l == 6) ? Lpp * p2 : ca;
+            ca = (l == 7) ? Lpp * p1 * p1 : ca;
+            ca = (l == 8) ? Lpp * p1 * p2 : ca;
+            ca = (l == 9) ? Lpp * p2 * p2 : ca;
+            accA += ca;
+        }
+    }
+    // lane -> accumulator slot of PP_NACC
+    {
+        const int slot = (l < 4) ? l : (l == 4 ? 6 : (l == 5 ? 7 : (l == 6 ? 8 : (l == 7 ? 11 : (l == 8 ? 12 : 15)))));
+        if (l >= 10) { /* no accumulator */ }
+        else red[g * PP_NACC + slot] = accA;
+        // zero the scattering slots once per group
+        if (l >= 10) {
+            const int z[6] = {4, 5, 9, 10, 13, 14};
+            red[g * PP_NACC + z[l - 10]] = 0.0;
+        }
+        if (l < 5) red[g * PP_NACC + 16 + l] = 0.0;
     }
     __syncthreads();
     if (tid < PP_NACC) {

@@ -69,8 +69,8 @@ struct ModelSlot {
     DevBuf mft, msum, mmax, mdc;
 };
 
-enum KernelFamily { KF_MODEL = 0, KF_XSPEC, KF_PREP, KF_EVAL, KF_STEP, KF_FINAL, KF_SYNTH, KF_FPS, KF_COUNT };
-static const char* kFamilyNames[KF_COUNT] = {"model_fft", "xspec", "prep", "eval", "step", "finalize",
+enum KernelFamily { KF_MODEL = 0, KF_XSPEC, KF_PREP, KF_ACCUM, KF_EVAL, KF_STEP, KF_FINAL, KF_SYNTH, KF_FPS, KF_COUNT };
+static const char* kFamilyNames[KF_COUNT] = {"model_fft", "xspec", "prep", "accum", "eval", "step", "finalize",
                                             "synth", "fit_phase_shift"};
 
 struct pp_ctx {
@@ -244,22 +244,22 @@ static bool nbin_ok(int nbin) { return nbin >= 32 && nbin <= 8192 && (nbin & (nb
 
 static int fft_grid(int T, long long nrows) {
     // persistent workgroups: enough to fill 256 CUs at the LDS-limited residency
-    long long g = 256LL * (T == 64 ? 8 : (T == 128 ? 4 : 2));
+    long long g = 256LL * (T <= 128 ? 8 : (T == 256 ? 4 : 2));
     return (int)std::max(1LL, std::min(nrows, g));
 }
 
 // dispatch a templated kernel on (M, dtype)
-#define PP_DISPATCH_M(M_, BODY)        \
+#define PP_DISPATCH_M(M_, ...)         \
     switch (M_) {                      \
-        case 16: { constexpr int MM = 16; BODY; break; }     \
-        case 32: { constexpr int MM = 32; BODY; break; }     \
-        case 64: { constexpr int MM = 64; BODY; break; }     \
-        case 128: { constexpr int MM = 128; BODY; break; }   \
-        case 256: { constexpr int MM = 256; BODY; break; }   \
-        case 512: { constexpr int MM = 512; BODY; break; }   \
-        case 1024: { constexpr int MM = 1024; BODY; break; } \
-        case 2048: { constexpr int MM = 2048; BODY; break; } \
-        case 4096: { constexpr int MM = 4096; BODY; break; } \
+        case 16: { constexpr int MM = 16; __VA_ARGS__; break; }     \
+        case 32: { constexpr int MM = 32; __VA_ARGS__; break; }     \
+        case 64: { constexpr int MM = 64; __VA_ARGS__; break; }     \
+        case 128: { constexpr int MM = 128; __VA_ARGS__; break; }   \
+        case 256: { constexpr int MM = 256; __VA_ARGS__; break; }   \
+        case 512: { constexpr int MM = 512; __VA_ARGS__; break; }   \
+        case 1024: { constexpr int MM = 1024; __VA_ARGS__; break; } \
+        case 2048: { constexpr int MM = 2048; __VA_ARGS__; break; } \
+        case 4096: { constexpr int MM = 4096; __VA_ARGS__; break; } \
         default: return fail(PP_EINVAL, "unsupported nbin %d", 2 * (M_)); \
     }
 
@@ -311,7 +311,7 @@ extern "C" int pp_model_set(pp_ctx* c, int slot, const void* portrait, int dtype
         int kcut = 0;
         HIP_TRY(hipMemcpyAsync(&kcut, c->misc.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        Kt = std::min(M, std::max(32, ((kcut + 31) / 32) * 32));
+        Kt = std::min(M, std::max(64, ((kcut + 63) / 64) * 64));
     } else {
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
@@ -364,6 +364,19 @@ static int upload(pp_ctx* c, DevBuf& b, const void* src, size_t bytes) {
     return PP_OK;
 }
 
+template <int MM, typename TIN>
+static void launch_xspec(pp_ctx* c, const XspecArgs& xa, bool tail, bool fuse) {
+    const int T = FftPlan<MM>::T;
+    const dim3 grid(fft_grid(T, (long long)xa.nsub * xa.nchan)), blk(T);
+    if (tail) {
+        if (fuse) hipLaunchKernelGGL((k_xspec<MM, TIN, true, true>), grid, blk, 0, c->stream, xa);
+        else hipLaunchKernelGGL((k_xspec<MM, TIN, true, false>), grid, blk, 0, c->stream, xa);
+    } else {
+        if (fuse) hipLaunchKernelGGL((k_xspec<MM, TIN, false, true>), grid, blk, 0, c->stream, xa);
+        else hipLaunchKernelGGL((k_xspec<MM, TIN, false, false>), grid, blk, 0, c->stream, xa);
+    }
+}
+
 static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, int ns, int Kt, bool scat,
                      const std::vector<double>& nufit_h, const std::vector<double>& nuout_h) {
     const int C = in->nchan, B = in->nbin, M = B / 2;
@@ -383,8 +396,15 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     const size_t nc = (size_t)ns * C;
     if (in->freqs_stride) { if ((rc = upload(c, c->freqs, in->freqs + (size_t)s0 * C, nc * 8))) return rc; }
     else { if ((rc = upload(c, c->freqs, in->freqs, (size_t)C * 8))) return rc; }
-    if (in->errs) if ((rc = upload(c, c->errs, in->errs + (size_t)s0 * C, nc * 8))) return rc;
-    if (in->chan_mask) if ((rc = upload(c, c->mask, in->chan_mask + (size_t)s0 * C, nc))) return rc;
+    const double* d_errs = nullptr;
+    const unsigned char* d_mask = nullptr;
+    if (in->aux_on_device) {
+        if (in->errs) d_errs = in->errs + (size_t)s0 * C;
+        if (in->chan_mask) d_mask = in->chan_mask + (size_t)s0 * C;
+    } else {
+        if (in->errs) { if ((rc = upload(c, c->errs, in->errs + (size_t)s0 * C, nc * 8))) return rc; d_errs = c->errs.as<double>(); }
+        if (in->chan_mask) { if ((rc = upload(c, c->mask, in->chan_mask + (size_t)s0 * C, nc))) return rc; d_mask = c->mask.as<unsigned char>(); }
+    }
     if ((rc = upload(c, c->P, in->P + s0, (size_t)ns * 8))) return rc;
     if ((rc = upload(c, c->x0, in->init_params + (size_t)s0 * 5, (size_t)ns * 40))) return rc;
     if ((rc = upload(c, c->nufit, nufit_h.data() + (size_t)s0 * 3, (size_t)ns * 24))) return rc;
@@ -416,29 +436,38 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     if ((rc = c->o_f0.reserve((size_t)ns * 8))) return rc;
     if ((rc = c->o_g0.reserve((size_t)ns * 40))) return rc;
     if ((rc = c->o_H0.reserve((size_t)ns * 200))) return rc;
-    if (out->scales) if ((rc = c->o_scales.reserve(nc * 8))) return rc;
-    if (out->scale_errs) if ((rc = c->o_serrs.reserve(nc * 8))) return rc;
-    if (out->channel_snrs) if ((rc = c->o_csnr.reserve(nc * 8))) return rc;
+    const bool chan_dev = out->chan_on_device != 0;
+    if (!chan_dev) {
+        if (out->scales) if ((rc = c->o_scales.reserve(nc * 8))) return rc;
+        if (out->scale_errs) if ((rc = c->o_serrs.reserve(nc * 8))) return rc;
+        if (out->channel_snrs) if ((rc = c->o_csnr.reserve(nc * 8))) return rc;
+    }
 
     // ---- rFFT + cross-spectrum ----
-    XspecArgs xa{ddata, (const cplx* const*)c->mft_table.p, in->model_slot ? c->slot.as<int>() : nullptr,
-                 c->X.as<cplx>(), c->sdraw.as<double>(), c->noise.as<double>(), tw, ns, C, Kt};
+    const bool fuse = !scat;          // first evaluation folded into k_xspec
+    const bool tail = (in->errs == nullptr);
+    XspecArgs xa;
+    memset(&xa, 0, sizeof xa);
+    xa.data = ddata; xa.mft = (const cplx* const*)c->mft_table.p;
+    xa.mft0 = c->slots[0].mft.as<cplx>();
+    xa.slot = in->model_slot ? c->slot.as<int>() : nullptr;
+    xa.X = c->X.as<cplx>(); xa.sdraw = c->sdraw.as<double>(); xa.noise = c->noise.as<double>();
+    xa.twB = tw; xa.nsub = ns; xa.nchan = C; xa.Kt = Kt;
+    xa.x0 = c->x0.as<double>(); xa.P = c->P.as<double>(); xa.nu_fit = c->nufit.as<double>();
+    xa.freqs = c->freqs.as<double>(); xa.freqs_stride = in->freqs_stride ? C : 0;
+    xa.csum0 = c->csum.as<double>();
     {
         Prof pr(c, KF_XSPEC);
         PP_DISPATCH_M(M, {
-            const int T = FftPlan<MM>::T;
-            const int grid = fft_grid(T, (long long)ns * C);
-            if (in->data_dtype == PP_F64) hipLaunchKernelGGL((k_xspec<MM, double>), dim3(grid), dim3(T), 0, c->stream, xa);
-            else hipLaunchKernelGGL((k_xspec<MM, float>), dim3(grid), dim3(T), 0, c->stream, xa);
+            if (in->data_dtype == PP_F64) launch_xspec<MM, double>(c, xa, tail, fuse);
+            else launch_xspec<MM, float>(c, xa, tail, fuse);
         });
     }
     HIP_TRY(hipGetLastError());
     {
         Prof pr(c, KF_PREP);
         hipLaunchKernelGGL(k_prep, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, ns, C, B,
-                           in->errs ? c->errs.as<double>() : (const double*)nullptr, c->noise.as<double>(),
-                           in->chan_mask ? c->mask.as<unsigned char>() : (const unsigned char*)nullptr,
-                           c->wts.as<double>());
+                           d_errs, c->noise.as<double>(), d_mask, c->wts.as<double>());
     }
     HIP_TRY(hipGetLastError());
     FitArgs fa;
@@ -461,9 +490,15 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.o_params = c->o_params.as<double>(); fa.o_errs = c->o_errs.as<double>(); fa.o_nu = c->o_nu.as<double>();
     fa.o_cov = c->o_cov.as<double>(); fa.o_chi2 = c->o_chi2.as<double>(); fa.o_rchi2 = c->o_rchi2.as<double>();
     fa.o_snr = c->o_snr.as<double>(); fa.o_nfev = c->o_nfev.as<int>(); fa.o_rc = c->o_rc.as<int>();
-    fa.o_scales = out->scales ? c->o_scales.as<double>() : nullptr;
-    fa.o_scale_errs = out->scale_errs ? c->o_serrs.as<double>() : nullptr;
-    fa.o_csnr = out->channel_snrs ? c->o_csnr.as<double>() : nullptr;
+    if (chan_dev) {
+        fa.o_scales = out->scales ? out->scales + (size_t)s0 * C : nullptr;
+        fa.o_scale_errs = out->scale_errs ? out->scale_errs + (size_t)s0 * C : nullptr;
+        fa.o_csnr = out->channel_snrs ? out->channel_snrs + (size_t)s0 * C : nullptr;
+    } else {
+        fa.o_scales = out->scales ? c->o_scales.as<double>() : nullptr;
+        fa.o_scale_errs = out->scale_errs ? c->o_serrs.as<double>() : nullptr;
+        fa.o_csnr = out->channel_snrs ? c->o_csnr.as<double>() : nullptr;
+    }
     fa.o_f0 = c->o_f0.as<double>(); fa.o_g0 = c->o_g0.as<double>(); fa.o_H0 = c->o_H0.as<double>();
 
     hipLaunchKernelGGL(k_init_state, dim3((ns + 63) / 64), dim3(64), 0, c->stream, fa);
@@ -471,10 +506,13 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // ---- trust-region iterations: evaluation + step, until every subint is done
     const int max_evals = std::max(1, c->max_iter + 1);
     for (int it = 0; it < max_evals; ++it) {
-        {
+        if (it == 0 && fuse) {
+            Prof pr(c, KF_ACCUM);
+            hipLaunchKernelGGL(k_accum, dim3(nchunk, ns), dim3(256), 0, c->stream, fa);
+        } else {
             Prof pr(c, KF_EVAL);
             if (scat) hipLaunchKernelGGL(k_eval<true>, dim3(nchunk, ns), dim3(256), 0, c->stream, fa);
-            else hipLaunchKernelGGL(k_eval<false>, dim3(nchunk, ns), dim3(256), 0, c->stream, fa);
+            else hipLaunchKernelGGL(k_eval_fast, dim3(nchunk, ns), dim3(256), 0, c->stream, fa);
         }
         {
             Prof pr(c, KF_STEP);
@@ -504,9 +542,11 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     PP_D2H(out->snr, c->o_snr, (size_t)s0 * 8, (size_t)ns * 8);
     PP_D2H(out->nfeval, c->o_nfev, (size_t)s0 * 4, (size_t)ns * 4);
     PP_D2H(out->return_code, c->o_rc, (size_t)s0 * 4, (size_t)ns * 4);
-    PP_D2H(out->scales, c->o_scales, (size_t)s0 * C * 8, nc * 8);
-    PP_D2H(out->scale_errs, c->o_serrs, (size_t)s0 * C * 8, nc * 8);
-    PP_D2H(out->channel_snrs, c->o_csnr, (size_t)s0 * C * 8, nc * 8);
+    if (!chan_dev) {
+        PP_D2H(out->scales, c->o_scales, (size_t)s0 * C * 8, nc * 8);
+        PP_D2H(out->scale_errs, c->o_serrs, (size_t)s0 * C * 8, nc * 8);
+        PP_D2H(out->channel_snrs, c->o_csnr, (size_t)s0 * C * 8, nc * 8);
+    }
     PP_D2H(out->obj_f, c->o_f0, (size_t)s0 * 8, (size_t)ns * 8);
     PP_D2H(out->obj_grad, c->o_g0, (size_t)s0 * 40, (size_t)ns * 40);
     PP_D2H(out->obj_hess, c->o_H0, (size_t)s0 * 200, (size_t)ns * 200);

@@ -38,6 +38,18 @@ def _f64(a, shape=None):
     return a
 
 
+def _nu_array(nus, nsub):
+    """[nsub,3] float64 reference frequencies; None entries become NaN (= let
+    the engine choose: mean frequency for the fit, zero-covariance for output)."""
+    if nus is None:
+        return np.full((nsub, 3), np.nan)
+    a = np.asarray(nus)
+    if a.dtype == object:
+        a = np.where(np.equal(a, None), np.nan, a).astype(np.float64)
+    return np.ascontiguousarray(np.broadcast_to(a.astype(np.float64, copy=False),
+                                                (nsub, 3)))
+
+
 class Engine(object):
     """Device context + scratch; not thread-safe (one per host thread and GPU)."""
 
@@ -97,7 +109,9 @@ class Engine(object):
                   per_channel=True, objective=False):
         """Fit nsub subints.  data: [nsub,nchan,nbin] numpy array (f64/f32) or
         CUDA tensor.  freqs: [nchan] or [nsub,nchan].  Returns a dict of arrays
-        (see include/pp_toas.h pp_fit_out)."""
+        (see include/pp_toas.h pp_fit_out).  errs / chan_mask may be CUDA
+        tensors [nsub,nchan]; per_channel="device" leaves scales, scale_errs and
+        channel_snrs in HBM as CUDA tensors instead of copying them out."""
         if _is_device_array(data):
             nsub, nchan, nbin = (int(s) for s in data.shape)
             if not data.is_contiguous():
@@ -127,18 +141,27 @@ class Engine(object):
             fstride = nchan
         P = _f64(P, (nsub,))
         x0 = _f64(init_params, (nsub, 5))
-        errs = _f64(errs, (nsub, nchan))
-        nan3 = np.full((nsub, 3), np.nan)
-        nu_fits = nan3 if nu_fits is None else _f64(
-            [[np.nan if v is None else v for v in row] for row in
-             np.broadcast_to(np.asarray(nu_fits, dtype=object), (nsub, 3))])
-        nu_outs = nan3.copy() if nu_outs is None else _f64(
-            [[np.nan if v is None else v for v in row] for row in
-             np.broadcast_to(np.asarray(nu_outs, dtype=object), (nsub, 3))])
+        aux_dev = _is_device_array(errs) or _is_device_array(chan_mask)
+        if aux_dev:
+            for t, nm in ((errs, "errs"), (chan_mask, "chan_mask")):
+                if t is not None and not (_is_device_array(t) and t.is_contiguous()
+                                          and tuple(t.shape) == (nsub, nchan)):
+                    raise EngineError("%s must be a contiguous CUDA tensor "
+                                      "[nsub,nchan] when either aux input is" % nm)
+            if errs is not None and errs.element_size() != 8:
+                raise EngineError("device errs must be float64")
+            if chan_mask is not None and chan_mask.element_size() != 1:
+                raise EngineError("device chan_mask must be uint8")
+        else:
+            errs = _f64(errs, (nsub, nchan))
+        nu_fits = _nu_array(nu_fits, nsub)
+        nu_outs = _nu_array(nu_outs, nsub)
         slot = None if model_slot is None else np.ascontiguousarray(
             np.broadcast_to(model_slot, (nsub,)), dtype=np.int32)
-        mask = None if chan_mask is None else np.ascontiguousarray(
-            np.broadcast_to(chan_mask, (nsub, nchan)), dtype=np.uint8)
+        mask = None
+        if chan_mask is not None and not aux_dev:
+            mask = np.ascontiguousarray(np.broadcast_to(chan_mask, (nsub, nchan)),
+                                        dtype=np.uint8)
 
         fin = FitIn()
         fin.nsub, fin.nchan, fin.nbin = nsub, nchan, nbin
@@ -146,8 +169,14 @@ class Engine(object):
         fin.data_dtype, fin.data_on_device = dtype, on_dev
         fin.model_slot = None if slot is None else slot.ctypes.data_as(c_int32_p)
         fin.freqs, fin.freqs_stride = _dp(freqs), fstride
-        fin.errs = _dp(errs)
-        fin.chan_mask = None if mask is None else mask.ctypes.data_as(c_uint8_p)
+        fin.aux_on_device = int(aux_dev)
+        if aux_dev:
+            fin.errs = None if errs is None else C.cast(errs.data_ptr(), c_double_p)
+            fin.chan_mask = None if chan_mask is None else C.cast(
+                chan_mask.data_ptr(), c_uint8_p)
+        else:
+            fin.errs = _dp(errs)
+            fin.chan_mask = None if mask is None else mask.ctypes.data_as(c_uint8_p)
         fin.P, fin.init_params = _dp(P), _dp(x0)
         fin.nu_fits, fin.nu_outs = _dp(nu_fits), _dp(nu_outs)
         for j in range(5):
@@ -161,7 +190,13 @@ class Engine(object):
                    nfeval=np.empty(nsub, dtype=np.int32),
                    return_code=np.empty(nsub, dtype=np.int32),
                    duration=np.zeros(1))
-        if per_channel:
+        chan_dev = (per_channel == "device")
+        if chan_dev:
+            import torch
+            dev = data.device if on_dev else torch.device("cuda", self.device)
+            res.update({k: torch.empty((nsub, nchan), dtype=torch.float64, device=dev)
+                        for k in ("scales", "scale_errs", "channel_snrs")})
+        elif per_channel:
             res.update(scales=np.empty((nsub, nchan)),
                        scale_errs=np.empty((nsub, nchan)),
                        channel_snrs=np.empty((nsub, nchan)))
@@ -169,10 +204,15 @@ class Engine(object):
             res.update(obj_f=np.empty(nsub), obj_grad=np.empty((nsub, 5)),
                        obj_hess=np.empty((nsub, 5, 5)))
         fout = FitOut()
+        fout.chan_on_device = int(chan_dev)
         for name, _ in FitOut._fields_:
+            if name == "chan_on_device":
+                continue
             arr = res.get(name)
             if arr is None:
                 setattr(fout, name, None)
+            elif _is_device_array(arr):
+                setattr(fout, name, C.cast(arr.data_ptr(), c_double_p))
             elif arr.dtype == np.int32:
                 setattr(fout, name, arr.ctypes.data_as(c_int32_p))
             else:

@@ -1,0 +1,19 @@
+#!/bin/bash
+# usage: tools_pmc.sh <tag> ; collects two SQ counter passes for one bench step
+export TMPDIR=/tmp
+out=gpurun_out/pmc_$1
+mkdir -p $out
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $out/p1 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $out/p1.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $out/p2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $out/p2.err
+python3 - $out <<'PY'
+import csv,glob,collections,sys
+for p in ("p1","p2"):
+    fs=glob.glob(sys.argv[1]+"/"+p+"/*/*_counter_collection.csv")
+    if not fs: print("no output for",p); continue
+    agg=collections.defaultdict(float); n=collections.defaultdict(int)
+    for r in csv.DictReader(open(fs[0])):
+        k=r["Kernel_Name"]
+        if "k_xspec" in k or "k_eval" in k:
+            agg[(k[:40],r["Counter_Name"])]+=float(r["Counter_Value"])
+    for k,v in sorted(agg.items()): print(k, "%.4g"%v)
+PY
