@@ -106,6 +106,11 @@ typedef struct {
     int32_t log10_tau;
     int32_t option;            /* get_nu_zeros option (pptoaslib.py:734) */
     int32_t is_toa;
+    int32_t seed_ns;           /* > 0: ignore init_params[.][0] and seed the phase on
+                                  the device: seed_ns-point grid over [-0.5, 0.5] of
+                                  the channel-summed cross-correlation at the guessed
+                                  DM/GM/tau, polished to its maximum (the role of
+                                  pptoas.py:421-457, fit_phase_shift with Ns=100) */
 } pp_fit_in;
 
 typedef struct {

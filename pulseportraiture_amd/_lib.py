@@ -30,7 +30,7 @@ class FitIn(C.Structure):
                 ("init_params", c_double_p), ("nu_fits", c_double_p),
                 ("nu_outs", c_double_p), ("fit_flags", C.c_int32 * 5),
                 ("log10_tau", C.c_int32), ("option", C.c_int32),
-                ("is_toa", C.c_int32)]
+                ("is_toa", C.c_int32), ("seed_ns", C.c_int32)]
 
 
 class FitOut(C.Structure):

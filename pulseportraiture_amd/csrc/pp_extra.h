@@ -206,4 +206,109 @@ __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
     }
 }
 
+// --------------------------------------------------------------------------
+// Phase seed on the device (role of pptoas.py:421-457).  With the guessed
+// DM/GM the per-channel cross-correlations are aligned and summed:
+//   Y_k = sum_n w_n X_nk e^{2 pi i k (phi_n - phi)},   CCF(phi) = Re sum_k Y_k B_k^* e^{2 pi i k phi}
+// (B_k: scattering kernel of the guessed tau at nu_fit; w_n = 1/sigma_n^2).
+// k_seed_accum: grid (nchunk, nsub); thread t owns harmonics t+1, t+257, ...
+// k_seed_fit:   per subint, reduce the chunks, grid + Newton polish, write the
+//               phase into x0[i][0].
+// --------------------------------------------------------------------------
+#define PP_SEED_KPT 4   // harmonics per thread: Kt <= 1024
+__global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart) {
+    const int i = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const double P = a.P[i];
+    const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1];
+    const double DM = a.x0[i * 5 + 1], GM = a.x0[i * 5 + 2];
+    const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
+    const double* wts = a.wts + (size_t)i * a.nchan;
+    cplx y[PP_SEED_KPT];
+#pragma unroll
+    for (int j = 0; j < PP_SEED_KPT; ++j) y[j] = make_double2(0.0, 0.0);
+    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan);
+    for (int n = n0; n < n1; ++n) {
+        const double w = wts[n];
+        if (w == 0.0) continue;
+        double p1, p2;
+        phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
+        const double phin = DM * p1 + GM * p2;
+        const cplx* xrow = a.X + ((size_t)i * a.nchan + n) * a.Kt;
+#pragma unroll
+        for (int j = 0; j < PP_SEED_KPT; ++j) {
+            const int k = tid + 1 + 256 * j;
+            if (k <= a.Kt) {
+                const cplx z = cmul(xrow[k - 1], unit_phasor((double)k, phin));
+                y[j].x = fma(w, z.x, y[j].x);
+                y[j].y = fma(w, z.y, y[j].y);
+            }
+        }
+    }
+    cplx* yo = ypart + ((size_t)i * a.nchunk + chunk) * a.Kt;
+#pragma unroll
+    for (int j = 0; j < PP_SEED_KPT; ++j) {
+        const int k = tid + 1 + 256 * j;
+        if (k <= a.Kt) yo[k - 1] = y[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, cplx* ywork, double* x0, int Ns) {
+    const int i = blockIdx.x, tid = threadIdx.x, K = a.Kt;
+    __shared__ double scratch[4 * 4];
+    __shared__ double gridf[1024];
+    __shared__ double sh[2];
+    cplx* Y = ywork + (size_t)i * K;
+    // scattering kernel of the guessed tau at the fit reference frequency
+    const double taup = x0[i * 5 + 3];
+    const double tau = a.scat ? (a.log10_tau ? pow(10.0, taup) : taup) : 0.0;
+    for (int k = tid + 1; k <= K; k += 256) {
+        cplx s = make_double2(0.0, 0.0);
+        for (int c = 0; c < a.nchunk; ++c) {
+            const cplx v = ypart[((size_t)i * a.nchunk + c) * K + k - 1];
+            s.x += v.x; s.y += v.y;
+        }
+        if (tau != 0.0) {   // times conj(B_k) = (1 + i u)/(1 + u^2)
+            const double u = PP_TWO_PI * k * tau, D = 1.0 / fma(u, u, 1.0);
+            s = cmul(s, make_double2(D, u * D));
+        }
+        Y[k - 1] = s;
+    }
+    __syncthreads();
+    Ns = min(max(Ns, 2), 1024);
+    for (int j = tid; j < Ns; j += 256) {
+        const double phi = -0.5 + (double)j / (double)(Ns - 1);
+        double s0, s1, s2;
+        fps_sums(Y, K, phi, 0, 1, s0, s1, s2);
+        gridf[j] = -s0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int best = 0;
+        for (int j = 1; j < Ns; ++j) if (gridf[j] < gridf[best]) best = j;
+        sh[0] = -0.5 + (double)best / (double)(Ns - 1);
+    }
+    __syncthreads();
+    const double h = 1.0 / (double)(Ns - 1);
+    double phi = sh[0], lo = phi - h, hi = phi + h;
+    for (int it = 0; it < 60; ++it) {
+        double s[3];
+        fps_sums(Y, K, phi, tid, 256, s[0], s[1], s[2]);
+        block_sum<3>(s, scratch);
+        __syncthreads();
+        const double f1 = s[1], f2 = s[2];     // signs of df/dphi, d2f/dphi2 of f = -sum
+        if (f1 > 0.0) hi = phi; else lo = phi;
+        double nxt = (f2 > 0.0) ? phi - f1 / (PP_TWO_PI * f2) : 0.5 * (lo + hi);
+        if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);
+        const double step = fabs(nxt - phi);
+        phi = nxt;
+        if (step < 1e-13) break;
+    }
+    if (tid == 0) {
+        // wrap to [-0.5, 0.5) like phase_transform(..., mod=True)
+        if (fabs(phi) >= 0.5) { phi = fmod(phi, 1.0); if (phi < 0.0) phi += 1.0; }
+        if (phi >= 0.5) phi -= 1.0;
+        x0[i * 5] = phi;
+    }
+}
+
 }  // namespace pp

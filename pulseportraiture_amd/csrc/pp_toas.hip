@@ -69,8 +69,8 @@ struct ModelSlot {
     DevBuf mft, msum, mmax, mdc;
 };
 
-enum KernelFamily { KF_MODEL = 0, KF_XSPEC, KF_PREP, KF_ACCUM, KF_EVAL, KF_STEP, KF_FINAL, KF_SYNTH, KF_FPS, KF_COUNT };
-static const char* kFamilyNames[KF_COUNT] = {"model_fft", "xspec", "prep", "accum", "eval", "step", "finalize",
+enum KernelFamily { KF_MODEL = 0, KF_XSPEC, KF_PREP, KF_SEED, KF_ACCUM, KF_EVAL, KF_STEP, KF_FINAL, KF_SYNTH, KF_FPS, KF_COUNT };
+static const char* kFamilyNames[KF_COUNT] = {"model_fft", "xspec", "prep", "seed", "accum", "eval", "step", "finalize",
                                             "synth", "fit_phase_shift"};
 
 struct pp_ctx {
@@ -82,7 +82,7 @@ struct pp_ctx {
     // work buffers
     DevBuf data, X, sdraw, noise, wts, freqs, errs, mask, P, x0, nufit, nuout, slot, state, csum, partial;
     DevBuf o_params, o_errs, o_nu, o_cov, o_chi2, o_rchi2, o_snr, o_nfev, o_rc, o_scales, o_serrs, o_csnr,
-        o_f0, o_g0, o_H0, misc;
+        o_f0, o_g0, o_H0, misc, seedbuf;
     int* nactive_h = nullptr;   // pinned
     // options
     double harm_eps = 8.8817841970012523e-16;  // 2^-50
@@ -162,7 +162,7 @@ extern "C" int pp_destroy(pp_ctx* c) {
                       &c->errs, &c->mask, &c->P, &c->x0, &c->nufit, &c->nuout, &c->slot, &c->state, &c->csum,
                       &c->partial, &c->o_params, &c->o_errs, &c->o_nu, &c->o_cov, &c->o_chi2, &c->o_rchi2,
                       &c->o_snr, &c->o_nfev, &c->o_rc, &c->o_scales, &c->o_serrs, &c->o_csnr, &c->o_f0, &c->o_g0,
-                      &c->o_H0, &c->misc};
+                      &c->o_H0, &c->misc, &c->seedbuf};
     for (DevBuf* b : bufs) b->release();
     if (c->nactive_h) (void)hipHostFree(c->nactive_h);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -444,7 +444,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     }
 
     // ---- rFFT + cross-spectrum ----
-    const bool fuse = !scat;          // first evaluation folded into k_xspec
+    const bool fuse = !scat && in->seed_ns <= 0;   // first evaluation folded into k_xspec
     const bool tail = (in->errs == nullptr);
     XspecArgs xa;
     memset(&xa, 0, sizeof xa);
@@ -501,6 +501,17 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     }
     fa.o_f0 = c->o_f0.as<double>(); fa.o_g0 = c->o_g0.as<double>(); fa.o_H0 = c->o_H0.as<double>();
 
+    if (in->seed_ns > 0) {
+        if (Kt > 256 * PP_SEED_KPT) return fail(PP_EINVAL, "seed: Kt %d too large", Kt);
+        if ((rc = c->seedbuf.reserve(((size_t)ns * nchunk + ns) * Kt * sizeof(cplx)))) return rc;
+        cplx* ypart = c->seedbuf.as<cplx>();
+        cplx* ywork = ypart + (size_t)ns * nchunk * Kt;
+        Prof pr(c, KF_SEED);
+        hipLaunchKernelGGL(k_seed_accum, dim3(nchunk, ns), dim3(256), 0, c->stream, fa, ypart);
+        hipLaunchKernelGGL(k_seed_fit, dim3(ns), dim3(256), 0, c->stream, fa, (const cplx*)ypart, ywork,
+                           c->x0.as<double>(), (int)in->seed_ns);
+        HIP_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_init_state, dim3((ns + 63) / 64), dim3(64), 0, c->stream, fa);
     HIP_TRY(hipGetLastError());
     // ---- trust-region iterations: evaluation + step, until every subint is done

@@ -106,12 +106,13 @@ class Engine(object):
     def fit_batch(self, data, freqs, P, init_params, errs=None, nu_fits=None,
                   nu_outs=None, fit_flags=(1, 1, 0, 0, 0), log10_tau=False,
                   option=0, is_toa=True, model_slot=None, chan_mask=None,
-                  per_channel=True, objective=False):
+                  per_channel=True, objective=False, seed_ns=0):
         """Fit nsub subints.  data: [nsub,nchan,nbin] numpy array (f64/f32) or
         CUDA tensor.  freqs: [nchan] or [nsub,nchan].  Returns a dict of arrays
         (see include/pp_toas.h pp_fit_out).  errs / chan_mask may be CUDA
         tensors [nsub,nchan]; per_channel="device" leaves scales, scale_errs and
-        channel_snrs in HBM as CUDA tensors instead of copying them out."""
+        channel_snrs in HBM as CUDA tensors instead of copying them out.
+        seed_ns > 0 replaces init_params[:, 0] by a phase seeded on the device."""
         if _is_device_array(data):
             nsub, nchan, nbin = (int(s) for s in data.shape)
             if not data.is_contiguous():
@@ -183,6 +184,7 @@ class Engine(object):
             fin.fit_flags[j] = 1 if fit_flags[j] else 0
         fin.log10_tau = int(bool(log10_tau))
         fin.option, fin.is_toa = int(option), int(bool(is_toa))
+        fin.seed_ns = int(seed_ns)
 
         res = dict(params=np.empty((nsub, 5)), param_errs=np.empty((nsub, 5)),
                    nu_refs=np.empty((nsub, 3)), cov=np.empty((nsub, 5, 5)),

@@ -1,0 +1,531 @@
+"""Reference-shaped wideband TOA driver: `GetTOAs` / `TOA` (pptoas.py:31-743).
+
+`GetTOAs.get_TOAs` keeps the reference's arguments and result attributes but
+replaces the per-subint Python loop (pptoas.py:344-489) by ONE batched device
+call per archive: all good subints go to the engine as a [nsub, nchan, nbin]
+batch with a channel mask (the per-subint ok_ichans), the phase seed
+(pptoas.py:421-457) and the fit run in HIP kernels, and the TOA bookkeeping
+(pptoas.py:528-721) is done here on the host.
+
+PSRFITS I/O needs PSRCHIVE, which is outside this package: `datafiles` are
+`DataBunch` objects with the fields of the reference's `load_data`
+(pplib.py:2803-2813) -- see `data_from_arrays` -- or `.npz` files holding them.
+"""
+import sys
+import time
+
+import numpy as np
+
+from . import gmodel
+from .engine import default_engine
+from .pplib import DataBunch, guess_fit_freq, scattering_alpha
+
+max_nfile = 999
+rm_baseline = True
+
+
+# ---------------------------------------------------------------------------
+# epochs: integer day + fraction of a day (PSRCHIVE's MJD keeps day, seconds
+# and fractional seconds; a float64 fraction resolves 1e-16 d = 9 ps)
+# ---------------------------------------------------------------------------
+class MJD(object):
+    def __init__(self, day=0, frac=0.0):
+        if isinstance(day, MJD):
+            day, frac = day._day, day._frac
+        elif not isinstance(day, (int, np.integer)):
+            whole = np.floor(day)
+            day, frac = int(whole), float(day - whole) + float(frac)
+        carry = np.floor(frac)
+        self._day = int(day) + int(carry)
+        self._frac = float(frac - carry)
+
+    def intday(self):
+        return self._day
+
+    def fracday(self):
+        return self._frac
+
+    def in_days(self):
+        return self._day + self._frac
+
+    def __add__(self, other):
+        other = other if isinstance(other, MJD) else MJD(other)
+        return MJD(self._day + other._day, self._frac + other._frac)
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        other = other if isinstance(other, MJD) else MJD(other)
+        return MJD(self._day - other._day, self._frac - other._frac)
+
+    def __repr__(self):
+        return "MJD(%d%s)" % (self._day, ("%.15f" % self._frac)[1:])
+
+
+class TOA(object):
+    """TOA attributes bundled together (pptoas.py:31-73)."""
+
+    def __init__(self, archive, frequency, MJD, TOA_error, telescope,
+                 telescope_code, DM=None, DM_error=None, flags={}):
+        self.archive = archive
+        self.frequency = frequency
+        self.MJD = MJD
+        self.TOA_error = TOA_error
+        self.telescope = telescope
+        self.telescope_code = telescope_code
+        self.DM = DM
+        self.DM_error = DM_error
+        self.flags = flags
+        for flag in flags.keys():
+            setattr(self, flag, flags[flag])
+
+    def write_TOA(self, inf_is_zero=True, outfile=None):
+        write_TOAs(self, inf_is_zero=inf_is_zero, outfile=outfile, append=True)
+
+
+def toa_string(toa, inf_is_zero=True):
+    """One loosely IPTA-formatted TOA line (pplib.py:3465-3497)."""
+    freq = 0.0 if (toa.frequency == np.inf and inf_is_zero) else toa.frequency
+    s = "%s %.8f %d" % (toa.archive, freq, toa.MJD.intday()) + \
+        ("%.15f   %.3f  %s" % (toa.MJD.fracday(), toa.TOA_error,
+                               toa.telescope_code))[1:]
+    if toa.DM is not None:
+        s += " -pp_dm %.7f" % toa.DM
+    if toa.DM_error is not None:
+        s += " -pp_dme %.7f" % toa.DM_error
+    for flag, value in toa.flags.items():
+        if value is None:
+            continue
+        if hasattr(value, "lower"):
+            s += " -%s %s" % (flag, value)
+        elif 'int' in str(type(value)):
+            s += " -%s %d" % (flag, value)
+        elif flag.find("_cov") >= 0:
+            s += " -%s %.1e" % (flag, value)
+        elif flag.find("phs") >= 0:
+            s += " -%s %.8f" % (flag, value)
+        elif flag.find("flux") >= 0:
+            s += " -%s %.5f" % (flag, value)
+        else:
+            s += " -%s %.3f" % (flag, value)
+    return s
+
+
+def write_TOAs(TOAs, inf_is_zero=True, SNR_cutoff=0.0, outfile=None, append=True):
+    """Write TOAs to file or stdout (pplib.py:3445-3503); TOAs below the S/N
+    cutoff (or without an snr flag) are skipped like filter_TOAs does."""
+    toas = TOAs if hasattr(TOAs, "__len__") else [TOAs]
+    toas = [t for t in toas if hasattr(t, "snr") and t.snr >= SNR_cutoff]
+    lines = [toa_string(t, inf_is_zero) for t in toas]
+    if outfile is not None:
+        with open(outfile, 'a' if append else 'w') as of:
+            for line in lines:
+                of.write(line + "\n")
+    else:
+        for line in lines:
+            print(line)
+
+
+def data_from_arrays(subints, freqs, Ps, epochs, weights=None, noise_stds=None,
+                     SNRs=None, DM=0.0, dmc=0, doppler_factors=None,
+                     backend_delay=0.0, telescope="GBT", telescope_code="1",
+                     backend="GUPPI", frontend="Rcvr", bw=None, nu0=None,
+                     subtimes=None, parallactic_angles=None, source="noname",
+                     filename="arrays"):
+    """Build the DataBunch `load_data` would return (pplib.py:2650-2814) from
+    arrays: subints[nsub,npol,nchan,nbin], freqs[nsub,nchan], Ps[nsub], epochs
+    (MJD objects or floats).  Zero-weight channels are excluded like the
+    reference does (pplib.py:2755-2757); noise defaults to the power-spectrum
+    estimate per channel (get_noise_PS), computed on the device."""
+    subints = np.asarray(subints)
+    if subints.ndim == 3:
+        subints = subints[:, None]
+    nsub, npol, nchan, nbin = subints.shape
+    freqs = np.broadcast_to(np.asarray(freqs, dtype=np.float64), (nsub, nchan)).copy()
+    weights = np.ones((nsub, nchan)) if weights is None else \
+        np.asarray(weights, dtype=np.float64)
+    ok_ichans = [np.where(weights[i] > 0)[0] for i in range(nsub)]
+    ok_isubs = np.array([i for i in range(nsub) if len(ok_ichans[i])], dtype=int)
+    if SNRs is None:
+        SNRs = np.ones((nsub, npol, nchan))
+    epochs = [e if isinstance(e, MJD) else MJD(e) for e in epochs]
+    Ps = np.asarray(Ps, dtype=np.float64)
+    if doppler_factors is None:
+        doppler_factors = np.ones(nsub)
+    if subtimes is None:
+        subtimes = np.zeros(nsub)
+    if parallactic_angles is None:
+        parallactic_angles = np.zeros(nsub)
+    if bw is None:
+        bw = (freqs[0].max() - freqs[0].min()) * nchan / max(nchan - 1, 1)
+    if nu0 is None:
+        nu0 = freqs[0].mean()
+    from .pplib import get_bin_centers
+    return DataBunch(
+        subints=subints, freqs=freqs, weights=weights, noise_stds=noise_stds,
+        SNRs=np.asarray(SNRs, dtype=np.float64), Ps=Ps, epochs=epochs,
+        ok_isubs=ok_isubs, ok_ichans=ok_ichans, DM=DM, dmc=dmc,
+        doppler_factors=np.asarray(doppler_factors, dtype=np.float64), nbin=nbin,
+        nchan=nchan, nsub=nsub, npol=npol, phases=get_bin_centers(nbin),
+        backend_delay=backend_delay, telescope=telescope,
+        telescope_code=telescope_code, backend=backend, frontend=frontend, bw=bw,
+        nu0=nu0, subtimes=np.asarray(subtimes, dtype=np.float64),
+        integration_length=float(np.sum(subtimes)),
+        parallactic_angles=np.asarray(parallactic_angles, dtype=np.float64),
+        source=source, filename=filename, masks=(weights > 0)[:, None, :, None])
+
+
+def _load(datafile):
+    if isinstance(datafile, dict):
+        return datafile, datafile.get("filename", "arrays")
+    if str(datafile).endswith(".npz"):
+        z = np.load(datafile, allow_pickle=True)
+        kw = {k: z[k] for k in z.files}
+        for k in ("DM", "dmc", "backend_delay", "telescope", "telescope_code",
+                  "backend", "frontend", "source"):
+            if k in kw:
+                kw[k] = kw[k].item()
+        kw.setdefault("filename", str(datafile))
+        return data_from_arrays(**kw), str(datafile)
+    raise RuntimeError("Cannot load_data(%s): PSRFITS archives need PSRCHIVE; pass a "
+                       "DataBunch (data_from_arrays) or an .npz of its fields." % datafile)
+
+
+class GetTOAs(object):
+    """Measure wideband TOAs and DMs (pptoas.py:75-1419, the get_TOAs path)."""
+
+    def __init__(self, datafiles, modelfile, quiet=False):
+        if isinstance(datafiles, (list, tuple)):
+            self.datafiles = list(datafiles)
+        elif isinstance(datafiles, str) and not datafiles.endswith(".npz"):
+            self.datafiles = [line.rstrip("\n") for line in open(datafiles)]
+        else:
+            self.datafiles = [datafiles]
+        if len(self.datafiles) > max_nfile:
+            print("Too many archives.  See/change max_nfile(=%d) in pptoas.py." % max_nfile)
+            sys.exit()
+        self.is_FITS_model = False
+        self.modelfile = modelfile
+        for name in ("obs", "doppler_fs", "nu0s", "nu_fits", "nu_refs", "ok_idatafiles",
+                     "ok_isubs", "epochs", "MJDs", "Ps", "phis", "phi_errs", "TOAs",
+                     "TOA_errs", "DM0s", "DMs", "DM_errs", "DeltaDM_means",
+                     "DeltaDM_errs", "GMs", "GM_errs", "taus", "tau_errs", "alphas",
+                     "alpha_errs", "scales", "scale_errs", "snrs", "channel_snrs",
+                     "profile_fluxes", "profile_flux_errs", "fluxes", "flux_errs",
+                     "flux_freqs", "red_chi2s", "channel_red_chi2s", "covariances",
+                     "nfevals", "rcs", "fit_durations", "order", "TOA_list",
+                     "zap_channels"):
+            setattr(self, name, [])
+        self.instrumental_response_dict = self.ird = \
+            {'DM': 0.0, 'wids': [], 'irf_types': []}
+        self.quiet = quiet
+
+    # -- template ----------------------------------------------------------
+    def _model_for(self, freqs_row, nbin, P, unscattered=False):
+        if isinstance(self.modelfile, dict):
+            mdl = self.modelfile
+        else:
+            mdl = gmodel.read_gmodel(self.modelfile)
+        self.model_name, self.ngauss = mdl["name"], mdl["ngauss"]
+        self.model_code, self.model_nu_ref = mdl["code"], mdl["nu_ref"]
+        self.gparams, self.alpha = mdl["params"], mdl["alpha"]
+        if unscattered:
+            mdl = dict(mdl)
+            mdl["params"] = mdl["params"].copy()
+            mdl["params"][1] = 0.0
+        return gmodel.gaussian_portrait(mdl, freqs_row, nbin, P)
+
+    def get_TOAs(self, datafile=None, tscrunch=False, nu_refs=None, DM0=None,
+                 bary=True, fit_DM=True, fit_GM=False, fit_scat=False,
+                 log10_tau=True, scat_guess=None, fix_alpha=False,
+                 print_phase=False, print_flux=False, print_parangle=False,
+                 add_instrumental_response=False, addtnl_toa_flags={},
+                 method='trust-ncg', bounds=None, nu_fits=None, show_plot=False,
+                 quiet=None):
+        """Same arguments as the reference (pptoas.py:150-156).  Not supported
+        here: tscrunch, add_instrumental_response, print_flux, show_plot (they
+        raise) -- they live outside the fit path."""
+        if quiet is None:
+            quiet = self.quiet
+        if tscrunch or add_instrumental_response or print_flux or show_plot:
+            raise NotImplementedError("tscrunch / instrumental response / flux / "
+                                      "plots are outside the accelerated path")
+        if method not in ('trust-ncg', 'Newton-CG', 'TNC'):
+            print("Method '%s' is not implemented." % method)
+            sys.exit()
+        self.nfit = 1 + int(fit_DM) + int(fit_GM) + 2 * int(fit_scat) - int(fix_alpha)
+        self.fit_phi, self.fit_DM, self.fit_GM = True, fit_DM, fit_GM
+        self.fit_tau = self.fit_alpha = fit_scat
+        if fit_scat:
+            self.fit_alpha = not fix_alpha
+        self.fit_flags = [1, int(self.fit_DM), int(self.fit_GM), int(self.fit_tau),
+                          int(self.fit_alpha)]
+        self.log10_tau = log10_tau if fit_scat else False
+        log10_tau = self.log10_tau
+        if (self.fit_GM or fit_scat) and not quiet:
+            print("You are using an experimental functionality of pptoas!")
+        self.scat_guess = scat_guess
+        self.DM0, self.bary = DM0, bary
+        self.tscrunch = tscrunch
+        self.add_instrumental_response = add_instrumental_response
+        start = time.time()
+        datafiles = self.datafiles if datafile is None else [datafile]
+        eng = default_engine()
+        for iarch, datafile in enumerate(datafiles):
+            try:
+                data, fname = _load(datafile)
+            except RuntimeError as err:
+                if not quiet:
+                    print("Cannot load_data(%s).  Skipping it." % datafile)
+                    print(err)
+                continue
+            if not len(data.ok_isubs):
+                if not quiet:
+                    print("No subints to fit for %s.  Skipping it." % fname)
+                continue
+            self.ok_idatafiles.append(iarch)
+            d = data
+            nsub, nchan, nbin = d.nsub, d.nchan, d.nbin
+            ok_isubs = np.asarray(d.ok_isubs, dtype=int)
+            source = d.source if d.source is not None else "noname"
+            obs = DataBunch(telescope=d.telescope, backend=d.backend, frontend=d.frontend)
+            DM_stored = d.DM
+            DM0_arch = DM_stored if self.DM0 is None else self.DM0
+            MJDs = np.array([e.in_days() for e in d.epochs], dtype=np.double)
+
+            # ---- batch marshalling: good subints, channel masks, templates ----
+            nok = len(ok_isubs)
+            mask = np.zeros((nok, nchan), dtype=np.uint8)
+            nu_fit_arr = np.zeros((nok, 3))
+            nu_ref_arr = np.full((nok, 3), np.nan)
+            x0 = np.zeros((nok, 5))
+            flags_per = []
+            slots, slot_of = {}, np.zeros(nok, dtype=np.int32)
+            errs = None if d.noise_stds is None else \
+                np.ascontiguousarray(np.asarray(d.noise_stds)[ok_isubs, 0], dtype=np.float64)
+            for j, isub in enumerate(ok_isubs):
+                ich = np.asarray(d.ok_ichans[isub], dtype=int)
+                mask[j, ich] = 1
+                freqsx = d.freqs[isub, ich]
+                key = d.freqs[isub].tobytes() + np.float64(d.Ps[isub]).tobytes() \
+                    if fit_scat else d.freqs[isub].tobytes()
+                if key not in slots:
+                    if len(slots) >= 64:
+                        raise NotImplementedError("more than 64 distinct frequency rows "
+                                                  "in one archive")
+                    slots[key] = len(slots)
+                    eng.set_model(self._model_for(d.freqs[isub], nbin, d.Ps[isub],
+                                                  unscattered=fit_scat), slot=slots[key])
+                slot_of[j] = slots[key]
+                if nu_fits is None:
+                    nu_fit = guess_fit_freq(freqsx, d.SNRs[isub, 0, ich])
+                    nu_fit_arr[j] = nu_fit
+                else:
+                    nu_fit_arr[j] = [nu_fits[0], nu_fits[0], nu_fits[-1]]
+                if nu_refs is not None:
+                    nu_ref_arr[j] = [nu_refs[0], nu_refs[0], nu_refs[-1]]
+                    if bary and nu_refs[-1]:
+                        nu_ref_arr[j, 2] = nu_refs[-1] / d.doppler_factors[isub]
+                # initial guesses (pptoas.py:421-460); the phase comes from the
+                # device seed
+                tau_guess, alpha_guess = 0.0, 0.0
+                if fit_scat:
+                    P = d.Ps[isub]
+                    if self.scat_guess is not None:
+                        tau_s, tau_ref, alpha_guess = self.scat_guess
+                        tau_guess = (tau_s / P) * (nu_fit_arr[j, 2] / tau_ref) ** alpha_guess
+                    else:
+                        alpha_guess = self.alpha if hasattr(self, 'alpha') else scattering_alpha
+                        tau_guess = (self.gparams[1] / P) * \
+                            (nu_fit_arr[j, 2] / self.model_nu_ref) ** alpha_guess
+                    if log10_tau:
+                        if tau_guess == 0.0:
+                            tau_guess = nbin ** -1
+                        tau_guess = np.log10(tau_guess)
+                x0[j] = [0.0, DM_stored, 0.0, tau_guess, alpha_guess]
+                if len(freqsx) == 1:
+                    fl = [1, 0, 0, 0, 0]
+                elif len(freqsx) == 2 and self.fit_DM and self.fit_GM:
+                    fl = list(self.fit_flags)
+                    fl[2] = 0
+                else:
+                    fl = list(self.fit_flags)
+                flags_per.append(tuple(fl))
+            port = np.ascontiguousarray(np.asarray(d.subints)[ok_isubs, 0])
+            # ---- one device call per distinct flag set (normally one) ----
+            res = None
+            for fl in sorted(set(flags_per)):
+                sel = np.array([k for k, f in enumerate(flags_per) if f == fl])
+                r = eng.fit_batch(port[sel], d.freqs[ok_isubs][sel], d.Ps[ok_isubs][sel],
+                                  x0[sel], errs=None if errs is None else errs[sel],
+                                  nu_fits=nu_fit_arr[sel], nu_outs=nu_ref_arr[sel],
+                                  fit_flags=fl, log10_tau=log10_tau, option=0,
+                                  is_toa=True, model_slot=slot_of[sel],
+                                  chan_mask=mask[sel], seed_ns=100)
+                if res is None:
+                    res = {k: (np.zeros((nok,) + v.shape[1:], dtype=v.dtype)
+                               if isinstance(v, np.ndarray) else v) for k, v in r.items()}
+                    res["duration"] = 0.0
+                for k, v in r.items():
+                    if isinstance(v, np.ndarray):
+                        res[k][sel] = v
+                res["duration"] += r["duration"]
+            fit_duration = res["duration"]
+
+            # ---- TOA bookkeeping on the host (pptoas.py:528-721) ----
+            phis = np.zeros(nsub); phi_errs = np.zeros(nsub)
+            TOAs = np.zeros(nsub, dtype="object"); TOA_errs = np.zeros(nsub, dtype="object")
+            DMs = np.zeros(nsub); DM_errs = np.zeros(nsub)
+            GMs = np.zeros(nsub); GM_errs = np.zeros(nsub)
+            taus = np.zeros(nsub); tau_errs = np.zeros(nsub)
+            alphas = np.zeros(nsub); alpha_errs = np.zeros(nsub)
+            scales = np.zeros([nsub, nchan]); scale_errs = np.zeros([nsub, nchan])
+            snrs = np.zeros(nsub); channel_snrs = np.zeros([nsub, nchan])
+            red_chi2s = np.zeros(nsub)
+            covariances = np.zeros([nsub, self.nfit, self.nfit])
+            nfevals = np.zeros(nsub, dtype="int"); rcs = np.zeros(nsub, dtype="int")
+            nu_fits_out = list(np.zeros([nsub, 3])); nu_refs_out = list(np.zeros([nsub, 3]))
+            for j, isub in enumerate(ok_isubs):
+                fl = flags_per[j]
+                P = d.Ps[isub]
+                p, e = res["params"][j].copy(), res["param_errs"][j]
+                ifit = np.where(fl)[0]
+                cov = res["cov"][j][np.ix_(ifit, ifit)]
+                TOA_MJD = d.epochs[isub] + MJD(0, (p[0] * P + d.backend_delay) / (3600 * 24.))
+                TOA_err = e[0] * P * 1e6   # [us]
+                df = d.doppler_factors[isub] if self.bary else 1.0
+                DM_out, GM_out = p[1], p[2]
+                if self.bary:
+                    if fl[1]:
+                        DM_out *= df
+                    if fl[2]:
+                        GM_out *= df ** 3
+                nu_fits_out[isub] = list(nu_fit_arr[j])
+                nu_refs_out[isub] = list(res["nu_refs"][j])
+                phis[isub], phi_errs[isub] = p[0], e[0]
+                TOAs[isub], TOA_errs[isub] = TOA_MJD, TOA_err
+                DMs[isub], DM_errs[isub] = DM_out, e[1]
+                GMs[isub], GM_errs[isub] = GM_out, e[2]
+                taus[isub], tau_errs[isub] = p[3], e[3]
+                alphas[isub], alpha_errs[isub] = p[4], e[4]
+                nfevals[isub], rcs[isub] = res["nfeval"][j], res["return_code"][j]
+                ich = np.asarray(d.ok_ichans[isub], dtype=int)
+                scales[isub, ich] = res["scales"][j, ich]
+                scale_errs[isub, ich] = res["scale_errs"][j, ich]
+                snrs[isub] = res["snr"][j]
+                channel_snrs[isub, ich] = res["channel_snrs"][j, ich]
+                if cov.shape == covariances[isub].shape:
+                    covariances[isub] = cov
+                else:
+                    for ii, a_ in enumerate(ifit):
+                        for jj, b_ in enumerate(ifit):
+                            if a_ < self.nfit and b_ < self.nfit:
+                                covariances[isub][a_, b_] = cov[ii, jj]
+                red_chi2s[isub] = res["red_chi2"][j]
+                freqsx = d.freqs[isub, ich]
+                toa_flags = {}
+                DM_flag, DM_err_flag = (DM_out, e[1]) if fl[1] else (None, None)
+                if fl[2]:
+                    toa_flags['gm'] = GM_out
+                    toa_flags['gm_err'] = e[2]
+                if fl[3]:
+                    if log10_tau:
+                        toa_flags['scat_time'] = 10 ** p[3] * P / df * 1e6
+                        toa_flags['log10_scat_time'] = p[3] + np.log10(P / df)
+                        toa_flags['log10_scat_time_err'] = e[3]
+                    else:
+                        toa_flags['scat_time'] = p[3] * P / df * 1e6
+                        toa_flags['scat_time_err'] = e[3] * P / df * 1e6
+                    toa_flags['scat_ref_freq'] = res["nu_refs"][j, 2] * df
+                    toa_flags['scat_ind'] = p[4]
+                if fl[4]:
+                    toa_flags['scat_ind_err'] = e[4]
+                toa_flags['be'] = d.backend
+                toa_flags['fe'] = d.frontend
+                toa_flags['f'] = d.frontend + "_" + d.backend
+                toa_flags['nbin'] = int(nbin)
+                toa_flags['nch'] = int(nchan)
+                toa_flags['nchx'] = int(len(freqsx))
+                toa_flags['bw'] = freqsx.max() - freqsx.min()
+                toa_flags['chbw'] = abs(d.bw) / nchan
+                toa_flags['subint'] = int(isub)
+                toa_flags['tobs'] = d.subtimes[isub]
+                toa_flags['fratio'] = freqsx.max() / freqsx.min()
+                toa_flags['tmplt'] = self.modelfile if isinstance(self.modelfile, str) \
+                    else self.model_name
+                toa_flags['snr'] = res["snr"][j]
+                if nu_refs is not None and fl[0] and fl[1]:
+                    toa_flags['phi_DM_cov'] = cov[0, 1]
+                toa_flags['gof'] = res["red_chi2"][j]
+                if print_phase:
+                    toa_flags['phs'] = p[0]
+                    toa_flags['phs_err'] = e[0]
+                if print_parangle:
+                    toa_flags['par_angle'] = d.parallactic_angles[isub]
+                for k, v in addtnl_toa_flags.items():
+                    toa_flags[k] = v
+                self.TOA_list.append(TOA(fname, res["nu_refs"][j, 0], TOA_MJD, TOA_err,
+                                         d.telescope, d.telescope_code, DM_flag,
+                                         DM_err_flag, toa_flags))
+            # mean DM offset of the archive (pptoas.py:665-682)
+            DeltaDMs = DMs - DM0_arch
+            if np.all(DM_errs[ok_isubs]):
+                DM_weights = DM_errs[ok_isubs] ** -2
+            else:
+                DM_weights = np.ones(len(ok_isubs))
+            DeltaDM_mean, DeltaDM_var = np.average(DeltaDMs[ok_isubs], weights=DM_weights,
+                                                   returned=True)
+            DeltaDM_var = DeltaDM_var ** -1
+            if len(ok_isubs) > 1:
+                DeltaDM_var *= np.sum(((DeltaDMs[ok_isubs] - DeltaDM_mean) ** 2) *
+                                      DM_weights) / (len(ok_isubs) - 1)
+            self.order.append(fname)
+            self.obs.append(obs)
+            self.doppler_fs.append(d.doppler_factors)
+            self.nu0s.append(d.nu0)
+            self.nu_fits.append(nu_fits_out)
+            self.nu_refs.append(nu_refs_out)
+            self.ok_isubs.append(ok_isubs)
+            self.epochs.append(d.epochs)
+            self.MJDs.append(MJDs)
+            self.Ps.append(d.Ps)
+            self.phis.append(phis)
+            self.phi_errs.append(phi_errs)
+            self.TOAs.append(TOAs)
+            self.TOA_errs.append(TOA_errs)
+            self.DM0s.append(DM0_arch)
+            self.DMs.append(DMs)
+            self.DM_errs.append(DM_errs)
+            self.DeltaDM_means.append(DeltaDM_mean)
+            self.DeltaDM_errs.append(DeltaDM_var ** 0.5)
+            self.GMs.append(GMs)
+            self.GM_errs.append(GM_errs)
+            self.taus.append(taus)
+            self.tau_errs.append(tau_errs)
+            self.alphas.append(alphas)
+            self.alpha_errs.append(alpha_errs)
+            self.scales.append(scales)
+            self.scale_errs.append(scale_errs)
+            self.snrs.append(snrs)
+            self.channel_snrs.append(channel_snrs)
+            self.profile_fluxes.append(np.zeros([nsub, nchan]))
+            self.profile_flux_errs.append(np.zeros([nsub, nchan]))
+            self.fluxes.append(np.zeros(nsub))
+            self.flux_errs.append(np.zeros(nsub))
+            self.flux_freqs.append(np.zeros(nsub))
+            self.covariances.append(covariances)
+            self.red_chi2s.append(red_chi2s)
+            self.nfevals.append(nfevals)
+            self.rcs.append(rcs)
+            self.fit_durations.append(fit_duration)
+            if not quiet:
+                print("--------------------------")
+                print(fname)
+                print("~%.6f sec/TOA" % (fit_duration / len(ok_isubs)))
+                print("Med. TOA error is %.3f us" % (np.median(phi_errs[ok_isubs]) *
+                                                     d.Ps.mean() * 1e6))
+        tot_duration = time.time() - start
+        if not quiet and len(self.ok_isubs):
+            print("--------------------------")
+            print("Total time: %.2f sec, ~%.4f sec/TOA" %
+                  (tot_duration, tot_duration / sum(len(o) for o in self.ok_isubs)))

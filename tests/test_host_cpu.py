@@ -55,3 +55,20 @@ def test_philox_known_answers():
     z0, z1 = philox_normal_pairs(20260101, 7, 3, 50000)
     assert abs(z0.mean()) < 0.02 and abs(z0.std() - 1) < 0.02
     assert abs(z1.mean()) < 0.02 and abs(np.corrcoef(z0, z1)[0, 1]) < 0.02
+
+
+def test_mjd_and_tim_line():
+    from pulseportraiture_amd.pptoas import MJD, TOA, toa_string
+    t = MJD(55000, 0.999999999) + MJD(0, 2e-9)
+    assert t.intday() == 55001 and abs(t.fracday() - 1e-9) < 1e-15
+    assert MJD(55000.25).intday() == 55000 and MJD(55000.25).fracday() == 0.25
+    toa = TOA("a.fits", np.inf, MJD(55000, 0.123456789012345), 0.1234, "GBT", "1",
+              DM=34.5678901, DM_error=1.2e-4,
+              flags={"be": "GUPPI", "nbin": 256, "snr": 123.4567, "phi_DM_cov": 1.23e-12,
+                     "phs": 0.123456789, "flux": 1.234567, "skip": None})
+    line = toa_string(toa)
+    # format of pplib.py:3465-3497
+    assert line == ("a.fits 0.00000000 55000.123456789012345   0.123  1 -pp_dm 34.5678901"
+                    " -pp_dme 0.0001200 -be GUPPI -nbin 256 -snr 123.457"
+                    " -phi_DM_cov 1.2e-12 -phs 0.12345679 -flux 1.23457")
+    assert toa.snr == 123.4567 and toa.be == "GUPPI"
