@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart) {
     const double DM = a.x0[i * 5 + 1], GM = a.x0[i * 5 + 2];
     const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
     const double* wts = a.wts + (size_t)i * a.nchan;
+    const int* ktv = a.ktab ? a.ktab[a.slot ? a.slot[i] : 0] : nullptr;
     cplx y[PP_SEED_KPT];
 #pragma unroll
     for (int j = 0; j < PP_SEED_KPT; ++j) y[j] = make_double2(0.0, 0.0);
@@ -234,10 +235,11 @@ __global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart) {
         phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
         const double phin = DM * p1 + GM * p2;
         const cplx* xrow = a.X + ((size_t)i * a.nchan + n) * a.Kt;
+        const int ktn = ktv ? ktv[n] : a.Kt;
 #pragma unroll
         for (int j = 0; j < PP_SEED_KPT; ++j) {
             const int k = tid + 1 + 256 * j;
-            if (k <= a.Kt) {
+            if (k <= ktn) {
                 const cplx z = cmul(xrow[k - 1], unit_phasor((double)k, phin));
                 y[j].x = fma(w, z.x, y[j].x);
                 y[j].y = fma(w, z.y, y[j].y);

@@ -32,6 +32,8 @@ struct XspecArgs {
     const void* data;         // [nsub][nchan][B]
     const cplx* const* mft;   // [nslot] device table of model FT base pointers
     const cplx* mft0;         // slot 0's base (no pointer chase when slot == nullptr)
+    const int* const* ktab;   // [nslot] per-channel kept-harmonic counts, or nullptr (= Kt)
+    const int* kt0;           // slot 0's
     const int* slot;          // [nsub] or nullptr
     cplx* X;                  // [nsub][nchan][Kt]
     double* sdraw;            // [nsub][nchan] sum_{k>=1} |d|^2
@@ -53,6 +55,7 @@ struct FitArgs {
     const cplx* X;
     const cplx* const* mft;
     const double* const* msum;
+    const int* const* ktab;   // per-slot per-channel kept harmonics, nullptr = Kt everywhere
     const int* slot;
     const double* freqs; long long freqs_stride;
     const double* wts;        // [nsub][nchan] 1/(sigma^2 B/2), 0 = masked
@@ -113,16 +116,21 @@ __global__ __launch_bounds__(FftPlan<M>::T) void k_model_fft(ModelFftArgs a) {
     }
 }
 
-// kcut = max over channels of the last k (1-based) with |m_nk|^2 > eps2*max
+// per channel: last harmonic k (1-based) with |m_nk|^2 > eps2 * max_k |m_nk|^2,
+// rounded up to a multiple of 64 (>= 64, <= M) -> kt[n]; kmax = max_n kt[n]
 __global__ void k_model_kcut(const cplx* mft, const double* mmax, int nchan, int M, double eps2,
-                             int* kcut) {
+                             int* kt, int* kmax) {
     const int n = blockIdx.x;
     const double thr = eps2 * mmax[n];
     int last = 0;
     for (int k = 1 + threadIdx.x; k <= M; k += blockDim.x)
         if (cnorm(mft[(size_t)n * M + k - 1]) > thr) last = k;
     for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(kcut, last);
+    if ((threadIdx.x & 63) == 0) {
+        const int v = min(M, max(64, ((last + 63) / 64) * 64));
+        kt[n] = v;
+        atomicMax(kmax, v);
+    }
 }
 
 // --------------------------------------------------------------------------
@@ -167,6 +175,8 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         // needed late: vector-memory results return in order, so these must be
         // older than the prefetch of the next row or consuming them would drain it.
         const cplx* mrow = (a.slot ? a.mft[a.slot[i]] : a.mft0) + (size_t)n * M;
+        // harmonics this channel's template keeps (multiple of 64)
+        const int ktn = a.ktab ? (a.slot ? a.ktab[a.slot[i]] : a.kt0)[n] : a.Kt;
         double fP = 1.0, fnu = 1.0, fnuDM = 1.0, fnuGM = 1.0, fx0 = 0.0, fx1 = 0.0, fx2 = 0.0;
         if (FUSE) {
             fP = a.P[i]; fnu = a.freqs[(size_t)i * a.freqs_stride + n];
@@ -224,17 +234,17 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             for (int q = 1; q < NW; q <<= 1) wst = cmul(wst, wst);
         }
         cplx wb = wb0;
-        for (int kb = 1 + tid; kb <= a.Kt; kb += 4 * T) {
+        for (int kb = 1 + tid; kb <= ktn; kb += 4 * T) {
             cplx mv[4];   // four independent model loads in flight per chunk
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = kb + j * T;
-                mv[j] = (k <= a.Kt) ? mrow[k - 1] : make_double2(0.0, 0.0);
+                mv[j] = (k <= ktn) ? mrow[k - 1] : make_double2(0.0, 0.0);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = kb + j * T;
-                if (k <= a.Kt) {
+                if (k <= ktn) {
                     const cplx d = rfft_harmonic_w<M>(lds, wb, k);
                     const cplx x = cmulc(d, mv[j]);
                     xrow[k - 1] = x;
@@ -593,6 +603,7 @@ __global__ __launch_bounds__(256) void k_eval_fast(FitArgs a) {
     const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
     const double* wts = a.wts + (size_t)i * a.nchan;
     const double* msum = a.msum[a.slot ? a.slot[i] : 0];
+    const int* ktv = a.ktab ? a.ktab[a.slot ? a.slot[i] : 0] : nullptr;
     const int trial = 1 - st.cur;
     double* csum = a.csum + ((size_t)trial * a.nsub + i) * a.nchan * a.ncs;
     double accA = 0.0;
@@ -609,10 +620,16 @@ __global__ __launch_bounds__(256) void k_eval_fast(FitArgs a) {
         const cplx* xrow = a.X + ((size_t)i * a.nchan + n) * a.Kt;
         double s0a = 0, s1a = 0, s2a = 0, s0b = 0, s1b = 0, s2b = 0;
         double k = (double)(l + 1);
+        const int ktn = ktv ? ktv[n] : a.Kt;
         if (w != 0.0) {
 #pragma unroll 1
-            for (int j = l; j < a.Kt; j += 4 * LPC) {
-                const cplx x0 = xrow[j], x1 = xrow[j + LPC], x2 = xrow[j + 2 * LPC], x3 = xrow[j + 3 * LPC];
+            for (int j = l; j < ktn; j += 4 * LPC) {
+                // ktn is a multiple of 64 except for nbin < 128 (ktn = M = 16 or 32)
+                const cplx zero = make_double2(0.0, 0.0);
+                const cplx x0 = xrow[j];
+                const cplx x1 = (j + LPC < ktn) ? xrow[j + LPC] : zero;
+                const cplx x2 = (j + 2 * LPC < ktn) ? xrow[j + 2 * LPC] : zero;
+                const cplx x3 = (j + 3 * LPC < ktn) ? xrow[j + 3 * LPC] : zero;
                 const cplx e1 = cmul(e0, w1), e2 = cmul(e0, w2), e3 = cmul(e0, w3);
                 const cplx z0 = cmul(x0, e0), z1 = cmul(x1, e1), z2 = cmul(x2, e2), z3 = cmul(x3, e3);
                 const double k1 = k + LPC, k2 = k + 2 * LPC, k3 = k + 3 * LPC;

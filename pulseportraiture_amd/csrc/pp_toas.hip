@@ -66,7 +66,7 @@ struct DevBuf {
 struct ModelSlot {
     bool set = false;
     int nchan = 0, nbin = 0, Kt = 0;
-    DevBuf mft, msum, mmax, mdc;
+    DevBuf mft, msum, mmax, mdc, kt;
 };
 
 enum KernelFamily { KF_MODEL = 0, KF_XSPEC, KF_PREP, KF_SEED, KF_ACCUM, KF_EVAL, KF_STEP, KF_FINAL, KF_SYNTH, KF_FPS, KF_COUNT };
@@ -78,7 +78,7 @@ struct pp_ctx {
     hipStream_t stream = nullptr;
     std::map<int, DevBuf> twiddles;   // by nbin
     ModelSlot slots[PP_MAX_SLOTS];
-    DevBuf mft_table, msum_table;     // device arrays of slot base pointers
+    DevBuf mft_table, msum_table, kt_table;   // device arrays of slot base pointers
     // work buffers
     DevBuf data, X, sdraw, noise, wts, freqs, errs, mask, P, x0, nufit, nuout, slot, state, csum, partial;
     DevBuf o_params, o_errs, o_nu, o_cov, o_chi2, o_rchi2, o_snr, o_nfev, o_rc, o_scales, o_serrs, o_csnr,
@@ -145,6 +145,9 @@ extern "C" int pp_create(int device_id, pp_ctx** out) {
     if (rc) return rc;
     rc = c->msum_table.reserve(sizeof(void*) * PP_MAX_SLOTS);
     if (rc) return rc;
+    rc = c->kt_table.reserve(sizeof(void*) * PP_MAX_SLOTS);
+    if (rc) return rc;
+    HIP_TRY(hipMemset(c->kt_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
     HIP_TRY(hipMemset(c->mft_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
     HIP_TRY(hipMemset(c->msum_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
     *out = c;
@@ -157,8 +160,8 @@ extern "C" int pp_destroy(pp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     resolve_spans(c);
     for (auto& kv : c->twiddles) kv.second.release();
-    for (auto& s : c->slots) { s.mft.release(); s.msum.release(); s.mmax.release(); s.mdc.release(); }
-    DevBuf* bufs[] = {&c->mft_table, &c->msum_table, &c->data, &c->X, &c->sdraw, &c->noise, &c->wts, &c->freqs,
+    for (auto& s : c->slots) { s.mft.release(); s.msum.release(); s.mmax.release(); s.mdc.release(); s.kt.release(); }
+    DevBuf* bufs[] = {&c->mft_table, &c->msum_table, &c->kt_table, &c->data, &c->X, &c->sdraw, &c->noise, &c->wts, &c->freqs,
                       &c->errs, &c->mask, &c->P, &c->x0, &c->nufit, &c->nuout, &c->slot, &c->state, &c->csum,
                       &c->partial, &c->o_params, &c->o_errs, &c->o_nu, &c->o_cov, &c->o_chi2, &c->o_rchi2,
                       &c->o_snr, &c->o_nfev, &c->o_rc, &c->o_scales, &c->o_serrs, &c->o_csnr, &c->o_f0, &c->o_g0,
@@ -282,6 +285,7 @@ extern "C" int pp_model_set(pp_ctx* c, int slot, const void* portrait, int dtype
     if ((rc = s.msum.reserve((size_t)nchan * sizeof(double)))) return rc;
     if ((rc = s.mmax.reserve((size_t)nchan * sizeof(double)))) return rc;
     if ((rc = s.mdc.reserve((size_t)nchan * sizeof(double)))) return rc;
+    if ((rc = s.kt.reserve((size_t)nchan * sizeof(int)))) return rc;
     const void* dport = portrait;
     if (!on_device) {
         if ((rc = c->data.reserve((size_t)nchan * nbin * esz))) return rc;
@@ -300,26 +304,27 @@ extern "C" int pp_model_set(pp_ctx* c, int slot, const void* portrait, int dtype
         });
     }
     HIP_TRY(hipGetLastError());
-    // harmonic truncation
+    // harmonic truncation: per-channel kept harmonics kt[n] and their maximum
     int Kt = M;
-    if (c->harm_eps > 0.0) {
+    {
         if ((rc = c->misc.reserve(256))) return rc;
         HIP_TRY(hipMemsetAsync(c->misc.p, 0, sizeof(int), c->stream));
+        // eps = 0 keeps everything: threshold -1 makes every harmonic "significant"
+        const double eps2 = c->harm_eps > 0.0 ? c->harm_eps * c->harm_eps : -1.0;
         hipLaunchKernelGGL(k_model_kcut, dim3(nchan), dim3(64), 0, c->stream, s.mft.as<cplx>(), s.mmax.as<double>(),
-                           nchan, M, c->harm_eps * c->harm_eps, c->misc.as<int>());
+                           nchan, M, eps2, s.kt.as<int>(), c->misc.as<int>());
         HIP_TRY(hipGetLastError());
-        int kcut = 0;
-        HIP_TRY(hipMemcpyAsync(&kcut, c->misc.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&Kt, c->misc.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        Kt = std::min(M, std::max(64, ((kcut + 63) / 64) * 64));
-    } else {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        Kt = std::min(M, std::max(64, Kt));
     }
     s.set = true; s.nchan = nchan; s.nbin = nbin; s.Kt = Kt;
     void* pm = s.mft.p;
     void* ps = s.msum.p;
     HIP_TRY(hipMemcpy((char*)c->mft_table.p + sizeof(void*) * slot, &pm, sizeof(void*), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy((char*)c->msum_table.p + sizeof(void*) * slot, &ps, sizeof(void*), hipMemcpyHostToDevice));
+    void* pk = s.kt.p;
+    HIP_TRY(hipMemcpy((char*)c->kt_table.p + sizeof(void*) * slot, &pk, sizeof(void*), hipMemcpyHostToDevice));
     return PP_OK;
 }
 
@@ -450,6 +455,8 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     memset(&xa, 0, sizeof xa);
     xa.data = ddata; xa.mft = (const cplx* const*)c->mft_table.p;
     xa.mft0 = c->slots[0].mft.as<cplx>();
+    xa.ktab = scat ? nullptr : (const int* const*)c->kt_table.p;   // scattering keeps every harmonic
+    xa.kt0 = c->slots[0].kt.as<int>();
     xa.slot = in->model_slot ? c->slot.as<int>() : nullptr;
     xa.X = c->X.as<cplx>(); xa.sdraw = c->sdraw.as<double>(); xa.noise = c->noise.as<double>();
     xa.twB = tw; xa.nsub = ns; xa.nchan = C; xa.Kt = Kt;
@@ -479,6 +486,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.X = c->X.as<cplx>();
     fa.mft = (const cplx* const*)c->mft_table.p;
     fa.msum = (const double* const*)c->msum_table.p;
+    fa.ktab = scat ? nullptr : (const int* const*)c->kt_table.p;
     fa.slot = in->model_slot ? c->slot.as<int>() : nullptr;
     fa.freqs = c->freqs.as<double>(); fa.freqs_stride = in->freqs_stride ? C : 0;
     fa.wts = c->wts.as<double>(); fa.sdraw = c->sdraw.as<double>();

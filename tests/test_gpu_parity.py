@@ -448,3 +448,24 @@ def test_get_TOAs_matches_reference_caller(name):
     line = toa_string(t0)
     assert line.startswith("fake.fits ") and " -pp_dm " in line and " -snr " in line
     assert len(gt.TOA_list) == len(ok)
+
+
+@pytest.mark.parametrize("nbin", [32, 64, 128])
+def test_small_nbin_fits_match_oracle(eng, nbin):
+    """Shapes below the 64-harmonic granule of the truncated cross-spectrum."""
+    from oracle import pptoas_oracle as orc
+    from tests.synth_host import make_inputs, caller_guess, model_portrait
+    C = 8
+    freqs, model = model_portrait(C, nbin)
+    inp = make_inputs(C, nbin, 4242 + nbin, model=model, sigma=0.2)
+    gss = caller_guess(inp)
+    eng.set_model(model)
+    r = eng.fit_batch(inp["data"][None], freqs, inp["P"], gss["init_params"],
+                      errs=inp["errs"], nu_fits=[[gss["nu_fit"]] * 3],
+                      fit_flags=[1, 1, 0, 0, 0])
+    o = orc.fit_portrait_full(inp["data"], model, gss["init_params"], inp["P"], freqs,
+                              [gss["nu_fit"]] * 3, [None] * 3, inp["errs"], [1, 1, 0, 0, 0],
+                              log10_tau=False)
+    assert _dphi(r["params"][0, 0], o.phi) < PHI_BAR
+    assert abs(r["params"][0, 1] - o.DM) < DM_BAR
+    np.testing.assert_allclose(r["param_errs"][0, :2], o.param_errs[:2], rtol=1e-6)
