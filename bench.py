@@ -177,9 +177,21 @@ def main():
         per_step_s = fam_s / args.steps
         abytes = algorithmic_bytes_per_fit(C, B, s_bytes, nsub)
         achieved = abytes * nsub / per_step_s / 1e9
+        # HBM bytes per launch of that kernel from the PMC passes (FETCH_SIZE x2 +
+        # WRITE_SIZE, collected separately with rocprofv3 --pmc and committed under
+        # profiles/); null when no matching profile exists
+        traffic = None
+        try:
+            tp = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+            if (tp["workload"] == args.workload and tp["input_dtype"] == args.input_dtype
+                    and tp["kernel"] == fam):
+                traffic = tp["hbm_bytes_per_fit"] * nsub
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {"bound": "hbm", "kernel": fam, "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": abytes * nsub,
                     "algorithmic_bytes_per_fit": abytes,
                     "fits_per_launch_group": nsub,
                     "launches_per_step": fam_n / args.steps,

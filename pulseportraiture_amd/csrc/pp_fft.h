@@ -173,7 +173,8 @@ __device__ __forceinline__ void stage_load_lds(cplx (&v)[PER][R], const cplx* ld
 // tw[i] = W_M^(t - t%S) of this thread's i-th butterfly (unused in the last
 // stage): loop-invariant per thread, so callers hoist it out of their row loop.
 template <int M, int T, int R, int S, int PADLOG, int PER, typename TW>
-__device__ __forceinline__ void stage_finish(cplx (&v)[PER][R], cplx* lds, const TW& tw, int tid) {
+__device__ __forceinline__ void stage_finish(cplx (&v)[PER][R], cplx* lds, const TW& tw, int tid,
+                                             double* power = nullptr) {
     constexpr int NBF = StageGeom<M, T, R>::NBF;
     static_assert(PER == StageGeom<M, T, R>::PER, "register tile does not match the stage");
     constexpr bool LAST = (S * R == M);
@@ -196,6 +197,16 @@ __device__ __forceinline__ void stage_finish(cplx (&v)[PER][R], cplx* lds, const
                         if (j & b) v[i][j] = cmul(v[i][j], wp);
                     if (2 * b < R) wp = cmul(wp, wp);
                 }
+            }
+            if (LAST && power) {
+                // sum_{k=1}^{M-1} |Z_k|^2 + (Re Z_0 - Im Z_0)^2 = sum_{k=1}^{M} |d_k|^2
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    if (j == 0 && ob == 0) { const double dM = v[i][0].x - v[i][0].y; acc += dM * dM; }
+                    else acc += cnorm(v[i][j]);
+                }
+                *power += acc;
             }
             // pad(ob + S*j) = pad(ob) + j*(S + S/2^PADLOG) for S a multiple of the
             // padding period; for the first stage (S = 1, R = 2^PADLOG) it is
@@ -225,11 +236,11 @@ __device__ __forceinline__ void stage_twiddles(cplx (&tw)[PER], const cplx* __re
 
 // a later stage: LDS -> registers -> LDS
 template <int M, int T, int R, int S, int PADLOG, typename TW>
-__device__ __forceinline__ void stage_lds(cplx* lds, const TW& tw, int tid) {
+__device__ __forceinline__ void stage_lds(cplx* lds, const TW& tw, int tid, double* power = nullptr) {
     cplx v[StageGeom<M, T, R>::PER][R];
     stage_load_lds<M, T, R, PADLOG>(v, lds, tid);
     lds_sync<T>();     // every read of this stage before any in-place write
-    stage_finish<M, T, R, S, PADLOG>(v, lds, tw, tid);
+    stage_finish<M, T, R, S, PADLOG>(v, lds, tw, tid, power);
 }
 
 // Plans: T threads per row and up to four radices R1*R2*R3*R4 = M (1 = unused).
@@ -289,14 +300,17 @@ __device__ __forceinline__ void fft_first_stage(cplx* lds, cplx (&v)[PER1_][R1_]
 }
 
 // the remaining stages, LDS to LDS
+// `power` (optional) receives this thread's share of sum_{k=1}^{M} |d_k|^2, taken
+// from the last stage's registers.
 template <int M>
-__device__ __forceinline__ void fft_later_stages(cplx* lds, const RowTwiddles<M>& tw, int tid) {
+__device__ __forceinline__ void fft_later_stages(cplx* lds, const RowTwiddles<M>& tw, int tid,
+                                                 double* power = nullptr) {
     typedef FftPlan<M> P;
-    stage_lds<M, P::T, P::R2, P::R1, P::PADLOG>(lds, tw.t2, tid);
+    stage_lds<M, P::T, P::R2, P::R1, P::PADLOG>(lds, tw.t2, tid, power);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (P::R3 > 1) stage_lds<M, P::T, P::R3, P::R1 * P::R2, P::PADLOG>(lds, tw.t3, tid);
+    if constexpr (P::R3 > 1) stage_lds<M, P::T, P::R3, P::R1 * P::R2, P::PADLOG>(lds, tw.t3, tid, power);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (P::R4 > 1) stage_lds<M, P::T, P::R4, P::R1 * P::R2 * P::R3, P::PADLOG>(lds, tw.t3, tid);
+    if constexpr (P::R4 > 1) stage_lds<M, P::T, P::R4, P::R1 * P::R2 * P::R3, P::PADLOG>(lds, tw.t3, tid, power);
 }
 
 // Complex FFT of the M = B/2 packed pairs of one real row; result Z[0..M-1] is

@@ -146,6 +146,15 @@ __global__ void k_model_kcut(const cplx* mft, const double* mmax, int nchan, int
 // (errs == NULL).  FUSE: accumulate the evaluator's sums A0, A1, A2 at the
 // initial parameters while X is still in registers (saves one pass over X).
 // --------------------------------------------------------------------------
+#ifndef PP_SPLIT_U
+#define PP_SPLIT_U 4          // harmonics per thread processed together in the split loop
+#endif
+#ifndef PP_SD_FUSED
+#define PP_SD_FUSED 0         // S_d from the last stage's registers (else an LDS pass)
+#endif
+#ifndef PP_LATE_SCALARS
+#define PP_LATE_SCALARS 0     // load the per-row fit scalars right before the split
+#endif
 template <int M, typename Tin, bool TAIL, bool FUSE>
 __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void k_xspec(XspecArgs a) {
     constexpr int T = FftPlan<M>::T, R1 = FftPlan<M>::R1, PER1 = FftPlan<M>::PER1;
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         // harmonics this channel's template keeps (multiple of 64)
         const int ktn = a.ktab ? (a.slot ? a.ktab[a.slot[i]] : a.kt0)[n] : a.Kt;
         double fP = 1.0, fnu = 1.0, fnuDM = 1.0, fnuGM = 1.0, fx0 = 0.0, fx1 = 0.0, fx2 = 0.0;
-        if (FUSE) {
+        if (FUSE && !PP_LATE_SCALARS) {
             fP = a.P[i]; fnu = a.freqs[(size_t)i * a.freqs_stride + n];
             fnuDM = a.nu_fit[i * 3]; fnuGM = a.nu_fit[i * 3 + 1];
             fx0 = a.x0[i * 5]; fx1 = a.x0[i * 5 + 1]; fx2 = a.x0[i * 5 + 2];
@@ -200,14 +209,23 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);
         }
         __builtin_amdgcn_sched_barrier(0);
-        fft_later_stages<M>(lds, tw, tid);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- S_d from the packed transform ----
+        // ---- S_d comes out of the last stage's registers ----
         double sd = 0.0, tail = 0.0;
+#if PP_SD_FUSED
+        fft_later_stages<M>(lds, tw, tid, &sd);
+#else
+        fft_later_stages<M>(lds, tw, tid);
         for (int k = tid; k < M; k += T) {
             const cplx z = lds[lds_pad<PL>(k)];
             if (k == 0) { const double dM = z.x - z.y; sd += dM * dM; }
             else sd += cnorm(z);
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        if (FUSE && PP_LATE_SCALARS) {
+            fP = a.P[i]; fnu = a.freqs[(size_t)i * a.freqs_stride + n];
+            fnuDM = a.nu_fit[i * 3]; fnuGM = a.nu_fit[i * 3 + 1];
+            fx0 = a.x0[i * 5]; fx1 = a.x0[i * 5 + 1]; fx2 = a.x0[i * 5 + 2];
         }
         if (TAIL) {
             for (int k = kc + tid; k <= M; k += T) tail += cnorm(rfft_harmonic<M>(lds, a.twB, k));
@@ -234,15 +252,15 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             for (int q = 1; q < NW; q <<= 1) wst = cmul(wst, wst);
         }
         cplx wb = wb0;
-        for (int kb = 1 + tid; kb <= ktn; kb += 4 * T) {
-            cplx mv[4];   // four independent model loads in flight per chunk
+        for (int kb = 1 + tid; kb <= ktn; kb += PP_SPLIT_U * T) {
+            cplx mv[PP_SPLIT_U];   // independent model loads in flight per chunk
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < PP_SPLIT_U; ++j) {
                 const int k = kb + j * T;
                 mv[j] = (k <= ktn) ? mrow[k - 1] : make_double2(0.0, 0.0);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < PP_SPLIT_U; ++j) {
                 const int k = kb + j * T;
                 if (k <= ktn) {
                     const cplx d = rfft_harmonic_w<M>(lds, wb, k);
