@@ -86,11 +86,16 @@ struct SubState {
     double pred_red;   // predicted reduction of the pending proposal
     int hits_boundary;
     int iter, nfev, status, done, cur;  // cur: csum buffer of the accepted point
+    int fresh;         // the next evaluation is an initial one (no ratio test)
 };
 
 // number of per-subint accumulators of one evaluation: f, g[5], H upper[15]
 #define PP_NACC 21
 // raw per-channel sums kept for the post-fit stage
 #define PP_NCS 9   // A0 A1 A2 T1 T2 A1T S0 S1 S2
+// order of the per-channel Taylor model of C_n(phi_n) about the initial point:
+// A_0 .. A_PP_TJ (derivatives) + a rigorous remainder coefficient
+#define PP_TJ 10
+#define PP_TSTRIDE (PP_TJ + 2)
 
 }  // namespace pp

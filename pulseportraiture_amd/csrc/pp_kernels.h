@@ -67,6 +67,7 @@ struct FitArgs {
     SubState* st;
     double* csum;             // [2][nsub][nchan][ncs]
     int ncs;                  // 3 (no scattering) or 9
+    double* tay;              // [nsub][nchan][PP_TSTRIDE] Taylor model about x0 (no scattering)
     double* partial;          // [nsub][nchunk][PP_NACC]
     int nchunk, cpc;          // channels per chunk
     int* nactive;
@@ -351,7 +352,7 @@ __global__ void k_init_state(FitArgs a) {
     s.radius = 1.0;          // scipy initial_trust_radius
     s.pred_red = 0.0;
     s.hits_boundary = 0;
-    s.iter = 0; s.nfev = 0; s.status = PP_RC_MAXITER; s.done = 0; s.cur = 1;
+    s.iter = 0; s.nfev = 0; s.status = PP_RC_MAXITER; s.done = 0; s.cur = 1; s.fresh = 1;
     if (i == 0) *a.nactive = a.nsub;
 }
 
@@ -815,6 +816,253 @@ __device__ inline void tr_subproblem(int n, const double* g, const double* H, do
     for (int i = 0; i < n; ++i) p[i] = z[i];
 }
 
+// --------------------------------------------------------------------------
+// One pass over X that makes further passes unnecessary (no scattering): the
+// per-channel cross-correlation C_n(phi_n + d) = Re sum_k X_nk e^{2 pi i k (phi_n + d)}
+// is an entire function of d, so its derivatives at the initial point
+//   A_j = Re sum_k (2 pi i k)^j X_nk e^{2 pi i k phi_n},  j = 0..PP_TJ
+// give C_n, C_n', C_n'' anywhere nearby, with the rigorous remainder
+//   |R| <= Bn |d|^(PP_TJ+1-m) / (PP_TJ+1-m)!,  Bn = sum_k (|Re X|+|Im X|) (2 pi k)^(PP_TJ+1)
+// for the m-th derivative.  k_taylor_solve then runs the whole Newton solve on
+// these 12 numbers per channel and certifies the truncation error; subints that
+// move too far for the certificate fall back to evaluations over X.
+// Same work layout as k_eval_fast.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_eval_moments(FitArgs a) {
+    constexpr int LPC = 16;
+    const int i = blockIdx.y, chunk = blockIdx.x;
+    const SubState& st = a.st[i];
+    const int tid = threadIdx.x, g = tid / LPC, l = tid % LPC;
+    const double phi = st.xe[0], DM = st.xe[1], GM = st.xe[2];
+    const double P = a.P[i];
+    const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1];
+    const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
+    const double* wts = a.wts + (size_t)i * a.nchan;
+    const int* ktv = a.ktab ? a.ktab[a.slot ? a.slot[i] : 0] : nullptr;
+    double* tay = a.tay + (size_t)i * a.nchan * PP_TSTRIDE;
+    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan);
+    const int src = ((tid & 63) & ~(LPC - 1)) | (LPC - 1);
+    for (int n = n0 + g; n < n1; n += 256 / LPC) {
+        const double w = wts[n];
+        double p1, p2;
+        phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
+        const double phin = phi + DM * p1 + GM * p2;
+        cplx e0 = unit_phasor((double)(l + 1), phin);
+        const cplx w1 = make_double2(__shfl(e0.x, src, 64), __shfl(e0.y, src, 64));
+        const cplx w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+        const cplx* xrow = a.X + ((size_t)i * a.nchan + n) * a.Kt;
+        const int ktn = ktv ? ktv[n] : a.Kt;
+        double s[PP_TSTRIDE];
+#pragma unroll
+        for (int j = 0; j < PP_TSTRIDE; ++j) s[j] = 0.0;
+        double k = (double)(l + 1);
+        if (w != 0.0) {
+#pragma unroll 1
+            for (int jj = l; jj < ktn; jj += 4 * LPC) {
+                // four independent 16-byte loads in flight per lane
+                const cplx zero = make_double2(0.0, 0.0);
+                cplx xv[4];
+                xv[0] = xrow[jj];
+                xv[1] = (jj + LPC < ktn) ? xrow[jj + LPC] : zero;
+                xv[2] = (jj + 2 * LPC < ktn) ? xrow[jj + 2 * LPC] : zero;
+                xv[3] = (jj + 3 * LPC < ktn) ? xrow[jj + 3 * LPC] : zero;
+                cplx ev[4];
+                ev[0] = e0; ev[1] = cmul(e0, w1); ev[2] = cmul(e0, w2); ev[3] = cmul(e0, w3);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const cplx z = cmul(xv[q], ev[q]);
+                    const double kap = PP_TWO_PI * (k + (double)(q * LPC));
+                    const double kap2 = kap * kap;
+                    double ur = z.x, ui = z.y * kap;     // even / odd orders advance by kap^2
+#pragma unroll
+                    for (int j = 0; j <= PP_TJ; j += 2) {
+                        s[j] += ur;
+                        ur *= kap2;
+                        if (j + 1 <= PP_TJ) { s[j + 1] += ui; ui *= kap2; }
+                    }
+                    // remainder coefficient: (2 pi k)^(PP_TJ+1) (|Re X| + |Im X|)
+                    static_assert(PP_TJ % 2 == 0, "PP_TJ must be even");
+                    double pw = kap;
+#pragma unroll
+                    for (int j = 0; j < PP_TJ / 2; ++j) pw *= kap2;
+                    s[PP_TJ + 1] = fma(pw, fabs(xv[q].x) + fabs(xv[q].y), s[PP_TJ + 1]);
+                }
+                e0 = cmul(e0, w4);
+                k += 4.0 * LPC;
+            }
+        }
+        // Re(i^j z): +Re, -Im, -Re, +Im, ...
+#pragma unroll
+        for (int j = 0; j < PP_TSTRIDE; ++j) {
+            double v = group_sum<LPC>(s[j]);
+            if (j <= PP_TJ && ((j & 3) == 1 || (j & 3) == 2)) v = -v;
+            if (l == (j % LPC)) tay[(size_t)n * PP_TSTRIDE + j] = v;
+        }
+    }
+}
+
+// Horner evaluation of the shifted sums A0', A1', A2' from the Taylor model
+__device__ __forceinline__ void taylor_shift(const double* t, double d, double& A0, double& A1, double& A2) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int j = PP_TJ; j >= 0; --j) {
+        a0 = fma(a0, d * (1.0 / (double)(j + 1)), t[j]);
+        if (j >= 1) a1 = fma(a1, d * (1.0 / (double)j), t[j]);
+        if (j >= 2) a2 = fma(a2, d * (1.0 / (double)(j - 1)), t[j]);
+    }
+    // a0 = sum_j t[j] d^j/j!  (Horner with the 1/(j+1) factors);  a1, a2 the same
+    // series started at t[1], t[2]
+    A0 = a0; A1 = a1; A2 = a2;
+}
+
+// Newton solve on the Taylor model, one 256-thread block per subint.
+__global__ __launch_bounds__(256) void k_taylor_solve(FitArgs a) {
+    const int i = blockIdx.x, tid = threadIdx.x;
+    SubState& st = a.st[i];
+    __shared__ double scratch[4 * 12];
+    __shared__ double shx[8];
+    const double P = a.P[i];
+    const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1];
+    const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
+    const double* wts = a.wts + (size_t)i * a.nchan;
+    const double* msum = a.msum[a.slot ? a.slot[i] : 0];
+    const double* tay = a.tay + (size_t)i * a.nchan * PP_TSTRIDE;
+    const int* fl = a.flags;
+    int idx[3], nf = 0;
+    for (int j = 0; j < 3; ++j) if (fl[j]) idx[nf++] = j;
+    double dx[3] = {0.0, 0.0, 0.0};      // displacement from x0 in (phi, DM, GM)
+    double fprev = INFINITY, f0 = 0.0;
+    double g[5], H[25];
+    bool ok = true;
+    int it;
+    for (it = 0; it < 24; ++it) {
+        double acc[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) acc[j] = 0.0;
+        for (int n = tid; n < a.nchan; n += 256) {
+            const double w = wts[n];
+            if (w == 0.0) continue;
+            double p1, p2;
+            phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
+            const double d = dx[0] + dx[1] * p1 + dx[2] * p2;
+            double A0, A1, A2;
+            taylor_shift(tay + (size_t)n * PP_TSTRIDE, d, A0, A1, A2);
+            const double S0 = msum[n], r = A0 / S0;
+            const double F = -w * A0 * r, Gp = -2.0 * w * r * A1;
+            const double Lpp = -2.0 * w * (A1 * A1 / S0 + r * A2);
+            acc[0] += F;
+            acc[1] += Gp; acc[2] += Gp * p1; acc[3] += Gp * p2;
+            acc[4] += Lpp; acc[5] += Lpp * p1; acc[6] += Lpp * p2;
+            acc[7] += Lpp * p1 * p1; acc[8] += Lpp * p1 * p2; acc[9] += Lpp * p2 * p2;
+        }
+        block_sum<10>(acc, scratch);
+        __syncthreads();
+        const double f = acc[0];
+        for (int j = 0; j < 5; ++j) g[j] = 0.0;
+        for (int j = 0; j < 25; ++j) H[j] = 0.0;
+        g[0] = fl[0] ? acc[1] : 0.0; g[1] = fl[1] ? acc[2] : 0.0; g[2] = fl[2] ? acc[3] : 0.0;
+        const double hh[3][3] = {{acc[4], acc[5], acc[6]}, {acc[5], acc[7], acc[8]}, {acc[6], acc[8], acc[9]}};
+        for (int r_ = 0; r_ < 3; ++r_)
+            for (int c_ = 0; c_ < 3; ++c_) H[r_ * 5 + c_] = (fl[r_] && fl[c_]) ? hh[r_][c_] : 0.0;
+        if (it == 0) {
+            f0 = f;
+            if (tid == 0) {
+                st.f0 = f;
+                for (int j = 0; j < 5; ++j) st.g0[j] = g[j];
+                for (int j = 0; j < 25; ++j) st.H0[j] = H[j];
+            }
+        }
+        if (!isfinite(f)) { ok = false; break; }
+        // Newton step on the fit subspace (every thread computes the same)
+        double gs[3], Hs[9], p[3];
+        for (int r_ = 0; r_ < nf; ++r_) {
+            gs[r_] = g[idx[r_]];
+            for (int c_ = 0; c_ < nf; ++c_) Hs[r_ * nf + c_] = H[idx[r_] * 5 + idx[c_]];
+        }
+        double mg[3];
+        for (int r_ = 0; r_ < nf; ++r_) mg[r_] = -gs[r_];
+        if (!chol_solve(nf, Hs, mg, p)) { ok = false; break; }
+        double Hp[3];
+        for (int r_ = 0; r_ < nf; ++r_) Hp[r_] = vdot(nf, Hs + r_ * nf, p);
+        const double pred = -(vdot(nf, gs, p) + 0.5 * vdot(nf, p, Hp));
+        if (f > fprev + 1e-9 * fabs(fprev)) { ok = false; break; }   // not descending: leave it to the trust region
+        fprev = f;
+        if (!(pred > 64.0 * 2.220446049250313e-16 * fabs(f))) {
+            // converged to the rounding of f: take the last step and stop
+            for (int r_ = 0; r_ < nf; ++r_) dx[idx[r_]] += p[r_];
+            break;
+        }
+        for (int r_ = 0; r_ < nf; ++r_) dx[idx[r_]] += p[r_];
+    }
+    if (it >= 24) ok = false;
+    // ---- certificate: truncation error of the gradient, in parameter units ----
+    double ev[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // err bounds g_phi, g_DM, g_GM; H00; max |d|
+    if (ok) {
+        double jf = 1.0;
+        for (int j = 2; j <= PP_TJ; ++j) jf *= (double)j;   // PP_TJ!
+        for (int n = tid; n < a.nchan; n += 256) {
+            const double w = wts[n];
+            if (w == 0.0) continue;
+            double p1, p2;
+            phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
+            const double d = dx[0] + dx[1] * p1 + dx[2] * p2;
+            const double* t = tay + (size_t)n * PP_TSTRIDE;
+            // remainder of A1's series (one derivative): Bn |d|^PP_TJ / PP_TJ!
+            const double e1 = t[PP_TJ + 1] * pow(fabs(d), (double)PP_TJ) / jf;
+            const double r = fabs(t[0] / msum[n]) + 1e-300;
+            const double ge = 2.0 * w * r * e1 * 1.5;   // + remainder through A0 (smaller by |d|/PP_TJ)
+            ev[0] += ge; ev[1] += ge * fabs(p1); ev[2] += ge * fabs(p2);
+            ev[4] = fmax(ev[4], fabs(d));
+        }
+        double mx = ev[4];
+        mx = group_max<64>(mx);
+        block_sum<4>(reinterpret_cast<double(&)[4]>(ev), scratch);
+        __syncthreads();
+        if ((tid & 63) == 0) shx[tid >> 6] = mx;
+        __syncthreads();
+        mx = fmax(fmax(shx[0], shx[1]), fmax(shx[2], shx[3]));
+        // position error <= gradient error / curvature, per fitted parameter
+        const double tol[3] = {1e-12, 1e-10, 1e-7};   // turns, pc cm^-3, GM units
+        for (int j = 0; j < 3; ++j)
+            if (fl[j]) {
+                const double hjj = fabs(H[j * 5 + j]);
+                if (!(ev[j] <= tol[j] * hjj)) ok = false;
+            }
+        if (!(mx < 0.02)) ok = false;
+    }
+    __syncthreads();
+    if (ok) {
+        // accepted point = x0 + dx; publish its sums for the post-fit stage
+        const int buf = 1 - st.cur;
+        double* csum = a.csum + ((size_t)buf * a.nsub + i) * a.nchan * a.ncs;
+        double fsum = 0.0;
+        for (int n = tid; n < a.nchan; n += 256) {
+            double p1, p2;
+            phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
+            const double d = dx[0] + dx[1] * p1 + dx[2] * p2;
+            double A0, A1, A2;
+            taylor_shift(tay + (size_t)n * PP_TSTRIDE, d, A0, A1, A2);
+            csum[(size_t)n * 3] = A0; csum[(size_t)n * 3 + 1] = A1; csum[(size_t)n * 3 + 2] = A2;
+            if (wts[n] != 0.0) fsum += -wts[n] * A0 * A0 / msum[n];
+        }
+        double fv[1] = {fsum};
+        block_sum<1>(fv, scratch);
+        if (tid == 0) {
+            for (int j = 0; j < 3; ++j) st.x[j] = st.xe[j] + dx[j];
+            st.x[3] = st.xe[3]; st.x[4] = st.xe[4];
+            st.f = fv[0];
+            for (int j = 0; j < 5; ++j) st.g[j] = g[j];
+            for (int j = 0; j < 25; ++j) st.H[j] = H[j];
+            st.cur = buf; st.nfev = 1; st.iter = it; st.status = PP_RC_STALL; st.done = 1; st.fresh = 0;
+            atomicSub(a.nactive, 1);
+        }
+    } else if (tid == 0) {
+        // fall back to evaluations over X, starting from the initial point
+        st.fresh = 1;
+    }
+    (void)f0;
+}
+
 // unpack the 21 accumulators into g[5], H[25] with the fit flags applied
 // (pptoaslib.py:573, 629-630)
 __device__ inline void unpack_acc(const double* acc, const int* flags, double& f, double* g, double* H) {
@@ -848,7 +1096,8 @@ __global__ __launch_bounds__(64) void k_step(FitArgs a) {
     bool finite = isfinite(f);
     for (int j = 0; j < 5; ++j) finite = finite && isfinite(g[j]);
     for (int j = 0; j < 25; ++j) finite = finite && isfinite(H[j]);
-    const bool first = (s.nfev == 0);
+    const bool first = (s.fresh != 0);
+    s.fresh = 0;
     s.nfev += 1;
     bool done = false;
     if (first) {

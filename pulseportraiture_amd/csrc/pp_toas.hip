@@ -69,8 +69,8 @@ struct ModelSlot {
     DevBuf mft, msum, mmax, mdc, kt;
 };
 
-enum KernelFamily { KF_MODEL = 0, KF_XSPEC, KF_PREP, KF_SEED, KF_ACCUM, KF_EVAL, KF_STEP, KF_FINAL, KF_SYNTH, KF_FPS, KF_COUNT };
-static const char* kFamilyNames[KF_COUNT] = {"model_fft", "xspec", "prep", "seed", "accum", "eval", "step", "finalize",
+enum KernelFamily { KF_MODEL = 0, KF_XSPEC, KF_PREP, KF_SEED, KF_ACCUM, KF_EVAL, KF_TAYLOR, KF_STEP, KF_FINAL, KF_SYNTH, KF_FPS, KF_COUNT };
+static const char* kFamilyNames[KF_COUNT] = {"model_fft", "xspec", "prep", "seed", "accum", "eval", "taylor_solve", "step", "finalize",
                                             "synth", "fit_phase_shift"};
 
 struct pp_ctx {
@@ -82,13 +82,14 @@ struct pp_ctx {
     // work buffers
     DevBuf data, X, sdraw, noise, wts, freqs, errs, mask, P, x0, nufit, nuout, slot, state, csum, partial;
     DevBuf o_params, o_errs, o_nu, o_cov, o_chi2, o_rchi2, o_snr, o_nfev, o_rc, o_scales, o_serrs, o_csnr,
-        o_f0, o_g0, o_H0, misc, seedbuf;
+        o_f0, o_g0, o_H0, misc, seedbuf, tay;
     int* nactive_h = nullptr;   // pinned
     // options
     double harm_eps = 8.8817841970012523e-16;  // 2^-50
     int max_iter = 64;
     int profile = 0;
     int check_every = 1;
+    int use_taylor = 1;
     double max_work_bytes = 96e9;
     // profiling
     struct Span { int fam; hipEvent_t a, b; };
@@ -165,7 +166,7 @@ extern "C" int pp_destroy(pp_ctx* c) {
                       &c->errs, &c->mask, &c->P, &c->x0, &c->nufit, &c->nuout, &c->slot, &c->state, &c->csum,
                       &c->partial, &c->o_params, &c->o_errs, &c->o_nu, &c->o_cov, &c->o_chi2, &c->o_rchi2,
                       &c->o_snr, &c->o_nfev, &c->o_rc, &c->o_scales, &c->o_serrs, &c->o_csnr, &c->o_f0, &c->o_g0,
-                      &c->o_H0, &c->misc, &c->seedbuf};
+                      &c->o_H0, &c->misc, &c->seedbuf, &c->tay};
     for (DevBuf* b : bufs) b->release();
     if (c->nactive_h) (void)hipHostFree(c->nactive_h);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -191,6 +192,7 @@ extern "C" int pp_set_option(pp_ctx* c, const char* name, double value) {
     else if (n == "profile") c->profile = (int)value;
     else if (n == "check_every") c->check_every = std::max(1, (int)value);
     else if (n == "max_work_bytes") c->max_work_bytes = value;
+    else if (n == "taylor") c->use_taylor = (int)value;
     else return fail(PP_EINVAL, "pp_set_option: unknown option '%s'", name);
     return PP_OK;
 }
@@ -416,6 +418,10 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     if ((rc = upload(c, c->nuout, nuout_h.data() + (size_t)s0 * 3, (size_t)ns * 24))) return rc;
     if (in->model_slot) if ((rc = upload(c, c->slot, in->model_slot + s0, (size_t)ns * 4))) return rc;
     // ---- work ----
+    // no scattering: one moments pass over X + a Taylor-model solve replace the
+    // evaluation loop (fallback: the loop below); otherwise evaluate as usual
+    const bool taylor = !scat && c->max_iter > 0 && c->use_taylor;
+    const bool fuse = !scat && !taylor && in->seed_ns <= 0;   // first evaluation folded into k_xspec
     const int ncs = scat ? PP_NCS : 3;
     int nchunk = std::min(std::max(1, C / 64), std::max(1, (4096 + ns - 1) / ns));
     int cpc = (C + nchunk - 1) / nchunk;
@@ -428,6 +434,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     if ((rc = c->state.reserve((size_t)ns * sizeof(SubState)))) return rc;
     if ((rc = c->csum.reserve(2 * nc * ncs * 8))) return rc;
     if ((rc = c->partial.reserve((size_t)ns * nchunk * PP_NACC * 8))) return rc;
+    if (taylor) if ((rc = c->tay.reserve(nc * PP_TSTRIDE * 8))) return rc;
     if ((rc = c->misc.reserve(256))) return rc;
     if ((rc = c->o_params.reserve((size_t)ns * 40))) return rc;
     if ((rc = c->o_errs.reserve((size_t)ns * 40))) return rc;
@@ -449,7 +456,6 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     }
 
     // ---- rFFT + cross-spectrum ----
-    const bool fuse = !scat && in->seed_ns <= 0;   // first evaluation folded into k_xspec
     const bool tail = (in->errs == nullptr);
     XspecArgs xa;
     memset(&xa, 0, sizeof xa);
@@ -493,6 +499,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.P = c->P.as<double>(); fa.nu_fit = c->nufit.as<double>(); fa.nu_out = c->nuout.as<double>();
     fa.x0 = c->x0.as<double>(); fa.st = c->state.as<SubState>();
     fa.csum = c->csum.as<double>(); fa.ncs = ncs;
+    fa.tay = c->tay.as<double>();
     fa.partial = c->partial.as<double>(); fa.nchunk = nchunk; fa.cpc = cpc;
     fa.nactive = c->misc.as<int>();
     fa.o_params = c->o_params.as<double>(); fa.o_errs = c->o_errs.as<double>(); fa.o_nu = c->o_nu.as<double>();
@@ -522,8 +529,23 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     }
     hipLaunchKernelGGL(k_init_state, dim3((ns + 63) / 64), dim3(64), 0, c->stream, fa);
     HIP_TRY(hipGetLastError());
+    bool all_done = false;
+    if (taylor) {
+        {
+            Prof pr(c, KF_EVAL);
+            hipLaunchKernelGGL(k_eval_moments, dim3(nchunk, ns), dim3(256), 0, c->stream, fa);
+        }
+        {
+            Prof pr(c, KF_TAYLOR);
+            hipLaunchKernelGGL(k_taylor_solve, dim3(ns), dim3(256), 0, c->stream, fa);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(c->nactive_h, fa.nactive, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        all_done = (c->nactive_h[0] <= 0);
+    }
     // ---- trust-region iterations: evaluation + step, until every subint is done
-    const int max_evals = std::max(1, c->max_iter + 1);
+    const int max_evals = all_done ? 0 : std::max(1, c->max_iter + 1);
     for (int it = 0; it < max_evals; ++it) {
         if (it == 0 && fuse) {
             Prof pr(c, KF_ACCUM);

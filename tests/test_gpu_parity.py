@@ -469,3 +469,31 @@ def test_small_nbin_fits_match_oracle(eng, nbin):
     assert _dphi(r["params"][0, 0], o.phi) < PHI_BAR
     assert abs(r["params"][0, 1] - o.DM) < DM_BAR
     np.testing.assert_allclose(r["param_errs"][0, :2], o.param_errs[:2], rtol=1e-6)
+
+
+def test_poor_guess_falls_back_to_evaluations(eng):
+    """The Taylor-model solve certifies its own truncation error; a guess far
+    from the optimum must fail the certificate, fall back to evaluations over
+    the cross-spectrum and still land on the reference optimum.  With the
+    model solve disabled the answer must be the same."""
+    g = _load("fpf_128x512_phiDM_scint")
+    eng.set_model(g["model"])
+    kw = dict(errs=g["errs"], nu_fits=[list(g["nu_fits"])], fit_flags=[1, 1, 0, 0, 0])
+    good = eng.fit_batch(g["data"][None], g["freqs"], float(g["P"]), g["init_params"], **kw)
+    bad0 = g["init_params"].copy()
+    bad0[0] += 6e-3
+    bad0[1] += 4e-3
+    bad = eng.fit_batch(g["data"][None], g["freqs"], float(g["P"]), bad0, **kw)
+    eng.set_option("taylor", 0)
+    try:
+        plain = eng.fit_batch(g["data"][None], g["freqs"], float(g["P"]),
+                              g["init_params"], **kw)
+    finally:
+        eng.set_option("taylor", 1)
+    assert good["nfeval"][0] == 1 and bad["nfeval"][0] >= 3 and plain["nfeval"][0] >= 3
+    for r in (good, bad, plain):
+        assert _dphi(r["params"][0, 0], float(g["out_phi"])) < PHI_BAR
+        assert abs(r["params"][0, 1] - float(g["out_DM"])) < DM_BAR
+        np.testing.assert_allclose(r["param_errs"][0, :2], g["out_param_errs"][:2], rtol=1e-6)
+        np.testing.assert_allclose(r["chi2"][0], g["out_chi2"], rtol=1e-10)
+        np.testing.assert_allclose(r["scales"][0], g["out_scales"], rtol=1e-6, atol=1e-9)
