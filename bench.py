@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--seed", type=int, default=20260101)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1)
+    ap.add_argument("--harm-eps", type=float, default=None,
+                    help="override the harmonic-truncation threshold (experiments)")
     args = ap.parse_args()
 
     import torch
@@ -81,7 +83,8 @@ def main():
                              % args.gpus)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # launched by torchrun
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=device)
@@ -92,6 +95,8 @@ def main():
     s_bytes = 8 if args.input_dtype == "f64" else 4
 
     eng = Engine(local_rank)
+    if args.harm_eps is not None:
+        eng.set_option("harm_eps", args.harm_eps)
     freqs, model, P0 = gmodel.example_model(C, B)
     nharm = eng.set_model(model)
     # ---- synthetic batch, generated on the device (weak scaling: every rank
@@ -146,7 +151,7 @@ def main():
     def fence():
         eng.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -161,7 +166,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     eng.set_option("profile", 0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -220,7 +225,7 @@ def main():
                                                 log10_tau, res, args.cpu_sample,
                                                 model if not flags[3] else model)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -47,7 +47,7 @@ def gather_records(rec, counts=None, device=None, dst=0):
     initialised process group this is the identity."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return rec
     world, rank = dist.get_world_size(), dist.get_rank()
     if counts is None:
