@@ -417,6 +417,23 @@ __device__ __forceinline__ Local local_terms(const double* s /*9 raw sums*/, dou
     return L;
 }
 
+// accumulate one channel's local terms into the 21 per-subint sums
+__device__ __forceinline__ void accumulate_channel(const Local& L, const ChanGeom& cg, double (&c)[PP_NACC]) {
+    const double p1 = cg.p1, p2 = cg.p2;
+    c[0] = L.F;
+    c[1] = L.Gp; c[2] = L.Gp * p1; c[3] = L.Gp * p2;
+    c[4] = L.Gt * cg.q1; c[5] = L.Gt * cg.q2;
+    c[6] = L.Lpp; c[7] = L.Lpp * p1; c[8] = L.Lpp * p2;
+    c[9] = L.Lpt * cg.q1; c[10] = L.Lpt * cg.q2;
+    c[11] = L.Lpp * p1 * p1; c[12] = L.Lpp * p1 * p2;
+    c[13] = L.Lpt * p1 * cg.q1; c[14] = L.Lpt * p1 * cg.q2;
+    c[15] = L.Lpp * p2 * p2;
+    c[16] = L.Lpt * p2 * cg.q1; c[17] = L.Lpt * p2 * cg.q2;
+    c[18] = L.Ltt * cg.q1 * cg.q1 + L.Gt * cg.q11;
+    c[19] = L.Ltt * cg.q1 * cg.q2 + L.Gt * cg.q12;
+    c[20] = L.Ltt * cg.q2 * cg.q2 + L.Gt * cg.q22;
+}
+
 // --------------------------------------------------------------------------
 // chi^2 evaluator.  grid = (nchunk, nsub), 256 threads; 16 lanes per channel.
 // Each lane owns harmonics k = l+1, l+17, ... and advances its phasor by
@@ -442,9 +459,7 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
     const cplx* mft = a.mft[slot];
     const int trial = 1 - st.cur;
     double* csum = a.csum + ((size_t)trial * a.nsub + i) * a.nchan * a.ncs;
-    double acc[PP_NACC];
-#pragma unroll
-    for (int j = 0; j < PP_NACC; ++j) acc[j] = 0.0;
+    double accA = 0.0, accB = 0.0;   // lane l of a group owns sums l and 16+l of the 21
     const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan);
     for (int n = n0 + g; n < n1; n += 256 / LPC) {
         const double w = wts[n];
@@ -458,8 +473,12 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
         const cplx* xrow = a.X + ((size_t)i * a.nchan + n) * a.Kt;
         double s0 = 0, s1 = 0, s2 = 0, t1 = 0, t2 = 0, a1t = 0, S0 = 0, S1 = 0, S2 = 0;
         double k = (double)(l + 1);
+        // harmonics beyond the template's kept range carry |m_nk|^2 < 2^-100 of
+        // the channel's power: they drop out of S_n(tau) and of C_n alike
+        const int ktn = a.ktab ? a.ktab[slot][n] : a.Kt;
         if (w != 0.0) {
-            for (int j = l; j < a.Kt; j += LPC) {
+#pragma unroll 2
+            for (int j = l; j < ktn; j += LPC) {
                 const cplx x = xrow[j];
                 const cplx z = cmul(x, e);
                 if (!SCAT) {
@@ -510,58 +529,37 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
             cs[7] = -2.0 * group_sum<LPC>(S1);
             cs[8] = 2.0 * group_sum<LPC>(S2);
         }
-        if (l == 0) {
+        if (l < PP_NCS) {
             double* co = csum + (size_t)n * a.ncs;
-            if (a.ncs == 3) { co[0] = cs[0]; co[1] = cs[1]; co[2] = cs[2]; }
+            if (a.ncs == 3) { if (l < 3) co[l] = (l == 0) ? cs[0] : (l == 1 ? cs[1] : cs[2]); }
             else {
+                double v = cs[0];
 #pragma unroll
-                for (int j = 0; j < PP_NCS; ++j) co[j] = cs[j];
-            }
-            if (w != 0.0) {
-                const Local L = local_terms(cs, w);
-                const double p1 = cg.p1, p2 = cg.p2;
-                acc[0] += L.F;
-                acc[1] += L.Gp; acc[2] += L.Gp * p1; acc[3] += L.Gp * p2;
-                acc[4] += L.Gt * cg.q1; acc[5] += L.Gt * cg.q2;
-                acc[6] += L.Lpp; acc[7] += L.Lpp * p1; acc[8] += L.Lpp * p2;
-                acc[9] += L.Lpt * cg.q1; acc[10] += L.Lpt * cg.q2;
-                acc[11] += L.Lpp * p1 * p1; acc[12] += L.Lpp * p1 * p2;
-                acc[13] += L.Lpt * p1 * cg.q1; acc[14] += L.Lpt * p1 * cg.q2;
-                acc[15] += L.Lpp * p2 * p2;
-                acc[16] += L.Lpt * p2 * cg.q1; acc[17] += L.Lpt * p2 * cg.q2;
-                acc[18] += L.Ltt * cg.q1 * cg.q1 + L.Gt * cg.q11;
-                acc[19] += L.Ltt * cg.q1 * cg.q2 + L.Gt * cg.q12;
-                acc[20] += L.Ltt * cg.q2 * cg.q2 + L.Gt * cg.q22;
+                for (int j = 1; j < PP_NCS; ++j) v = (l == j) ? cs[j] : v;
+                co[l] = v;
             }
         }
-    }
-    if (l == 0) {
+        if (w != 0.0) {
+            const Local L = local_terms(cs, w);
+            double c[PP_NACC];
+            accumulate_channel(L, cg, c);
+            double ca = c[0], cb = c[16];
 #pragma unroll
-        for (int j = 0; j < PP_NACC; ++j) red[g * PP_NACC + j] = acc[j];
+            for (int u = 1; u < 16; ++u) ca = (l == u) ? c[u] : ca;
+#pragma unroll
+            for (int u = 1; u < PP_NACC - 16; ++u) cb = (l == u) ? c[16 + u] : cb;
+            accA += ca;
+            accB += cb;
+        }
     }
+    red[g * PP_NACC + l] = accA;
+    if (l < PP_NACC - 16) red[g * PP_NACC + 16 + l] = accB;
     __syncthreads();
     if (tid < PP_NACC) {
         double s = 0.0;
         for (int gg = 0; gg < 256 / LPC; ++gg) s += red[gg * PP_NACC + tid];
         a.partial[((size_t)i * a.nchunk + chunk) * PP_NACC + tid] = s;
     }
-}
-
-// accumulate one channel's local terms into the 21 per-subint sums
-__device__ __forceinline__ void accumulate_channel(const Local& L, const ChanGeom& cg, double (&c)[PP_NACC]) {
-    const double p1 = cg.p1, p2 = cg.p2;
-    c[0] = L.F;
-    c[1] = L.Gp; c[2] = L.Gp * p1; c[3] = L.Gp * p2;
-    c[4] = L.Gt * cg.q1; c[5] = L.Gt * cg.q2;
-    c[6] = L.Lpp; c[7] = L.Lpp * p1; c[8] = L.Lpp * p2;
-    c[9] = L.Lpt * cg.q1; c[10] = L.Lpt * cg.q2;
-    c[11] = L.Lpp * p1 * p1; c[12] = L.Lpp * p1 * p2;
-    c[13] = L.Lpt * p1 * cg.q1; c[14] = L.Lpt * p1 * cg.q2;
-    c[15] = L.Lpp * p2 * p2;
-    c[16] = L.Lpt * p2 * cg.q1; c[17] = L.Lpt * p2 * cg.q2;
-    c[18] = L.Ltt * cg.q1 * cg.q1 + L.Gt * cg.q11;
-    c[19] = L.Ltt * cg.q1 * cg.q2 + L.Gt * cg.q12;
-    c[20] = L.Ltt * cg.q2 * cg.q2 + L.Gt * cg.q22;
 }
 
 // First evaluation when k_xspec already produced the per-channel sums (FUSE):

@@ -461,7 +461,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     memset(&xa, 0, sizeof xa);
     xa.data = ddata; xa.mft = (const cplx* const*)c->mft_table.p;
     xa.mft0 = c->slots[0].mft.as<cplx>();
-    xa.ktab = scat ? nullptr : (const int* const*)c->kt_table.p;   // scattering keeps every harmonic
+    xa.ktab = (const int* const*)c->kt_table.p;
     xa.kt0 = c->slots[0].kt.as<int>();
     xa.slot = in->model_slot ? c->slot.as<int>() : nullptr;
     xa.X = c->X.as<cplx>(); xa.sdraw = c->sdraw.as<double>(); xa.noise = c->noise.as<double>();
@@ -492,7 +492,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.X = c->X.as<cplx>();
     fa.mft = (const cplx* const*)c->mft_table.p;
     fa.msum = (const double* const*)c->msum_table.p;
-    fa.ktab = scat ? nullptr : (const int* const*)c->kt_table.p;
+    fa.ktab = (const int* const*)c->kt_table.p;
     fa.slot = in->model_slot ? c->slot.as<int>() : nullptr;
     fa.freqs = c->freqs.as<double>(); fa.freqs_stride = in->freqs_stride ? C : 0;
     fa.wts = c->wts.as<double>(); fa.sdraw = c->sdraw.as<double>();
@@ -622,7 +622,6 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
     bool scat = in->fit_flags[3] || in->fit_flags[4] || in->log10_tau;
     if (!scat)
         for (int i = 0; i < N; ++i) if (in->init_params[(size_t)i * 5 + 3] != 0.0) { scat = true; break; }
-    if (scat) Kt = M;   // S_n(tau) needs every harmonic of the model
     // default reference frequencies: mean of the (unmasked) channel frequencies
     std::vector<double> nufit((size_t)N * 3), nuout((size_t)N * 3);
     for (int i = 0; i < N; ++i) {

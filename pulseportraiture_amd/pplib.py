@@ -49,6 +49,43 @@ class DataBunch(dict):
         self.__dict__ = self
 
 
+class DataPortrait(object):
+    """Holder of the data a model is fit to, built FROM ARRAYS.
+
+    The reference's DataPortrait (pplib.py:138-650) loads PSRCHIVE archives and
+    carries joining / normalising / plotting methods; only its single-archive
+    field layout (pplib.py:306-327) is part of the fit path and is what this
+    class provides: every key of the load_data DataBunch as an attribute, plus
+    port, portx, freqsxs, noise_stdsxs, SNRsxs.  `data` is a DataBunch with the
+    load_data fields (see pulseportraiture_amd.pptoas.data_from_arrays)."""
+
+    def __init__(self, data=None, joinfile=None, quiet=False, **kwargs):
+        if data is None or not isinstance(data, dict):
+            raise RuntimeError("DataPortrait needs a DataBunch built from arrays "
+                               "(PSRFITS loading requires PSRCHIVE)")
+        self.init_params = []
+        self.joinfile = joinfile
+        self.njoin = 0
+        self.join_params = []
+        self.join_ichans = []
+        self.all_join_params = []
+        self.datafile = data.get("filename", "arrays")
+        self.datafiles = [self.datafile]
+        self.data = data
+        for key in data.keys():
+            setattr(self, key, data[key])
+        if getattr(self, "source", None) is None:
+            self.source = "noname"
+        self.port = (self.masks * self.subints)[0, 0]
+        self.portx = self.port[self.ok_ichans[0]]
+        self.freqsxs = [self.freqs[0, self.ok_ichans[0]]]
+        if self.noise_stds is not None:
+            self.noise_stdsxs = np.asarray(self.noise_stds)[0, 0, self.ok_ichans[0]]
+        self.SNRsxs = np.asarray(self.SNRs)[0, 0, self.ok_ichans[0]]
+        if data.get("flux_prof") is not None:
+            self.flux_profx = data["flux_prof"][self.ok_ichans[0]]
+
+
 # ---- small host helpers ------------------------------------------------------
 def get_bin_centers(nbin, lo=0.0, hi=1.0):
     lo, hi = np.double(lo), np.double(hi)

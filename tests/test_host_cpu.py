@@ -72,3 +72,20 @@ def test_mjd_and_tim_line():
                     " -pp_dme 0.0001200 -be GUPPI -nbin 256 -snr 123.457"
                     " -phi_DM_cov 1.2e-12 -phs 0.12345679 -flux 1.23457")
     assert toa.snr == 123.4567 and toa.be == "GUPPI"
+
+
+def test_dataportrait_from_arrays_field_names():
+    from pulseportraiture_amd.pptoas import data_from_arrays
+    rng = np.random.default_rng(0)
+    sub = rng.normal(size=(2, 1, 6, 32))
+    w = np.ones((2, 6)); w[0, 2] = 0
+    d = data_from_arrays(sub, np.linspace(1100, 1900, 6), [0.003, 0.003], [55000.1, 55000.2],
+                         weights=w, noise_stds=np.full((2, 1, 6), 0.1), DM=12.0)
+    dp = pplib.DataPortrait(d)
+    assert dp.port.shape == (6, 32) and dp.portx.shape == (5, 32)
+    assert np.all(dp.port[2] == 0) and np.array_equal(dp.portx[2], sub[0, 0, 3])
+    np.testing.assert_array_equal(dp.freqsxs[0], d.freqs[0, [0, 1, 3, 4, 5]])
+    assert dp.noise_stdsxs.shape == (5,) and dp.SNRsxs.shape == (5,)
+    assert dp.DM == 12.0 and dp.nbin == 32 and dp.nchan == 6 and list(dp.ok_isubs) == [0, 1]
+    with np.testing.assert_raises(RuntimeError):
+        pplib.DataPortrait("some.fits")
