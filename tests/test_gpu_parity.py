@@ -497,3 +497,95 @@ def test_poor_guess_falls_back_to_evaluations(eng):
         np.testing.assert_allclose(r["param_errs"][0, :2], g["out_param_errs"][:2], rtol=1e-6)
         np.testing.assert_allclose(r["chi2"][0], g["out_chi2"], rtol=1e-10)
         np.testing.assert_allclose(r["scales"][0], g["out_scales"], rtol=1e-6, atol=1e-9)
+
+
+def test_sub_batching_and_model_slots(eng):
+    """A batch larger than the work-memory budget is processed in sub-batches
+    and gives the same answers; subints may reference different template slots."""
+    from tests.synth_host import make_inputs, caller_guess, model_portrait
+    C, B, N = 16, 256, 7
+    freqs, model = model_portrait(C, B)
+    model2 = model * 1.7 + 0.01          # a second template (scaled copy)
+    eng.set_model(model, slot=0)
+    eng.set_model(model2, slot=3)
+    data, x0, nuf = [], [], []
+    for i in range(N):
+        inp = make_inputs(C, B, 700 + i, model=model)
+        gss = caller_guess(inp)
+        data.append(inp["data"]); x0.append(gss["init_params"]); nuf.append([gss["nu_fit"]] * 3)
+    data = np.array(data); P = np.full(N, inp["P"])
+    slots = np.array([0, 3, 0, 3, 3, 0, 0], dtype=np.int32)
+    kw = dict(errs=np.full((N, C), 0.05), nu_fits=nuf, fit_flags=[1, 1, 0, 0, 0],
+              model_slot=slots)
+    whole = eng.fit_batch(data, freqs, P, np.array(x0), **kw)
+    eng.set_option("max_work_bytes", 2.5 * C * B * 16)     # ~2 subints per sub-batch
+    try:
+        parts = eng.fit_batch(data, freqs, P, np.array(x0), **kw)
+    finally:
+        eng.set_option("max_work_bytes", 96e9)
+    for k in ("params", "param_errs", "nu_refs", "chi2", "snr", "scales", "nfeval"):
+        np.testing.assert_array_equal(whole[k], parts[k])
+    # the scaled template changes the amplitudes, not the timing
+    sc = whole["scales"]
+    assert np.allclose(sc[1].mean() * 1.7, sc[0].mean(), rtol=0.2)
+    single = eng.fit_batch(data[1:2], freqs, P[1:2], np.array(x0[1:2]), errs=kw["errs"][1:2],
+                           nu_fits=nuf[1:2], fit_flags=[1, 1, 0, 0, 0],
+                           model_slot=np.array([3], dtype=np.int32))
+    np.testing.assert_array_equal(single["params"][0], whole["params"][1])
+
+
+def test_degenerate_and_bad_inputs(eng):
+    """One usable channel (phase-only fit), NaN samples (reported through
+    return_code, never raised), and argument errors (negative status + message)."""
+    from oracle import pptoas_oracle as orc
+    from pulseportraiture_amd.engine import EngineError
+    from tests.synth_host import make_inputs, caller_guess, model_portrait
+    C, B = 8, 256
+    freqs, model = model_portrait(C, B)
+    eng.set_model(model)
+    inp = make_inputs(C, B, 55, model=model)
+    gss = caller_guess(inp)
+    mask = np.zeros((1, C), dtype=np.uint8); mask[0, 5] = 1
+    r = eng.fit_batch(inp["data"][None], freqs, inp["P"], gss["init_params"],
+                      errs=inp["errs"], nu_fits=[[gss["nu_fit"]] * 3],
+                      fit_flags=[1, 0, 0, 0, 0], chan_mask=mask)
+    o = orc.fit_portrait_full(inp["data"][5:6], model[5:6], gss["init_params"], inp["P"],
+                              freqs[5:6], [gss["nu_fit"]] * 3, [None] * 3, inp["errs"][5:6],
+                              [1, 0, 0, 0, 0], log10_tau=False)
+    assert _dphi(r["params"][0, 0], o.phi) < PHI_BAR
+    np.testing.assert_allclose(r["param_errs"][0, 0], o.param_errs[0], rtol=1e-6)
+    np.testing.assert_allclose(r["red_chi2"][0], o.red_chi2, rtol=1e-9)
+    # NaN in one subint of a batch of two
+    two = np.array([inp["data"], inp["data"]])
+    two[1, 3, 7] = np.nan
+    r2 = eng.fit_batch(two, freqs, inp["P"], gss["init_params"], errs=inp["errs"],
+                       nu_fits=[[gss["nu_fit"]] * 3], fit_flags=[1, 1, 0, 0, 0])
+    assert r2["return_code"][0] == 2 and r2["return_code"][1] == 3
+    assert np.isfinite(r2["params"][0]).all()
+    # argument errors
+    with pytest.raises(EngineError):
+        eng.fit_batch(np.zeros((1, C, 100)), freqs, 0.003, gss["init_params"])   # nbin not 2^n
+    with pytest.raises(EngineError):
+        eng.fit_batch(np.zeros((1, C + 1, B)), np.ones(C + 1), 0.003, gss["init_params"])
+    with pytest.raises(EngineError):
+        eng.fit_batch(inp["data"][None], freqs, inp["P"], gss["init_params"],
+                      model_slot=np.array([9], dtype=np.int32))               # slot not set
+
+
+def test_max_nbin_8192(eng):
+    from oracle import pptoas_oracle as orc
+    from tests.synth_host import make_inputs, caller_guess, model_portrait
+    C, B = 4, 8192
+    freqs, model = model_portrait(C, B)
+    inp = make_inputs(C, B, 8192, model=model, sigma=0.3)
+    gss = caller_guess(inp)
+    eng.set_model(model)
+    r = eng.fit_batch(inp["data"][None], freqs, inp["P"], gss["init_params"],
+                      errs=inp["errs"], nu_fits=[[gss["nu_fit"]] * 3],
+                      fit_flags=[1, 1, 0, 0, 0])
+    o = orc.fit_portrait_full(inp["data"], model, gss["init_params"], inp["P"], freqs,
+                              [gss["nu_fit"]] * 3, [None] * 3, inp["errs"], [1, 1, 0, 0, 0],
+                              log10_tau=False)
+    assert _dphi(r["params"][0, 0], o.phi) < PHI_BAR
+    assert abs(r["params"][0, 1] - o.DM) < DM_BAR
+    np.testing.assert_allclose(r["red_chi2"][0], o.red_chi2, rtol=1e-9)
