@@ -59,6 +59,7 @@ class Engine(object):
         _check(self._lib.pp_create(int(device), C.byref(ctx)), "pp_create")
         self._ctx = ctx
         self.device = int(device)
+        self._digests = {}      # slot -> content digest of the resident template
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -75,13 +76,17 @@ class Engine(object):
     def set_option(self, name, value):
         _check(self._lib.pp_set_option(self._ctx, name.encode(), float(value)),
                "pp_set_option(%s)" % name)
+        if name == "harm_eps":
+            self._digests.clear()      # truncation is decided when a template is set
 
     def synchronize(self):
         _check(self._lib.pp_synchronize(self._ctx), "pp_synchronize")
 
     # -- model ------------------------------------------------------------
-    def set_model(self, model, slot=0):
-        """Upload an nchan x nbin template (numpy array or CUDA tensor)."""
+    def set_model(self, model, slot=0, digest=None):
+        """Upload an nchan x nbin template (numpy array or CUDA tensor).
+        `digest` (optional) tags the slot's content for set_model_cached."""
+        self._digests[int(slot)] = digest
         if _is_device_array(model):
             nchan, nbin = int(model.shape[-2]), int(model.shape[-1])
             dtype = PP_F64 if model.element_size() == 8 else PP_F32
@@ -98,6 +103,21 @@ class Engine(object):
                                       on_dev, nchan, nbin), "pp_model_set")
         del keep
         return self._lib.pp_model_nharm(self._ctx, int(slot))
+
+    def set_model_cached(self, model, slot=0):
+        """Upload the template unless the same bytes are already resident in the
+        slot (the reference re-reads and re-transforms it for every subint,
+        pptoas.py:352-379)."""
+        m = np.ascontiguousarray(model)
+        try:
+            import xxhash
+            digest = (m.shape, m.dtype.str,
+                      xxhash.xxh3_128_digest(m.view(np.uint8).reshape(-1)))
+        except ImportError:
+            digest = None
+        if digest is None or self._digests.get(int(slot)) != digest:
+            self.set_model(m, slot=slot, digest=digest)
+        return self.model_nharm(slot)
 
     def model_nharm(self, slot=0):
         return self._lib.pp_model_nharm(self._ctx, int(slot))

@@ -46,7 +46,7 @@ def fit_portrait_full(data_port, model_port, init_params, P, freqs,
         sys.exit()
     eng = default_engine()
     flags = [1 if f else 0 for f in fit_flags]
-    eng.set_model(model_port, slot=0)
+    eng.set_model_cached(model_port, slot=0)
     data = np.asarray(data_port)
     res = eng.fit_batch(data[None] if data.ndim == 2 else data, freqs, P,
                         init_params, errs=errs, nu_fits=[list(nu_fits)],
@@ -74,7 +74,7 @@ def fit_portrait_full_batch(data_ports, model_port, init_params, Ps, freqs,
     pre-loaded slots); returns the dict of result arrays of Engine.fit_batch."""
     eng = engine or default_engine()
     if model_port is not None:
-        eng.set_model(model_port, slot=0)
+        eng.set_model_cached(model_port, slot=0)
     return eng.fit_batch(data_ports, freqs, Ps, init_params, errs=errs,
                          nu_fits=nu_fits, nu_outs=nu_outs, fit_flags=fit_flags,
                          log10_tau=log10_tau, option=option, is_toa=is_toa,
