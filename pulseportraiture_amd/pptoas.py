@@ -222,10 +222,22 @@ class GetTOAs(object):
 
     # -- template ----------------------------------------------------------
     def _model_for(self, freqs_row, nbin, P, unscattered=False):
-        if isinstance(self.modelfile, dict):
-            mdl = self.modelfile
-        else:
-            mdl = gmodel.read_gmodel(self.modelfile)
+        """Template at this subint's frequencies: Gaussian-component (.gmodel)
+        or, failing that, spline (.spl) model -- the reference's fallback order
+        (pptoas.py:352-379)."""
+        mdl = self.modelfile if isinstance(self.modelfile, dict) else None
+        if mdl is None:
+            try:
+                mdl = gmodel.read_gmodel(self.modelfile)
+                if mdl["nu_ref"] is None or not mdl["ngauss"]:
+                    mdl = None
+            except (UnicodeDecodeError, ValueError, IndexError):
+                mdl = None
+        if mdl is None:
+            from .splmodel import read_spline_model
+            self.model_name, port = read_spline_model(self.modelfile, freqs_row, nbin,
+                                                      quiet=True)
+            return port
         self.model_name, self.ngauss = mdl["name"], mdl["ngauss"]
         self.model_code, self.model_nu_ref = mdl["code"], mdl["nu_ref"]
         self.gparams, self.alpha = mdl["params"], mdl["alpha"]
@@ -336,8 +348,11 @@ class GetTOAs(object):
                         tau_guess = (tau_s / P) * (nu_fit_arr[j, 2] / tau_ref) ** alpha_guess
                     else:
                         alpha_guess = self.alpha if hasattr(self, 'alpha') else scattering_alpha
-                        tau_guess = (self.gparams[1] / P) * \
-                            (nu_fit_arr[j, 2] / self.model_nu_ref) ** alpha_guess
+                        if hasattr(self, 'gparams'):
+                            tau_guess = (self.gparams[1] / P) * \
+                                (nu_fit_arr[j, 2] / self.model_nu_ref) ** alpha_guess
+                        else:
+                            tau_guess = 0.0
                     if log10_tau:
                         if tau_guess == 0.0:
                             tau_guess = nbin ** -1

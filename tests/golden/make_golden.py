@@ -295,6 +295,26 @@ def main():
          nu_fit_snr=ref.guess_fit_freq(freqs, np.linspace(1.0, 3.0, 64)),
          noise_ps=ref.get_noise_PS(inp["data"], chans=True),
          phase_tr=ref.phase_transform(0.3, 34.5, 1500.0, 1200.0, P, mod=True))
+    # ---- spline (PCA + B-spline) model portraits: gen_spline_portrait ----
+    import pickle
+    import scipy.interpolate as si
+    rng = np.random.default_rng(SEED + 40)
+    nb, ncomp = 256, 2
+    mean_prof = model.mean(axis=0)
+    u, sv, vt = np.linalg.svd(model - mean_prof, full_matrices=False)
+    eigvec = vt[:ncomp].T                                   # [nbin, ncomp]
+    proj = np.dot(model - mean_prof, eigvec)                # [nchan, ncomp]
+    (tck, uu), fp, ier, msg = si.splprep(proj.T, u=freqs, k=3, s=len(freqs) * 1e-6,
+                                         full_output=True)
+    spl_path = os.path.join(HERE, "example.spl")
+    with open(spl_path, "wb") as fh:
+        pickle.dump(["example_spline", "J1234-5678", "fake.fits", mean_prof, eigvec, tck],
+                    fh, protocol=2)
+    f_eval = np.linspace(1110.0, 1890.0, 40)
+    save("spline_model_256", freqs=f_eval,
+         port=ref.gen_spline_portrait(mean_prof, f_eval, eigvec, tck, None),
+         port_512=ref.gen_spline_portrait(mean_prof, f_eval, eigvec, tck, 512),
+         port_flat=ref.gen_spline_portrait(mean_prof, f_eval, eigvec[:, :0], tck, None))
     shutil.rmtree(tmp, ignore_errors=True)
 
 

@@ -589,3 +589,41 @@ def test_max_nbin_8192(eng):
     assert _dphi(r["params"][0, 0], o.phi) < PHI_BAR
     assert abs(r["params"][0, 1] - o.DM) < DM_BAR
     np.testing.assert_allclose(r["red_chi2"][0], o.red_chi2, rtol=1e-9)
+
+
+def test_get_TOAs_with_spline_model():
+    """A .spl (PCA + B-spline) template goes through the same path; compare with
+    the oracle fed the same template portrait."""
+    from oracle import pptoas_oracle as orc
+    from pulseportraiture_amd import splmodel
+    from pulseportraiture_amd.pptoas import GetTOAs, data_from_arrays
+    from pulseportraiture_amd.pplib import guess_fit_freq
+    path = os.path.join(GOLDEN, "example.spl")
+    C, B, P = 24, 256, 1.0 / 345.67890123456789
+    freqs = np.linspace(1120.0, 1880.0, C)
+    model = splmodel.read_spline_model(path, freqs, B, quiet=True)[1]
+    rng = np.random.default_rng(77)
+    DM0, sig = 12.345, 0.05
+    sub = np.zeros((2, 1, C, B))
+    for i in range(2):
+        sub[i, 0] = orc.rotate_portrait_full(model, -rng.uniform(-0.4, 0.4),
+                                             -(DM0 + rng.normal(3e-4, 2e-4)), 0.0, freqs,
+                                             np.inf, np.inf, P) + rng.normal(0, sig, (C, B))
+    data = data_from_arrays(sub, freqs, [P, P], [56000.0, 56000.1],
+                            noise_stds=np.full((2, 1, C), sig), DM=DM0)
+    gt = GetTOAs(data, path, quiet=True)
+    gt.get_TOAs(bary=False, quiet=True)
+    nu_fit = guess_fit_freq(freqs, np.ones(C))
+    for i in range(2):
+        # start the oracle at the device answer, referred to its fit frequency
+        x0 = [gt.phis[0][i] + orc.Dconst * gt.DMs[0][i] / P *
+              (nu_fit ** -2 - gt.nu_refs[0][i][0] ** -2), gt.DMs[0][i], 0.0, 0.0, 0.0]
+        o = orc.fit_portrait_full(sub[i, 0], model, x0, P, freqs, [nu_fit] * 3, [None] * 3,
+                                  np.full(C, sig), [1, 1, 0, 0, 0], log10_tau=False)
+        # same optimum: phases compared at the oracle's zero-covariance frequency
+        phi_dev = gt.phis[0][i] + orc.Dconst * gt.DMs[0][i] / P * \
+            (o.nu_DM ** -2 - gt.nu_refs[0][i][0] ** -2)
+        assert _dphi(phi_dev, o.phi) < PHI_BAR
+        assert abs(gt.DMs[0][i] - o.DM) < DM_BAR
+        np.testing.assert_allclose(gt.nu_refs[0][i][0], o.nu_DM, rtol=1e-8)
+        np.testing.assert_allclose(gt.red_chi2s[0][i], o.red_chi2, rtol=1e-8)

@@ -89,3 +89,18 @@ def test_dataportrait_from_arrays_field_names():
     assert dp.DM == 12.0 and dp.nbin == 32 and dp.nchan == 6 and list(dp.ok_isubs) == [0, 1]
     with np.testing.assert_raises(RuntimeError):
         pplib.DataPortrait("some.fits")
+
+
+def test_spline_model_portraits_match_reference():
+    from pulseportraiture_amd import splmodel
+    g = np.load(os.path.join(GOLDEN, "spline_model_256.npz"))
+    path = os.path.join(GOLDEN, "example.spl")
+    name, src, dfile, mean_prof, eigvec, tck = splmodel.read_spline_model(path, quiet=True)
+    assert name == "example_spline" and eigvec.shape == (256, 2)
+    np.testing.assert_allclose(splmodel.read_spline_model(path, g["freqs"], None, True)[1],
+                               g["port"], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(splmodel.read_spline_model(path, g["freqs"], 512, True)[1],
+                               g["port_512"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(
+        splmodel.gen_spline_portrait(mean_prof, g["freqs"], eigvec[:, :0], tck),
+        g["port_flat"], rtol=0, atol=0)
