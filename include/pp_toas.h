@@ -155,6 +155,17 @@ int pp_fit_phase_shift_batch(pp_ctx* ctx, const double* data,
                              int nprof, int nbin, double lo, double hi, int Ns,
                              double* out7);
 
+/* Fourier rotation / (de)dispersion of portraits: dst[i][n] = irfft(rfft(src[i][n])
+ * e^{2 pi i k phi_in}), phi_in = par[i][0] + Dconst par[i][1] (nu_n^-2 - nu_DM^-2)/P_i
+ * + Dconst^2 par[i][2] (nu_n^-4 - nu_GM^-4)/P_i.  rotate_data (pplib.py:2338-2426),
+ * rotate_portrait (:2428-2460), rotate_portrait_full (pptoaslib.py:52-81).
+ * src/dst: [nsub][nchan][nbin] of `dtype`, both host or both device pointers
+ * (dst may equal src on the device); nu_DM / nu_GM may be INFINITY. */
+int pp_rotate_portraits(pp_ctx* ctx, const void* src, void* dst, int dtype,
+                        int on_device, int nsub, int nchan, int nbin,
+                        const double* freqs, int64_t freqs_stride, const double* P,
+                        const double* par3, double nu_DM, double nu_GM);
+
 /* ---- synthetic portraits generated on the device ------------------------- */
 /* Fill dst[nsub][nchan][nbin] (device pointer, dtype) with
  *   gain[i][n] * rotate(model slot, -phi_i, -DM_i, -GM_i) + N(0, sigma)

@@ -100,6 +100,73 @@ __global__ __launch_bounds__(FftPlan<M>::T) void k_synth(SynthArgs a) {
 }
 
 // --------------------------------------------------------------------------
+// Fourier rotation of portraits (rotate_data pplib.py:2338-2426,
+// rotate_portrait_full pptoaslib.py:52-81): every row is transformed, its
+// harmonics multiplied by e^{2 pi i k phi_n}, phi_n = phi + Dconst DM
+// (nu_n^-2 - nu_DM^-2)/P + Dconst^2 GM (nu_n^-4 - nu_GM^-4)/P, and transformed
+// back -- both FFTs of a row stay in LDS.  Positive values rotate to earlier
+// phase.
+// --------------------------------------------------------------------------
+struct RotateArgs {
+    const void* src;      // [nsub][nchan][B]
+    void* dst;            // [nsub][nchan][B] (may alias src)
+    const double* freqs; long long freqs_stride;
+    const double* P;      // [nsub] (1.0 where delays are already in rotations)
+    const double* par;    // [nsub][3] phi, DM, GM
+    const cplx* twB;
+    double inv_nuDM2, inv_nuGM4;   // 1/nu_DM^2, 1/nu_GM^4 (0 for infinite reference)
+    int nsub, nchan;
+};
+
+template <int M, typename Tio>
+__global__ __launch_bounds__(FftPlan<M>::T) void k_rotate(RotateArgs a) {
+    constexpr int T = FftPlan<M>::T;
+    constexpr int PL = FftPlan<M>::PADLOG;
+    __shared__ cplx lds[FftPlan<M>::LDS_ELEMS];
+    __shared__ cplx zin[M];
+    const int tid = threadIdx.x;
+    const long long nrows = (long long)a.nsub * a.nchan;
+    for (long long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int i = (int)(row / a.nchan), n = (int)(row % a.nchan);
+        const double nu = a.freqs[(size_t)i * a.freqs_stride + n], P = a.P[i];
+        const double a2 = 1.0 / (nu * nu);
+        const double phin = a.par[i * 3] + PP_DCONST * a.par[i * 3 + 1] * (a2 - a.inv_nuDM2) / P +
+                            PP_DCONST * PP_DCONST * a.par[i * 3 + 2] * (a2 * a2 - a.inv_nuGM4) / P;
+        fft_row<M, Tio>(lds, reinterpret_cast<const Tio*>(a.src) + (size_t)row * (2 * M), a.twB, tid);
+        // rotated harmonics Y_k, k = 0..M, then the packed spectrum of the inverse
+        const cplx z0 = lds[0];
+        const double y0 = z0.x + z0.y;                                   // DC, unchanged
+        const double yM = (z0.x - z0.y) * unit_phasor((double)M, phin).x; // Nyquist: real part kept
+        for (int k = tid; k < M; k += T) {
+            cplx yk, ym;
+            if (k == 0) { yk = make_double2(y0, 0.0); ym = make_double2(yM, 0.0); }
+            else {
+                yk = cmul(rfft_harmonic<M>(lds, a.twB, k), unit_phasor((double)k, phin));
+                ym = cmul(rfft_harmonic<M>(lds, a.twB, M - k), unit_phasor((double)(M - k), phin));
+            }
+            ym.y = -ym.y;
+            const cplx ev = make_double2(0.5 * (yk.x + ym.x), 0.5 * (yk.y + ym.y));
+            cplx od = make_double2(0.5 * (yk.x - ym.x), 0.5 * (yk.y - ym.y));
+            cplx w = a.twB[k];
+            w.y = -w.y;
+            od = cmul(od, w);
+            zin[k] = make_double2(ev.x - od.y, -(ev.y + od.x));   // conj(ev + i od)
+        }
+        __syncthreads();
+        fft_row<M, cplx>(lds, zin, a.twB, tid);
+        Tio* out = reinterpret_cast<Tio*>(a.dst) + (size_t)row * (2 * M);
+        const double inv = 1.0 / (double)M;
+        for (int j = tid; j < M; j += T) {
+            const cplx r = lds[lds_pad<PL>(j)];
+            const double x0 = r.x * inv, x1 = -r.y * inv;
+            if (sizeof(Tio) == 8) reinterpret_cast<double2*>(out)[j] = make_double2(x0, x1);
+            else reinterpret_cast<float2*>(out)[j] = make_float2((float)x0, (float)x1);
+        }
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------
 // 1-D FFTFIT.  spec[2*i] = rfft(data_i), spec[2*i+1] = rfft(model_i), each
 // M+1 complex.  One 256-thread block per pair.
 // --------------------------------------------------------------------------

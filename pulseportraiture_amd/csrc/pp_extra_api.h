@@ -76,3 +76,45 @@ extern "C" int pp_synth_portraits(pp_ctx* c, int slot, void* dst, int dtype, int
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PP_OK;
 }
+
+extern "C" int pp_rotate_portraits(pp_ctx* c, const void* src, void* dst, int dtype, int on_device, int nsub,
+                                   int nchan, int nbin, const double* freqs, int64_t freqs_stride,
+                                   const double* P, const double* par3, double nu_DM, double nu_GM) {
+    if (!c || !src || !dst || !freqs || !P || !par3) return fail(PP_EINVAL, "pp_rotate_portraits: null argument");
+    if (!nbin_ok(nbin) || nsub < 1 || nchan < 1) return fail(PP_EINVAL, "pp_rotate_portraits: bad shape");
+    if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_rotate_portraits: dtype %d", dtype);
+    if (freqs_stride != 0 && freqs_stride != nchan) return fail(PP_EINVAL, "freqs_stride must be 0 or nchan");
+    HIP_TRY(hipSetDevice(c->device));
+    const int M = nbin / 2;
+    const size_t esz = dtype == PP_F64 ? 8 : 4;
+    const size_t bytes = (size_t)nsub * nchan * nbin * esz;
+    int rc;
+    const void* dsrc = src;
+    void* ddst = dst;
+    if (!on_device) {
+        if ((rc = c->data.reserve(bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->data.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+        dsrc = c->data.p; ddst = c->data.p;
+    }
+    if ((rc = upload(c, c->freqs, freqs, (size_t)(freqs_stride ? (size_t)nsub * nchan : nchan) * 8))) return rc;
+    if ((rc = upload(c, c->P, P, (size_t)nsub * 8))) return rc;
+    if ((rc = upload(c, c->x0, par3, (size_t)nsub * 24))) return rc;
+    const cplx* tw = nullptr;
+    if ((rc = get_twiddles(c, nbin, &tw))) return rc;
+    RotateArgs a{dsrc, ddst, c->freqs.as<double>(), (long long)freqs_stride, c->P.as<double>(), c->x0.as<double>(), tw,
+                 std::isinf(nu_DM) ? 0.0 : 1.0 / (nu_DM * nu_DM),
+                 std::isinf(nu_GM) ? 0.0 : 1.0 / (nu_GM * nu_GM * nu_GM * nu_GM), nsub, nchan};
+    {
+        Prof pr(c, KF_SYNTH);
+        PP_DISPATCH_M(M, {
+            const int T = FftPlan<MM>::T;
+            const int grid = fft_grid(T, (long long)nsub * nchan);
+            if (dtype == PP_F64) hipLaunchKernelGGL((k_rotate<MM, double>), dim3(grid), dim3(T), 0, c->stream, a);
+            else hipLaunchKernelGGL((k_rotate<MM, float>), dim3(grid), dim3(T), 0, c->stream, a);
+        });
+    }
+    HIP_TRY(hipGetLastError());
+    if (!on_device) HIP_TRY(hipMemcpyAsync(dst, c->data.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PP_OK;
+}

@@ -276,6 +276,36 @@ class Engine(object):
             float(bounds[1]), int(Ns), _dp(out)), "pp_fit_phase_shift_batch")
         return out
 
+    def rotate_portraits(self, ports, freqs, P, phi=0.0, DM=0.0, GM=0.0, nu_DM=np.inf,
+                         nu_GM=np.inf):
+        """Fourier-rotate ports[nsub,nchan,nbin] (numpy -> new numpy array; CUDA
+        tensor -> rotated in place) by per-subint (phi, DM, GM)."""
+        if _is_device_array(ports):
+            nsub, nchan, nbin = (int(v) for v in ports.shape)
+            dtype = PP_F64 if ports.element_size() == 8 else PP_F32
+            src = dst = C.c_void_p(ports.data_ptr())
+            on_dev, out = 1, ports
+        else:
+            a = np.asarray(ports)
+            if a.dtype != np.float32:
+                a = a.astype(np.float64, copy=False)
+            a = np.ascontiguousarray(a)
+            nsub, nchan, nbin = a.shape
+            dtype = PP_F64 if a.dtype == np.float64 else PP_F32
+            out = np.empty_like(a)
+            src, dst, on_dev = C.c_void_p(a.ctypes.data), C.c_void_p(out.ctypes.data), 0
+        freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+        fstride = 0 if freqs.ndim == 1 else nchan
+        P = _f64(P, (nsub,))
+        par = np.ascontiguousarray(np.stack([
+            np.broadcast_to(np.asarray(v, dtype=np.float64), (nsub,)) for v in (phi, DM, GM)],
+            axis=1))
+        _check(self._lib.pp_rotate_portraits(self._ctx, src, dst, dtype, on_dev, nsub, nchan,
+                                             nbin, _dp(freqs), fstride, _dp(P), _dp(par),
+                                             float(nu_DM), float(nu_GM)),
+               "pp_rotate_portraits")
+        return out
+
     def synth_portraits(self, dst, freqs, P, inj, sigma, seed, first_subint=0,
                         slot=0):
         """Fill a CUDA tensor dst[nsub,nchan,nbin] with synthetic subints."""

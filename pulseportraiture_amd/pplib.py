@@ -120,6 +120,49 @@ def guess_fit_freq(freqs, SNRs=None):
     return nu0 + diff
 
 
+# ---- Fourier rotation (device) ---------------------------------------------------
+def rotate_data(data, phase=0.0, DM=0.0, Ps=None, freqs=None, nu_ref=np.inf):
+    """Rotate and/or dedisperse a profile [nbin], portrait [nchan,nbin] or
+    subint cube [nsub,npol,nchan,nbin]; positive phase / DM rotate to earlier
+    phase (pplib.py:2338-2426).  Runs on the GPU."""
+    data = np.asarray(data, dtype=np.float64)
+    shape = data.shape
+    if data.ndim == 1:
+        cube = data[None, None]
+    elif data.ndim == 2:
+        cube = data[None]
+    elif data.ndim == 4:
+        cube = data.reshape(shape[0], shape[1] * shape[2], shape[3])
+    else:
+        print("Wrong number of dimensions.")
+        return 0
+    nsub, nch = cube.shape[0], cube.shape[1]
+    if DM == 0.0 or freqs is None:
+        fr, P, DM = np.full(nch, np.inf), np.ones(nsub), 0.0
+    else:
+        P = np.ones(nsub) * Ps
+        fr = np.asarray(freqs, dtype=np.float64)
+        if fr.ndim == 0:
+            fr = np.full(shape[-2] if data.ndim > 1 else 1, float(fr))
+        if data.ndim == 4:
+            fr = np.broadcast_to(fr, (nsub, shape[2]))[:, None, :].repeat(shape[1], axis=1)
+            fr = fr.reshape(nsub, nch)
+    with np.errstate(divide='ignore'):
+        out = default_engine().rotate_portraits(cube, fr, P, phi=phase, DM=DM, nu_DM=nu_ref)
+    return out.reshape(shape)
+
+
+def rotate_portrait(port, phase=0.0, DM=None, P=None, freqs=None, nu_ref=np.inf):
+    """pplib.py:2428-2460."""
+    if DM is None and freqs is None:
+        return rotate_data(port, phase)
+    return rotate_data(port, phase, DM, P, freqs, nu_ref)
+
+
+def rotate_profile(profile, phase=0.0):
+    return rotate_data(profile, phase)
+
+
 # ---- 1-D FFTFIT ----------------------------------------------------------------
 def fit_phase_shift(data, model, noise=None, bounds=[-0.5, 0.5], Ns=100):
     """Fit a phase shift between a data and a model profile on the GPU:

@@ -65,6 +65,16 @@ def fit_portrait_full(data_port, model_port, init_params, P, freqs,
     return r
 
 
+def rotate_portrait_full(port, phi, DM, GM, freqs, nu_DM=np.inf, nu_GM=np.inf, P=None):
+    """Rotate / dedisperse a portrait by (phi, DM, GM) on the GPU
+    (pptoaslib.py:52-81)."""
+    if P is None:
+        P = 1.0
+    port = np.asarray(port, dtype=np.float64)
+    return default_engine().rotate_portraits(port[None], freqs, P, phi=phi, DM=DM, GM=GM,
+                                             nu_DM=nu_DM, nu_GM=nu_GM)[0]
+
+
 def fit_portrait_full_batch(data_ports, model_port, init_params, Ps, freqs,
                             nu_fits=None, nu_outs=None, errs=None,
                             fit_flags=[1, 1, 0, 0, 0], log10_tau=False, option=0,

@@ -627,3 +627,44 @@ def test_get_TOAs_with_spline_model():
         assert abs(gt.DMs[0][i] - o.DM) < DM_BAR
         np.testing.assert_allclose(gt.nu_refs[0][i][0], o.nu_DM, rtol=1e-8)
         np.testing.assert_allclose(gt.red_chi2s[0][i], o.red_chi2, rtol=1e-8)
+
+
+def test_rotate_functions_match_oracle():
+    """rotate_data / rotate_portrait / rotate_portrait_full on the device vs the
+    oracle's NumPy restatement (which is pinned to the reference)."""
+    from oracle import pptoas_oracle as orc
+    from pulseportraiture_amd import pplib, pptoaslib
+    rng = np.random.default_rng(3)
+    C, B, P = 12, 512, 0.00289
+    freqs = np.linspace(1150.0, 1850.0, C)
+    port = rng.normal(size=(C, B)) + 3.0
+    prof = port[0]
+    np.testing.assert_allclose(pplib.rotate_data(prof, 0.1234), orc.rotate_data(prof, 0.1234),
+                               rtol=0, atol=5e-13)
+    np.testing.assert_allclose(pplib.rotate_data(port, -0.31), orc.rotate_data(port, -0.31),
+                               rtol=0, atol=5e-13)
+    # large non-dedispersed shifts: NumPy forms k*phi_n (1e4-1e5 turns) in double
+    # before the exp, which costs it ~1e-11; the device reduces phi_n mod 1 first
+    np.testing.assert_allclose(pplib.rotate_data(port, 0.2, 34.5, P, freqs, 1500.0),
+                               orc.rotate_data(port, 0.2, 34.5, P, freqs, 1500.0),
+                               rtol=0, atol=1e-10)
+    np.testing.assert_allclose(pplib.rotate_portrait(port, 0.05, 3.2, P, freqs),
+                               orc.rotate_data(port, 0.05, 3.2, P, freqs, np.inf),
+                               rtol=0, atol=5e-12)
+    np.testing.assert_allclose(
+        pptoaslib.rotate_portrait_full(port, 0.4, 12.0, 0.3, freqs, 1400.0, 1300.0, P),
+        orc.rotate_portrait_full(port, 0.4, 12.0, 0.3, freqs, 1400.0, 1300.0, P),
+        rtol=0, atol=1e-10)
+    cube = rng.normal(size=(2, 2, C, 64))
+    got = pplib.rotate_data(cube, 0.11, 5.0, np.array([P, 1.1 * P]), freqs, 1500.0)
+    for i, Pi in enumerate([P, 1.1 * P]):
+        for ip in range(2):
+            np.testing.assert_allclose(got[i, ip],
+                                       orc.rotate_data(cube[i, ip], 0.11, 5.0, Pi, freqs, 1500.0),
+                                       rtol=0, atol=1e-10)
+    # a rotation and its inverse restore everything but the Nyquist harmonic (irfft
+    # keeps only its real part, in NumPy and here alike)
+    back = pplib.rotate_data(pplib.rotate_data(port, 0.3, 7.0, P, freqs, 1500.0), -0.3, -7.0, P,
+                             freqs, 1500.0)
+    d = np.fft.rfft(back - port, axis=-1)
+    assert np.abs(d[:, :-1]).max() < 1e-9 and np.abs(d[:, -1]).max() > 1e-3
