@@ -151,7 +151,10 @@ __global__ void k_model_kcut(const cplx* mft, const double* mmax, int nchan, int
 #define PP_SPLIT_U 4          // harmonics per thread processed together in the split loop
 #endif
 #ifndef PP_SD_FUSED
-#define PP_SD_FUSED 0         // S_d from the last stage's registers (else an LDS pass)
+#define PP_SD_FUSED 1         // S_d from the last stage's registers (else an LDS pass)
+#endif
+#ifndef PP_XSPEC_ABLATE
+#define PP_XSPEC_ABLATE 0     // timing-only builds: 1 = loads only, 2 = + stage 1, 3 = + all stages
 #endif
 #ifndef PP_LATE_SCALARS
 #define PP_LATE_SCALARS 0     // load the per-row fit scalars right before the split
@@ -199,7 +202,16 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             for (int ii = 0; ii < PER1; ++ii)
 #pragma unroll
                 for (int k = 0; k < R1; ++k) v[ii][k] = to_cplx(cur[ii][k]);
+#if PP_XSPEC_ABLATE == 1
+            double keep = 0.0;
+#pragma unroll
+            for (int ii = 0; ii < PER1; ++ii)
+#pragma unroll
+                for (int k = 0; k < R1; ++k) keep += v[ii][k].x * v[ii][k].y;
+            if (keep == 1.2345e300) a.sdraw[0] = keep;
+#else
             fft_first_stage<M>(lds, v, tw, tid);
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         // the first stage has consumed the row: its registers now receive the
@@ -210,6 +222,10 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);
         }
         __builtin_amdgcn_sched_barrier(0);
+#if PP_XSPEC_ABLATE == 1 || PP_XSPEC_ABLATE == 2
+        lds_sync<T>();
+        continue;
+#endif
         // ---- S_d comes out of the last stage's registers ----
         double sd = 0.0, tail = 0.0;
 #if PP_SD_FUSED
@@ -231,6 +247,11 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         if (TAIL) {
             for (int k = kc + tid; k <= M; k += T) tail += cnorm(rfft_harmonic<M>(lds, a.twB, k));
         }
+#if PP_XSPEC_ABLATE == 3
+        if (tid == 0) a.sdraw[rc] = sd;
+        lds_sync<T>();
+        continue;
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // ---- cross-spectrum (and the first evaluation's sums) ----
         cplx* xrow = a.X + rc * a.Kt;
