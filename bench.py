@@ -25,16 +25,16 @@ if ROOT not in sys.path:
 
 WORKLOADS = {
     # name: (nchan, nbin, fit_flags, log10_tau, default nsub per GPU, note)
-    "toa-4096x2048-phiDM": (4096, 2048, [1, 1, 0, 0, 0], False, 512,
+    "toa-4096x2048-phiDM": (4096, 2048, [1, 1, 0, 0, 0], False, 1024,
                             "BASELINE.json target shape (configs[4] per-GPU "
                             "shard): 4096 chan x 2048 bin, phase+DM"),
     "cfg2-512x1024-phiDM": (512, 1024, [1, 1, 0, 0, 0], False, 1024,
                             "configs[1]: 1024 subints, 512 chan x 1024 bin, "
                             "phase+DM"),
-    "cfg3-4096x2048-phiDMGM": (4096, 2048, [1, 1, 1, 0, 0], False, 512,
+    "cfg3-4096x2048-phiDMGM": (4096, 2048, [1, 1, 1, 0, 0], False, 1024,
                                "configs[2] shape: 4096 chan x 2048 bin, "
                                "phase+DM+GM"),
-    "cfg4-2048x2048-scat": (2048, 2048, [1, 1, 0, 1, 1], True, 256,
+    "cfg4-2048x2048-scat": (2048, 2048, [1, 1, 0, 1, 1], True, 512,
                             "configs[3] shape: 2048 chan x 2048 bin, "
                             "phase+DM+tau+alpha"),
     "cfg1-64x256-phiDM": (64, 256, [1, 1, 0, 0, 0], False, 1,
