@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--seed", type=int, default=20260101)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1)
+    ap.add_argument("--seed-ns", type=int, default=0,
+                    help="> 0: ignore the phase guesses and seed the phase on the device "
+                         "with an N-point grid (the whole pptoas preamble + fit)")
     ap.add_argument("--harm-eps", type=float, default=None,
                     help="override the harmonic-truncation threshold (experiments)")
     args = ap.parse_args()
@@ -140,7 +143,7 @@ def main():
     # per-channel inputs and outputs stay in HBM (inputs resident before the timed
     # region; the fitted TOA records are what leaves the GPU)
     kw = dict(errs=errs_dev, nu_fits=nu_fits, fit_flags=flags, log10_tau=log10_tau,
-              per_channel="device")
+              per_channel="device", seed_ns=args.seed_ns)
 
     def step():
         res = eng.fit_batch(data, freqs, P, x0, **kw)
@@ -214,6 +217,7 @@ def main():
                            "fit_flags": flags, "input_dtype": args.input_dtype,
                            "bytes_per_sample_resident": s_bytes, "dm0": args.dm0,
                            "sigma": args.sigma, "model_harmonics_kept": nharm,
+                           "device_phase_seed_ns": args.seed_ns,
                            "parallelism": "subint shards, %d rank(s), 1 gather" % world},
                 "roofline": roofline,
                 "convergence": {"nfeval_mean": float(np.mean(res["nfeval"])),

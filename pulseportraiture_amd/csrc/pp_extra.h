@@ -282,42 +282,74 @@ __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
 // k_seed_fit:   per subint, reduce the chunks, grid + Newton polish, write the
 //               phase into x0[i][0].
 // --------------------------------------------------------------------------
-#define PP_SEED_KPT 4   // harmonics per thread: Kt <= 1024
+#define PP_SEED_KPT 16   // harmonics per lane (one wave per channel): Kt <= 1024
 __global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart) {
     const int i = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    __shared__ cplx ysh[3 * 64 * PP_SEED_KPT / 4];   // three waves' partial spectra, one quarter at a time
     const double P = a.P[i];
     const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1];
     const double DM = a.x0[i * 5 + 1], GM = a.x0[i * 5 + 2];
     const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
     const double* wts = a.wts + (size_t)i * a.nchan;
     const int* ktv = a.ktab ? a.ktab[a.slot ? a.slot[i] : 0] : nullptr;
+    // lane owns harmonics lane+1 + 64 j; each wave walks its own channels with the
+    // phasor advanced by e^{2 pi i 64 phi_n} (one sincos per lane per channel)
     cplx y[PP_SEED_KPT];
 #pragma unroll
     for (int j = 0; j < PP_SEED_KPT; ++j) y[j] = make_double2(0.0, 0.0);
     const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan);
-    for (int n = n0; n < n1; ++n) {
+    for (int n = n0 + wave; n < n1; n += 4) {
         const double w = wts[n];
         if (w == 0.0) continue;
         double p1, p2;
         phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
         const double phin = DM * p1 + GM * p2;
+        cplx e = unit_phasor((double)(lane + 1), phin);
+        const cplx wst = make_double2(__shfl(e.x, 63, 64), __shfl(e.y, 63, 64));
         const cplx* xrow = a.X + ((size_t)i * a.nchan + n) * a.Kt;
         const int ktn = ktv ? ktv[n] : a.Kt;
+        // all of the row's loads first (independent, 1 KB per wave-instruction)
+        cplx xv[PP_SEED_KPT];
 #pragma unroll
         for (int j = 0; j < PP_SEED_KPT; ++j) {
-            const int k = tid + 1 + 256 * j;
-            if (k <= ktn) {
-                const cplx z = cmul(xrow[k - 1], unit_phasor((double)k, phin));
+            const int k = lane + 1 + 64 * j;
+            xv[j] = (k <= ktn) ? xrow[k - 1] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int j = 0; j < PP_SEED_KPT; ++j) {
+            if (64 * j < ktn) {
+                const cplx z = cmul(xv[j], e);
                 y[j].x = fma(w, z.x, y[j].x);
                 y[j].y = fma(w, z.y, y[j].y);
+                e = cmul(e, wst);
             }
         }
     }
+    // sum the four waves' spectra (a quarter of the harmonics per round) and store
     cplx* yo = ypart + ((size_t)i * a.nchunk + chunk) * a.Kt;
 #pragma unroll
-    for (int j = 0; j < PP_SEED_KPT; ++j) {
-        const int k = tid + 1 + 256 * j;
-        if (k <= a.Kt) yo[k - 1] = y[j];
+    for (int q = 0; q < 4; ++q) {
+        __syncthreads();
+        if (wave > 0) {
+#pragma unroll
+            for (int j = 0; j < PP_SEED_KPT / 4; ++j)
+                ysh[((wave - 1) * (PP_SEED_KPT / 4) + j) * 64 + lane] = y[q * (PP_SEED_KPT / 4) + j];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < PP_SEED_KPT / 4; ++j) {
+                const int jj = q * (PP_SEED_KPT / 4) + j;
+                cplx s = y[jj];
+                for (int ww = 0; ww < 3; ++ww) {
+                    const cplx v = ysh[(ww * (PP_SEED_KPT / 4) + j) * 64 + lane];
+                    s.x += v.x; s.y += v.y;
+                }
+                const int k = lane + 1 + 64 * jj;
+                if (k <= a.Kt) yo[k - 1] = s;
+            }
+        }
     }
 }
 

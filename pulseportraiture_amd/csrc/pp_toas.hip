@@ -517,7 +517,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.o_f0 = c->o_f0.as<double>(); fa.o_g0 = c->o_g0.as<double>(); fa.o_H0 = c->o_H0.as<double>();
 
     if (in->seed_ns > 0) {
-        if (Kt > 256 * PP_SEED_KPT) return fail(PP_EINVAL, "seed: Kt %d too large", Kt);
+        if (Kt > 64 * PP_SEED_KPT) return fail(PP_EINVAL, "seed: Kt %d too large", Kt);
         if ((rc = c->seedbuf.reserve(((size_t)ns * nchunk + ns) * Kt * sizeof(cplx)))) return rc;
         cplx* ypart = c->seedbuf.as<cplx>();
         cplx* ywork = ypart + (size_t)ns * nchunk * Kt;
