@@ -53,6 +53,36 @@ __device__ __forceinline__ double group_max(double v) {
     return v;
 }
 
+// Sum 16 per-lane values over the 64 lanes of a wave with 17 exchanges instead of
+// 96: each xor step halves the values a lane carries (it keeps the half selected
+// by that lane bit and adds the partner's copy of it).  On return lane l holds
+// the wave total of s[wave_reduce16_index(l)].
+__device__ __forceinline__ int wave_reduce16_index(int lane) { return (lane >> 2) & 15; }
+__device__ __forceinline__ double wave_reduce16(const double (&s)[16], int lane) {
+    double t8[8], t4[4], t2[2];
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double keep = b5 ? s[j + 8] : s[j], send = b5 ? s[j] : s[j + 8];
+        t8[j] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double keep = b4 ? t8[j + 4] : t8[j], send = b4 ? t8[j] : t8[j + 4];
+        t4[j] = keep + __shfl_xor(send, 16, 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const double keep = b3 ? t4[j + 2] : t4[j], send = b3 ? t4[j] : t4[j + 2];
+        t2[j] = keep + __shfl_xor(send, 8, 64);
+    }
+    const double keep = b2 ? t2[1] : t2[0], send = b2 ? t2[0] : t2[1];
+    double v = keep + __shfl_xor(send, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;   // index 8*b5 + 4*b4 + 2*b3 + b2 = (lane >> 2) & 15
+}
+
 // block-wide sum of NV values held by every thread; result valid in all
 // threads.  scratch must hold (blockDim.x/64)*NV doubles.
 template <int NV>

@@ -46,6 +46,7 @@ struct XspecArgs {
     const double* nu_fit;     // [nsub][3]
     const double* freqs; long long freqs_stride;
     double* csum0;            // [nsub][nchan][3]: A0 A1 A2 at x0 (csum buffer 0)
+    double* tay;              // [nsub][nchan][PP_TSTRIDE]: Taylor model at x0 (MODE 2)
 };
 
 struct FitArgs {
@@ -159,14 +160,19 @@ __global__ void k_model_kcut(const cplx* mft, const double* mmax, int nchan, int
 #ifndef PP_LATE_SCALARS
 #define PP_LATE_SCALARS 0     // load the per-row fit scalars right before the split
 #endif
-template <int M, typename Tin, bool TAIL, bool FUSE>
+// MODE 0: store X.  MODE 1: store X and the sums A0, A1, A2 at the initial
+// parameters.  MODE 2: store NO cross-spectrum, only the Taylor model of every
+// channel about the initial parameters (A_0..A_PP_TJ + remainder coefficient,
+// see k_eval_moments): the fit then needs no further pass over the data.
+template <int M, typename Tin, bool TAIL, int MODE>
 __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void k_xspec(XspecArgs a) {
+    constexpr bool FUSE = (MODE != 0);
     constexpr int T = FftPlan<M>::T, R1 = FftPlan<M>::R1, PER1 = FftPlan<M>::PER1;
     constexpr int PL = FftPlan<M>::PADLOG;
     constexpr int NW = T / 64;
     typedef typename RawOf<Tin>::type Raw;
     __shared__ cplx lds[FftPlan<M>::LDS_ELEMS];
-    __shared__ double red[5 * NW + 4];
+    __shared__ double red[(MODE == 2 ? 16 : 5) * NW + 4];
     const int tid = threadIdx.x;
     const long long nrows = (long long)a.nsub * a.nchan;
     const int H = M + 1;
@@ -274,6 +280,11 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             for (int q = 1; q < NW; q <<= 1) wst = cmul(wst, wst);
         }
         cplx wb = wb0;
+        double tm[16];      // MODE 2: Taylor sums (12 used)
+        if (MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) tm[j] = 0.0;
+        }
         for (int kb = 1 + tid; kb <= ktn; kb += PP_SPLIT_U * T) {
             cplx mv[PP_SPLIT_U];   // independent model loads in flight per chunk
 #pragma unroll
@@ -287,13 +298,28 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                 if (k <= ktn) {
                     const cplx d = rfft_harmonic_w<M>(lds, wb, k);
                     const cplx x = cmulc(d, mv[j]);
-                    xrow[k - 1] = x;
-                    if (FUSE) {
+                    if (MODE != 2) xrow[k - 1] = x;
+                    if (MODE == 1) {
                         const cplx z = cmul(x, e);
                         const double kk = (double)k;
                         s0 += z.x;
                         s1 = fma(kk, z.y, s1);
                         s2 = fma(kk * kk, z.x, s2);
+                    }
+                    if (MODE == 2) {
+                        const cplx z = cmul(x, e);
+                        const double kap = PP_TWO_PI * (double)k, kap2 = kap * kap;
+                        double ur = z.x, ui = z.y * kap;
+#pragma unroll
+                        for (int q = 0; q <= PP_TJ; q += 2) {
+                            tm[q] += ur;
+                            ur *= kap2;
+                            if (q + 1 <= PP_TJ) { tm[q + 1] += ui; ui *= kap2; }
+                        }
+                        double pw = kap;
+#pragma unroll
+                        for (int q = 0; q < PP_TJ / 2; ++q) pw *= kap2;
+                        tm[PP_TJ + 1] = fma(pw, fabs(x.x) + fabs(x.y), tm[PP_TJ + 1]);
                     }
                 }
                 wb = cmul(wb, wbT);
@@ -302,8 +328,19 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         }
         sd = group_sum<64>(sd);
         if (TAIL) tail = group_sum<64>(tail);
-        if (FUSE) { s0 = group_sum<64>(s0); s1 = group_sum<64>(s1); s2 = group_sum<64>(s2); }
+        if (MODE == 1) { s0 = group_sum<64>(s0); s1 = group_sum<64>(s1); s2 = group_sum<64>(s2); }
+        double tv = 0.0;
+        if (MODE == 2) tv = wave_reduce16(tm, tid & 63);
         if (NW > 1) {
+            if (MODE == 2) {
+                if (((tid & 63) & 3) == 0) red[16 * (tid >> 6) + wave_reduce16_index(tid & 63)] = tv;
+                lds_sync<T>();
+                if (tid < 64) {
+                    tv = 0.0;
+                    for (int w = 0; w < NW; ++w) tv += red[16 * w + wave_reduce16_index(tid)];
+                }
+                lds_sync<T>();
+            }
             if ((tid & 63) == 0) {
                 double* r = red + 5 * (tid >> 6);
                 r[0] = sd; r[1] = tail; r[2] = s0; r[3] = s1; r[4] = s2;
@@ -317,10 +354,17 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                 }
             }
         }
+        if (MODE == 2 && tid < 64 && (tid & 3) == 0) {
+            const int q = wave_reduce16_index(tid);
+            if (q < PP_TSTRIDE) {
+                // Re(i^q z): +Re, -Im, -Re, +Im, ...
+                a.tay[rc * PP_TSTRIDE + q] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
+            }
+        }
         if (tid == 0) {
             a.sdraw[rc] = sd;
             if (TAIL) a.noise[rc] = sqrt(tail / (2.0 * M) / (double)(H - kc));
-            if (FUSE) {
+            if (MODE == 1) {
                 double* co = a.csum0 + rc * 3;
                 co[0] = s0;
                 co[1] = -PP_TWO_PI * s1;

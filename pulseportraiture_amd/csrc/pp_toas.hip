@@ -372,16 +372,16 @@ static int upload(pp_ctx* c, DevBuf& b, const void* src, size_t bytes) {
 }
 
 template <int MM, typename TIN>
-static void launch_xspec(pp_ctx* c, const XspecArgs& xa, bool tail, bool fuse) {
+static void launch_xspec(pp_ctx* c, const XspecArgs& xa, bool tail, int mode) {
     const int T = FftPlan<MM>::T;
     const dim3 grid(fft_grid(T, (long long)xa.nsub * xa.nchan)), blk(T);
+#define PP_XS(TL, MD) hipLaunchKernelGGL((k_xspec<MM, TIN, TL, MD>), grid, blk, 0, c->stream, xa)
     if (tail) {
-        if (fuse) hipLaunchKernelGGL((k_xspec<MM, TIN, true, true>), grid, blk, 0, c->stream, xa);
-        else hipLaunchKernelGGL((k_xspec<MM, TIN, true, false>), grid, blk, 0, c->stream, xa);
+        if (mode == 2) PP_XS(true, 2); else if (mode == 1) PP_XS(true, 1); else PP_XS(true, 0);
     } else {
-        if (fuse) hipLaunchKernelGGL((k_xspec<MM, TIN, false, true>), grid, blk, 0, c->stream, xa);
-        else hipLaunchKernelGGL((k_xspec<MM, TIN, false, false>), grid, blk, 0, c->stream, xa);
+        if (mode == 2) PP_XS(false, 2); else if (mode == 1) PP_XS(false, 1); else PP_XS(false, 0);
     }
+#undef PP_XS
 }
 
 static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, int ns, int Kt, bool scat,
@@ -422,12 +422,15 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // evaluation loop (fallback: the loop below); otherwise evaluate as usual
     const bool taylor = !scat && c->max_iter > 0 && c->use_taylor;
     const bool fuse = !scat && !taylor && in->seed_ns <= 0;   // first evaluation folded into k_xspec
+    // k_xspec mode: 2 = Taylor model only, no cross-spectrum stored (the seed
+    // needs X at a phase not known yet, so it keeps mode 0 + k_eval_moments)
+    const int xmode = (taylor && in->seed_ns <= 0) ? 2 : (fuse ? 1 : 0);
     const int ncs = scat ? PP_NCS : 3;
     int nchunk = std::min(std::max(1, C / 64), std::max(1, (4096 + ns - 1) / ns));
     int cpc = (C + nchunk - 1) / nchunk;
     cpc = ((cpc + 15) / 16) * 16;
     nchunk = (C + cpc - 1) / cpc;
-    if ((rc = c->X.reserve(nc * Kt * sizeof(cplx)))) return rc;
+    if (xmode != 2) if ((rc = c->X.reserve(nc * Kt * sizeof(cplx)))) return rc;
     if ((rc = c->sdraw.reserve(nc * 8))) return rc;
     if ((rc = c->noise.reserve(nc * 8))) return rc;
     if ((rc = c->wts.reserve(nc * 8))) return rc;
@@ -469,11 +472,12 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     xa.x0 = c->x0.as<double>(); xa.P = c->P.as<double>(); xa.nu_fit = c->nufit.as<double>();
     xa.freqs = c->freqs.as<double>(); xa.freqs_stride = in->freqs_stride ? C : 0;
     xa.csum0 = c->csum.as<double>();
+    xa.tay = c->tay.as<double>();
     {
         Prof pr(c, KF_XSPEC);
         PP_DISPATCH_M(M, {
-            if (in->data_dtype == PP_F64) launch_xspec<MM, double>(c, xa, tail, fuse);
-            else launch_xspec<MM, float>(c, xa, tail, fuse);
+            if (in->data_dtype == PP_F64) launch_xspec<MM, double>(c, xa, tail, xmode);
+            else launch_xspec<MM, float>(c, xa, tail, xmode);
         });
     }
     HIP_TRY(hipGetLastError());
@@ -531,7 +535,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     HIP_TRY(hipGetLastError());
     bool all_done = false;
     if (taylor) {
-        {
+        if (xmode != 2) {
             Prof pr(c, KF_EVAL);
             hipLaunchKernelGGL(k_eval_moments, dim3(nchunk, ns), dim3(256), 0, c->stream, fa);
         }
@@ -543,6 +547,18 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         HIP_TRY(hipMemcpyAsync(c->nactive_h, fa.nactive, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         all_done = (c->nactive_h[0] <= 0);
+        if (!all_done && xmode == 2) {
+            // some subints failed the certificate: they need evaluations over the
+            // cross-spectrum, which was not stored -- transform the batch again
+            if ((rc = c->X.reserve(nc * Kt * sizeof(cplx)))) return rc;
+            xa.X = c->X.as<cplx>(); fa.X = c->X.as<cplx>();
+            Prof pr(c, KF_XSPEC);
+            PP_DISPATCH_M(M, {
+                if (in->data_dtype == PP_F64) launch_xspec<MM, double>(c, xa, tail, 0);
+                else launch_xspec<MM, float>(c, xa, tail, 0);
+            });
+            HIP_TRY(hipGetLastError());
+        }
     }
     // ---- trust-region iterations: evaluation + step, until every subint is done
     const int max_evals = all_done ? 0 : std::max(1, c->max_iter + 1);
