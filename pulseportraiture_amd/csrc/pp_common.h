@@ -26,6 +26,15 @@ __device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x -
 __device__ __forceinline__ cplx cmul_mi(cplx a) { return make_double2(a.y, -a.x); }
 __device__ __forceinline__ double cnorm(cplx a) { return fma(a.x, a.x, a.y * a.y); }
 
+// Pointers fetched from a pointer table in memory are generic ("flat") to the
+// compiler; flat loads count on both vmcnt and lgkmcnt and force a full drain of
+// the vector-memory queue before use.  Everything here lives in global memory.
+template <typename T>
+__device__ __forceinline__ const T* as_global(const T* p) {
+    typedef const T __attribute__((address_space(1)))* gp_t;
+    return (const T*)(gp_t)(uintptr_t)p;
+}
+
 // exp(2 pi i k phi) with the product reduced modulo 1 before the sincos:
 // k*phi is formed exactly (fma residual), so large non-dedispersed phase
 // shifts do not lose the fraction.
@@ -58,12 +67,14 @@ __device__ __forceinline__ double group_max(double v) {
 // by that lane bit and adds the partner's copy of it).  On return lane l holds
 // the wave total of s[wave_reduce16_index(l)].
 __device__ __forceinline__ int wave_reduce16_index(int lane) { return (lane >> 2) & 15; }
-__device__ __forceinline__ double wave_reduce16(const double (&s)[16], int lane) {
+template <int NS>   // NS <= 16 values given, the rest are zero
+__device__ __forceinline__ double wave_reduce16(const double (&s)[NS], int lane) {
     double t8[8], t4[4], t2[2];
     const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const double keep = b5 ? s[j + 8] : s[j], send = b5 ? s[j] : s[j + 8];
+        const double hi = (j + 8 < NS) ? s[j + 8] : 0.0;
+        const double keep = b5 ? hi : s[j], send = b5 ? s[j] : hi;
         t8[j] = keep + __shfl_xor(send, 32, 64);
     }
 #pragma unroll
@@ -82,6 +93,28 @@ __device__ __forceinline__ double wave_reduce16(const double (&s)[16], int lane)
     v += __shfl_xor(v, 1, 64);
     return v;   // index 8*b5 + 4*b4 + 2*b3 + b2 = (lane >> 2) & 15
 }
+
+// The same reduction through LDS: every lane stores its NS values, lane 4q + p
+// (q < NS, p < 4) adds up value q of lanes 16p .. 16p+15, and two quad exchanges
+// finish.  ~3 NS + 22 instructions instead of ~230; `buf` holds NS * 68 doubles
+// (rows padded so that the strided reads spread over the banks).  On return lane l
+// holds the wave total of s[(l >> 2)] for l < 4 NS (same indexing as above).
+template <int NS>
+__device__ __forceinline__ double wave_reduce_lds(const double (&s)[NS], int lane, double* buf) {
+    static_assert(NS <= 16, "one value per lane quad");
+    const int wpos = (lane >> 4) * 17 + (lane & 15);
+#pragma unroll
+    for (int q = 0; q < NS; ++q) buf[q * 68 + wpos] = s[q];
+    const int q = min(lane >> 2, NS - 1), part = lane & 3;
+    const double* src = buf + q * 68 + part * 17;
+    double v = 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v += src[t];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    return v;
+}
+#define PP_WRED_DOUBLES(NS) ((NS) * 68)
 
 // block-wide sum of NV values held by every thread; result valid in all
 // threads.  scratch must hold (blockDim.x/64)*NV doubles.

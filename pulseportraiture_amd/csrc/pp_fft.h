@@ -290,6 +290,22 @@ __device__ __forceinline__ void load_row_twiddles(RowTwiddles<M>& tw, const cplx
     if constexpr (P::R4 > 1) stage_twiddles<M, P::T, P::R3, P::R1 * P::R2>(tw.t3, twB, tid);
 }
 
+// make the compiler forget what it knows about the twiddle registers
+template <int M>
+__device__ __forceinline__ void opaque_twiddles(RowTwiddles<M>& tw) {
+    typedef FftPlan<M> P;
+#pragma unroll
+    for (int j = 0; j < P::PER1; ++j) asm volatile("" : "+v"(tw.t1[j].x), "+v"(tw.t1[j].y));
+    if constexpr (P::R3 > 1) {
+#pragma unroll
+        for (int j = 0; j < P::PER2; ++j) asm volatile("" : "+v"(tw.t2[j].x), "+v"(tw.t2[j].y));
+    }
+    if constexpr (P::R4 > 1) {
+#pragma unroll
+        for (int j = 0; j < P::PER3; ++j) asm volatile("" : "+v"(tw.t3[j].x), "+v"(tw.t3[j].y));
+    }
+}
+
 // first stage from registers
 template <int M, int PER1_, int R1_>
 __device__ __forceinline__ void fft_first_stage(cplx* lds, cplx (&v)[PER1_][R1_], const RowTwiddles<M>& tw,

@@ -157,6 +157,9 @@ __global__ void k_model_kcut(const cplx* mft, const double* mmax, int nchan, int
 #ifndef PP_XSPEC_ABLATE
 #define PP_XSPEC_ABLATE 0     // timing-only builds: 1 = loads only, 2 = + stage 1, 3 = + all stages
 #endif
+#ifndef PP_OPAQUE_ROW
+#define PP_OPAQUE_ROW 2         // 0 never, 1 always, 2 only in MODE 2 (register-bound)
+#endif
 #ifndef PP_LATE_SCALARS
 #define PP_LATE_SCALARS 0     // load the per-row fit scalars right before the split
 #endif
@@ -171,9 +174,12 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
     constexpr int PL = FftPlan<M>::PADLOG;
     constexpr int NW = T / 64;
     typedef typename RawOf<Tin>::type Raw;
-    __shared__ cplx lds[FftPlan<M>::LDS_ELEMS];
+    // the image doubles as scratch of the MODE 2 reduction (one region per wave)
+    constexpr int WRED = PP_WRED_DOUBLES(PP_TSTRIDE) / 2;   // in cplx
+    constexpr int LDSN = (MODE == 2 && NW * WRED > FftPlan<M>::LDS_ELEMS) ? NW * WRED : FftPlan<M>::LDS_ELEMS;
+    __shared__ cplx lds[LDSN];
     __shared__ double red[(MODE == 2 ? 16 : 5) * NW + 4];
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
     const long long nrows = (long long)a.nsub * a.nchan;
     const int H = M + 1;
     const int kc = (int)(0.75 * H);   // get_noise_PS: int((1 - 1/4) * len(pows))
@@ -182,20 +188,52 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
     load_row_twiddles<M>(tw, a.twB, tid);
     // W_B^(tid+1) and W_B^T: split twiddles by recurrence (no loads in the loop)
     const cplx wb0 = a.twB[min(tid + 1, M)], wbT = a.twB[min(T, M)];
-    long long row = blockIdx.x;
-    if (row < nrows) {
-        const size_t rc = (size_t)(row % a.nsub) * a.nchan + (size_t)(row / a.nsub);
+    // Each block takes a contiguous run of rows in (channel, subint) order: the
+    // channel -- hence the template row -- changes once per nsub rows, and the
+    // (subint, channel) indices advance without divisions.
+    const long long R = (nrows + gridDim.x - 1) / gridDim.x;
+    long long row = (long long)blockIdx.x * R;
+    const long long rend = min(nrows, row + R);
+    int n = 0, i = 0;
+    if (row < rend) {
+        n = __builtin_amdgcn_readfirstlane((int)(row / a.nsub));
+        i = __builtin_amdgcn_readfirstlane((int)(row % a.nsub));
+        const size_t rc = (size_t)i * a.nchan + n;
         stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rc * (2 * M), tid);
     }
-    for (; row < nrows; row += gridDim.x) {
-        const int n = (int)(row / a.nsub), i = (int)(row % a.nsub);
+    // MODE 2 keeps this thread's harmonics of the template row in registers; they
+    // are reloaded only when the row changes, so the split issues no vector loads
+    // (which would have to wait behind the prefetch of the next data row)
+    constexpr int KPT = (M / 2 + T - 1) / T;
+    cplx mv2[KPT];
+    const cplx* mheld = nullptr;
+    int i_nx = i, n_nx = n;
+    for (; row < rend; ++row, i = i_nx, n = n_nx) {
+        i_nx = i + 1; n_nx = n;
+        if (i_nx == a.nsub) { i_nx = 0; ++n_nx; }
+        // Everything derived from the thread index and the twiddles is invariant
+        // over this loop, and the compiler hoists all of it (LDS addresses of every
+        // stage, twiddle powers: ~50 VGPRs held across the whole row).  Recomputing
+        // them per row frees those registers; it only pays where that buys occupancy.
+        if (PP_OPAQUE_ROW == 1 || (PP_OPAQUE_ROW == 2 && MODE == 2)) {
+            asm volatile("" : "+v"(tid));
+            opaque_twiddles<M>(tw);
+        }
         const size_t rc = (size_t)i * a.nchan + n;
         // Issue, BEFORE anything waits, every load of this row whose result is
         // needed late: vector-memory results return in order, so these must be
         // older than the prefetch of the next row or consuming them would drain it.
-        const cplx* mrow = (a.slot ? a.mft[a.slot[i]] : a.mft0) + (size_t)n * M;
+        const cplx* mrow = as_global(a.slot ? a.mft[a.slot[i]] : a.mft0) + (size_t)n * M;
         // harmonics this channel's template keeps (multiple of 64)
-        const int ktn = a.ktab ? (a.slot ? a.ktab[a.slot[i]] : a.kt0)[n] : a.Kt;
+        const int ktn = a.ktab ? as_global(a.slot ? a.ktab[a.slot[i]] : a.kt0)[n] : a.Kt;
+        if (MODE == 2 && mrow != mheld) {
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const int k = tid + 1 + j * T;
+                mv2[j] = (k <= ktn) ? mrow[k - 1] : make_double2(0.0, 0.0);
+            }
+            mheld = mrow;
+        }
         double fP = 1.0, fnu = 1.0, fnuDM = 1.0, fnuGM = 1.0, fx0 = 0.0, fx1 = 0.0, fx2 = 0.0;
         if (FUSE && !PP_LATE_SCALARS) {
             fP = a.P[i]; fnu = a.freqs[(size_t)i * a.freqs_stride + n];
@@ -222,9 +260,12 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         __builtin_amdgcn_sched_barrier(0);
         // the first stage has consumed the row: its registers now receive the
         // NEXT row, whose HBM loads stay in flight under the rest of this one
-        const long long nrow = row + gridDim.x;
-        if (nrow < nrows) {
-            const size_t rn = (size_t)(nrow % a.nsub) * a.nchan + (size_t)(nrow / a.nsub);
+        // (unconditional -- the last row of the run fetches itself again: a prefetch
+        // under a branch makes the compiler drain the whole queue, vmcnt(0), before
+        // every use of an earlier load, because on the path without it no younger
+        // loads exist)
+        {
+            const size_t rn = (row + 1 < rend) ? (size_t)i_nx * a.nchan + n_nx : rc;
             stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -263,7 +304,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         cplx* xrow = a.X + rc * a.Kt;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         cplx e = make_double2(1.0, 0.0), wst = make_double2(1.0, 0.0);
-        if (FUSE) {
+        auto setup_phasors = [&]() {
             const double a2 = 1.0 / (fnu * fnu);
             const double p1 = PP_DCONST * (a2 - 1.0 / (fnuDM * fnuDM)) / fP;
             const double p2 = PP_DCONST * PP_DCONST * (a2 * a2 - 1.0 / (fnuGM * fnuGM * fnuGM * fnuGM)) / fP;
@@ -278,14 +319,33 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             wst = w64;
 #pragma unroll
             for (int q = 1; q < NW; q <<= 1) wst = cmul(wst, wst);
-        }
+        };
+        if (MODE == 1) setup_phasors();
         cplx wb = wb0;
-        double tm[16];      // MODE 2: Taylor sums (12 used)
         if (MODE == 2) {
+            // X_k is parked in the slot of Z_k, which only this thread reads (the
+            // host guarantees 2 ktn < M, so no kept M-k' equals a kept k).  T is a
+            // multiple of the padding period: the padded slots of k + jT and of
+            // M - k - jT are affine in j (constant LDS offsets).
+            static_assert(T % (1 << PL) == 0, "padding period must divide the block size");
+            constexpr int JS = T + (T >> PL);
+            cplx* pk = lds + lds_pad<PL>(tid + 1);
+            const cplx* pc = lds + lds_pad<PL>(M - 1 - tid);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) tm[j] = 0.0;
+            for (int j = 0; j < KPT; ++j) {
+                if (tid + 1 + j * T <= ktn) {
+                    const cplx zk = pk[j * JS];
+                    cplx zc = pc[-j * JS];
+                    zc.y = -zc.y;
+                    const cplx E = make_double2(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
+                    const cplx O = make_double2(0.5 * (zk.x - zc.x), 0.5 * (zk.y - zc.y));
+                    const cplx wo = cmul(wb, O);
+                    pk[j * JS] = cmulc(make_double2(E.x + wo.y, E.y - wo.x), mv2[j]);
+                }
+                wb = cmul(wb, wbT);
+            }
         }
-        for (int kb = 1 + tid; kb <= ktn; kb += PP_SPLIT_U * T) {
+        for (int kb = 1 + tid; MODE != 2 && kb <= ktn; kb += PP_SPLIT_U * T) {
             cplx mv[PP_SPLIT_U];   // independent model loads in flight per chunk
 #pragma unroll
             for (int j = 0; j < PP_SPLIT_U; ++j) {
@@ -298,7 +358,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                 if (k <= ktn) {
                     const cplx d = rfft_harmonic_w<M>(lds, wb, k);
                     const cplx x = cmulc(d, mv[j]);
-                    if (MODE != 2) xrow[k - 1] = x;
+                    xrow[k - 1] = x;
                     if (MODE == 1) {
                         const cplx z = cmul(x, e);
                         const double kk = (double)k;
@@ -306,31 +366,55 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                         s1 = fma(kk, z.y, s1);
                         s2 = fma(kk * kk, z.x, s2);
                     }
-                    if (MODE == 2) {
-                        const cplx z = cmul(x, e);
-                        const double kap = PP_TWO_PI * (double)k, kap2 = kap * kap;
-                        double ur = z.x, ui = z.y * kap;
-#pragma unroll
-                        for (int q = 0; q <= PP_TJ; q += 2) {
-                            tm[q] += ur;
-                            ur *= kap2;
-                            if (q + 1 <= PP_TJ) { tm[q + 1] += ui; ui *= kap2; }
-                        }
-                        double pw = kap;
-#pragma unroll
-                        for (int q = 0; q < PP_TJ / 2; ++q) pw *= kap2;
-                        tm[PP_TJ + 1] = fma(pw, fabs(x.x) + fabs(x.y), tm[PP_TJ + 1]);
-                    }
                 }
                 wb = cmul(wb, wbT);
-                if (FUSE) e = cmul(e, wst);
+                if (MODE == 1) e = cmul(e, wst);
             }
+        }
+        // MODE 2: Taylor sums of this thread's harmonics in a loop of their own,
+        // so that the 12 accumulators are not live together with the split
+        double tm[PP_TSTRIDE];
+        if (MODE == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            setup_phasors();
+#pragma unroll
+            for (int j = 0; j < PP_TSTRIDE; ++j) tm[j] = 0.0;
+#ifndef PP_EXP_NOMOM
+            const cplx* px = lds + lds_pad<PL>(tid + 1);
+            constexpr int JSm = T + (T >> PL);
+            double kd = (double)(tid + 1);
+            for (int k = 1 + tid; k <= ktn; k += T, px += JSm, kd += (double)T) {
+                const cplx x = *px;
+                const cplx z = cmul(x, e);
+                // kappa^2, ^4, .. ^10 once; every sum is then one FMA
+                const double kap = PP_TWO_PI * kd, p2 = kap * kap, p4 = p2 * p2, p6 = p4 * p2, p8 = p4 * p4,
+                             p10 = p8 * p2;
+                const double ui = z.y * kap;
+                static_assert(PP_TJ == 10, "power ladder written for order 10");
+                tm[0] += z.x;
+                tm[1] += ui;
+                tm[2] = fma(p2, z.x, tm[2]);
+                tm[3] = fma(p2, ui, tm[3]);
+                tm[4] = fma(p4, z.x, tm[4]);
+                tm[5] = fma(p4, ui, tm[5]);
+                tm[6] = fma(p6, z.x, tm[6]);
+                tm[7] = fma(p6, ui, tm[7]);
+                tm[8] = fma(p8, z.x, tm[8]);
+                tm[9] = fma(p8, ui, tm[9]);
+                tm[10] = fma(p10, z.x, tm[10]);
+                tm[11] = fma(p10 * kap, fabs(x.x) + fabs(x.y), tm[11]);
+                e = cmul(e, wst);
+            }
+#endif
         }
         sd = group_sum<64>(sd);
         if (TAIL) tail = group_sum<64>(tail);
         if (MODE == 1) { s0 = group_sum<64>(s0); s1 = group_sum<64>(s1); s2 = group_sum<64>(s2); }
         double tv = 0.0;
-        if (MODE == 2) tv = wave_reduce16(tm, tid & 63);
+        if (MODE == 2) {
+            if (NW > 1) lds_sync<T>();   // other waves may still read their parked X
+            tv = wave_reduce_lds(tm, tid & 63, reinterpret_cast<double*>(lds + (tid >> 6) * WRED));
+        }
         if (NW > 1) {
             if (MODE == 2) {
                 if (((tid & 63) & 3) == 0) red[16 * (tid >> 6) + wave_reduce16_index(tid & 63)] = tv;
@@ -520,8 +604,8 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
     const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
     const double* wts = a.wts + (size_t)i * a.nchan;
     const int slot = a.slot ? a.slot[i] : 0;
-    const double* msum = a.msum[slot];
-    const cplx* mft = a.mft[slot];
+    const double* msum = as_global(a.msum[slot]);
+    const cplx* mft = as_global(a.mft[slot]);
     const int trial = 1 - st.cur;
     double* csum = a.csum + ((size_t)trial * a.nsub + i) * a.nchan * a.ncs;
     double accA = 0.0, accB = 0.0;   // lane l of a group owns sums l and 16+l of the 21
@@ -540,7 +624,7 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
         double k = (double)(l + 1);
         // harmonics beyond the template's kept range carry |m_nk|^2 < 2^-100 of
         // the channel's power: they drop out of S_n(tau) and of C_n alike
-        const int ktn = a.ktab ? a.ktab[slot][n] : a.Kt;
+        const int ktn = a.ktab ? as_global(a.ktab[slot])[n] : a.Kt;
         if (w != 0.0) {
 #pragma unroll 2
             for (int j = l; j < ktn; j += LPC) {
@@ -638,7 +722,7 @@ __global__ __launch_bounds__(256) void k_accum(FitArgs a) {
     const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1];
     const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
     const double* wts = a.wts + (size_t)i * a.nchan;
-    const double* msum = a.msum[a.slot ? a.slot[i] : 0];
+    const double* msum = as_global(a.msum[a.slot ? a.slot[i] : 0]);
     const int trial = 1 - st.cur;
     const double* csum = a.csum + ((size_t)trial * a.nsub + i) * a.nchan * a.ncs;
     double acc[PP_NACC];
@@ -684,8 +768,8 @@ __global__ __launch_bounds__(256) void k_eval_fast(FitArgs a) {
     const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1];
     const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
     const double* wts = a.wts + (size_t)i * a.nchan;
-    const double* msum = a.msum[a.slot ? a.slot[i] : 0];
-    const int* ktv = a.ktab ? a.ktab[a.slot ? a.slot[i] : 0] : nullptr;
+    const double* msum = as_global(a.msum[a.slot ? a.slot[i] : 0]);
+    const int* ktv = a.ktab ? as_global(a.ktab[a.slot ? a.slot[i] : 0]) : nullptr;
     const int trial = 1 - st.cur;
     double* csum = a.csum + ((size_t)trial * a.nsub + i) * a.nchan * a.ncs;
     double accA = 0.0;
@@ -901,7 +985,7 @@ __global__ __launch_bounds__(256) void k_eval_moments(FitArgs a) {
     const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1];
     const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
     const double* wts = a.wts + (size_t)i * a.nchan;
-    const int* ktv = a.ktab ? a.ktab[a.slot ? a.slot[i] : 0] : nullptr;
+    const int* ktv = a.ktab ? as_global(a.ktab[a.slot ? a.slot[i] : 0]) : nullptr;
     double* tay = a.tay + (size_t)i * a.nchan * PP_TSTRIDE;
     const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan);
     const int src = ((tid & 63) & ~(LPC - 1)) | (LPC - 1);
@@ -988,7 +1072,7 @@ __global__ __launch_bounds__(256) void k_taylor_solve(FitArgs a) {
     const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1];
     const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
     const double* wts = a.wts + (size_t)i * a.nchan;
-    const double* msum = a.msum[a.slot ? a.slot[i] : 0];
+    const double* msum = as_global(a.msum[a.slot ? a.slot[i] : 0]);
     const double* tay = a.tay + (size_t)i * a.nchan * PP_TSTRIDE;
     const int* fl = a.flags;
     int idx[3], nf = 0;
@@ -1310,7 +1394,7 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs a) {
     const double* wts = a.wts + (size_t)i * a.nchan;
     const double* csum = a.csum + ((size_t)s.cur * a.nsub + i) * a.nchan * a.ncs;
     const int slot = a.slot ? a.slot[i] : 0;
-    const double* msum = a.msum[slot];
+    const double* msum = as_global(a.msum[slot]);
     const int* fl = a.flags;
     const double phi = s.x[0], DM = s.x[1], GM = s.x[2], alpha = s.x[4];
     const double taup = s.x[3];

@@ -424,7 +424,9 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     const bool fuse = !scat && !taylor && in->seed_ns <= 0;   // first evaluation folded into k_xspec
     // k_xspec mode: 2 = Taylor model only, no cross-spectrum stored (the seed
     // needs X at a phase not known yet, so it keeps mode 0 + k_eval_moments)
-    const int xmode = (taylor && in->seed_ns <= 0) ? 2 : (fuse ? 1 : 0);
+    // mode 2 parks X_k in the LDS slot of Z_k, which is safe while no kept harmonic
+    // M-k aliases a kept k: 2 Kt < M
+    const int xmode = (taylor && in->seed_ns <= 0 && 2 * Kt < M) ? 2 : (fuse ? 1 : 0);
     const int ncs = scat ? PP_NCS : 3;
     int nchunk = std::min(std::max(1, C / 64), std::max(1, (4096 + ns - 1) / ns));
     int cpc = (C + nchunk - 1) / nchunk;
