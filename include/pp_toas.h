@@ -70,6 +70,12 @@ void* pp_stream(pp_ctx* ctx);
  *   "max_iter"     trust-region iteration limit (default 64; reference: 1000)
  *   "profile"      1 = record HIP events around every kernel (pp_kernel_times)
  *   "check_every"  iterations between host checks of the active count
+ *   "max_work_bytes"  cap on device scratch per call (larger batches are split)
+ *   "taylor"       1 (default) = fits without scattering first try the
+ *                  per-channel Taylor-model solve; 0 = always iterate
+ *   "moments_in_xspec"  1 (default) = the Taylor moments are accumulated inside
+ *                  the transform kernel and no cross-spectrum is stored; 0 = store
+ *                  the cross-spectrum and take the moments in a second pass
  */
 int pp_set_option(pp_ctx* ctx, const char* name, double value);
 

@@ -149,7 +149,7 @@ struct SubState {
     double pred_red;   // predicted reduction of the pending proposal
     int hits_boundary;
     int iter, nfev, status, done, cur;  // cur: csum buffer of the accepted point
-    int fresh;         // the next evaluation is an initial one (no ratio test)
+    int fresh;         // the next evaluation is 1: an initial one, 2: the closing one (no ratio test)
 };
 
 // number of per-subint accumulators of one evaluation: f, g[5], H upper[15]

@@ -1243,11 +1243,22 @@ __global__ __launch_bounds__(64) void k_step(FitArgs a) {
     bool finite = isfinite(f);
     for (int j = 0; j < 5; ++j) finite = finite && isfinite(g[j]);
     for (int j = 0; j < 25; ++j) finite = finite && isfinite(H[j]);
-    const bool first = (s.fresh != 0);
+    const bool first = (s.fresh == 1), closing = (s.fresh == 2);
     s.fresh = 0;
     s.nfev += 1;
     bool done = false;
-    if (first) {
+    if (closing) {
+        // evaluation at the point of the final Newton step: the post-fit stage
+        // (zero-covariance frequencies, errors, scales) uses sums taken AT the
+        // returned parameters, as the reference does
+        if (finite) {
+            for (int j = 0; j < 5; ++j) { s.x[j] = s.xe[j]; s.g[j] = g[j]; }
+            for (int j = 0; j < 25; ++j) s.H[j] = H[j];
+            s.f = f;
+            s.cur = 1 - s.cur;
+        }
+        s.status = PP_RC_STALL; done = true;
+    } else if (first) {
         s.f = f; s.f0 = f;
         for (int j = 0; j < 5; ++j) { s.g[j] = g[j]; s.g0[j] = g[j]; }
         for (int j = 0; j < 25; ++j) { s.H[j] = H[j]; s.H0[j] = H[j]; }
@@ -1284,14 +1295,26 @@ __global__ __launch_bounds__(64) void k_step(FitArgs a) {
         const double pred = -(vdot(n, gs, p) + 0.5 * vdot(n, p, Hp));
         // scipy: predicted_reduction <= 0 -> status 2 (the reference's normal exit)
         const double fpred = s.f - pred;     // what scipy compares: m(p) vs m(0)
-        if (!(pred > 0.0) || !(fpred < s.f)) { s.status = PP_RC_STALL; done = true; }
-        else if (pred <= 64.0 * 2.220446049250313e-16 * fabs(s.f) && !hits) {
-            // the predicted reduction is below the rounding noise of f itself, so
-            // the ratio test can no longer see it: take the (interior) Newton
-            // step and stop.  The reference keeps evaluating until the reduction
-            // underflows; this lands at least as close to the optimum.
-            for (int r = 0; r < n; ++r) s.x[idx[r]] += p[r];
-            s.status = PP_RC_STALL; done = true;
+        const double noise = 2.220446049250313e-16 * fabs(s.f);
+        if (!(pred > 0.0) || !(fpred < s.f) || pred <= 64.0 * noise) {
+            // The predicted reduction is below the rounding noise of f itself, so
+            // the ratio test can no longer see it (scipy stops here with status 2,
+            // the reference's normal exit, up to ~1e-9 rot short of the optimum).
+            // Finish with the full Newton step when that step too is worth no more
+            // than noise in f -- this close the quadratic model is exact to working
+            // precision -- which lands at least as close to the optimum.
+            double pn[5], Hpn[5];
+            int hn = 0;
+            tr_subproblem(n, gs, Hs, 1e150, pn, &hn);
+            for (int r = 0; r < n; ++r) Hpn[r] = vdot(n, Hs + r * n, pn);
+            const double predn = -(vdot(n, gs, pn) + 0.5 * vdot(n, pn, Hpn));
+            if (!hn && predn >= 0.0 && predn <= 4096.0 * noise && s.iter + 1 < a.max_iter) {
+                for (int j = 0; j < 5; ++j) s.xe[j] = s.x[j];
+                for (int r = 0; r < n; ++r) s.xe[idx[r]] = s.x[idx[r]] + pn[r];
+                s.fresh = 2;
+            } else {
+                s.status = PP_RC_STALL; done = true;
+            }
         } else {
             for (int j = 0; j < 5; ++j) s.xe[j] = s.x[j];
             for (int r = 0; r < n; ++r) s.xe[idx[r]] = s.x[idx[r]] + p[r];

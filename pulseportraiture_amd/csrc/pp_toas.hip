@@ -90,6 +90,7 @@ struct pp_ctx {
     int profile = 0;
     int check_every = 1;
     int use_taylor = 1;
+    int moments_in_xspec = 1;   // fold the Taylor moments into k_xspec (mode 2) when it applies
     double max_work_bytes = 96e9;
     // profiling
     struct Span { int fam; hipEvent_t a, b; };
@@ -193,6 +194,7 @@ extern "C" int pp_set_option(pp_ctx* c, const char* name, double value) {
     else if (n == "check_every") c->check_every = std::max(1, (int)value);
     else if (n == "max_work_bytes") c->max_work_bytes = value;
     else if (n == "taylor") c->use_taylor = (int)value;
+    else if (n == "moments_in_xspec") c->moments_in_xspec = (int)value;
     else return fail(PP_EINVAL, "pp_set_option: unknown option '%s'", name);
     return PP_OK;
 }
@@ -426,7 +428,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // needs X at a phase not known yet, so it keeps mode 0 + k_eval_moments)
     // mode 2 parks X_k in the LDS slot of Z_k, which is safe while no kept harmonic
     // M-k aliases a kept k: 2 Kt < M
-    const int xmode = (taylor && in->seed_ns <= 0 && 2 * Kt < M) ? 2 : (fuse ? 1 : 0);
+    const int xmode = (taylor && c->moments_in_xspec && in->seed_ns <= 0 && 2 * Kt < M) ? 2 : (fuse ? 1 : 0);
     const int ncs = scat ? PP_NCS : 3;
     int nchunk = std::min(std::max(1, C / 64), std::max(1, (4096 + ns - 1) / ns));
     int cpc = (C + nchunk - 1) / nchunk;

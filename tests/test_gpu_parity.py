@@ -499,6 +499,62 @@ def test_poor_guess_falls_back_to_evaluations(eng):
         np.testing.assert_allclose(r["scales"][0], g["out_scales"], rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("nbin", [512, 1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("flags", [[1, 1, 0, 0, 0], [1, 1, 1, 0, 0]])
+def test_moments_in_xspec_match_two_pass_flow(nbin, flags):
+    """When the template keeps fewer than nbin/4 harmonics the transform kernel
+    accumulates the Taylor moments itself and stores no cross-spectrum.  That flow,
+    the two-pass flow (stored cross-spectrum + moments kernel) and the plain
+    evaluation loop must agree far inside the parity bars, and the first two must
+    both finish without falling back to evaluations."""
+    from pulseportraiture_amd.engine import Engine
+    from pulseportraiture_amd import gmodel
+    from pulseportraiture_amd.pplib import guess_fit_freq, Dconst
+    import torch
+    C, nsub = 24, 7
+    e = Engine(0)
+    freqs, _, P0 = gmodel.example_model(C, nbin)
+    # two gaussian components ~20 bins wide: about nbin/15 harmonics above 2^-50
+    ph = (np.arange(nbin) + 0.5) / nbin
+    w = (20.0 / nbin) * (freqs[:, None] / 1500.0) ** -0.3
+    model = np.exp(-0.5 * ((ph - 0.5) / w) ** 2) + 0.4 * np.exp(-0.5 * ((ph - 0.5 - 3 * w) / w) ** 2)
+    nharm = e.set_model(model)
+    assert 4 * nharm < nbin, "case must exercise the in-kernel moments (2 Kt < nbin/2)"
+    rng = np.random.default_rng(nbin)
+    P = np.full(nsub, P0)
+    inj = np.zeros((nsub, 3))
+    inj[:, 0] = rng.uniform(-0.5, 0.5, nsub)
+    inj[:, 1] = 12.0 + rng.normal(0, 2e-4, nsub)
+    if flags[2]:
+        inj[:, 2] = rng.normal(0.2, 0.05, nsub)
+    data = torch.empty((nsub, C, nbin), dtype=torch.float64, device="cuda:0")
+    e.synth_portraits(data, freqs, P, inj, 0.05, 99, 0)
+    nu_fit = float(guess_fit_freq(freqs))
+    x0 = np.zeros((nsub, 5))
+    x0[:, 0] = (inj[:, 0] + Dconst * inj[:, 1] / P / nu_fit ** 2 + Dconst ** 2 * inj[:, 2] / P / nu_fit ** 4
+                + 5e-5 * rng.standard_normal(nsub) + 0.5) % 1.0 - 0.5
+    x0[:, 1] = 12.0
+    kw = dict(errs=np.full((nsub, C), 0.05), nu_fits=np.full((nsub, 3), nu_fit), fit_flags=flags,
+              log10_tau=False)
+    fused = e.fit_batch(data, freqs, P, x0, **kw)
+    e.set_option("moments_in_xspec", 0)
+    twopass = e.fit_batch(data, freqs, P, x0, **kw)
+    e.set_option("taylor", 0)
+    loop = e.fit_batch(data, freqs, P, x0, **kw)
+    assert (fused["nfeval"] == 1).all() and (twopass["nfeval"] == 1).all() and (loop["nfeval"] >= 2).all()
+    nfit = sum(flags)
+    # the three-parameter problem is nearly degenerate (phi, DM, GM covary): its
+    # optimum is defined less sharply, still far inside the 1e-9 / 1e-6 bars
+    phi_tol, dm_tol, err_tol = (1e-12, 1e-9, 1e-9) if not flags[2] else (2e-10, 1e-7, 1e-6)
+    for r in (twopass, loop):
+        assert np.max(np.abs((fused["params"][:, 0] - r["params"][:, 0] + 0.5) % 1.0 - 0.5)) < phi_tol
+        assert np.max(np.abs(fused["params"][:, 1] - r["params"][:, 1])) < dm_tol
+        np.testing.assert_allclose(fused["param_errs"][:, :nfit], r["param_errs"][:, :nfit], rtol=err_tol)
+        np.testing.assert_allclose(fused["chi2"], r["chi2"], rtol=1e-11)
+        np.testing.assert_allclose(fused["scales"], r["scales"], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(fused["snr"], r["snr"], rtol=1e-9)
+
+
 def test_sub_batching_and_model_slots(eng):
     """A batch larger than the work-memory budget is processed in sub-batches
     and gives the same answers; subints may reference different template slots."""
