@@ -160,6 +160,9 @@ __global__ void k_model_kcut(const cplx* mft, const double* mmax, int nchan, int
 #ifndef PP_OPAQUE_ROW
 #define PP_OPAQUE_ROW 2         // 0 never, 1 always, 2 only in MODE 2 (register-bound)
 #endif
+#ifndef PP_M2_MERGE
+#define PP_M2_MERGE 1          // MODE 2: Taylor sums inside the split sweep (no LDS parking of X)
+#endif
 #ifndef PP_LATE_SCALARS
 #define PP_LATE_SCALARS 0     // load the per-row fit scalars right before the split
 #endif
@@ -187,7 +190,8 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
     RowTwiddles<M> tw;
     load_row_twiddles<M>(tw, a.twB, tid);
     // W_B^(tid+1) and W_B^T: split twiddles by recurrence (no loads in the loop)
-    const cplx wb0 = a.twB[min(tid + 1, M)], wbT = a.twB[min(T, M)];
+    cplx wb0 = a.twB[min(tid + 1, M)];
+    const cplx wbT = a.twB[min(T, M)];
     // Each block takes a contiguous run of rows in (channel, subint) order: the
     // channel -- hence the template row -- changes once per nsub rows, and the
     // (subint, channel) indices advance without divisions.
@@ -218,6 +222,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         if (PP_OPAQUE_ROW == 1 || (PP_OPAQUE_ROW == 2 && MODE == 2)) {
             asm volatile("" : "+v"(tid));
             opaque_twiddles<M>(tw);
+            asm volatile("" : "+v"(wb0.x), "+v"(wb0.y));   // or all of wb0 wbT^j are hoisted
         }
         const size_t rc = (size_t)i * a.nchan + n;
         // Issue, BEFORE anything waits, every load of this row whose result is
@@ -230,7 +235,9 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const int k = tid + 1 + j * T;
-                mv2[j] = (k <= ktn) ? mrow[k - 1] : make_double2(0.0, 0.0);
+                // halved: the split below then forms 2 d_k without its factors 1/2
+                const cplx mk = (k <= ktn) ? mrow[k - 1] : make_double2(0.0, 0.0);
+                mv2[j] = make_double2(0.5 * mk.x, 0.5 * mk.y);
             }
             mheld = mrow;
         }
@@ -322,27 +329,58 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         };
         if (MODE == 1) setup_phasors();
         cplx wb = wb0;
+        double tm[PP_TSTRIDE];
         if (MODE == 2) {
-            // X_k is parked in the slot of Z_k, which only this thread reads (the
-            // host guarantees 2 ktn < M, so no kept M-k' equals a kept k).  T is a
-            // multiple of the padding period: the padded slots of k + jT and of
-            // M - k - jT are affine in j (constant LDS offsets).
+            // T is a multiple of the padding period: the padded slots of k + jT and
+            // of M - k - jT are affine in j (constant LDS offsets)
             static_assert(T % (1 << PL) == 0, "padding period must divide the block size");
+            static_assert(PP_TJ == 10, "power ladder written for order 10");
             constexpr int JS = T + (T >> PL);
             cplx* pk = lds + lds_pad<PL>(tid + 1);
             const cplx* pc = lds + lds_pad<PL>(M - 1 - tid);
+#if PP_M2_MERGE
+            // split and Taylor sums in one sweep (no parking of X in LDS)
+            setup_phasors();
+#pragma unroll
+            for (int j = 0; j < PP_TSTRIDE; ++j) tm[j] = 0.0;
+#endif
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 if (tid + 1 + j * T <= ktn) {
                     const cplx zk = pk[j * JS];
                     cplx zc = pc[-j * JS];
                     zc.y = -zc.y;
-                    const cplx E = make_double2(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
-                    const cplx O = make_double2(0.5 * (zk.x - zc.x), 0.5 * (zk.y - zc.y));
+                    const cplx E = make_double2(zk.x + zc.x, zk.y + zc.y);
+                    const cplx O = make_double2(zk.x - zc.x, zk.y - zc.y);
                     const cplx wo = cmul(wb, O);
-                    pk[j * JS] = cmulc(make_double2(E.x + wo.y, E.y - wo.x), mv2[j]);
+                    const cplx x = cmulc(make_double2(E.x + wo.y, E.y - wo.x), mv2[j]);
+#if PP_M2_MERGE
+                    const cplx z = cmul(x, e);
+                    const double kap = PP_TWO_PI * (double)(tid + 1 + j * T), p2 = kap * kap, p4 = p2 * p2,
+                                 p6 = p4 * p2, p8 = p4 * p4, p10 = p8 * p2;
+                    const double ui = z.y * kap;
+                    tm[0] += z.x;
+                    tm[1] += ui;
+                    tm[2] = fma(p2, z.x, tm[2]);
+                    tm[3] = fma(p2, ui, tm[3]);
+                    tm[4] = fma(p4, z.x, tm[4]);
+                    tm[5] = fma(p4, ui, tm[5]);
+                    tm[6] = fma(p6, z.x, tm[6]);
+                    tm[7] = fma(p6, ui, tm[7]);
+                    tm[8] = fma(p8, z.x, tm[8]);
+                    tm[9] = fma(p8, ui, tm[9]);
+                    tm[10] = fma(p10, z.x, tm[10]);
+                    tm[11] = fma(p10 * kap, fabs(x.x) + fabs(x.y), tm[11]);
+#else
+                    // X_k is parked in the slot of Z_k, which only this thread reads
+                    // (the host guarantees 2 ktn < M: no kept M-k' equals a kept k)
+                    pk[j * JS] = x;
+#endif
                 }
                 wb = cmul(wb, wbT);
+#if PP_M2_MERGE
+                e = cmul(e, wst);
+#endif
             }
         }
         for (int kb = 1 + tid; MODE != 2 && kb <= ktn; kb += PP_SPLIT_U * T) {
@@ -373,8 +411,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         }
         // MODE 2: Taylor sums of this thread's harmonics in a loop of their own,
         // so that the 12 accumulators are not live together with the split
-        double tm[PP_TSTRIDE];
-        if (MODE == 2) {
+        if (MODE == 2 && !PP_M2_MERGE) {
             __builtin_amdgcn_sched_barrier(0);
             setup_phasors();
 #pragma unroll
