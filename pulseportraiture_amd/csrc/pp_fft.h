@@ -139,8 +139,13 @@ __device__ __forceinline__ void stage_load_global(Raw (&v)[PER][R], const Tin* _
     for (int i = 0; i < PER; ++i) {
         const int t = tid + T * i;
         if (NBF % T == 0 || t < NBF) {
+            // (uniform row base + constant) + 32-bit unsigned lane offset: selects
+            // the SGPR-base addressing mode, no 64-bit vector address per load
+            const char* gb = reinterpret_cast<const char*>(grow);
+            const unsigned boff = (unsigned)t * (unsigned)sizeof(Raw);
 #pragma unroll
-            for (int k = 0; k < R; ++k) v[i][k] = load_raw(grow, t + k * NBF);
+            for (int k = 0; k < R; ++k)
+                v[i][k] = *reinterpret_cast<const Raw*>(gb + (size_t)(k * NBF) * sizeof(Raw) + boff);
         }
     }
 }

@@ -47,6 +47,7 @@ struct XspecArgs {
     const double* freqs; long long freqs_stride;
     double* csum0;            // [nsub][nchan][3]: A0 A1 A2 at x0 (csum buffer 0)
     double* tay;              // [nsub][nchan][PP_TSTRIDE]: Taylor model at x0 (MODE 2)
+    const double* ph0;        // [nsub][nchan]: phi_n at x0 (k_phase0), MODE 1 and 2
 };
 
 struct FitArgs {
@@ -163,9 +164,6 @@ __global__ void k_model_kcut(const cplx* mft, const double* mmax, int nchan, int
 #ifndef PP_M2_MERGE
 #define PP_M2_MERGE 1          // MODE 2: Taylor sums inside the split sweep (no LDS parking of X)
 #endif
-#ifndef PP_LATE_SCALARS
-#define PP_LATE_SCALARS 0     // load the per-row fit scalars right before the split
-#endif
 // MODE 0: store X.  MODE 1: store X and the sums A0, A1, A2 at the initial
 // parameters.  MODE 2: store NO cross-spectrum, only the Taylor model of every
 // channel about the initial parameters (A_0..A_PP_TJ + remainder coefficient,
@@ -241,12 +239,10 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             }
             mheld = mrow;
         }
-        double fP = 1.0, fnu = 1.0, fnuDM = 1.0, fnuGM = 1.0, fx0 = 0.0, fx1 = 0.0, fx2 = 0.0;
-        if (FUSE && !PP_LATE_SCALARS) {
-            fP = a.P[i]; fnu = a.freqs[(size_t)i * a.freqs_stride + n];
-            fnuDM = a.nu_fit[i * 3]; fnuGM = a.nu_fit[i * 3 + 1];
-            fx0 = a.x0[i * 5]; fx1 = a.x0[i * 5 + 1]; fx2 = a.x0[i * 5 + 2];
-        }
+        // phi_n at the initial parameters (k_phase0); loaded here, before the
+        // prefetch of the next row is queued
+        double phin = 0.0;
+        if (FUSE) phin = a.ph0[rc];
         {
             cplx v[PER1][R1];
 #pragma unroll
@@ -293,11 +289,6 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        if (FUSE && PP_LATE_SCALARS) {
-            fP = a.P[i]; fnu = a.freqs[(size_t)i * a.freqs_stride + n];
-            fnuDM = a.nu_fit[i * 3]; fnuGM = a.nu_fit[i * 3 + 1];
-            fx0 = a.x0[i * 5]; fx1 = a.x0[i * 5 + 1]; fx2 = a.x0[i * 5 + 2];
-        }
         if (TAIL) {
             for (int k = kc + tid; k <= M; k += T) tail += cnorm(rfft_harmonic<M>(lds, a.twB, k));
         }
@@ -312,10 +303,6 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         cplx e = make_double2(1.0, 0.0), wst = make_double2(1.0, 0.0);
         auto setup_phasors = [&]() {
-            const double a2 = 1.0 / (fnu * fnu);
-            const double p1 = PP_DCONST * (a2 - 1.0 / (fnuDM * fnuDM)) / fP;
-            const double p2 = PP_DCONST * PP_DCONST * (a2 * a2 - 1.0 / (fnuGM * fnuGM * fnuGM * fnuGM)) / fP;
-            const double phin = fx0 + fx1 * p1 + fx2 * p2;
             // e^{2 pi i (tid+1) phi}: one sincos per lane (k = lane+1); lane 63
             // holds e^{2 pi i 64 phi}, whose powers give the wave offset and the
             // per-iteration step e^{2 pi i T phi}
@@ -581,6 +568,20 @@ __device__ __forceinline__ void phase_geom(double nu, double P, double nuDM, dou
     const double iGM = (nuGM == INFINITY) ? 0.0 : 1.0 / (nuGM * nuGM * nuGM * nuGM);
     p1 = PP_DCONST * (a2 - iDM) / P;
     p2 = PP_DCONST * PP_DCONST * (a2 * a2 - iGM) / P;
+}
+
+// phi_n of every (subint, channel) at the initial parameters: the expansion
+// point of the Taylor model k_xspec accumulates (reference order of operations,
+// pptoaslib.py:181-198)
+__global__ __launch_bounds__(256) void k_phase0(int nsub, int nchan, const double* x0, const double* P,
+                                                const double* nu_fit, const double* freqs, int freqs_stride,
+                                                double* ph0) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)nsub * nchan) return;
+    const int i = (int)(idx / nchan), n = (int)(idx % nchan);
+    double p1, p2;
+    phase_geom(freqs[(size_t)i * freqs_stride + n], P[i], nu_fit[i * 3], nu_fit[i * 3 + 1], p1, p2);
+    ph0[idx] = x0[i * 5] + x0[i * 5 + 1] * p1 + x0[i * 5 + 2] * p2;
 }
 
 // local (phi_n, tau_n) derivatives of F_n = -C^2/S from weighted sums

@@ -82,7 +82,7 @@ struct pp_ctx {
     // work buffers
     DevBuf data, X, sdraw, noise, wts, freqs, errs, mask, P, x0, nufit, nuout, slot, state, csum, partial;
     DevBuf o_params, o_errs, o_nu, o_cov, o_chi2, o_rchi2, o_snr, o_nfev, o_rc, o_scales, o_serrs, o_csnr,
-        o_f0, o_g0, o_H0, misc, seedbuf, tay;
+        o_f0, o_g0, o_H0, misc, seedbuf, tay, ph0;
     int* nactive_h = nullptr;   // pinned
     // options
     double harm_eps = 8.8817841970012523e-16;  // 2^-50
@@ -167,7 +167,7 @@ extern "C" int pp_destroy(pp_ctx* c) {
                       &c->errs, &c->mask, &c->P, &c->x0, &c->nufit, &c->nuout, &c->slot, &c->state, &c->csum,
                       &c->partial, &c->o_params, &c->o_errs, &c->o_nu, &c->o_cov, &c->o_chi2, &c->o_rchi2,
                       &c->o_snr, &c->o_nfev, &c->o_rc, &c->o_scales, &c->o_serrs, &c->o_csnr, &c->o_f0, &c->o_g0,
-                      &c->o_H0, &c->misc, &c->seedbuf, &c->tay};
+                      &c->o_H0, &c->misc, &c->seedbuf, &c->tay, &c->ph0};
     for (DevBuf* b : bufs) b->release();
     if (c->nactive_h) (void)hipHostFree(c->nactive_h);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -442,6 +442,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     if ((rc = c->csum.reserve(2 * nc * ncs * 8))) return rc;
     if ((rc = c->partial.reserve((size_t)ns * nchunk * PP_NACC * 8))) return rc;
     if (taylor) if ((rc = c->tay.reserve(nc * PP_TSTRIDE * 8))) return rc;
+    if (xmode != 0) if ((rc = c->ph0.reserve(nc * 8))) return rc;
     if ((rc = c->misc.reserve(256))) return rc;
     if ((rc = c->o_params.reserve((size_t)ns * 40))) return rc;
     if ((rc = c->o_errs.reserve((size_t)ns * 40))) return rc;
@@ -477,6 +478,12 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     xa.freqs = c->freqs.as<double>(); xa.freqs_stride = in->freqs_stride ? C : 0;
     xa.csum0 = c->csum.as<double>();
     xa.tay = c->tay.as<double>();
+    xa.ph0 = c->ph0.as<double>();
+    if (xmode != 0) {
+        Prof pr(c, KF_PREP);
+        hipLaunchKernelGGL(k_phase0, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, ns, C,
+                           xa.x0, xa.P, xa.nu_fit, xa.freqs, xa.freqs_stride, c->ph0.as<double>());
+    }
     {
         Prof pr(c, KF_XSPEC);
         PP_DISPATCH_M(M, {
