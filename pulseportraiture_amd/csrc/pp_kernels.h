@@ -161,25 +161,26 @@ __global__ void k_model_kcut(const cplx* mft, const double* mmax, int nchan, int
 #ifndef PP_OPAQUE_ROW
 #define PP_OPAQUE_ROW 2         // 0 never, 1 always, 2 only in MODE 2 (register-bound)
 #endif
-#ifndef PP_M2_MERGE
-#define PP_M2_MERGE 1          // MODE 2: Taylor sums inside the split sweep (no LDS parking of X)
-#endif
 // MODE 0: store X.  MODE 1: store X and the sums A0, A1, A2 at the initial
 // parameters.  MODE 2: store NO cross-spectrum, only the Taylor model of every
 // channel about the initial parameters (A_0..A_PP_TJ + remainder coefficient,
 // see k_eval_moments): the fit then needs no further pass over the data.
+// MODE 2 requires 2 Kt < M (each thread then owns harmonics k only); MODE 3 is
+// the same for any Kt <= M: harmonic M-k is formed with k from the same two
+// transform outputs.
 template <int M, typename Tin, bool TAIL, int MODE>
 __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void k_xspec(XspecArgs a) {
     constexpr bool FUSE = (MODE != 0);
+    constexpr bool M2 = (MODE == 2 || MODE == 3), PAIR = (MODE == 3);
     constexpr int T = FftPlan<M>::T, R1 = FftPlan<M>::R1, PER1 = FftPlan<M>::PER1;
     constexpr int PL = FftPlan<M>::PADLOG;
     constexpr int NW = T / 64;
     typedef typename RawOf<Tin>::type Raw;
     // the image doubles as scratch of the MODE 2 reduction (one region per wave)
     constexpr int WRED = PP_WRED_DOUBLES(PP_TSTRIDE) / 2;   // in cplx
-    constexpr int LDSN = (MODE == 2 && NW * WRED > FftPlan<M>::LDS_ELEMS) ? NW * WRED : FftPlan<M>::LDS_ELEMS;
+    constexpr int LDSN = (M2 && NW * WRED > FftPlan<M>::LDS_ELEMS) ? NW * WRED : FftPlan<M>::LDS_ELEMS;
     __shared__ cplx lds[LDSN];
-    __shared__ double red[(MODE == 2 ? 16 : 5) * NW + 4];
+    __shared__ double red[(M2 ? 16 : 5) * NW + 4];
     int tid = threadIdx.x;
     const long long nrows = (long long)a.nsub * a.nchan;
     const int H = M + 1;
@@ -208,6 +209,9 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
     // (which would have to wait behind the prefetch of the next data row)
     constexpr int KPT = (M / 2 + T - 1) / T;
     cplx mv2[KPT];
+    // MODE 3: the partners' template values m_{M-k} too, where registers allow
+    constexpr bool CRES = PAIR && M != 1024;
+    cplx mc2[CRES ? KPT : 1];
     const cplx* mheld = nullptr;
     int i_nx = i, n_nx = n;
     for (; row < rend; ++row, i = i_nx, n = n_nx) {
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         // over this loop, and the compiler hoists all of it (LDS addresses of every
         // stage, twiddle powers: ~50 VGPRs held across the whole row).  Recomputing
         // them per row frees those registers; it only pays where that buys occupancy.
-        if (PP_OPAQUE_ROW == 1 || (PP_OPAQUE_ROW == 2 && MODE == 2)) {
+        if (PP_OPAQUE_ROW == 1 || (PP_OPAQUE_ROW == 2 && M2)) {
             asm volatile("" : "+v"(tid));
             opaque_twiddles<M>(tw);
             asm volatile("" : "+v"(wb0.x), "+v"(wb0.y));   // or all of wb0 wbT^j are hoisted
@@ -229,13 +233,18 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         const cplx* mrow = as_global(a.slot ? a.mft[a.slot[i]] : a.mft0) + (size_t)n * M;
         // harmonics this channel's template keeps (multiple of 64)
         const int ktn = a.ktab ? as_global(a.slot ? a.ktab[a.slot[i]] : a.kt0)[n] : a.Kt;
-        if (MODE == 2 && mrow != mheld) {
+        if (M2 && mrow != mheld) {
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const int k = tid + 1 + j * T;
                 // halved: the split below then forms 2 d_k without its factors 1/2
                 const cplx mk = (k <= ktn) ? mrow[k - 1] : make_double2(0.0, 0.0);
                 mv2[j] = make_double2(0.5 * mk.x, 0.5 * mk.y);
+                if (CRES) {
+                    const int kp = M - k;
+                    const cplx mp = (kp <= ktn && kp != k && kp > 0) ? mrow[kp - 1] : make_double2(0.0, 0.0);
+                    mc2[j] = make_double2(0.5 * mp.x, 0.5 * mp.y);
+                }
             }
             mheld = mrow;
         }
@@ -317,60 +326,84 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         if (MODE == 1) setup_phasors();
         cplx wb = wb0;
         double tm[PP_TSTRIDE];
-        if (MODE == 2) {
-            // T is a multiple of the padding period: the padded slots of k + jT and
-            // of M - k - jT are affine in j (constant LDS offsets)
+        if (M2) {
+            // Split and Taylor sums in one sweep over this thread's harmonics.  T is
+            // a multiple of the padding period: the padded slots of k + jT and of
+            // M - k - jT are affine in j (constant LDS offsets).
             static_assert(T % (1 << PL) == 0, "padding period must divide the block size");
             static_assert(PP_TJ == 10, "power ladder written for order 10");
             constexpr int JS = T + (T >> PL);
-            cplx* pk = lds + lds_pad<PL>(tid + 1);
+            const cplx* pk = lds + lds_pad<PL>(tid + 1);
             const cplx* pc = lds + lds_pad<PL>(M - 1 - tid);
-#if PP_M2_MERGE
-            // split and Taylor sums in one sweep (no parking of X in LDS)
             setup_phasors();
 #pragma unroll
             for (int j = 0; j < PP_TSTRIDE; ++j) tm[j] = 0.0;
-#endif
+            // kappa^2, ^4 .. ^10 once per harmonic; every sum is then one FMA
+            auto taylor_sums = [&](const cplx& x, const cplx& z, double kap) {
+                const double p2 = kap * kap, p4 = p2 * p2, p6 = p4 * p2, p8 = p4 * p4, p10 = p8 * p2;
+                const double ui = z.y * kap;
+                tm[0] += z.x;
+                tm[1] += ui;
+                tm[2] = fma(p2, z.x, tm[2]);
+                tm[3] = fma(p2, ui, tm[3]);
+                tm[4] = fma(p4, z.x, tm[4]);
+                tm[5] = fma(p4, ui, tm[5]);
+                tm[6] = fma(p6, z.x, tm[6]);
+                tm[7] = fma(p6, ui, tm[7]);
+                tm[8] = fma(p8, z.x, tm[8]);
+                tm[9] = fma(p8, ui, tm[9]);
+                tm[10] = fma(p10, z.x, tm[10]);
+                tm[11] = fma(p10 * kap, fabs(x.x) + fabs(x.y), tm[11]);
+            };
+            cplx eM = wst;     // e^{2 pi i M phi}: the partner of e_k is eM conj(e_k)
+            if (PAIR) {
+                if constexpr (M < T) {
+                    // one wave, lane l holds e^{2 pi i (l+1) phi}
+                    eM = make_double2(__shfl(e.x, M - 1, 64), __shfl(e.y, M - 1, 64));
+                } else {
+#pragma unroll
+                    for (int q = T; q < M; q <<= 1) eM = cmul(eM, eM);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
-                if (tid + 1 + j * T <= ktn) {
+                const int k = tid + 1 + j * T;
+                // (pairs: k runs to M/2 only -- the upper half comes as partners;
+                // matters when M/2 is not a multiple of the block size)
+                if (k <= ktn && (!PAIR || 2 * k <= M)) {
                     const cplx zk = pk[j * JS];
                     cplx zc = pc[-j * JS];
                     zc.y = -zc.y;
                     const cplx E = make_double2(zk.x + zc.x, zk.y + zc.y);
                     const cplx O = make_double2(zk.x - zc.x, zk.y - zc.y);
                     const cplx wo = cmul(wb, O);
+                    // 2 d_k = E - i W^k O
                     const cplx x = cmulc(make_double2(E.x + wo.y, E.y - wo.x), mv2[j]);
-#if PP_M2_MERGE
-                    const cplx z = cmul(x, e);
-                    const double kap = PP_TWO_PI * (double)(tid + 1 + j * T), p2 = kap * kap, p4 = p2 * p2,
-                                 p6 = p4 * p2, p8 = p4 * p4, p10 = p8 * p2;
-                    const double ui = z.y * kap;
-                    tm[0] += z.x;
-                    tm[1] += ui;
-                    tm[2] = fma(p2, z.x, tm[2]);
-                    tm[3] = fma(p2, ui, tm[3]);
-                    tm[4] = fma(p4, z.x, tm[4]);
-                    tm[5] = fma(p4, ui, tm[5]);
-                    tm[6] = fma(p6, z.x, tm[6]);
-                    tm[7] = fma(p6, ui, tm[7]);
-                    tm[8] = fma(p8, z.x, tm[8]);
-                    tm[9] = fma(p8, ui, tm[9]);
-                    tm[10] = fma(p10, z.x, tm[10]);
-                    tm[11] = fma(p10 * kap, fabs(x.x) + fabs(x.y), tm[11]);
-#else
-                    // X_k is parked in the slot of Z_k, which only this thread reads
-                    // (the host guarantees 2 ktn < M: no kept M-k' equals a kept k)
-                    pk[j * JS] = x;
-#endif
+                    taylor_sums(x, cmul(x, e), PP_TWO_PI * (double)k);
+                    if (PAIR) {
+                        // 2 d_{M-k} = conj(E) - i conj(W^k O)   (W^{M-k} = -conj W^k)
+                        const int kp = M - k;
+                        if (kp <= ktn && kp != k) {
+                            cplx mp;
+                            if (CRES) mp = mc2[j];
+                            else { const cplx t = mrow[kp - 1]; mp = make_double2(0.5 * t.x, 0.5 * t.y); }
+                            const cplx xp = cmulc(make_double2(E.x - wo.y, -E.y - wo.x), mp);
+                            taylor_sums(xp, cmul(xp, cmulc(eM, e)), PP_TWO_PI * (double)kp);
+                        }
+                    }
                 }
                 wb = cmul(wb, wbT);
-#if PP_M2_MERGE
                 e = cmul(e, wst);
-#endif
+            }
+            if (PAIR && ktn == M && tid == 0) {
+                // Nyquist harmonic: d_M = Re Z_0 - Im Z_0
+                const cplx z0 = lds[0], mM = mrow[M - 1];
+                const double dM = z0.x - z0.y;
+                const cplx x = make_double2(dM * mM.x, -dM * mM.y);
+                taylor_sums(x, cmul(x, eM), PP_TWO_PI * (double)M);
             }
         }
-        for (int kb = 1 + tid; MODE != 2 && kb <= ktn; kb += PP_SPLIT_U * T) {
+        for (int kb = 1 + tid; !M2 && kb <= ktn; kb += PP_SPLIT_U * T) {
             cplx mv[PP_SPLIT_U];   // independent model loads in flight per chunk
 #pragma unroll
             for (int j = 0; j < PP_SPLIT_U; ++j) {
@@ -396,51 +429,16 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                 if (MODE == 1) e = cmul(e, wst);
             }
         }
-        // MODE 2: Taylor sums of this thread's harmonics in a loop of their own,
-        // so that the 12 accumulators are not live together with the split
-        if (MODE == 2 && !PP_M2_MERGE) {
-            __builtin_amdgcn_sched_barrier(0);
-            setup_phasors();
-#pragma unroll
-            for (int j = 0; j < PP_TSTRIDE; ++j) tm[j] = 0.0;
-#ifndef PP_EXP_NOMOM
-            const cplx* px = lds + lds_pad<PL>(tid + 1);
-            constexpr int JSm = T + (T >> PL);
-            double kd = (double)(tid + 1);
-            for (int k = 1 + tid; k <= ktn; k += T, px += JSm, kd += (double)T) {
-                const cplx x = *px;
-                const cplx z = cmul(x, e);
-                // kappa^2, ^4, .. ^10 once; every sum is then one FMA
-                const double kap = PP_TWO_PI * kd, p2 = kap * kap, p4 = p2 * p2, p6 = p4 * p2, p8 = p4 * p4,
-                             p10 = p8 * p2;
-                const double ui = z.y * kap;
-                static_assert(PP_TJ == 10, "power ladder written for order 10");
-                tm[0] += z.x;
-                tm[1] += ui;
-                tm[2] = fma(p2, z.x, tm[2]);
-                tm[3] = fma(p2, ui, tm[3]);
-                tm[4] = fma(p4, z.x, tm[4]);
-                tm[5] = fma(p4, ui, tm[5]);
-                tm[6] = fma(p6, z.x, tm[6]);
-                tm[7] = fma(p6, ui, tm[7]);
-                tm[8] = fma(p8, z.x, tm[8]);
-                tm[9] = fma(p8, ui, tm[9]);
-                tm[10] = fma(p10, z.x, tm[10]);
-                tm[11] = fma(p10 * kap, fabs(x.x) + fabs(x.y), tm[11]);
-                e = cmul(e, wst);
-            }
-#endif
-        }
         sd = group_sum<64>(sd);
         if (TAIL) tail = group_sum<64>(tail);
         if (MODE == 1) { s0 = group_sum<64>(s0); s1 = group_sum<64>(s1); s2 = group_sum<64>(s2); }
         double tv = 0.0;
-        if (MODE == 2) {
-            if (NW > 1) lds_sync<T>();   // other waves may still read their parked X
+        if (M2) {
+            if (NW > 1) lds_sync<T>();   // other waves may still read the transform
             tv = wave_reduce_lds(tm, tid & 63, reinterpret_cast<double*>(lds + (tid >> 6) * WRED));
         }
         if (NW > 1) {
-            if (MODE == 2) {
+            if (M2) {
                 if (((tid & 63) & 3) == 0) red[16 * (tid >> 6) + wave_reduce16_index(tid & 63)] = tv;
                 lds_sync<T>();
                 if (tid < 64) {
@@ -462,7 +460,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                 }
             }
         }
-        if (MODE == 2 && tid < 64 && (tid & 3) == 0) {
+        if (M2 && tid < 64 && (tid & 3) == 0) {
             const int q = wave_reduce16_index(tid);
             if (q < PP_TSTRIDE) {
                 // Re(i^q z): +Re, -Im, -Re, +Im, ...

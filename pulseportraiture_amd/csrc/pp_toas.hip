@@ -379,9 +379,9 @@ static void launch_xspec(pp_ctx* c, const XspecArgs& xa, bool tail, int mode) {
     const dim3 grid(fft_grid(T, (long long)xa.nsub * xa.nchan)), blk(T);
 #define PP_XS(TL, MD) hipLaunchKernelGGL((k_xspec<MM, TIN, TL, MD>), grid, blk, 0, c->stream, xa)
     if (tail) {
-        if (mode == 2) PP_XS(true, 2); else if (mode == 1) PP_XS(true, 1); else PP_XS(true, 0);
+        if (mode == 3) PP_XS(true, 3); else if (mode == 2) PP_XS(true, 2); else if (mode == 1) PP_XS(true, 1); else PP_XS(true, 0);
     } else {
-        if (mode == 2) PP_XS(false, 2); else if (mode == 1) PP_XS(false, 1); else PP_XS(false, 0);
+        if (mode == 3) PP_XS(false, 3); else if (mode == 2) PP_XS(false, 2); else if (mode == 1) PP_XS(false, 1); else PP_XS(false, 0);
     }
 #undef PP_XS
 }
@@ -424,17 +424,18 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // evaluation loop (fallback: the loop below); otherwise evaluate as usual
     const bool taylor = !scat && c->max_iter > 0 && c->use_taylor;
     const bool fuse = !scat && !taylor && in->seed_ns <= 0;   // first evaluation folded into k_xspec
-    // k_xspec mode: 2 = Taylor model only, no cross-spectrum stored (the seed
-    // needs X at a phase not known yet, so it keeps mode 0 + k_eval_moments)
-    // mode 2 parks X_k in the LDS slot of Z_k, which is safe while no kept harmonic
-    // M-k aliases a kept k: 2 Kt < M
-    const int xmode = (taylor && c->moments_in_xspec && in->seed_ns <= 0 && 2 * Kt < M) ? 2 : (fuse ? 1 : 0);
+    // k_xspec mode: 2/3 = Taylor model only, no cross-spectrum stored (the seed
+    // needs X at a phase not known yet, so it keeps mode 0 + k_eval_moments);
+    // 2 while every thread owns single harmonics (2 Kt < M), else 3 (pairs k, M-k)
+    const bool xmom = taylor && c->moments_in_xspec && in->seed_ns <= 0;
+    const int xmode = xmom ? (2 * Kt < M ? 2 : 3) : (fuse ? 1 : 0);
+    const bool xstore = (xmode < 2);
     const int ncs = scat ? PP_NCS : 3;
     int nchunk = std::min(std::max(1, C / 64), std::max(1, (4096 + ns - 1) / ns));
     int cpc = (C + nchunk - 1) / nchunk;
     cpc = ((cpc + 15) / 16) * 16;
     nchunk = (C + cpc - 1) / cpc;
-    if (xmode != 2) if ((rc = c->X.reserve(nc * Kt * sizeof(cplx)))) return rc;
+    if (xstore) if ((rc = c->X.reserve(nc * Kt * sizeof(cplx)))) return rc;
     if ((rc = c->sdraw.reserve(nc * 8))) return rc;
     if ((rc = c->noise.reserve(nc * 8))) return rc;
     if ((rc = c->wts.reserve(nc * 8))) return rc;
@@ -546,7 +547,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     HIP_TRY(hipGetLastError());
     bool all_done = false;
     if (taylor) {
-        if (xmode != 2) {
+        if (xstore) {
             Prof pr(c, KF_EVAL);
             hipLaunchKernelGGL(k_eval_moments, dim3(nchunk, ns), dim3(256), 0, c->stream, fa);
         }
@@ -558,7 +559,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         HIP_TRY(hipMemcpyAsync(c->nactive_h, fa.nactive, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         all_done = (c->nactive_h[0] <= 0);
-        if (!all_done && xmode == 2) {
+        if (!all_done && !xstore) {
             // some subints failed the certificate: they need evaluations over the
             // cross-spectrum, which was not stored -- transform the batch again
             if ((rc = c->X.reserve(nc * Kt * sizeof(cplx)))) return rc;
