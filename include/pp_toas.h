@@ -173,6 +173,29 @@ int pp_rotate_portraits(pp_ctx* ctx, const void* src, void* dst, int dtype,
                         const double* par3, double nu_DM, double nu_GM);
 
 /* ---- synthetic portraits generated on the device ------------------------- */
+/* ppalign's accumulation (ppalign.py:199-206): aligned[n][:] = sum_i w[i][n] *
+ * rotate_data(src[i][n], phase_i, DM_i, P_i, freqs, nu_ref_i) and total_weights[n] =
+ * sum_i w[i][n]; rows with w <= 0 (or NaN) are skipped.  par3[i] = {phase, DM, nu_ref}
+ * (nu_ref may be INFINITY).  src: [nsub][nchan][nbin] of `dtype`, host or device;
+ * aligned [nchan][nbin] and total_weights [nchan] are host arrays, overwritten. */
+int pp_align_accumulate(pp_ctx* ctx, const void* src, int dtype, int on_device,
+                        int nsub, int nchan, int nbin, const double* freqs,
+                        int64_t freqs_stride, const double* P, const double* par3,
+                        const double* weights, double* aligned, double* total_weights);
+
+/* Per-channel reduced chi^2 of fitted subints in the time domain, as
+ * get_channels_to_zap forms it (pptoas.py:1239-1245 via show_fit :1394-1404 and
+ * get_red_chi2 pplib.py:727-750): sum over bins of (data rotated by the fitted
+ * phi, DM, GM  -  scales[n] x template, scattered by tau, alpha when tau != 0)^2
+ * / errs[n]^2 / (nbin - 2).  params5[i] = {phi, DM, GM, tau [rot, linear], alpha}
+ * at nu_refs3[i]; the template is the model slot of each subint (null: slot 0);
+ * red_chi2: [nsub][nchan] host array. */
+int pp_channel_red_chi2(pp_ctx* ctx, const void* src, int dtype, int on_device,
+                        int nsub, int nchan, int nbin, const int32_t* model_slot,
+                        const double* freqs, int64_t freqs_stride, const double* P,
+                        const double* params5, const double* nu_refs3,
+                        const double* scales, const double* errs, double* red_chi2);
+
 /* Fill dst[nsub][nchan][nbin] (device pointer, dtype) with
  *   gain[i][n] * rotate(model slot, -phi_i, -DM_i, -GM_i) + N(0, sigma)
  * using a counter-based RNG keyed on (seed, first_subint + i, channel, bin).

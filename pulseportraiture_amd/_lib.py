@@ -71,6 +71,13 @@ SYMBOLS = {
     "pp_synth_portraits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                      C.c_int, c_double_p, c_double_p, c_double_p,
                                      C.c_double, C.c_uint64, C.c_int64]),
+    "pp_align_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, c_double_p, C.c_int64, c_double_p,
+                                      c_double_p, c_double_p, c_double_p, c_double_p]),
+    "pp_channel_red_chi2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.POINTER(C.c_int32), c_double_p,
+                                      C.c_int64, c_double_p, c_double_p, c_double_p,
+                                      c_double_p, c_double_p, c_double_p]),
     "pp_kernel_times": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p),
                                   c_double_p, C.POINTER(C.c_int64)]),
     "pp_kernel_times_reset": (C.c_int, [C.c_void_p]),

@@ -167,6 +167,162 @@ __global__ __launch_bounds__(FftPlan<M>::T) void k_rotate(RotateArgs a) {
 }
 
 // --------------------------------------------------------------------------
+// ppalign's accumulation (ppalign.py:199-206): aligned[n] = sum_i w_in *
+// rotate_data(data_in, phase_i, DM_i, P_i, freqs, nu_ref_i), totw[n] = sum_i w_in.
+// Rotation is linear, so the weighted harmonics of all subints of a channel are
+// summed in the packed spectrum (LDS) and transformed back ONCE per channel: one
+// forward FFT per row, one inverse per channel.  One workgroup per channel;
+// subints are added in index order (deterministic).
+// --------------------------------------------------------------------------
+struct AlignArgs {
+    const void* src;      // [nsub][nchan][B]
+    const double* freqs; long long freqs_stride;
+    const double* P;      // [nsub]
+    const double* par;    // [nsub][3] phase, DM, nu_ref
+    const double* w;      // [nsub][nchan] weights (<= 0 or NaN: row skipped)
+    const cplx* twB;
+    double* aligned;      // [nchan][B]
+    double* totw;         // [nchan]
+    int nsub, nchan;
+};
+
+template <int M, typename Tio>
+__global__ __launch_bounds__(FftPlan<M>::T) void k_align_accum(AlignArgs a) {
+    constexpr int T = FftPlan<M>::T;
+    constexpr int PL = FftPlan<M>::PADLOG;
+    __shared__ cplx lds[FftPlan<M>::LDS_ELEMS];
+    __shared__ cplx zin[M];
+    const int tid = threadIdx.x;
+    for (int n = blockIdx.x; n < a.nchan; n += gridDim.x) {
+        for (int k = tid; k < M; k += T) zin[k] = make_double2(0.0, 0.0);
+        double wsum = 0.0;
+        for (int i = 0; i < a.nsub; ++i) {
+            const double w = a.w[(size_t)i * a.nchan + n];
+            if (!(w > 0.0)) continue;          // uniform over the workgroup
+            const double nu = a.freqs[(size_t)i * a.freqs_stride + n], P = a.P[i];
+            const double phase = a.par[i * 3], DM = a.par[i * 3 + 1], nuref = a.par[i * 3 + 2];
+            // reference order of operations (pplib.py:2419-2424)
+            const double D = PP_DCONST * DM / P;
+            const double iref = (nuref == INFINITY) ? 0.0 : 1.0 / (nuref * nuref);
+            const double phin = (DM == 0.0) ? phase : phase + D * (1.0 / (nu * nu) - iref);
+            fft_row<M, Tio>(lds, reinterpret_cast<const Tio*>(a.src) + ((size_t)i * a.nchan + n) * (2 * M), a.twB,
+                            tid);
+            const cplx z0 = lds[0];
+            const double y0 = z0.x + z0.y;                                    // DC, unchanged
+            const double yM = (z0.x - z0.y) * unit_phasor((double)M, phin).x; // Nyquist: real part kept
+            for (int k = tid; k < M; k += T) {
+                cplx yk, ym;
+                if (k == 0) { yk = make_double2(y0, 0.0); ym = make_double2(yM, 0.0); }
+                else {
+                    yk = cmul(rfft_harmonic<M>(lds, a.twB, k), unit_phasor((double)k, phin));
+                    ym = cmul(rfft_harmonic<M>(lds, a.twB, M - k), unit_phasor((double)(M - k), phin));
+                }
+                ym.y = -ym.y;
+                const cplx ev = make_double2(0.5 * (yk.x + ym.x), 0.5 * (yk.y + ym.y));
+                cplx od = make_double2(0.5 * (yk.x - ym.x), 0.5 * (yk.y - ym.y));
+                cplx tw = a.twB[k];
+                tw.y = -tw.y;
+                od = cmul(od, tw);
+                cplx acc = zin[k];      // this thread's own slot
+                acc.x = fma(w, ev.x - od.y, acc.x);
+                acc.y = fma(w, -(ev.y + od.x), acc.y);    // conj(ev + i od)
+                zin[k] = acc;
+            }
+            wsum += w;
+            __syncthreads();            // the image is overwritten by the next row
+        }
+        __syncthreads();
+        fft_row<M, cplx>(lds, zin, a.twB, tid);
+        double* out = a.aligned + (size_t)n * (2 * M);
+        const double inv = 1.0 / (double)M;
+        for (int j = tid; j < M; j += T) {
+            const cplx r = lds[lds_pad<PL>(j)];
+            reinterpret_cast<double2*>(out)[j] = make_double2(r.x * inv, -r.y * inv);
+        }
+        if (tid == 0) a.totw[n] = wsum;
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------
+// Per-channel reduced chi^2 of a fitted subint in the time domain, as
+// get_channels_to_zap forms it (pptoas.py:1239-1245 with show_fit :1394-1404 and
+// get_red_chi2 pplib.py:727-750): the data rotated by the fitted (phi, DM, GM)
+// minus scale_n x (scattered) template, summed over bins, / sigma_n^2 / (nbin-2).
+// Evaluated with Parseval on the residual spectrum (DC and Nyquist at weight 1,
+// the rest at 2; irfft keeps only the real part at Nyquist), all harmonics.
+// --------------------------------------------------------------------------
+struct ChanChi2Args {
+    const void* src;      // [nsub][nchan][B]
+    const cplx* const* mft; const double* const* mdc; const int* slot;   // model slots (slot may be null: 0)
+    const double* freqs; long long freqs_stride;
+    const double* P;      // [nsub]
+    const double* par;    // [nsub][5] phi, DM, GM, tau [rot, linear], alpha -- at nu_refs
+    const double* nuref;  // [nsub][3]
+    const double* scales; // [nsub][nchan]
+    const double* errs;   // [nsub][nchan] time-domain sigma
+    const cplx* twB;
+    double* out;          // [nsub][nchan]
+    int nsub, nchan;
+};
+
+template <int M, typename Tio>
+__global__ __launch_bounds__(FftPlan<M>::T) void k_chan_chi2(ChanChi2Args a) {
+    constexpr int T = FftPlan<M>::T;
+    __shared__ cplx lds[FftPlan<M>::LDS_ELEMS];
+    __shared__ double scratch[(T / 64) + 1];
+    const int tid = threadIdx.x;
+    const long long nrows = (long long)a.nsub * a.nchan;
+    for (long long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int i = (int)(row / a.nchan), n = (int)(row % a.nchan);
+        const double nu = a.freqs[(size_t)i * a.freqs_stride + n], P = a.P[i];
+        const double* pr = a.par + (size_t)i * 5;
+        const double nuDM = a.nuref[i * 3], nuGM = a.nuref[i * 3 + 1], nutau = a.nuref[i * 3 + 2];
+        const double a2 = 1.0 / (nu * nu);
+        const double iDM = (nuDM == INFINITY) ? 0.0 : 1.0 / (nuDM * nuDM);
+        const double iGM = (nuGM == INFINITY) ? 0.0 : 1.0 / (nuGM * nuGM * nuGM * nuGM);
+        const double phin = pr[0] + PP_DCONST * pr[1] * (a2 - iDM) / P +
+                            PP_DCONST * PP_DCONST * pr[2] * (a2 * a2 - iGM) / P;
+        const double taun = (pr[3] != 0.0) ? pr[3] * pow(nu / nutau, pr[4]) : 0.0;
+        const int sl = a.slot ? a.slot[i] : 0;
+        const cplx* mrow = as_global(a.mft[sl]) + (size_t)n * M;
+        const double m0 = as_global(a.mdc[sl])[n];
+        const double sc = a.scales[(size_t)i * a.nchan + n], sg = a.errs[(size_t)i * a.nchan + n];
+        fft_row<M, Tio>(lds, reinterpret_cast<const Tio*>(a.src) + (size_t)row * (2 * M), a.twB, tid);
+        const cplx z0 = lds[0];
+        double sum = 0.0;
+        for (int k = tid; k <= M; k += T) {
+            double wgt = 2.0;
+            cplx d, m;
+            if (k == 0) { d = make_double2(z0.x + z0.y, 0.0); m = make_double2(m0, 0.0); wgt = 1.0; }
+            else {
+                d = (k == M) ? make_double2(z0.x - z0.y, 0.0) : rfft_harmonic<M>(lds, a.twB, k);
+                d = cmul(d, unit_phasor((double)k, phin));
+                m = mrow[k - 1];
+                if (taun != 0.0) {
+                    // B_k = 1 / (1 + 2 pi i k tau_n)
+                    const double x = PP_TWO_PI * (double)k * taun, den = 1.0 / (1.0 + x * x);
+                    m = cmul(m, make_double2(den, -x * den));
+                }
+            }
+            cplx r = make_double2(d.x - sc * m.x, d.y - sc * m.y);
+            if (k == M) { r.y = 0.0; wgt = 1.0; }     // irfft drops the imaginary part at Nyquist
+            sum = fma(wgt, cnorm(r), sum);
+        }
+        sum = group_sum<64>(sum);
+        if ((tid & 63) == 0) scratch[tid >> 6] = sum;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int wv = 0; wv < T / 64; ++wv) tot += scratch[wv];
+            // Parseval: sum_t r_t^2 = (1/B) sum_k wgt_k |R_k|^2
+            a.out[row] = tot / (2.0 * M) / (sg * sg) / (double)(2 * M - 2);
+        }
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------
 // 1-D FFTFIT.  spec[2*i] = rfft(data_i), spec[2*i+1] = rfft(model_i), each
 // M+1 complex.  One 256-thread block per pair.
 // --------------------------------------------------------------------------

@@ -118,3 +118,107 @@ extern "C" int pp_rotate_portraits(pp_ctx* c, const void* src, void* dst, int dt
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PP_OK;
 }
+
+// ---- ppalign accumulation -------------------------------------------------
+extern "C" int pp_align_accumulate(pp_ctx* c, const void* src, int dtype, int on_device, int nsub, int nchan,
+                                   int nbin, const double* freqs, int64_t freqs_stride, const double* P,
+                                   const double* par3, const double* weights, double* aligned,
+                                   double* total_weights) {
+    if (!c || !src || !freqs || !P || !par3 || !weights || !aligned || !total_weights)
+        return fail(PP_EINVAL, "pp_align_accumulate: null argument");
+    if (!nbin_ok(nbin) || nsub < 1 || nchan < 1) return fail(PP_EINVAL, "pp_align_accumulate: bad shape");
+    if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_align_accumulate: dtype %d", dtype);
+    if (freqs_stride != 0 && freqs_stride != nchan) return fail(PP_EINVAL, "freqs_stride must be 0 or nchan");
+    HIP_TRY(hipSetDevice(c->device));
+    const int M = nbin / 2;
+    const size_t esz = dtype == PP_F64 ? 8 : 4;
+    const size_t bytes = (size_t)nsub * nchan * nbin * esz;
+    int rc;
+    const void* dsrc = src;
+    if (!on_device) {
+        if ((rc = c->data.reserve(bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->data.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+        dsrc = c->data.p;
+    }
+    if ((rc = upload(c, c->freqs, freqs, (size_t)(freqs_stride ? (size_t)nsub * nchan : nchan) * 8))) return rc;
+    if ((rc = upload(c, c->P, P, (size_t)nsub * 8))) return rc;
+    if ((rc = upload(c, c->x0, par3, (size_t)nsub * 24))) return rc;
+    if ((rc = upload(c, c->wts, weights, (size_t)nsub * nchan * 8))) return rc;
+    if ((rc = c->X.reserve((size_t)nchan * nbin * 8))) return rc;          // aligned portrait
+    if ((rc = c->sdraw.reserve((size_t)nchan * 8))) return rc;             // total weights
+    const cplx* tw = nullptr;
+    if ((rc = get_twiddles(c, nbin, &tw))) return rc;
+    AlignArgs a{dsrc, c->freqs.as<double>(), (long long)freqs_stride, c->P.as<double>(), c->x0.as<double>(),
+                c->wts.as<double>(), tw, c->X.as<double>(), c->sdraw.as<double>(), nsub, nchan};
+    {
+        Prof pr(c, KF_SYNTH);
+        PP_DISPATCH_M(M, {
+            const int T = FftPlan<MM>::T;
+            if (dtype == PP_F64) hipLaunchKernelGGL((k_align_accum<MM, double>), dim3(nchan), dim3(T), 0, c->stream, a);
+            else hipLaunchKernelGGL((k_align_accum<MM, float>), dim3(nchan), dim3(T), 0, c->stream, a);
+        });
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(aligned, c->X.p, (size_t)nchan * nbin * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(total_weights, c->sdraw.p, (size_t)nchan * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PP_OK;
+}
+
+// ---- per-channel reduced chi^2 of fitted subints ---------------------------
+extern "C" int pp_channel_red_chi2(pp_ctx* c, const void* src, int dtype, int on_device, int nsub, int nchan,
+                                   int nbin, const int32_t* model_slot, const double* freqs,
+                                   int64_t freqs_stride, const double* P, const double* params5,
+                                   const double* nu_refs3, const double* scales, const double* errs,
+                                   double* red_chi2) {
+    if (!c || !src || !freqs || !P || !params5 || !nu_refs3 || !scales || !errs || !red_chi2)
+        return fail(PP_EINVAL, "pp_channel_red_chi2: null argument");
+    if (!nbin_ok(nbin) || nsub < 1 || nchan < 1) return fail(PP_EINVAL, "pp_channel_red_chi2: bad shape");
+    if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_channel_red_chi2: dtype %d", dtype);
+    if (freqs_stride != 0 && freqs_stride != nchan) return fail(PP_EINVAL, "freqs_stride must be 0 or nchan");
+    HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < nsub; ++i) {
+        const int sl = model_slot ? model_slot[i] : 0;
+        if (sl < 0 || sl >= PP_MAX_SLOTS || !c->slots[sl].set || c->slots[sl].nchan != nchan ||
+            c->slots[sl].nbin != nbin)
+            return fail(PP_EINVAL, "pp_channel_red_chi2: model slot %d is not a %d x %d template", sl, nchan, nbin);
+    }
+    const int M = nbin / 2;
+    const size_t esz = dtype == PP_F64 ? 8 : 4;
+    const size_t bytes = (size_t)nsub * nchan * nbin * esz;
+    const size_t nc = (size_t)nsub * nchan;
+    int rc;
+    const void* dsrc = src;
+    if (!on_device) {
+        if ((rc = c->data.reserve(bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->data.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+        dsrc = c->data.p;
+    }
+    if ((rc = upload(c, c->freqs, freqs, (size_t)(freqs_stride ? nc : (size_t)nchan) * 8))) return rc;
+    if ((rc = upload(c, c->P, P, (size_t)nsub * 8))) return rc;
+    if ((rc = upload(c, c->x0, params5, (size_t)nsub * 40))) return rc;
+    if ((rc = upload(c, c->nufit, nu_refs3, (size_t)nsub * 24))) return rc;
+    if ((rc = upload(c, c->wts, scales, nc * 8))) return rc;
+    if ((rc = upload(c, c->errs, errs, nc * 8))) return rc;
+    if (model_slot) if ((rc = upload(c, c->slot, model_slot, (size_t)nsub * 4))) return rc;
+    if ((rc = c->sdraw.reserve(nc * 8))) return rc;
+    const cplx* tw = nullptr;
+    if ((rc = get_twiddles(c, nbin, &tw))) return rc;
+    ChanChi2Args a{dsrc, (const cplx* const*)c->mft_table.p, (const double* const*)c->mdc_table.p,
+                   model_slot ? c->slot.as<int>() : nullptr, c->freqs.as<double>(), (long long)freqs_stride,
+                   c->P.as<double>(), c->x0.as<double>(), c->nufit.as<double>(), c->wts.as<double>(),
+                   c->errs.as<double>(), tw, c->sdraw.as<double>(), nsub, nchan};
+    {
+        Prof pr(c, KF_FINAL);
+        PP_DISPATCH_M(M, {
+            const int T = FftPlan<MM>::T;
+            const int grid = fft_grid(T, (long long)nc);
+            if (dtype == PP_F64) hipLaunchKernelGGL((k_chan_chi2<MM, double>), dim3(grid), dim3(T), 0, c->stream, a);
+            else hipLaunchKernelGGL((k_chan_chi2<MM, float>), dim3(grid), dim3(T), 0, c->stream, a);
+        });
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(red_chi2, c->sdraw.p, nc * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PP_OK;
+}

@@ -78,7 +78,7 @@ struct pp_ctx {
     hipStream_t stream = nullptr;
     std::map<int, DevBuf> twiddles;   // by nbin
     ModelSlot slots[PP_MAX_SLOTS];
-    DevBuf mft_table, msum_table, kt_table;   // device arrays of slot base pointers
+    DevBuf mft_table, msum_table, kt_table, mdc_table;   // device arrays of slot base pointers
     // work buffers
     DevBuf data, X, sdraw, noise, wts, freqs, errs, mask, P, x0, nufit, nuout, slot, state, csum, partial;
     DevBuf o_params, o_errs, o_nu, o_cov, o_chi2, o_rchi2, o_snr, o_nfev, o_rc, o_scales, o_serrs, o_csnr,
@@ -149,6 +149,9 @@ extern "C" int pp_create(int device_id, pp_ctx** out) {
     if (rc) return rc;
     rc = c->kt_table.reserve(sizeof(void*) * PP_MAX_SLOTS);
     if (rc) return rc;
+    rc = c->mdc_table.reserve(sizeof(void*) * PP_MAX_SLOTS);
+    if (rc) return rc;
+    HIP_TRY(hipMemset(c->mdc_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
     HIP_TRY(hipMemset(c->kt_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
     HIP_TRY(hipMemset(c->mft_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
     HIP_TRY(hipMemset(c->msum_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
@@ -163,7 +166,7 @@ extern "C" int pp_destroy(pp_ctx* c) {
     resolve_spans(c);
     for (auto& kv : c->twiddles) kv.second.release();
     for (auto& s : c->slots) { s.mft.release(); s.msum.release(); s.mmax.release(); s.mdc.release(); s.kt.release(); }
-    DevBuf* bufs[] = {&c->mft_table, &c->msum_table, &c->kt_table, &c->data, &c->X, &c->sdraw, &c->noise, &c->wts, &c->freqs,
+    DevBuf* bufs[] = {&c->mft_table, &c->msum_table, &c->kt_table, &c->mdc_table, &c->data, &c->X, &c->sdraw, &c->noise, &c->wts, &c->freqs,
                       &c->errs, &c->mask, &c->P, &c->x0, &c->nufit, &c->nuout, &c->slot, &c->state, &c->csum,
                       &c->partial, &c->o_params, &c->o_errs, &c->o_nu, &c->o_cov, &c->o_chi2, &c->o_rchi2,
                       &c->o_snr, &c->o_nfev, &c->o_rc, &c->o_scales, &c->o_serrs, &c->o_csnr, &c->o_f0, &c->o_g0,
@@ -329,6 +332,8 @@ extern "C" int pp_model_set(pp_ctx* c, int slot, const void* portrait, int dtype
     HIP_TRY(hipMemcpy((char*)c->msum_table.p + sizeof(void*) * slot, &ps, sizeof(void*), hipMemcpyHostToDevice));
     void* pk = s.kt.p;
     HIP_TRY(hipMemcpy((char*)c->kt_table.p + sizeof(void*) * slot, &pk, sizeof(void*), hipMemcpyHostToDevice));
+    void* pd = s.mdc.p;
+    HIP_TRY(hipMemcpy((char*)c->mdc_table.p + sizeof(void*) * slot, &pd, sizeof(void*), hipMemcpyHostToDevice));
     return PP_OK;
 }
 

@@ -306,6 +306,60 @@ class Engine(object):
                "pp_rotate_portraits")
         return out
 
+    def _ports_arg(self, ports):
+        if _is_device_array(ports):
+            nsub, nchan, nbin = (int(v) for v in ports.shape)
+            dtype = PP_F64 if ports.element_size() == 8 else PP_F32
+            return C.c_void_p(ports.data_ptr()), dtype, 1, (nsub, nchan, nbin), ports
+        a = np.asarray(ports)
+        if a.dtype != np.float32:
+            a = a.astype(np.float64, copy=False)
+        a = np.ascontiguousarray(a)
+        return (C.c_void_p(a.ctypes.data), PP_F64 if a.dtype == np.float64 else PP_F32, 0,
+                a.shape, a)
+
+    def align_accumulate(self, ports, freqs, P, phase, DM, nu_ref, weights):
+        """ppalign's accumulation (ppalign.py:199-206): returns
+        (sum_i w[i,n] * rotate_data(ports[i,n], phase_i, DM_i, P_i, freqs, nu_ref_i)
+        as [nchan,nbin], sum_i w[i,n] as [nchan]); rows with w <= 0 are skipped."""
+        src, dtype, on_dev, (nsub, nchan, nbin), keep = self._ports_arg(ports)
+        freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+        fstride = 0 if freqs.ndim == 1 else nchan
+        P = _f64(P, (nsub,))
+        par = np.ascontiguousarray(np.stack([
+            np.broadcast_to(np.asarray(v, dtype=np.float64), (nsub,))
+            for v in (phase, DM, nu_ref)], axis=1))
+        w = _f64(weights, (nsub, nchan))
+        aligned = np.empty((nchan, nbin))
+        totw = np.empty(nchan)
+        _check(self._lib.pp_align_accumulate(self._ctx, src, dtype, on_dev, nsub, nchan, nbin,
+                                             _dp(freqs), fstride, _dp(P), _dp(par), _dp(w),
+                                             _dp(aligned), _dp(totw)), "pp_align_accumulate")
+        return aligned, totw
+
+    def channel_red_chi2(self, ports, freqs, P, params, nu_refs, scales, errs, slots=None):
+        """Per-channel reduced chi^2 of fitted subints, time domain, dof = nbin-2
+        (get_channels_to_zap, pptoas.py:1239-1245).  params[nsub,5] = phi, DM, GM,
+        tau [rot, linear], alpha at nu_refs[nsub,3]; the template is the resident
+        model slot of each subint."""
+        src, dtype, on_dev, (nsub, nchan, nbin), keep = self._ports_arg(ports)
+        freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+        fstride = 0 if freqs.ndim == 1 else nchan
+        P = _f64(P, (nsub,))
+        params = _f64(params, (nsub, 5))
+        nu_refs = _f64(nu_refs, (nsub, 3))
+        scales = _f64(scales, (nsub, nchan))
+        errs = _f64(errs, (nsub, nchan))
+        sl = None
+        if slots is not None:
+            sl = np.ascontiguousarray(np.broadcast_to(np.asarray(slots, dtype=np.int32), (nsub,)))
+        out = np.empty((nsub, nchan))
+        _check(self._lib.pp_channel_red_chi2(
+            self._ctx, src, dtype, on_dev, nsub, nchan, nbin,
+            None if sl is None else sl.ctypes.data_as(c_int32_p), _dp(freqs), fstride, _dp(P),
+            _dp(params), _dp(nu_refs), _dp(scales), _dp(errs), _dp(out)), "pp_channel_red_chi2")
+        return out
+
     def synth_portraits(self, dst, freqs, P, inj, sigma, seed, first_subint=0,
                         slot=0):
         """Fill a CUDA tensor dst[nsub,nchan,nbin] with synthetic subints."""

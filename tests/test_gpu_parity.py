@@ -739,3 +739,59 @@ def test_rotate_functions_match_oracle():
                              freqs, 1500.0)
     d = np.fft.rfft(back - port, axis=-1)
     assert np.abs(d[:, :-1]).max() < 1e-9 and np.abs(d[:, -1]).max() > 1e-3
+
+
+@pytest.mark.parametrize("nbin,dtype", [(256, np.float64), (2048, np.float64), (512, np.float32)])
+def test_align_accumulate_matches_oracle(eng, nbin, dtype):
+    """ppalign's weighted accumulation of rotated subints (ppalign.py:199-206):
+    per-subint phase, DM and reference frequency, ragged zero-weight channels, a
+    dedispersed (DM = 0) subint and an infinite reference frequency."""
+    from oracle import pptoas_oracle as orc
+    from tests.synth_host import model_portrait
+    C_, nsub = 12, 5
+    freqs, model = model_portrait(C_, nbin)
+    rng = np.random.default_rng(nbin)
+    ports = np.stack([model * rng.uniform(0.5, 2.0) + 0.1 * rng.standard_normal(model.shape)
+                      for _ in range(nsub)]).astype(dtype)
+    Ps = rng.uniform(0.002, 0.005, nsub)
+    phases = rng.uniform(-0.5, 0.5, nsub)
+    DMs = np.array([0.0, 3e-3, -2e-3, 15.0, 1e-4])
+    nu_refs = np.array([1400.0, np.inf, 1234.5, 1500.0, 1100.0])
+    w = rng.uniform(0.5, 3.0, (nsub, C_))
+    w[1, 3] = 0.0
+    w[2, :] = 0.0
+    w[4, 7:] = 0.0
+    al, tw = eng.align_accumulate(ports, freqs, Ps, phases, DMs, nu_refs, w)
+    oal, otw = orc.align_accumulate(ports.astype(np.float64), freqs, Ps, phases, DMs, nu_refs, w)
+    np.testing.assert_allclose(tw, otw, rtol=1e-15)
+    # DM = 15 at 3 ms is thousands of turns: NumPy's k*phi rounds at ~1e-16 * k * phi
+    np.testing.assert_allclose(al, oal, rtol=0, atol=5e-10 * np.abs(oal).max())
+    ok = [0, 1, 2, 4]   # without the large-DM subint the agreement is at rounding level
+    al2, _ = eng.align_accumulate(ports[ok], freqs, Ps[ok], phases[ok], DMs[ok], nu_refs[ok], w[ok])
+    oal2, _ = orc.align_accumulate(ports[ok].astype(np.float64), freqs, Ps[ok], phases[ok], DMs[ok],
+                                   nu_refs[ok], w[ok])
+    np.testing.assert_allclose(al2, oal2, rtol=0, atol=2e-13 * np.abs(oal2).max())
+
+
+@pytest.mark.parametrize("name", ["fpf_64x256_phiDM", "fpf_64x256_phiDMGM", "fpf_64x256_scat",
+                                  "fpf_64x256_scat_lin", "fpf_64x256_lowsnr_scint"])
+def test_channel_red_chi2_matches_oracle(eng, name):
+    """Per-channel reduced chi^2 of a fitted subint (get_channels_to_zap,
+    pptoas.py:1239-1245): rotated data minus scaled (scattered) template in the
+    time domain, from the reference's own fit results in the golden."""
+    from oracle import pptoas_oracle as orc
+    g = _load(name)
+    eng.set_model(g["model"])
+    tau = float(g["out_tau"])
+    if bool(g["log10_tau"]) and int(g["fit_flags"][3]):
+        tau = 10.0 ** tau
+    params = np.array([float(g["out_phi"]), float(g["out_DM"]), float(g["out_GM"]), tau,
+                       float(g["out_alpha"])])
+    nu_refs = np.array([float(g["out_nu_DM"]), float(g["out_nu_GM"]), float(g["out_nu_tau"])])
+    got = eng.channel_red_chi2(g["data"][None], g["freqs"], float(g["P"]), params, nu_refs,
+                               g["out_scales"], g["errs"])
+    want = orc.channel_red_chi2s(g["data"], g["model"], params[0], params[1], params[2], tau,
+                                 params[4], g["freqs"], nu_refs, float(g["P"]), g["out_scales"],
+                                 g["errs"])
+    np.testing.assert_allclose(got[0], want, rtol=1e-10)
+    assert 0.5 < np.median(want) < 2.0
