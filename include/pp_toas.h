@@ -175,7 +175,7 @@ int pp_rotate_portraits(pp_ctx* ctx, const void* src, void* dst, int dtype,
 /* ---- synthetic portraits generated on the device ------------------------- */
 /* ppalign's accumulation (ppalign.py:199-206): aligned[n][:] = sum_i w[i][n] *
  * rotate_data(src[i][n], phase_i, DM_i, P_i, freqs, nu_ref_i) and total_weights[n] =
- * sum_i w[i][n]; rows with w <= 0 (or NaN) are skipped.  par3[i] = {phase, DM, nu_ref}
+ * sum_i w[i][n]; rows with w = 0 (or NaN) are skipped.  par3[i] = {phase, DM, nu_ref}
  * (nu_ref may be INFINITY).  src: [nsub][nchan][nbin] of `dtype`, host or device;
  * aligned [nchan][nbin] and total_weights [nchan] are host arrays, overwritten. */
 int pp_align_accumulate(pp_ctx* ctx, const void* src, int dtype, int on_device,

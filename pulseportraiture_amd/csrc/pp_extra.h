@@ -179,7 +179,7 @@ struct AlignArgs {
     const double* freqs; long long freqs_stride;
     const double* P;      // [nsub]
     const double* par;    // [nsub][3] phase, DM, nu_ref
-    const double* w;      // [nsub][nchan] weights (<= 0 or NaN: row skipped)
+    const double* w;      // [nsub][nchan] weights (0 or NaN: row skipped)
     const cplx* twB;
     double* aligned;      // [nchan][B]
     double* totw;         // [nchan]
@@ -198,7 +198,8 @@ __global__ __launch_bounds__(FftPlan<M>::T) void k_align_accum(AlignArgs a) {
         double wsum = 0.0;
         for (int i = 0; i < a.nsub; ++i) {
             const double w = a.w[(size_t)i * a.nchan + n];
-            if (!(w > 0.0)) continue;          // uniform over the workgroup
+            if (w == 0.0 || w != w) continue;  // (uniform over the workgroup; negative fitted
+                                               // amplitudes weigh negatively, as in the reference)
             const double nu = a.freqs[(size_t)i * a.freqs_stride + n], P = a.P[i];
             const double phase = a.par[i * 3], DM = a.par[i * 3 + 1], nuref = a.par[i * 3 + 2];
             // reference order of operations (pplib.py:2419-2424)

@@ -321,7 +321,7 @@ class Engine(object):
     def align_accumulate(self, ports, freqs, P, phase, DM, nu_ref, weights):
         """ppalign's accumulation (ppalign.py:199-206): returns
         (sum_i w[i,n] * rotate_data(ports[i,n], phase_i, DM_i, P_i, freqs, nu_ref_i)
-        as [nchan,nbin], sum_i w[i,n] as [nchan]); rows with w <= 0 are skipped."""
+        as [nchan,nbin], sum_i w[i,n] as [nchan]); rows with w = 0 are skipped."""
         src, dtype, on_dev, (nsub, nchan, nbin), keep = self._ports_arg(ports)
         freqs = np.ascontiguousarray(freqs, dtype=np.float64)
         fstride = 0 if freqs.ndim == 1 else nchan

@@ -164,6 +164,22 @@ def rotate_profile(profile, phase=0.0):
 
 
 # ---- 1-D FFTFIT ----------------------------------------------------------------
+def get_noise(data, method=default_noise_method, frac=4, chans=False):
+    """Off-pulse noise from the mean of the top 1/frac of the power spectrum
+    (get_noise / get_noise_PS, pplib.py:2206-2253; only the "PS" method).  Host
+    helper for normalisation; inside a fit the engine measures the same quantity
+    itself when errs is None."""
+    if method != "PS":
+        print("Unknown get_noise method.")
+        return 0
+    a = np.asarray(data, dtype=np.float64)
+    rows = a if chans else a.reshape(1, -1)
+    power = np.abs(np.fft.rfft(rows, axis=-1)) ** 2.0 / rows.shape[-1]
+    kc = int((1 - frac ** -1) * power.shape[-1])
+    noise = np.sqrt(power[:, kc:].mean(axis=-1))
+    return noise if chans else noise[0]
+
+
 def fit_phase_shift(data, model, noise=None, bounds=[-0.5, 0.5], Ns=100):
     """Fit a phase shift between a data and a model profile on the GPU:
     Ns-point brute grid over `bounds` (both ends included), refined to the

@@ -544,3 +544,74 @@ class GetTOAs(object):
             print("--------------------------")
             print("Total time: %.2f sec, ~%.4f sec/TOA" %
                   (tot_duration, tot_duration / sum(len(o) for o in self.ok_isubs)))
+
+    def get_channels_to_zap(self, SNR_threshold=8.0, rchi2_threshold=1.3, iterate=True,
+                            show=False):
+        """Flag channels by per-channel reduced chi^2 and S/N (pptoas.py:1208-1285;
+        get_TOAs must have been called first).  The reduced chi^2 of every channel of
+        every fitted subint -- rotated data minus scaled template in the time domain,
+        dof = nbin - 2, as show_fit / get_red_chi2 form it -- comes from one device
+        pass per archive; the threshold logic is the reference's.  Appends to
+        self.channel_red_chi2s and self.zap_channels (one entry per archive, each a
+        list over its fitted subints)."""
+        if show:
+            raise NotImplementedError("plots are outside the accelerated path")
+        eng = default_engine()
+        for iarch, ok_idatafile in enumerate(self.ok_idatafiles):
+            data, fname = _load(self.datafiles[ok_idatafile])
+            d = data
+            nbin = d.nbin
+            ok_isubs = np.asarray(self.ok_isubs[iarch], dtype=int)
+            nok = len(ok_isubs)
+            params = np.zeros((nok, 5))
+            slots, slot_of = {}, np.zeros(nok, dtype=np.int32)
+            scales = np.zeros((nok, d.nchan))
+            for j, isub in enumerate(ok_isubs):
+                df = self.doppler_fs[iarch][isub] if self.bary else 1.0
+                tau = self.taus[iarch][isub]
+                if tau != 0.0 and self.log10_tau:
+                    tau = 10.0 ** tau
+                params[j] = [self.phis[iarch][isub], self.DMs[iarch][isub] / df,
+                             self.GMs[iarch][isub] / df ** 3, tau, self.alphas[iarch][isub]]
+                scat = bool(tau != 0.0)
+                key = (d.freqs[isub].tobytes(), scat)
+                if key not in slots:
+                    if len(slots) >= 64:
+                        raise NotImplementedError("more than 64 distinct templates in one archive")
+                    slots[key] = len(slots)
+                    eng.set_model(self._model_for(d.freqs[isub], nbin, d.Ps.mean(),
+                                                  unscattered=scat), slot=slots[key])
+                slot_of[j] = slots[key]
+                scales[j] = self.scales[iarch][isub]
+            port = np.ascontiguousarray(np.asarray(d.subints)[ok_isubs, 0])
+            noise = np.ascontiguousarray(np.asarray(d.noise_stds)[ok_isubs, 0], dtype=np.float64)
+            nu_refs = np.array([self.nu_refs[iarch][isub] for isub in ok_isubs], dtype=np.float64)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                rchi2 = eng.channel_red_chi2(port, d.freqs[ok_isubs], d.Ps[ok_isubs], params,
+                                             nu_refs, scales, noise, slots=slot_of)
+            channel_red_chi2s, zap_channels = [], []
+            for j, isub in enumerate(ok_isubs):
+                ok_ichans = [int(v) for v in d.ok_ichans[isub]]
+                channel_snrs = self.channel_snrs[iarch][isub]
+                thresh = (SNR_threshold ** 2.0 / len(ok_ichans)) ** 0.5
+                red_chi2s, bad = [], []
+                for ichan in ok_ichans:
+                    r = rchi2[j, ichan]
+                    red_chi2s.append(r)
+                    if r > rchi2_threshold or np.isnan(r):
+                        bad.append(ichan)
+                    elif SNR_threshold and channel_snrs[ichan] < thresh:
+                        bad.append(ichan)
+                if iterate and SNR_threshold and len(bad):
+                    old_len, added_new = len(bad), True
+                    while added_new and (len(ok_ichans) - len(bad)):
+                        thresh = (SNR_threshold ** 2.0 / (len(ok_ichans) - len(bad))) ** 0.5
+                        for ichan in ok_ichans:
+                            if ichan not in bad and channel_snrs[ichan] < thresh:
+                                bad.append(ichan)
+                        added_new = bool(len(bad) - old_len)
+                        old_len = len(bad)
+                channel_red_chi2s.append(red_chi2s)
+                zap_channels.append(bad)
+            self.channel_red_chi2s.append(channel_red_chi2s)
+            self.zap_channels.append(zap_channels)

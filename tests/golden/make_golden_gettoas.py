@@ -70,7 +70,7 @@ def import_pptoas():
 
 
 def synth_archive(ref, seed, nsub=5, C=32, B=256, DM0=34.56789, sigma=0.05, GM=None,
-                  tau_us=None):
+                  tau_us=None, corrupt=False):
     rng = np.random.default_rng(seed)
     P0 = 1.0 / 345.67890123456789
     d = 800.0 / C
@@ -94,6 +94,13 @@ def synth_archive(ref, seed, nsub=5, C=32, B=256, DM0=34.56789, sigma=0.05, GM=N
         port = ref.rotate_portrait_full(port, -phi, -(DM0 + dDM), -gm, freqs[i],
                                         np.inf, np.inf, Ps[i])
         subints[i, 0] = port + rng.normal(0, sigma, size=port.shape)
+        if corrupt:
+            # channels for get_channels_to_zap to find: narrow-band interference
+            # (bad chi^2) and nearly dead channels (low S/N)
+            subints[i, 0, 5 + i] += 0.3 * np.sin(2 * np.pi * 7 * phases + i)
+            subints[i, 0, 20] = 0.01 * port[20] + rng.normal(0, sigma, size=B)
+            if i == 3:
+                subints[i, 0, 11] = 0.02 * port[11] + rng.normal(0, sigma, size=B)
         inj.append([phi, DM0 + dDM, gm])
         if i % 2:
             weights[i, rng.choice(C, size=4, replace=False)] = 0.0
@@ -146,6 +153,16 @@ def run(pptoas, data, **kw):
     out["toa0_frequency"] = t0.frequency
     out["toa0_flag_names"] = np.array(sorted(t0.flags.keys()))
     out["toa0_flag_values"] = np.array([str(t0.flags[k]) for k in sorted(t0.flags.keys())])
+    # per-channel goodness of fit and the channels it would zap (pptoas.py:1208-1285)
+    gt.get_channels_to_zap(SNR_threshold=8.0, rchi2_threshold=1.3, iterate=True, show=False)
+    nok, C = len(gt.ok_isubs[0]), data.nchan
+    rc2 = np.full((nok, C), np.nan)
+    zap = np.zeros((nok, C), dtype=bool)
+    for j, isub in enumerate(gt.ok_isubs[0]):
+        rc2[j, data.ok_ichans[isub]] = gt.channel_red_chi2s[0][j]
+        zap[j, np.asarray(gt.zap_channels[0][j], dtype=int)] = True
+    out["channel_red_chi2s"] = rc2
+    out["zap_channels"] = zap
     return out
 
 
@@ -156,7 +173,8 @@ def main():
                                                         bary=False, print_phase=True)),
              ("gettoas_GM", dict(seed=33, GM=0.25), dict(fit_GM=True)),
              ("gettoas_scat", dict(seed=34, tau_us=20.0),
-              dict(fit_scat=True, log10_tau=True, scat_guess=(30e-6, 1500.0, -4.0)))]
+              dict(fit_scat=True, log10_tau=True, scat_guess=(30e-6, 1500.0, -4.0))),
+             ("gettoas_zap", dict(seed=35, corrupt=True), dict())]
     for name, skw, gkw in cases:
         data, arrays, scal = synth_archive(ref, **skw)
         out = run(pptoas, data, **gkw)

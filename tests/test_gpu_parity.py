@@ -386,7 +386,7 @@ def _check_against_polished_reference(g, gt, isub, kw):
 
 
 @pytest.mark.parametrize("name", ["gettoas_phiDM", "gettoas_phiDM_nurefs", "gettoas_GM",
-                                  "gettoas_scat"])
+                                  "gettoas_scat", "gettoas_zap"])
 def test_get_TOAs_matches_reference_caller(name):
     """Caller level: GetTOAs.get_TOAs on a synthetic archive (ragged channel
     masks, a fully zapped subint, Doppler factors, backend delay) against what
@@ -448,6 +448,20 @@ def test_get_TOAs_matches_reference_caller(name):
     line = toa_string(t0)
     assert line.startswith("fake.fits ") and " -pp_dm " in line and " -snr " in line
     assert len(gt.TOA_list) == len(ok)
+    # per-channel goodness of fit and zap proposals (get_channels_to_zap,
+    # pptoas.py:1208-1285) against the reference's own, same thresholds
+    gt.get_channels_to_zap(SNR_threshold=8.0, rchi2_threshold=1.3, iterate=True)
+    for j, isub in enumerate(ok):
+        ich = np.where(g["weights"][isub] > 0)[0]
+        want = g["out_channel_red_chi2s"][j, ich]
+        got = np.asarray(gt.channel_red_chi2s[0][j])
+        np.testing.assert_allclose(got, want, rtol=2e-5 if hard else 1e-7)
+        # a channel whose statistic sits within rounding of a threshold may flip
+        edge = ich[np.abs(want - 1.3) < 1e-4]
+        zap_want = set(np.where(g["out_zap_channels"][j])[0]) - set(edge)
+        assert set(gt.zap_channels[0][j]) - set(edge) == zap_want
+    if name == "gettoas_zap":
+        assert all(len(z) >= 1 for z in gt.zap_channels[0])
 
 
 @pytest.mark.parametrize("nbin", [32, 64, 128])
@@ -795,3 +809,51 @@ def test_channel_red_chi2_matches_oracle(eng, name):
                                  g["errs"])
     np.testing.assert_allclose(got[0], want, rtol=1e-10)
     assert 0.5 < np.median(want) < 2.0
+
+
+@pytest.mark.parametrize("fit_dm", [True, False])
+def test_align_subints_matches_oracle_loop(eng, fit_dm):
+    """ppalign's iteration (ppalign.py:110-214) on arrays: fit every subint
+    against the current template, rotate by the fit, average with weights
+    scales/errs^2, repeat -- against the same loop written with the oracle's
+    fit_portrait_full, fit_phase_shift and rotate_data."""
+    from oracle import pptoas_oracle as orc
+    from pulseportraiture_amd.ppalign import align_subints
+    from tests.synth_host import model_portrait
+    C_, nbin, nsub, sigma = 16, 256, 6, 0.05
+    freqs, model = model_portrait(C_, nbin)
+    rng = np.random.default_rng(77)
+    Ps = np.full(nsub, 0.0031) * (1 + 1e-6 * np.arange(nsub))
+    ports = np.zeros((nsub, C_, nbin))
+    for i in range(nsub):
+        rot = orc.rotate_portrait_full(model * rng.uniform(0.7, 1.5), -rng.uniform(-0.5, 0.5),
+                                       -(rng.normal(0, 3e-4) if fit_dm else 0.0), 0.0, freqs,
+                                       np.inf, np.inf, Ps[i])
+        ports[i] = rot + rng.normal(0, sigma, rot.shape)
+    weights = np.ones((nsub, C_))
+    weights[1, [2, 9]] = 0.0
+    weights[4, :3] = 0.0
+    errs = np.full((nsub, C_), sigma)
+    snrs = rng.uniform(5, 50, (nsub, C_))
+    # a deliberately imperfect initial template: smoothed and shifted
+    init = orc.rotate_data(model, 0.013) * 0.8
+    got = align_subints(ports, freqs, Ps, errs, init, weights=weights, SNRs=snrs,
+                        DM_guess=0.0, fit_dm=fit_dm, niter=2, engine=eng)
+    tmpl = init
+    for it in range(2):
+        acc = np.zeros((C_, nbin)); tw = np.zeros(C_)
+        for i in range(nsub):
+            ich = np.where(weights[i] > 0)[0]
+            nu_fit = orc.guess_fit_freq(freqs[ich], snrs[i, ich])
+            rp = orc.rotate_data(ports[i, ich], 0.0, 0.0, Ps[i], freqs[ich], nu_fit)
+            guess = orc.fit_phase_shift(np.average(rp, axis=0, weights=weights[i, ich]),
+                                        tmpl[ich].mean(axis=0), Ns=nbin).phase
+            r = orc.fit_portrait_full(ports[i, ich], tmpl[ich], [guess, 0.0, 0.0, 0.0, 0.0], Ps[i],
+                                      freqs[ich], [nu_fit] * 3, [None] * 3, errs[i, ich],
+                                      [1, int(fit_dm), 0, 0, 0], log10_tau=False)
+            w = r.scales / errs[i, ich] ** 2
+            acc[ich] += w[:, None] * orc.rotate_data(ports[i, ich], r.phi, r.DM, Ps[i], freqs[ich],
+                                                     r.nu_DM)
+            tw[ich] += w
+        tmpl = acc / tw[:, None]
+    np.testing.assert_allclose(got, tmpl, rtol=0, atol=2e-7 * np.abs(tmpl).max())
