@@ -90,6 +90,24 @@ int pp_model_set(pp_ctx* ctx, int slot, const void* portrait, int dtype,
 /* number of harmonics (of nbin/2) kept for this slot after truncation */
 int pp_model_nharm(pp_ctx* ctx, int slot);
 
+/* Gaussian-component template portraits synthesised on the device (.gmodel
+ * files: read_model / gen_gaussian_portrait / gaussian_profile / evolve_parameter,
+ * pplib.py:2867-2953, 853-930, 770-825, 996-1046).  code[3]: '0' = power-law,
+ * '1' = linear evolution of (loc, wid, amp); comps[ngauss][6] = loc, m_loc, wid,
+ * m_wid, amp, m_amp at nu_ref; dc = baseline; tau_rot = scattering time at nu_ref
+ * in rotations (TAU / P, 0 = none), scaled as (nu/nu_ref)^alpha and applied in the
+ * Fourier domain (pplib.py:915-922).  pp_gaussian_portrait writes the
+ * [nchan][nbin] f64 portrait (host or device pointer); pp_model_set_gaussian
+ * loads it straight into a model slot (no host copy of the portrait at all). */
+int pp_gaussian_portrait(pp_ctx* ctx, int nchan, int nbin, const double* freqs,
+                         const char* code, double nu_ref, double dc, double tau_rot,
+                         double alpha, int ngauss, const double* comps,
+                         double* portrait, int out_on_device);
+int pp_model_set_gaussian(pp_ctx* ctx, int slot, int nchan, int nbin,
+                          const double* freqs, const char* code, double nu_ref,
+                          double dc, double tau_rot, double alpha, int ngauss,
+                          const double* comps);
+
 /* ---- the batched fit ----------------------------------------------------- */
 typedef struct {
     int32_t nsub, nchan, nbin;

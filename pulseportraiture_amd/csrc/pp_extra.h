@@ -167,6 +167,138 @@ __global__ __launch_bounds__(FftPlan<M>::T) void k_rotate(RotateArgs a) {
 }
 
 // --------------------------------------------------------------------------
+// Gaussian-component template portraits on the device:
+// gen_gaussian_portrait + gaussian_profile + evolve_parameter (pplib.py:853-930,
+// 770-825, 996-1046), optionally scattered in the Fourier domain
+// (pplib.py:915-922, 4049-4095).  One workgroup per channel: evolve the component
+// parameters to the channel frequency, sum the wrapped unit-peak Gaussians on the
+// bin centres, and -- if the model carries a scattering time -- filter the row
+// with 1/(1 + 2 pi i k tau_n) between a forward and an inverse FFT in LDS.
+// The arithmetic follows the host construction (gmodel.py) operation by
+// operation; only exp/log may differ from NumPy's by an ulp.
+// --------------------------------------------------------------------------
+#define PP_MAX_GAUSS 64
+struct GaussArgs {
+    const double* freqs;      // [nchan]
+    const double* comps;      // [ngauss][6] loc, m_loc, wid, m_wid, amp, m_amp
+    const cplx* twB;
+    double* out;              // [nchan][B]
+    double nu_ref, dc, tau_ref /* rot at nu_ref, 0 = unscattered */, alpha;
+    int nchan, ngauss;
+    int code_loc, code_wid, code_amp;   // 0 = power law, else linear
+};
+
+__device__ __forceinline__ double gauss_evolve(double nu, double nu_ref, double value, double evol, int code) {
+    // power law in logs (pplib.py:1017-1030), else linear in frequency
+    if (code == 0) return exp(__dadd_rn(__dmul_rn(log(nu) - log(nu_ref), evol), log(value)));
+    return __dadd_rn(__dmul_rn(nu - nu_ref, evol), value);
+}
+
+// bin centre j of nbin (get_bin_centers -> numpy.linspace: j*step + start, last = stop)
+__device__ __forceinline__ double gauss_bin_centre(int j, int nbin) {
+    const double start = 1.0 / (double)(nbin * 2), stop = 1.0 - start;
+    if (j == nbin - 1) return stop;
+    const double step = (stop - start) / (double)(nbin - 1);
+    return __dadd_rn(__dmul_rn((double)j, step), start);
+}
+
+struct GaussComp { double mean, sigma, norm, fact, amp; int on; };
+
+__device__ __forceinline__ double gauss_wrap(double x, double mean) {
+    if (mean < 0.5) return (x > mean + 0.5) ? x - 1.0 : x;
+    return (x < mean - 0.5) ? x + 1.0 : x;
+}
+__device__ __forceinline__ double gauss_val(double x, const GaussComp& g) {
+    const double z = (gauss_wrap(x, g.mean) - g.mean) / g.sigma;
+    return (fabs(z) < 20.0) ? exp(-0.5 * __dmul_rn(z, z)) / g.norm : 0.0;
+}
+
+template <int M>
+__global__ __launch_bounds__(FftPlan<M>::T) void k_gauss_portrait(GaussArgs a) {
+    constexpr int T = FftPlan<M>::T, B = 2 * M;
+    constexpr int PL = FftPlan<M>::PADLOG;
+    __shared__ cplx lds[FftPlan<M>::LDS_ELEMS];
+    __shared__ cplx zin[M];
+    __shared__ GaussComp gc[PP_MAX_GAUSS];
+    const int tid = threadIdx.x;
+    for (int n = blockIdx.x; n < a.nchan; n += gridDim.x) {
+        const double nu = a.freqs[n];
+        for (int c = tid; c < a.ngauss; c += T) {
+            const double* p = a.comps + c * 6;
+            const double loc = gauss_evolve(nu, a.nu_ref, p[0], p[1], a.code_loc);
+            const double wid = gauss_evolve(nu, a.nu_ref, p[2], p[3], a.code_wid);
+            GaussComp g;
+            g.amp = gauss_evolve(nu, a.nu_ref, p[4], p[5], a.code_amp);
+            g.on = wid > 0.0;
+            g.sigma = (g.on ? wid : 1.0) / (2.0 * sqrt(2.0 * log(2.0)));
+            g.mean = loc - floor(loc);                 // loc % 1.0
+            g.norm = g.sigma * sqrt(2.0 * PP_TWO_PI * 0.5);   // sigma sqrt(2 pi)
+            // peak bin = argmax of the sampled profile (first maximum): the bin
+            // centre nearest to the mean, searched among its neighbours
+            const int j0 = min(B - 1, max(0, (int)floor(g.mean * (double)B)));
+            int jb = -1; double vb = -1.0;
+            for (int dj = -1; dj <= 1; ++dj) {
+                const int j = (j0 + dj + B) % B;
+                const double v = gauss_val(gauss_bin_centre(j, B), g);
+                if (v > vb || (v == vb && j < jb)) { vb = v; jb = j; }
+            }
+            const double zpk = (gauss_wrap(gauss_bin_centre(jb, B), g.mean) - loc) / g.sigma;
+            g.fact = (vb > 0.0) ? exp(-0.5 * __dmul_rn(zpk, zpk)) / vb : 0.0;
+            gc[c] = g;
+        }
+        __syncthreads();
+        for (int j = tid; j < B; j += T) {
+            const double x = gauss_bin_centre(j, B);
+            double sum = 0.0;
+            for (int c = 0; c < a.ngauss; ++c) {
+                const GaussComp g = gc[c];
+                if (g.on) sum = __dadd_rn(sum, __dmul_rn(g.amp, __dmul_rn(g.fact, gauss_val(x, g))));
+            }
+            reinterpret_cast<double*>(zin)[j] = __dadd_rn(a.dc, sum);
+        }
+        __syncthreads();
+        double* out = a.out + (size_t)n * B;
+        const double taun = (a.tau_ref != 0.0) ? a.tau_ref * pow(nu / a.nu_ref, a.alpha) : 0.0;
+        if (taun == 0.0) {
+            for (int j = tid; j < B; j += T) out[j] = reinterpret_cast<const double*>(zin)[j];
+        } else {
+            // irfft(rfft(row) / (1 + 2 pi i k tau_n)): same packing as k_rotate
+            fft_row<M, double>(lds, reinterpret_cast<const double*>(zin), a.twB, tid);
+            __syncthreads();
+            const cplx z0 = lds[0];
+            const double y0 = z0.x + z0.y;
+            const double xM = PP_TWO_PI * (double)M * taun;
+            const double yM = (z0.x - z0.y) / (1.0 + xM * xM);     // Re(d_M B_M), d_M real
+            for (int k = tid; k < M; k += T) {
+                cplx yk, ym;
+                if (k == 0) { yk = make_double2(y0, 0.0); ym = make_double2(yM, 0.0); }
+                else {
+                    const double xk = PP_TWO_PI * (double)k * taun, dk = 1.0 / (1.0 + xk * xk);
+                    const double xm = PP_TWO_PI * (double)(M - k) * taun, dm = 1.0 / (1.0 + xm * xm);
+                    yk = cmul(rfft_harmonic<M>(lds, a.twB, k), make_double2(dk, -xk * dk));
+                    ym = cmul(rfft_harmonic<M>(lds, a.twB, M - k), make_double2(dm, -xm * dm));
+                }
+                ym.y = -ym.y;
+                const cplx ev = make_double2(0.5 * (yk.x + ym.x), 0.5 * (yk.y + ym.y));
+                cplx od = make_double2(0.5 * (yk.x - ym.x), 0.5 * (yk.y - ym.y));
+                cplx w = a.twB[k];
+                w.y = -w.y;
+                od = cmul(od, w);
+                zin[k] = make_double2(ev.x - od.y, -(ev.y + od.x));
+            }
+            __syncthreads();
+            fft_row<M, cplx>(lds, zin, a.twB, tid);
+            const double inv = 1.0 / (double)M;
+            for (int j = tid; j < M; j += T) {
+                const cplx r = lds[lds_pad<PL>(j)];
+                reinterpret_cast<double2*>(out)[j] = make_double2(r.x * inv, -r.y * inv);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------
 // ppalign's accumulation (ppalign.py:199-206): aligned[n] = sum_i w_in *
 // rotate_data(data_in, phase_i, DM_i, P_i, freqs, nu_ref_i), totw[n] = sum_i w_in.
 // Rotation is linear, so the weighted harmonics of all subints of a channel are

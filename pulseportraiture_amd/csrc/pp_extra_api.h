@@ -222,3 +222,62 @@ extern "C" int pp_channel_red_chi2(pp_ctx* c, const void* src, int dtype, int on
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PP_OK;
 }
+
+// ---- Gaussian-component templates on the device ------------------------------
+static int gauss_generate(pp_ctx* c, int nchan, int nbin, const double* freqs, const char* code, double nu_ref,
+                          double dc, double tau_rot, double alpha, int ngauss, const double* comps,
+                          double* dev_out) {
+    if (!freqs || !code || !comps) return fail(PP_EINVAL, "gaussian portrait: null argument");
+    if (!nbin_ok(nbin) || nchan < 1) return fail(PP_EINVAL, "gaussian portrait: bad shape");
+    if (ngauss < 1 || ngauss > PP_MAX_GAUSS) return fail(PP_EINVAL, "gaussian portrait: 1..%d components", PP_MAX_GAUSS);
+    for (int j = 0; j < 3; ++j)
+        if (code[j] != '0' && code[j] != '1') return fail(PP_EINVAL, "gaussian portrait: model code '%.3s'", code);
+    int rc;
+    if ((rc = upload(c, c->freqs, freqs, (size_t)nchan * 8))) return rc;
+    if ((rc = upload(c, c->misc, comps, (size_t)ngauss * 48))) return rc;
+    const cplx* tw = nullptr;
+    if ((rc = get_twiddles(c, nbin, &tw))) return rc;
+    GaussArgs a{c->freqs.as<double>(), c->misc.as<double>(), tw, dev_out, nu_ref, dc, tau_rot, alpha, nchan, ngauss,
+                code[0] - '0', code[1] - '0', code[2] - '0'};
+    const int M = nbin / 2;
+    {
+        Prof pr(c, KF_MODEL);
+        PP_DISPATCH_M(M, {
+            const int T = FftPlan<MM>::T;
+            hipLaunchKernelGGL((k_gauss_portrait<MM>), dim3(nchan), dim3(T), 0, c->stream, a);
+        });
+    }
+    HIP_TRY(hipGetLastError());
+    return PP_OK;
+}
+
+extern "C" int pp_gaussian_portrait(pp_ctx* c, int nchan, int nbin, const double* freqs, const char* code,
+                                    double nu_ref, double dc, double tau_rot, double alpha, int ngauss,
+                                    const double* comps, double* portrait, int out_on_device) {
+    if (!c || !portrait) return fail(PP_EINVAL, "pp_gaussian_portrait: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    double* dout = portrait;
+    if (!out_on_device) {
+        if ((rc = c->data.reserve((size_t)nchan * nbin * 8))) return rc;
+        dout = c->data.as<double>();
+    }
+    if ((rc = gauss_generate(c, nchan, nbin, freqs, code, nu_ref, dc, tau_rot, alpha, ngauss, comps, dout))) return rc;
+    if (!out_on_device)
+        HIP_TRY(hipMemcpyAsync(portrait, dout, (size_t)nchan * nbin * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PP_OK;
+}
+
+extern "C" int pp_model_set_gaussian(pp_ctx* c, int slot, int nchan, int nbin, const double* freqs,
+                                     const char* code, double nu_ref, double dc, double tau_rot, double alpha,
+                                     int ngauss, const double* comps) {
+    if (!c) return fail(PP_EINVAL, "pp_model_set_gaussian: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->X.reserve((size_t)nchan * nbin * 8))) return rc;     // scratch for the portrait
+    if ((rc = gauss_generate(c, nchan, nbin, freqs, code, nu_ref, dc, tau_rot, alpha, ngauss, comps,
+                             c->X.as<double>())))
+        return rc;
+    return pp_model_set(c, slot, c->X.p, PP_F64, 1, nchan, nbin);
+}

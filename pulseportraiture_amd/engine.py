@@ -306,6 +306,47 @@ class Engine(object):
                "pp_rotate_portraits")
         return out
 
+    @staticmethod
+    def _gauss_args(model, P):
+        p = np.asarray(model["params"], dtype=np.float64)
+        ng = int(model["ngauss"])
+        comps = np.ascontiguousarray(p[2:2 + 6 * ng].reshape(ng, 6))
+        tau_rot = 0.0
+        if p[1] != 0.0:
+            if P is None:
+                raise ValueError("need the period P for a model with TAU != 0")
+            tau_rot = float(p[1]) / float(P)
+        return (str(model["code"]).encode(), float(model["nu_ref"]), float(p[0]), tau_rot,
+                float(model["alpha"]), ng, comps)
+
+    def gaussian_portrait(self, model, freqs, nbin, P=None, out=None):
+        """nchan x nbin portrait of a parsed .gmodel (gmodel.parse_gmodel) built
+        on the device; `out` may be a CUDA float64 tensor [nchan,nbin] (filled in
+        place), else a NumPy array is returned."""
+        freqs = _f64(freqs)
+        nchan = len(freqs)
+        code, nu_ref, dc, tau_rot, alpha, ng, comps = self._gauss_args(model, P)
+        if out is not None and _is_device_array(out):
+            dst, on_dev, ret = C.c_void_p(out.data_ptr()), 1, out
+        else:
+            ret = np.empty((nchan, int(nbin)))
+            dst, on_dev = C.c_void_p(ret.ctypes.data), 0
+        _check(self._lib.pp_gaussian_portrait(self._ctx, nchan, int(nbin), _dp(freqs), code, nu_ref,
+                                              dc, tau_rot, alpha, ng, _dp(comps), dst, on_dev),
+               "pp_gaussian_portrait")
+        return ret
+
+    def set_model_gaussian(self, model, freqs, nbin, P=None, slot=0):
+        """Synthesise a .gmodel template on the device straight into a model slot;
+        returns the number of harmonics kept."""
+        freqs = _f64(freqs)
+        code, nu_ref, dc, tau_rot, alpha, ng, comps = self._gauss_args(model, P)
+        _check(self._lib.pp_model_set_gaussian(self._ctx, int(slot), len(freqs), int(nbin),
+                                               _dp(freqs), code, nu_ref, dc, tau_rot, alpha, ng,
+                                               _dp(comps)), "pp_model_set_gaussian")
+        self._digests.pop(int(slot), None)
+        return int(self._lib.pp_model_nharm(self._ctx, int(slot)))
+
     def _ports_arg(self, ports):
         if _is_device_array(ports):
             nsub, nchan, nbin = (int(v) for v in ports.shape)

@@ -221,10 +221,9 @@ class GetTOAs(object):
         self.quiet = quiet
 
     # -- template ----------------------------------------------------------
-    def _model_for(self, freqs_row, nbin, P, unscattered=False):
-        """Template at this subint's frequencies: Gaussian-component (.gmodel)
-        or, failing that, spline (.spl) model -- the reference's fallback order
-        (pptoas.py:352-379)."""
+    def _gmodel(self):
+        """The parsed .gmodel, or None if the model file is not one (then it is
+        tried as a spline model: the reference's fallback order, pptoas.py:352-379)."""
         mdl = self.modelfile if isinstance(self.modelfile, dict) else None
         if mdl is None:
             try:
@@ -233,19 +232,39 @@ class GetTOAs(object):
                     mdl = None
             except (UnicodeDecodeError, ValueError, IndexError):
                 mdl = None
+        if mdl is not None:
+            self.model_name, self.ngauss = mdl["name"], mdl["ngauss"]
+            self.model_code, self.model_nu_ref = mdl["code"], mdl["nu_ref"]
+            self.gparams, self.alpha = mdl["params"], mdl["alpha"]
+        return mdl
+
+    def _model_for(self, freqs_row, nbin, P, unscattered=False):
+        """Template portrait (host array) at this subint's frequencies."""
+        mdl = self._gmodel()
         if mdl is None:
             from .splmodel import read_spline_model
             self.model_name, port = read_spline_model(self.modelfile, freqs_row, nbin,
                                                       quiet=True)
             return port
-        self.model_name, self.ngauss = mdl["name"], mdl["ngauss"]
-        self.model_code, self.model_nu_ref = mdl["code"], mdl["nu_ref"]
-        self.gparams, self.alpha = mdl["params"], mdl["alpha"]
         if unscattered:
             mdl = dict(mdl)
             mdl["params"] = mdl["params"].copy()
             mdl["params"][1] = 0.0
         return gmodel.gaussian_portrait(mdl, freqs_row, nbin, P)
+
+    def _load_template(self, eng, slot, freqs_row, nbin, P, unscattered=False):
+        """Put the template for these frequencies into a model slot of the engine:
+        Gaussian-component models are synthesised on the device, spline models are
+        evaluated on the host and uploaded."""
+        mdl = self._gmodel()
+        if mdl is None or mdl["ngauss"] > 64:
+            eng.set_model(self._model_for(freqs_row, nbin, P, unscattered), slot=slot)
+            return
+        if unscattered:
+            mdl = dict(mdl)
+            mdl["params"] = mdl["params"].copy()
+            mdl["params"][1] = 0.0
+        eng.set_model_gaussian(mdl, freqs_row, nbin, P, slot=slot)
 
     def get_TOAs(self, datafile=None, tscrunch=False, nu_refs=None, DM0=None,
                  bary=True, fit_DM=True, fit_GM=False, fit_scat=False,
@@ -326,8 +345,8 @@ class GetTOAs(object):
                         raise NotImplementedError("more than 64 distinct frequency rows "
                                                   "in one archive")
                     slots[key] = len(slots)
-                    eng.set_model(self._model_for(d.freqs[isub], nbin, d.Ps[isub],
-                                                  unscattered=fit_scat), slot=slots[key])
+                    self._load_template(eng, slots[key], d.freqs[isub], nbin, d.Ps[isub],
+                                        unscattered=fit_scat)
                 slot_of[j] = slots[key]
                 if nu_fits is None:
                     nu_fit = guess_fit_freq(freqsx, d.SNRs[isub, 0, ich])
@@ -579,8 +598,8 @@ class GetTOAs(object):
                     if len(slots) >= 64:
                         raise NotImplementedError("more than 64 distinct templates in one archive")
                     slots[key] = len(slots)
-                    eng.set_model(self._model_for(d.freqs[isub], nbin, d.Ps.mean(),
-                                                  unscattered=scat), slot=slots[key])
+                    self._load_template(eng, slots[key], d.freqs[isub], nbin, d.Ps.mean(),
+                                        unscattered=scat)
                 slot_of[j] = slots[key]
                 scales[j] = self.scales[iarch][isub]
             port = np.ascontiguousarray(np.asarray(d.subints)[ok_isubs, 0])

@@ -857,3 +857,52 @@ def test_align_subints_matches_oracle_loop(eng, fit_dm):
             tw[ich] += w
         tmpl = acc / tw[:, None]
     np.testing.assert_allclose(got, tmpl, rtol=0, atol=2e-7 * np.abs(tmpl).max())
+
+
+def test_device_gaussian_portrait_matches_reference_and_host(eng):
+    """Templates synthesised on the device from .gmodel parameters: against the
+    reference's own read_model portrait stored in the goldens, and against the host
+    construction (gmodel.py) for linear evolution codes, a scattered model,
+    components wrapping around phase 0/1, a component outside [0,1) and a
+    vanishing width."""
+    from pulseportraiture_amd import gmodel
+    mdl = gmodel.read_gmodel(os.path.join(GOLDEN, "example.gmodel"))
+    for name in ("fpf_64x256_phiDM", "fpf_128x512_phiDM_scint"):
+        g = _load(name)
+        nbin = g["model"].shape[1]
+        got = eng.gaussian_portrait(mdl, g["freqs"], nbin, float(g["P"]))
+        np.testing.assert_allclose(got, g["model"], rtol=0, atol=4e-15 * np.abs(g["model"]).max())
+    freqs = np.linspace(1100.0, 1900.0, 40)
+    text = """MODEL test
+CODE 011
+FREQ 1500.0
+DC 0.01 0
+TAU 2.5e-5 0
+ALPHA -3.7 0
+COMP01 0.02 0 -1e-5 0 0.03 0 2e-6 0 3.0 0 -5e-4 0
+COMP02 0.97 0 2e-5 0 0.012 0 -1e-6 0 1.5 0 1e-3 0
+COMP03 0.50 0 0.0 0 0.2 0 1e-5 0 0.4 0 0.0 0
+COMP04 1.30 0 0.0 0 0.05 0 0.0 0 1.0 0 0.0 0
+COMP05 0.70 0 0.0 0 -0.01 0 0.0 0 1.0 0 0.0 0
+"""
+    m2 = gmodel.parse_gmodel(text)
+    for nbin in (64, 1024, 4096):
+        for P in (0.004, None):
+            mm = dict(m2)
+            if P is None:
+                mm["params"] = m2["params"].copy()
+                mm["params"][1] = 0.0
+            want = gmodel.gaussian_portrait(mm, freqs, nbin, P)
+            got = eng.gaussian_portrait(mm, freqs, nbin, P)
+            np.testing.assert_allclose(got, want, rtol=0, atol=2e-14 * np.abs(want).max())
+    # straight into a model slot: the fit must not care where the template came from
+    g = _load("fpf_64x256_phiDM")
+    kw = dict(errs=g["errs"], nu_fits=[list(g["nu_fits"])], fit_flags=[1, 1, 0, 0, 0])
+    eng.set_model(g["model"])
+    a = eng.fit_batch(g["data"][None], g["freqs"], float(g["P"]), g["init_params"], **kw)
+    nh = eng.set_model_gaussian(mdl, g["freqs"], g["model"].shape[1], float(g["P"]))
+    b = eng.fit_batch(g["data"][None], g["freqs"], float(g["P"]), g["init_params"], **kw)
+    assert nh > 0
+    assert _dphi(a["params"][0, 0], b["params"][0, 0]) < 1e-13
+    assert abs(a["params"][0, 1] - b["params"][0, 1]) < 1e-11
+    assert _dphi(b["params"][0, 0], float(g["out_phi"])) < PHI_BAR
