@@ -62,7 +62,8 @@ def main():
     ap.add_argument("--sigma", type=float, default=0.05)
     ap.add_argument("--seed", type=int, default=20260101)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="subints the CPU baseline fits (0 = as many as fit in ~12 s, at most 64)")
     ap.add_argument("--seed-ns", type=int, default=0,
                     help="> 0: ignore the phase guesses and seed the phase on the device "
                          "with an N-point grid (the whole pptoas preamble + fit)")
@@ -238,14 +239,20 @@ def cpu_baseline(data, freqs, P, x0, errs, nu_fit, flags, log10_tau, res, nsampl
     """Time the CPU oracle (a NumPy/SciPy port of the reference algorithm) on a
     bounded sample of the very batch the GPU fitted, and report parity on it."""
     from oracle import pptoas_oracle as orc
-    nsample = max(1, min(nsample, data.shape[0]))
-    host = data[:nsample].cpu().numpy().astype(np.float64)
+    budget_s, cap = 12.0, min(64, data.shape[0])
+    want = cap if nsample <= 0 else max(1, min(nsample, data.shape[0]))
     t0 = time.perf_counter()
     outs = []
-    for i in range(nsample):
-        outs.append(orc.fit_portrait_full(host[i], model, x0[i], P[i], freqs,
+    for i in range(want):
+        host = data[i].cpu().numpy().astype(np.float64)
+        outs.append(orc.fit_portrait_full(host, model, x0[i], P[i], freqs,
                                           [nu_fit] * 3, [None] * 3, errs[i], flags,
                                           log10_tau=log10_tau))
+        # bounded sample: stop when the next fit would overrun the time budget
+        el = time.perf_counter() - t0
+        if nsample <= 0 and el + el / (i + 1) > budget_s:
+            break
+    nsample = len(outs)
     dt = time.perf_counter() - t0
     dphi = max(abs(((o.phi - res["params"][i, 0]) + 0.5) % 1.0 - 0.5)
                for i, o in enumerate(outs))

@@ -13,6 +13,10 @@
 #pragma once
 #include "pp_common.h"
 
+#ifndef PP_SB_STAGES
+#define PP_SB_STAGES 1
+#endif
+
 namespace pp {
 
 __device__ __forceinline__ void dft2(cplx& a, cplx& b) {
@@ -328,9 +332,13 @@ __device__ __forceinline__ void fft_later_stages(cplx* lds, const RowTwiddles<M>
                                                  double* power = nullptr) {
     typedef FftPlan<M> P;
     stage_lds<M, P::T, P::R2, P::R1, P::PADLOG>(lds, tw.t2, tid, power);
+#if PP_SB_STAGES
     __builtin_amdgcn_sched_barrier(0);
+#endif
     if constexpr (P::R3 > 1) stage_lds<M, P::T, P::R3, P::R1 * P::R2, P::PADLOG>(lds, tw.t3, tid, power);
+#if PP_SB_STAGES
     __builtin_amdgcn_sched_barrier(0);
+#endif
     if constexpr (P::R4 > 1) stage_lds<M, P::T, P::R4, P::R1 * P::R2 * P::R3, P::PADLOG>(lds, tw.t3, tid, power);
 }
 

@@ -158,6 +158,12 @@ __global__ void k_model_kcut(const cplx* mft, const double* mmax, int nchan, int
 #ifndef PP_XSPEC_ABLATE
 #define PP_XSPEC_ABLATE 0     // timing-only builds: 1 = loads only, 2 = + stage 1, 3 = + all stages
 #endif
+#ifndef PP_SB_PREFETCH
+#define PP_SB_PREFETCH 1
+#endif
+#ifndef PP_SB_LATE
+#define PP_SB_LATE 1
+#endif
 #ifndef PP_OPAQUE_ROW
 #define PP_OPAQUE_ROW 2         // 0 never, 1 always, 2 only in MODE 2 (register-bound)
 #endif
@@ -269,7 +275,9 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             fft_first_stage<M>(lds, v, tw, tid);
 #endif
         }
+#if PP_SB_PREFETCH
         __builtin_amdgcn_sched_barrier(0);
+#endif
         // the first stage has consumed the row: its registers now receive the
         // NEXT row, whose HBM loads stay in flight under the rest of this one
         // (unconditional -- the last row of the run fetches itself again: a prefetch
@@ -280,7 +288,9 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             const size_t rn = (row + 1 < rend) ? (size_t)i_nx * a.nchan + n_nx : rc;
             stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);
         }
+#if PP_SB_PREFETCH
         __builtin_amdgcn_sched_barrier(0);
+#endif
 #if PP_XSPEC_ABLATE == 1 || PP_XSPEC_ABLATE == 2
         lds_sync<T>();
         continue;
@@ -297,7 +307,9 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             else sd += cnorm(z);
         }
 #endif
+#if PP_SB_LATE
         __builtin_amdgcn_sched_barrier(0);
+#endif
         if (TAIL) {
             for (int k = kc + tid; k <= M; k += T) tail += cnorm(rfft_harmonic<M>(lds, a.twB, k));
         }
@@ -306,7 +318,9 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         lds_sync<T>();
         continue;
 #endif
+#if PP_SB_LATE
         __builtin_amdgcn_sched_barrier(0);
+#endif
         // ---- cross-spectrum (and the first evaluation's sums) ----
         cplx* xrow = a.X + rc * a.Kt;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;

@@ -7,4 +7,5 @@ for ex in "$@"; do
   python bench.py --no-cpu-baseline | pj
   python bench.py --no-cpu-baseline --input-dtype f32 | pj
   python bench.py --no-cpu-baseline --workload cfg2-512x1024-phiDM | pj
+  python bench.py --no-cpu-baseline | pj
 done
