@@ -191,6 +191,17 @@ def _load(datafile):
                        "DataBunch (data_from_arrays) or an .npz of its fields." % datafile)
 
 
+def _take_subints(subints, ok_isubs):
+    """[nok, nchan, nbin] total-intensity portraits of the good subints, without
+    copying the archive when they are a contiguous run (fancy indexing would copy
+    gigabytes before the H2D transfer even starts)."""
+    a = np.asarray(subints)
+    idx = np.asarray(ok_isubs, dtype=int)
+    if len(idx) and np.array_equal(idx, np.arange(idx[0], idx[0] + len(idx))):
+        return np.ascontiguousarray(a[idx[0]:idx[0] + len(idx), 0])
+    return np.ascontiguousarray(a[idx, 0])
+
+
 class GetTOAs(object):
     """Measure wideband TOAs and DMs (pptoas.py:75-1419, the get_TOAs path)."""
 
@@ -385,12 +396,14 @@ class GetTOAs(object):
                 else:
                     fl = list(self.fit_flags)
                 flags_per.append(tuple(fl))
-            port = np.ascontiguousarray(np.asarray(d.subints)[ok_isubs, 0])
+            port = _take_subints(d.subints, ok_isubs)
             # ---- one device call per distinct flag set (normally one) ----
             res = None
             for fl in sorted(set(flags_per)):
                 sel = np.array([k for k, f in enumerate(flags_per) if f == fl])
-                r = eng.fit_batch(port[sel], d.freqs[ok_isubs][sel], d.Ps[ok_isubs][sel],
+                # (all subints in one call is the normal case: no gather copy then)
+                psel = port if len(sel) == nok else np.ascontiguousarray(port[sel])
+                r = eng.fit_batch(psel, d.freqs[ok_isubs][sel], d.Ps[ok_isubs][sel],
                                   x0[sel], errs=None if errs is None else errs[sel],
                                   nu_fits=nu_fit_arr[sel], nu_outs=nu_ref_arr[sel],
                                   fit_flags=fl, log10_tau=log10_tau, option=0,
@@ -602,7 +615,7 @@ class GetTOAs(object):
                                         unscattered=scat)
                 slot_of[j] = slots[key]
                 scales[j] = self.scales[iarch][isub]
-            port = np.ascontiguousarray(np.asarray(d.subints)[ok_isubs, 0])
+            port = _take_subints(d.subints, ok_isubs)
             noise = np.ascontiguousarray(np.asarray(d.noise_stds)[ok_isubs, 0], dtype=np.float64)
             nu_refs = np.array([self.nu_refs[iarch][isub] for isub in ok_isubs], dtype=np.float64)
             with np.errstate(divide="ignore", invalid="ignore"):
