@@ -90,8 +90,21 @@ def main():
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # launched by torchrun
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=device)
+        # RCCL writes a version banner to stdout when its first communicator comes
+        # up; stdout is reserved for the one JSON line, so route fd 1 to stderr
+        # until the communicator exists
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=device)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     C, B, flags, log10_tau, nsub_def, note = WORKLOADS[args.workload]
     nsub = args.nsub or nsub_def
