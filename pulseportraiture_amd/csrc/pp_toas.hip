@@ -378,11 +378,46 @@ static int upload(pp_ctx* c, DevBuf& b, const void* src, size_t bytes) {
     return PP_OK;
 }
 
+// persistent grid of exactly the resident capacity of this instantiation (its
+// register / LDS footprint decides how many workgroups a CU holds): a larger grid
+// would run its surplus workgroups in a second, mostly idle round
+template <typename K>
+static int resident_grid(pp_ctx* c, K kernel, int T, long long nrows, int fallback) {
+    static std::map<const void*, int> cache;
+    const void* key = reinterpret_cast<const void*>(kernel);
+    auto it = cache.find(key);
+    int per_cu = 0;
+    if (it != cache.end()) per_cu = it->second;
+    else {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, T, 0) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            per_cu = 0;
+        }
+        cache[key] = per_cu;
+    }
+    int ncu = 256;
+    hipDeviceProp_t prop;
+    static int ncu_cached = 0;
+    if (!ncu_cached) {
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
+            ncu_cached = prop.multiProcessorCount;
+        else ncu_cached = 256;
+    }
+    ncu = ncu_cached;
+    const long long g = per_cu > 0 ? (long long)per_cu * ncu : (long long)fallback;
+    return (int)std::max(1LL, std::min(nrows, g));
+}
+
 template <int MM, typename TIN>
 static void launch_xspec(pp_ctx* c, const XspecArgs& xa, bool tail, int mode) {
     const int T = FftPlan<MM>::T;
-    const dim3 grid(fft_grid(T, (long long)xa.nsub * xa.nchan)), blk(T);
-#define PP_XS(TL, MD) hipLaunchKernelGGL((k_xspec<MM, TIN, TL, MD>), grid, blk, 0, c->stream, xa)
+    const long long nrows = (long long)xa.nsub * xa.nchan;
+    const dim3 blk(T);
+#define PP_XS(TL, MD)                                                                                  \
+    do {                                                                                               \
+        const dim3 grid(resident_grid(c, k_xspec<MM, TIN, TL, MD>, T, nrows, fft_grid(T, nrows)));     \
+        hipLaunchKernelGGL((k_xspec<MM, TIN, TL, MD>), grid, blk, 0, c->stream, xa);                   \
+    } while (0)
     if (tail) {
         if (mode == 3) PP_XS(true, 3); else if (mode == 2) PP_XS(true, 2); else if (mode == 1) PP_XS(true, 1); else PP_XS(true, 0);
     } else {
