@@ -183,7 +183,7 @@ def save(name, **arrays):
 
 
 def fit_case(ref, name, C, B, seed, flags, log10_tau=False, nu_outs=None,
-             store_arrays=True, patch_cov=False, **kw):
+             store_arrays=True, patch_cov=False, option=0, is_toa=True, **kw):
     fit_scat = bool(flags[3] or flags[4])
     inp = make_inputs(ref, C, B, seed, **kw)
     tau_rot = None
@@ -199,9 +199,10 @@ def fit_case(ref, name, C, B, seed, flags, log10_tau=False, nu_outs=None,
     r = ref.fit_portrait_full(inp["data"], inp["model"], g["init_params"],
                               inp["P"], inp["freqs"], nu_fits, nu_outs,
                               inp["errs"], flags, [(None, None)] * 5,
-                              log10_tau, option=0, sub_id=None,
-                              method='trust-ncg', is_toa=True, quiet=True)
-    out = dict(C=C, B=B, seed=seed, fit_flags=np.array(flags),
+                              log10_tau, option=option, sub_id=None,
+                              method='trust-ncg', is_toa=is_toa, quiet=True)
+    out = dict(C=C, B=B, seed=seed, fit_flags=np.array(flags), option=option,
+               is_toa=is_toa,
                log10_tau=log10_tau, P=inp["P"], freqs=inp["freqs"],
                errs=inp["errs"], nu_fits=np.array(nu_fits, dtype=np.float64),
                nu_outs=np.array([np.nan if v is None else v for v in nu_outs]),

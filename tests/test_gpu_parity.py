@@ -73,9 +73,12 @@ def test_fit_matches_reference_golden(name):
     from pulseportraiture_amd.pptoaslib import fit_portrait_full
     g = _load(name)
     nu_outs = [None if np.isnan(v) else float(v) for v in g["nu_outs"]]
+    sw = {}
+    if "option" in g.files:     # goldens of the non-default switches
+        sw = dict(option=int(g["option"]), is_toa=bool(g["is_toa"]))
     r = fit_portrait_full(g["data"], g["model"], g["init_params"], float(g["P"]),
                           g["freqs"], list(g["nu_fits"]), nu_outs, g["errs"],
-                          list(g["fit_flags"]), log10_tau=bool(g["log10_tau"]))
+                          list(g["fit_flags"]), log10_tau=bool(g["log10_tau"]), **sw)
     scat = bool(g["fit_flags"][2] or g["fit_flags"][3] or g["fit_flags"][4])
     # phase+DM: the reference converges to rounding -> the 1e-9 bar applies to
     # its raw answer.  With GM / scattering its trust-ncg exit leaves it up to

@@ -29,6 +29,9 @@ def _load(name):
 
 def _run(g, **kw):
     nu_outs = [None if np.isnan(v) else float(v) for v in g["nu_outs"]]
+    if "option" in g.files:     # goldens of the non-default switches
+        kw.setdefault("option", int(g["option"]))
+        kw.setdefault("is_toa", bool(g["is_toa"]))
     return orc.fit_portrait_full(
         g["data"], g["model"], g["init_params"], float(g["P"]), g["freqs"],
         list(g["nu_fits"]), nu_outs, g["errs"], list(g["fit_flags"]),
