@@ -2,8 +2,13 @@
 //
 //   k_model_fft   rFFT of template rows -> m_nk (k = 1..M), sum_k |m_nk|^2
 //   k_model_kcut  last harmonic whose |m_nk| exceeds eps * max_k |m_nk|
+//   k_phase0      phi_n of every (subint, channel) at the initial parameters
 //   k_xspec       rFFT of data rows, X_nk = d_nk conj(m_nk), sum_k |d_nk|^2,
-//                 power-spectrum noise estimate        (pptoaslib.py:976-985)
+//                 power-spectrum noise estimate        (pptoaslib.py:976-985);
+//                 modes 2/3: the per-channel Taylor model of C_n instead of X
+//   k_eval_moments / k_taylor_solve   the same Taylor model from a stored X, and
+//                 the certified Newton solve on it     (replaces :1001-1014 when
+//                 there is no scattering)
 //   k_prep        per-channel weights 1/sigma_F^2, S_d   (pptoaslib.py:980-985)
 //   k_eval        chi^2 surface evaluator: per-channel Fourier sums by phasor
 //                 recurrence, reduced to f, grad f, Hess f (pptoaslib.py:525-643)
@@ -137,17 +142,17 @@ __global__ void k_model_kcut(const cplx* mft, const double* mmax, int nchan, int
 }
 
 // --------------------------------------------------------------------------
-// data rFFT + cross-spectrum.  Rows are visited channel-major (row = n*nsub+i)
-// so every workgroup in flight shares a handful of model rows (L2-resident).
-// The next row's samples are prefetched into registers while the current row is
-// transformed, so each resident workgroup always has one row of HBM loads in
-// flight.  Only the Kt harmonics the (truncated) model keeps go through the
-// even/odd split; S_d needs no split at all because
+// data rFFT + cross-spectrum.  Rows are ordered channel-major (row = n*nsub+i)
+// and every workgroup of the persistent grid takes a contiguous run of them, so
+// its template row changes once per nsub rows (modes 2/3 keep it in registers;
+// modes 0/1 re-read it from L2).  The next row's samples are prefetched into
+// registers while the current row is transformed, so each resident workgroup
+// always has one row of HBM loads in flight.  Only the harmonics the (truncated)
+// template keeps go through the even/odd split; S_d needs no split at all because
 //   sum_{k=1}^{M-1} |d_k|^2 = sum_{k=1}^{M-1} |Z_k|^2   (Z = packed complex FFT),
 // and d_M = Re Z_0 - Im Z_0.
 // TAIL: also measure the noise from the top quarter of the power spectrum
-// (errs == NULL).  FUSE: accumulate the evaluator's sums A0, A1, A2 at the
-// initial parameters while X is still in registers (saves one pass over X).
+// (errs == NULL).
 // --------------------------------------------------------------------------
 #ifndef PP_SPLIT_U
 #define PP_SPLIT_U 4          // harmonics per thread processed together in the split loop
@@ -158,6 +163,7 @@ __global__ void k_model_kcut(const cplx* mft, const double* mmax, int nchan, int
 #ifndef PP_XSPEC_ABLATE
 #define PP_XSPEC_ABLATE 0     // timing-only builds: 1 = loads only, 2 = + stage 1, 3 = + all stages
 #endif
+// scheduling fences around the prefetch / after the FFT (experiments: no effect either way)
 #ifndef PP_SB_PREFETCH
 #define PP_SB_PREFETCH 1
 #endif
