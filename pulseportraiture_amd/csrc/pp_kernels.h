@@ -1407,7 +1407,9 @@ __device__ inline double pick_poly_root(const double* cin, int deg, double targe
         sincos(PP_TWO_PI * j / n + 0.4, &s, &co);
         zr[j] = 0.5 * rad * co; zi[j] = 0.5 * rad * s;
     }
-    for (int it = 0; it < 200; ++it) {
+    // (stops a few ulp short: every selected root is polished by Newton below, and
+    // a step that hovers at the rounding level would otherwise never meet a tighter test)
+    for (int it = 0; it < 64; ++it) {
         double maxstep = 0.0;
         for (int j = 0; j < n; ++j) {
             // p(z), p'(z) by Horner
@@ -1434,7 +1436,7 @@ __device__ inline double pick_poly_root(const double* cin, int deg, double targe
             zr[j] -= stx; zi[j] -= sty;
             maxstep = fmax(maxstep, (fabs(stx) + fabs(sty)) / (fabs(zr[j]) + fabs(zi[j]) + 1e-300));
         }
-        if (maxstep < 1e-16) break;
+        if (maxstep < 8e-16) break;
     }
     double best = NAN, bestd = INFINITY;
     for (int j = 0; j < n; ++j) {
