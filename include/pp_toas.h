@@ -89,6 +89,9 @@ int pp_model_set(pp_ctx* ctx, int slot, const void* portrait, int dtype,
                  int on_device, int nchan, int nbin);
 /* number of harmonics (of nbin/2) kept for this slot after truncation */
 int pp_model_nharm(pp_ctx* ctx, int slot);
+/* DC harmonic of every channel of the slot's template, dc[nchan] (host): nbin x the
+ * profile mean the flux estimate of get_TOAs uses (pptoas.py:554-575) */
+int pp_model_dc(pp_ctx* ctx, int slot, double* dc);
 
 /* Gaussian-component template portraits synthesised on the device (.gmodel
  * files: read_model / gen_gaussian_portrait / gaussian_profile / evolve_parameter,

@@ -56,6 +56,7 @@ SYMBOLS = {
     "pp_model_set": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                C.c_int, C.c_int]),
     "pp_model_nharm": (C.c_int, [C.c_void_p, C.c_int]),
+    "pp_model_dc": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     "pp_fit_portrait_batch": (C.c_int, [C.c_void_p, C.POINTER(FitIn),
                                         C.POINTER(FitOut)]),
     "pp_rfft_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -337,6 +337,15 @@ extern "C" int pp_model_set(pp_ctx* c, int slot, const void* portrait, int dtype
     return PP_OK;
 }
 
+extern "C" int pp_model_dc(pp_ctx* c, int slot, double* dc) {
+    if (!c || !dc || slot < 0 || slot >= PP_MAX_SLOTS || !c->slots[slot].set) return fail(PP_ESTATE, "slot not set");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dc, c->slots[slot].mdc.p, (size_t)c->slots[slot].nchan * sizeof(double),
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PP_OK;
+}
+
 extern "C" int pp_model_nharm(pp_ctx* c, int slot) {
     if (!c || slot < 0 || slot >= PP_MAX_SLOTS || !c->slots[slot].set) return fail(PP_ESTATE, "slot not set");
     return c->slots[slot].Kt;

@@ -347,6 +347,13 @@ class Engine(object):
         self._digests.pop(int(slot), None)
         return int(self._lib.pp_model_nharm(self._ctx, int(slot)))
 
+    def model_means(self, slot, nchan, nbin):
+        """Mean over phase of every channel of the template in `slot` (its DC
+        harmonic / nbin)."""
+        dc = np.empty(int(nchan))
+        _check(self._lib.pp_model_dc(self._ctx, int(slot), _dp(dc)), "pp_model_dc")
+        return dc / float(nbin)
+
     def _ports_arg(self, ports):
         if _is_device_array(ports):
             nsub, nchan, nbin = (int(v) for v in ports.shape)

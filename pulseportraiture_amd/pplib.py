@@ -164,6 +164,18 @@ def rotate_profile(profile, phase=0.0):
 
 
 # ---- 1-D FFTFIT ----------------------------------------------------------------
+def weighted_mean(data, errs=1.0):
+    """Weighted mean and its standard error, weights errs**-2 over the entries
+    with errs > 0 (pplib.py:696-709)."""
+    data = np.asarray(data, dtype=np.float64)
+    if hasattr(errs, 'is_integer'):
+        errs = np.ones(len(data))
+    errs = np.asarray(errs, dtype=np.float64)
+    ii = np.where(errs > 0.0)[0]
+    w = errs[ii] ** -2.0
+    return (data[ii] * w).sum() / w.sum(), w.sum() ** -0.5
+
+
 def get_noise(data, method=default_noise_method, frac=4, chans=False):
     """Off-pulse noise from the mean of the top 1/frac of the power spectrum
     (get_noise / get_noise_PS, pplib.py:2206-2253; only the "PS" method).  Host

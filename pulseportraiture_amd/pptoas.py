@@ -18,7 +18,7 @@ import numpy as np
 
 from . import gmodel
 from .engine import default_engine
-from .pplib import DataBunch, guess_fit_freq, scattering_alpha
+from .pplib import DataBunch, guess_fit_freq, scattering_alpha, weighted_mean
 
 max_nfile = 999
 rm_baseline = True
@@ -285,13 +285,13 @@ class GetTOAs(object):
                  method='trust-ncg', bounds=None, nu_fits=None, show_plot=False,
                  quiet=None):
         """Same arguments as the reference (pptoas.py:150-156).  Not supported
-        here: tscrunch, add_instrumental_response, print_flux, show_plot (they
-        raise) -- they live outside the fit path."""
+        here: tscrunch, add_instrumental_response, show_plot (they raise) -- they
+        live outside the fit path."""
         if quiet is None:
             quiet = self.quiet
-        if tscrunch or add_instrumental_response or print_flux or show_plot:
-            raise NotImplementedError("tscrunch / instrumental response / flux / "
-                                      "plots are outside the accelerated path")
+        if tscrunch or add_instrumental_response or show_plot:
+            raise NotImplementedError("tscrunch / instrumental response / plots are "
+                                      "outside the accelerated path")
         if method not in ('trust-ncg', 'Newton-CG', 'TNC'):
             print("Method '%s' is not implemented." % method)
             sys.exit()
@@ -418,6 +418,12 @@ class GetTOAs(object):
                         res[k][sel] = v
                 res["duration"] += r["duration"]
             fit_duration = res["duration"]
+            # template profile means per slot, for the flux estimate (the scattering
+            # kernel leaves the mean of a profile unchanged: B_0 = 1)
+            slot_means = {}
+            if print_flux:
+                for sl in set(slots.values()):
+                    slot_means[sl] = eng.model_means(sl, nchan, nbin)
 
             # ---- TOA bookkeeping on the host (pptoas.py:528-721) ----
             phis = np.zeros(nsub); phi_errs = np.zeros(nsub)
@@ -429,6 +435,8 @@ class GetTOAs(object):
             scales = np.zeros([nsub, nchan]); scale_errs = np.zeros([nsub, nchan])
             snrs = np.zeros(nsub); channel_snrs = np.zeros([nsub, nchan])
             red_chi2s = np.zeros(nsub)
+            profile_fluxes = np.zeros([nsub, nchan]); profile_flux_errs = np.zeros([nsub, nchan])
+            fluxes = np.zeros(nsub); flux_errs = np.zeros(nsub); flux_freqs = np.zeros(nsub)
             covariances = np.zeros([nsub, self.nfit, self.nfit])
             nfevals = np.zeros(nsub, dtype="int"); rcs = np.zeros(nsub, dtype="int")
             nu_fits_out = list(np.zeros([nsub, 3])); nu_refs_out = list(np.zeros([nsub, 3]))
@@ -470,6 +478,13 @@ class GetTOAs(object):
                                 covariances[isub][a_, b_] = cov[ii, jj]
                 red_chi2s[isub] = res["red_chi2"][j]
                 freqsx = d.freqs[isub, ich]
+                if print_flux:       # pptoas.py:554-575
+                    means = slot_means[slot_of[j]][ich]
+                    profile_fluxes[isub, ich] = means * res["scales"][j, ich]
+                    profile_flux_errs[isub, ich] = np.abs(means) * res["scale_errs"][j, ich]
+                    fluxes[isub], flux_errs[isub] = weighted_mean(
+                        profile_fluxes[isub, ich], profile_flux_errs[isub, ich])
+                    flux_freqs[isub], _ = weighted_mean(freqsx, profile_flux_errs[isub, ich])
                 toa_flags = {}
                 DM_flag, DM_err_flag = (DM_out, e[1]) if fl[1] else (None, None)
                 if fl[2]:
@@ -507,6 +522,10 @@ class GetTOAs(object):
                 if print_phase:
                     toa_flags['phs'] = p[0]
                     toa_flags['phs_err'] = e[0]
+                if print_flux:
+                    toa_flags['flux'] = fluxes[isub]
+                    toa_flags['flux_err'] = flux_errs[isub]
+                    toa_flags['flux_ref_freq'] = flux_freqs[isub]
                 if print_parangle:
                     toa_flags['par_angle'] = d.parallactic_angles[isub]
                 for k, v in addtnl_toa_flags.items():
@@ -555,11 +574,11 @@ class GetTOAs(object):
             self.scale_errs.append(scale_errs)
             self.snrs.append(snrs)
             self.channel_snrs.append(channel_snrs)
-            self.profile_fluxes.append(np.zeros([nsub, nchan]))
-            self.profile_flux_errs.append(np.zeros([nsub, nchan]))
-            self.fluxes.append(np.zeros(nsub))
-            self.flux_errs.append(np.zeros(nsub))
-            self.flux_freqs.append(np.zeros(nsub))
+            self.profile_fluxes.append(profile_fluxes)
+            self.profile_flux_errs.append(profile_flux_errs)
+            self.fluxes.append(fluxes)
+            self.flux_errs.append(flux_errs)
+            self.flux_freqs.append(flux_freqs)
             self.covariances.append(covariances)
             self.red_chi2s.append(red_chi2s)
             self.nfevals.append(nfevals)

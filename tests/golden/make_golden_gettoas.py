@@ -140,6 +140,8 @@ def run(pptoas, data, **kw):
                  "tau_errs", "alphas", "alpha_errs", "snrs", "red_chi2s", "scales",
                  "scale_errs", "channel_snrs"):
         out[name] = np.asarray(getattr(gt, name)[0], dtype=np.float64)
+    for name in ("profile_fluxes", "profile_flux_errs", "fluxes", "flux_errs", "flux_freqs"):
+        out[name] = np.asarray(getattr(gt, name)[0], dtype=np.float64)
     out["nu_refs"] = np.array([list(map(float, r)) for r in gt.nu_refs[0]])
     out["nu_fits"] = np.array([list(map(float, r)) for r in gt.nu_fits[0]])
     out["ok_isubs"] = np.asarray(gt.ok_isubs[0])
@@ -174,7 +176,7 @@ def main():
              ("gettoas_GM", dict(seed=33, GM=0.25), dict(fit_GM=True)),
              ("gettoas_scat", dict(seed=34, tau_us=20.0),
               dict(fit_scat=True, log10_tau=True, scat_guess=(30e-6, 1500.0, -4.0))),
-             ("gettoas_zap", dict(seed=35, corrupt=True), dict())]
+             ("gettoas_zap", dict(seed=35, corrupt=True), dict(print_flux=True))]
     for name, skw, gkw in cases:
         data, arrays, scal = synth_archive(ref, **skw)
         out = run(pptoas, data, **gkw)

@@ -451,6 +451,15 @@ def test_get_TOAs_matches_reference_caller(name):
     line = toa_string(t0)
     assert line.startswith("fake.fits ") and " -pp_dm " in line and " -snr " in line
     assert len(gt.TOA_list) == len(ok)
+    if kw.get("print_flux"):
+        # flux estimate (pptoas.py:554-575): template means x fitted amplitudes
+        for fld, rt in (("fluxes", 1e-7), ("flux_errs", 1e-5), ("flux_freqs", 1e-7)):
+            np.testing.assert_allclose(np.asarray(getattr(gt, fld)[0])[ok], g["out_" + fld][ok], rtol=rt)
+        np.testing.assert_allclose(gt.profile_fluxes[0][ok], g["out_profile_fluxes"][ok], rtol=1e-5,
+                                   atol=1e-9)
+        np.testing.assert_allclose(gt.profile_flux_errs[0][ok], g["out_profile_flux_errs"][ok],
+                                   rtol=1e-5)
+        np.testing.assert_allclose(t0.flags["flux"], g["out_fluxes"][ok[0]], rtol=1e-7)
     # per-channel goodness of fit and zap proposals (get_channels_to_zap,
     # pptoas.py:1208-1285) against the reference's own, same thresholds
     gt.get_channels_to_zap(SNR_threshold=8.0, rchi2_threshold=1.3, iterate=True)
