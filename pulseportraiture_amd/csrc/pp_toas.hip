@@ -81,6 +81,8 @@ struct pp_ctx {
     DevBuf mft_table, msum_table, kt_table, mdc_table;   // device arrays of slot base pointers
     // work buffers
     DevBuf data, X, sdraw, noise, wts, freqs, errs, mask, P, x0, nufit, nuout, slot, state, csum, partial;
+    DevBuf o_pack;   // per-subint scalar outputs, one allocation -> one D2H copy
+    void* o_host = nullptr; size_t o_host_cap = 0;   // pinned staging of o_pack
     DevBuf o_params, o_errs, o_nu, o_cov, o_chi2, o_rchi2, o_snr, o_nfev, o_rc, o_scales, o_serrs, o_csnr,
         o_f0, o_g0, o_H0, misc, seedbuf, tay, ph0;
     int* nactive_h = nullptr;   // pinned
@@ -166,7 +168,8 @@ extern "C" int pp_destroy(pp_ctx* c) {
     resolve_spans(c);
     for (auto& kv : c->twiddles) kv.second.release();
     for (auto& s : c->slots) { s.mft.release(); s.msum.release(); s.mmax.release(); s.mdc.release(); s.kt.release(); }
-    DevBuf* bufs[] = {&c->mft_table, &c->msum_table, &c->kt_table, &c->mdc_table, &c->data, &c->X, &c->sdraw, &c->noise, &c->wts, &c->freqs,
+    if (c->o_host) (void)hipHostFree(c->o_host);
+    DevBuf* bufs[] = {&c->o_pack, &c->mft_table, &c->msum_table, &c->kt_table, &c->mdc_table, &c->data, &c->X, &c->sdraw, &c->noise, &c->wts, &c->freqs,
                       &c->errs, &c->mask, &c->P, &c->x0, &c->nufit, &c->nuout, &c->slot, &c->state, &c->csum,
                       &c->partial, &c->o_params, &c->o_errs, &c->o_nu, &c->o_cov, &c->o_chi2, &c->o_rchi2,
                       &c->o_snr, &c->o_nfev, &c->o_rc, &c->o_scales, &c->o_serrs, &c->o_csnr, &c->o_f0, &c->o_g0,
@@ -494,15 +497,17 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     if (taylor) if ((rc = c->tay.reserve(nc * PP_TSTRIDE * 8))) return rc;
     if (xmode != 0) if ((rc = c->ph0.reserve(nc * 8))) return rc;
     if ((rc = c->misc.reserve(256))) return rc;
-    if ((rc = c->o_params.reserve((size_t)ns * 40))) return rc;
-    if ((rc = c->o_errs.reserve((size_t)ns * 40))) return rc;
-    if ((rc = c->o_nu.reserve((size_t)ns * 24))) return rc;
-    if ((rc = c->o_cov.reserve((size_t)ns * 200))) return rc;
-    if ((rc = c->o_chi2.reserve((size_t)ns * 8))) return rc;
-    if ((rc = c->o_rchi2.reserve((size_t)ns * 8))) return rc;
-    if ((rc = c->o_snr.reserve((size_t)ns * 8))) return rc;
-    if ((rc = c->o_nfev.reserve((size_t)ns * 4))) return rc;
-    if ((rc = c->o_rc.reserve((size_t)ns * 4))) return rc;
+    // per-subint scalar outputs: blocks of one allocation (params 5, errs 5, nu 3,
+    // cov 25, chi2, red_chi2, snr doubles; nfeval, return_code ints) = 336 B / subint
+    const size_t o_bytes = (size_t)ns * 336;
+    if ((rc = c->o_pack.reserve(o_bytes))) return rc;
+    if (c->o_host_cap < o_bytes) {
+        if (c->o_host) (void)hipHostFree(c->o_host);
+        c->o_host = nullptr; c->o_host_cap = 0;
+        HIP_TRY(hipHostMalloc(&c->o_host, o_bytes, hipHostMallocDefault));
+        c->o_host_cap = o_bytes;
+    }
+    double* const o_base = c->o_pack.as<double>();
     if ((rc = c->o_f0.reserve((size_t)ns * 8))) return rc;
     if ((rc = c->o_g0.reserve((size_t)ns * 40))) return rc;
     if ((rc = c->o_H0.reserve((size_t)ns * 200))) return rc;
@@ -567,9 +572,10 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.tay = c->tay.as<double>();
     fa.partial = c->partial.as<double>(); fa.nchunk = nchunk; fa.cpc = cpc;
     fa.nactive = c->misc.as<int>();
-    fa.o_params = c->o_params.as<double>(); fa.o_errs = c->o_errs.as<double>(); fa.o_nu = c->o_nu.as<double>();
-    fa.o_cov = c->o_cov.as<double>(); fa.o_chi2 = c->o_chi2.as<double>(); fa.o_rchi2 = c->o_rchi2.as<double>();
-    fa.o_snr = c->o_snr.as<double>(); fa.o_nfev = c->o_nfev.as<int>(); fa.o_rc = c->o_rc.as<int>();
+    fa.o_params = o_base; fa.o_errs = o_base + (size_t)ns * 5; fa.o_nu = o_base + (size_t)ns * 10;
+    fa.o_cov = o_base + (size_t)ns * 13; fa.o_chi2 = o_base + (size_t)ns * 38; fa.o_rchi2 = o_base + (size_t)ns * 39;
+    fa.o_snr = o_base + (size_t)ns * 40;
+    fa.o_nfev = reinterpret_cast<int*>(o_base + (size_t)ns * 41); fa.o_rc = fa.o_nfev + ns;
     if (chan_dev) {
         fa.o_scales = out->scales ? out->scales + (size_t)s0 * C : nullptr;
         fa.o_scale_errs = out->scale_errs ? out->scale_errs + (size_t)s0 * C : nullptr;
@@ -651,15 +657,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // ---- outputs ----
 #define PP_D2H(dst, buf, off, bytes) \
     if (dst) HIP_TRY(hipMemcpyAsync((char*)(dst) + (off), (buf).p, (bytes), hipMemcpyDeviceToHost, c->stream))
-    PP_D2H(out->params, c->o_params, (size_t)s0 * 40, (size_t)ns * 40);
-    PP_D2H(out->param_errs, c->o_errs, (size_t)s0 * 40, (size_t)ns * 40);
-    PP_D2H(out->nu_refs, c->o_nu, (size_t)s0 * 24, (size_t)ns * 24);
-    PP_D2H(out->cov, c->o_cov, (size_t)s0 * 200, (size_t)ns * 200);
-    PP_D2H(out->chi2, c->o_chi2, (size_t)s0 * 8, (size_t)ns * 8);
-    PP_D2H(out->red_chi2, c->o_rchi2, (size_t)s0 * 8, (size_t)ns * 8);
-    PP_D2H(out->snr, c->o_snr, (size_t)s0 * 8, (size_t)ns * 8);
-    PP_D2H(out->nfeval, c->o_nfev, (size_t)s0 * 4, (size_t)ns * 4);
-    PP_D2H(out->return_code, c->o_rc, (size_t)s0 * 4, (size_t)ns * 4);
+    HIP_TRY(hipMemcpyAsync(c->o_host, c->o_pack.p, o_bytes, hipMemcpyDeviceToHost, c->stream));
     if (!chan_dev) {
         PP_D2H(out->scales, c->o_scales, (size_t)s0 * C * 8, nc * 8);
         PP_D2H(out->scale_errs, c->o_serrs, (size_t)s0 * C * 8, nc * 8);
@@ -670,6 +668,19 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     PP_D2H(out->obj_hess, c->o_H0, (size_t)s0 * 200, (size_t)ns * 200);
 #undef PP_D2H
     HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        const double* h = reinterpret_cast<const double*>(c->o_host);
+        memcpy(out->params + (size_t)s0 * 5, h, (size_t)ns * 40);
+        memcpy(out->param_errs + (size_t)s0 * 5, h + (size_t)ns * 5, (size_t)ns * 40);
+        memcpy(out->nu_refs + (size_t)s0 * 3, h + (size_t)ns * 10, (size_t)ns * 24);
+        memcpy(out->cov + (size_t)s0 * 25, h + (size_t)ns * 13, (size_t)ns * 200);
+        memcpy(out->chi2 + s0, h + (size_t)ns * 38, (size_t)ns * 8);
+        memcpy(out->red_chi2 + s0, h + (size_t)ns * 39, (size_t)ns * 8);
+        memcpy(out->snr + s0, h + (size_t)ns * 40, (size_t)ns * 8);
+        const int32_t* hi = reinterpret_cast<const int32_t*>(h + (size_t)ns * 41);
+        memcpy(out->nfeval + s0, hi, (size_t)ns * 4);
+        memcpy(out->return_code + s0, hi + ns, (size_t)ns * 4);
+    }
     return PP_OK;
 }
 
