@@ -561,6 +561,11 @@ __device__ __forceinline__ void chan_geom(double nu, double P, double nuDM, doub
     const double iGM = (nuGM == INFINITY) ? 0.0 : 1.0 / (nuGM * nuGM * nuGM * nuGM);
     c.p1 = PP_DCONST * (a2 - iDM) / P;
     c.p2 = PP_DCONST * PP_DCONST * (a2 * a2 - iGM) / P;
+    if (!scat_on) {
+        // tau = 0: every scattering quantity vanishes (log / pow skipped)
+        c.lnf = c.taun = c.q1 = c.q2 = c.q11 = c.q12 = c.q22 = 0.0;
+        return;
+    }
     const double r = nu / nutau;
     c.lnf = log(r);
     c.taun = tau * pow(r, alpha);
@@ -1523,7 +1528,7 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs a) {
             ChanGeom cg;
             const double nu = freqs[n];
             chan_geom(nu, P, nfDM, nfGM, nftau, tau, alpha, a.log10_tau, scat_on, cg);
-            const double a2 = 1.0 / (nu * nu), a4 = a2 * a2, lf = log(nu);
+            const double a2 = 1.0 / (nu * nu), a4 = a2 * a2, lf = scat_on ? log(nu) : 0.0;
             const double h = L.Lpp;
             const double q2p = cg.taun;                                  // q2 / lnf
             const double q12p = a.log10_tau ? PP_LN10 * cg.taun : (scat_on ? cg.taun / tau : 0.0);
