@@ -202,15 +202,22 @@ def main():
         # HBM bytes per launch of that kernel from the PMC passes (FETCH_SIZE x2 +
         # WRITE_SIZE, collected separately with rocprofv3 --pmc and committed under
         # profiles/); null when no matching profile exists
-        traffic = None
+        traffic, co_limit = None, None
         try:
             tp = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
             if (tp["workload"] == args.workload and tp["input_dtype"] == args.input_dtype
                     and tp["kernel"] == fam):
                 traffic = tp["hbm_bytes_per_fit"] * nsub
+                if "valu_issue_frac_per_wave" in tp:
+                    # what actually limits the kernel (counter passes under profiles/)
+                    co_limit = {"resource": "f64 VALU issue",
+                                "busy_frac": round(tp["valu_issue_frac_per_wave"] *
+                                                   tp.get("waves_per_simd", 1), 3),
+                                "source": tp.get("counters_source")}
         except (OSError, KeyError, ValueError):
             pass
-        roofline = {"bound": "hbm", "kernel": fam, "achieved": round(achieved, 2),
+        roofline = {"bound": "hbm", "kernel": fam, "co_limit": co_limit,
+                    "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": abytes * nsub,

@@ -49,10 +49,20 @@ fb = sum(v["sum_KiB"] for k, v in fetch.items() if kname in k) * 1024 * 2
 wb = sum(v["sum_KiB"] for k, v in write.items() if kname in k) * 1024
 nl = max(1, max([v["dispatches"] for k, v in fetch.items() if kname in k] or [1]))
 if fb > 0:
-    json.dump({"workload": bench["config"]["workload"], "input_dtype": bench["config"]["input_dtype"], "nsub": nsub,
-               "kernel": fam, "hbm_bytes_per_launch": (fb + wb) / nl, "hbm_bytes_per_fit": (fb + wb) / nl / nsub,
-               "source": f"profiles/{R}_pmc_hbm_counters.json (FETCH_SIZE x2 + WRITE_SIZE)"},
-              open(f"{O}/traffic_latest.json", "w"), indent=1)
+    tl = {"workload": bench["config"]["workload"], "input_dtype": bench["config"]["input_dtype"], "nsub": nsub,
+          "kernel": fam, "hbm_bytes_per_launch": (fb + wb) / nl, "hbm_bytes_per_fit": (fb + wb) / nl / nsub,
+          "source": f"profiles/{R}_pmc_hbm_counters.json (FETCH_SIZE x2 + WRITE_SIZE)"}
+    try:
+        import re
+        txt = open(f"{O}/{R}_sq_counters.txt").read()
+        def cval(name):
+            return float(re.search(r"%s[^\n]*'%s'\) ([0-9.e+]+)" % (kname, name), txt).group(1))
+        tl.update(valu_issue_frac_per_wave=round(cval("SQ_ACTIVE_INST_VALU") / cval("SQ_WAVE_CYCLES"), 4),
+                  waves_per_simd=2, valu_insts_per_launch=cval("SQ_INSTS_VALU"),
+                  counters_source=f"profiles/{R}_sq_counters.txt (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)")
+    except Exception as ex:
+        print("no SQ counters for the co-limit:", ex)
+    json.dump(tl, open(f"{O}/traffic_latest.json", "w"), indent=1)
 allw = {}
 for tag, fn in [("plain", f"{O}/{R}_bench.json")] + [(os.path.basename(f)[6:-5], f) for f in sorted(glob.glob(O + "/raw/bench_*.json"))]:
     try:
