@@ -81,6 +81,8 @@ struct pp_ctx {
     DevBuf mft_table, msum_table, kt_table, mdc_table;   // device arrays of slot base pointers
     // work buffers
     DevBuf data, X, sdraw, noise, wts, freqs, errs, mask, P, x0, nufit, nuout, slot, state, csum, partial;
+    std::map<const void*, int> occ_cache;   // resident workgroups per CU, by kernel
+    int ncu = 0;                            // compute units of the device
     DevBuf o_pack;   // per-subint scalar outputs, one allocation -> one D2H copy
     void* o_host = nullptr; size_t o_host_cap = 0;   // pinned staging of o_pack
     DevBuf o_params, o_errs, o_nu, o_cov, o_chi2, o_rchi2, o_snr, o_nfev, o_rc, o_scales, o_serrs, o_csnr,
@@ -395,28 +397,23 @@ static int upload(pp_ctx* c, DevBuf& b, const void* src, size_t bytes) {
 // would run its surplus workgroups in a second, mostly idle round
 template <typename K>
 static int resident_grid(pp_ctx* c, K kernel, int T, long long nrows, int fallback) {
-    static std::map<const void*, int> cache;
     const void* key = reinterpret_cast<const void*>(kernel);
-    auto it = cache.find(key);
+    auto it = c->occ_cache.find(key);
     int per_cu = 0;
-    if (it != cache.end()) per_cu = it->second;
+    if (it != c->occ_cache.end()) per_cu = it->second;
     else {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, T, 0) != hipSuccess || per_cu < 1) {
             (void)hipGetLastError();
             per_cu = 0;
         }
-        cache[key] = per_cu;
+        c->occ_cache[key] = per_cu;
     }
-    int ncu = 256;
-    hipDeviceProp_t prop;
-    static int ncu_cached = 0;
-    if (!ncu_cached) {
-        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
-            ncu_cached = prop.multiProcessorCount;
-        else ncu_cached = 256;
+    if (!c->ncu) {
+        hipDeviceProp_t prop;
+        c->ncu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
+                     ? prop.multiProcessorCount : 256;
     }
-    ncu = ncu_cached;
-    const long long g = per_cu > 0 ? (long long)per_cu * ncu : (long long)fallback;
+    const long long g = per_cu > 0 ? (long long)per_cu * c->ncu : (long long)fallback;
     return (int)std::max(1LL, std::min(nrows, g));
 }
 
