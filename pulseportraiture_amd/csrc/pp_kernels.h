@@ -126,7 +126,7 @@ __global__ __launch_bounds__(FftPlan<M>::T) void k_model_fft(ModelFftArgs a) {
 
 // per channel: last harmonic k (1-based) with |m_nk|^2 > eps2 * max_k |m_nk|^2,
 // rounded up to a multiple of 64 (>= 64, <= M) -> kt[n]; kmax = max_n kt[n]
-__global__ void k_model_kcut(const cplx* mft, const double* mmax, int nchan, int M, double eps2,
+__global__ void k_model_kcut(const cplx* mft, const double* mmax, int /*nchan*/, int M, double eps2,
                              int* kt, int* kmax) {
     const int n = blockIdx.x;
     const double thr = eps2 * mmax[n];

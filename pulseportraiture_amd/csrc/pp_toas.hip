@@ -692,7 +692,7 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
         !out->snr || !out->nfeval || !out->return_code)
         return fail(PP_EINVAL, "missing output array");
     HIP_TRY(hipSetDevice(c->device));
-    const int N = in->nsub, C = in->nchan, B = in->nbin, M = B / 2;
+    const int N = in->nsub, C = in->nchan, B = in->nbin;
     // models used by this batch
     int Kt = 0;
     for (int i = 0; i < N; ++i) {
