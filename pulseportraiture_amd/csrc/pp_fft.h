@@ -103,10 +103,20 @@ __device__ __forceinline__ int lds_pad(int i) { return i + (i >> PADLOG); }
 // `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`, which would stall on the
 // prefetched HBM loads of the next row.  A one-wave workgroup (T == 64) needs
 // no barrier at all: its LDS operations retire in order.
+#ifndef PP_WAVE_SYNC_WAITS
+#define PP_WAVE_SYNC_WAITS 0    // 1: a one-wave workgroup still drains lgkmcnt at every sync
+#endif
 template <int T>
 __device__ __forceinline__ void lds_sync() {
-    if (T == 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (T == 64) {
+        // one wave: the LDS unit executes its accesses in program order, so a read
+        // that follows a write in the instruction stream sees it; only the compiler
+        // has to be kept from reordering.  (Waiting here for lgkmcnt(0) would stop
+        // the wave until EVERY outstanding read has returned, where the compiler's
+        // own counted waits let the first butterfly start as its operands arrive.)
+        if (PP_WAVE_SYNC_WAITS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("" ::: "memory");
+    } else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // ---- one Stockham stage, split into its load and its finish ----------------
