@@ -39,6 +39,16 @@ __device__ __forceinline__ const T* as_global(const T* p) {
     return (const T*)(gp_t)(uintptr_t)p;
 }
 
+// 1/x for 1 <= x < 2^1000 (no zeros, denormals, infinities or NaNs to honour): the
+// hardware estimate refined by two Newton steps, ~1 ulp, instead of the dozen
+// instructions of the IEEE division sequence
+__device__ __forceinline__ double recip_ge1(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+}
+
 // sin and cos of 2 pi t for |t| <= 1/2 (a little beyond is fine): quarter-turn
 // reduction, then Taylor polynomials on |y| <= 1/8 (truncation < 1e-19; a few
 // rounding errors of 2^-53).  A third of the instructions of the library

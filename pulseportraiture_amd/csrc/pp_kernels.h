@@ -29,6 +29,7 @@ struct ModelFftArgs {
     double* msum;       // [nchan] sum_k |m|^2
     double* mmax;       // [nchan] max_k |m|^2
     double* mdc;        // [nchan] DC harmonic (kept for the synthetic generator only)
+    double* msq;        // [nchan][M]   |m_nk|^2 (what the scattering sums S_n(tau) read)
     const cplx* twB;
     int nchan;
 };
@@ -61,6 +62,7 @@ struct FitArgs {
     int log10_tau, option, is_toa, max_iter, scat;
     const cplx* X;
     const cplx* const* mft;
+    const double* const* msq;   // [nslot] |m_nk|^2 tables
     const double* const* msum;
     const int* const* ktab;   // per-slot per-channel kept harmonics, nullptr = Kt everywhere
     const int* slot;
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(FftPlan<M>::T) void k_model_fft(ModelFftArgs a) {
             const cplx d = rfft_harmonic<M>(lds, a.twB, k);
             a.mft[(size_t)n * M + (k - 1)] = d;
             const double p = cnorm(d);
+            a.msq[(size_t)n * M + (k - 1)] = p;
             s += p;
             mx = fmax(mx, p);
         }
@@ -649,6 +652,12 @@ __device__ __forceinline__ void accumulate_channel(const Local& L, const ChanGeo
 // Each lane owns harmonics k = l+1, l+17, ... and advances its phasor by
 // e^{2 pi i 16 phi_n} (taken from lane 15's start phasor, k = 16).
 // --------------------------------------------------------------------------
+#ifndef PP_FAST_RECIP
+#define PP_FAST_RECIP 1       // |B_nk|^2 = 1/(1 + u^2) by rcp + 2 Newton steps (~1 ulp)
+#endif
+#ifndef PP_EVAL_UNROLL
+#define PP_EVAL_UNROLL 2      // independent 16-byte loads in flight per lane
+#endif
 template <bool SCAT>
 __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
     constexpr int LPC = 16;
@@ -666,7 +675,7 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
     const double* wts = a.wts + (size_t)i * a.nchan;
     const int slot = a.slot ? a.slot[i] : 0;
     const double* msum = as_global(a.msum[slot]);
-    const cplx* mft = as_global(a.mft[slot]);
+    const double* msq = as_global(a.msq[slot]);
     const int trial = 1 - st.cur;
     double* csum = a.csum + ((size_t)trial * a.nsub + i) * a.nchan * a.ncs;
     double accA = 0.0, accB = 0.0;   // lane l of a group owns sums l and 16+l of the 21
@@ -687,7 +696,7 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
         // the channel's power: they drop out of S_n(tau) and of C_n alike
         const int ktn = a.ktab ? as_global(a.ktab[slot])[n] : a.Kt;
         if (w != 0.0) {
-#pragma unroll 2
+#pragma unroll PP_EVAL_UNROLL
             for (int j = l; j < ktn; j += LPC) {
                 const cplx x = xrow[j];
                 const cplx z = cmul(x, e);
@@ -697,13 +706,13 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
                     s2 = fma(k * k, z.x, s2);
                 } else {
                     const double kap = PP_TWO_PI * k, u = kap * cg.taun;
-                    const double D = 1.0 / fma(u, u, 1.0);
+                    const double D = PP_FAST_RECIP ? recip_ge1(fma(u, u, 1.0)) : 1.0 / fma(u, u, 1.0);
                     const cplx b = make_double2(D, u * D);      // conj(B)
                     const cplx zb = cmul(z, b);
                     s0 += zb.x;
                     s1 = fma(kap, zb.y, s1);                    // A1 = -sum kap Im(zb)
                     s2 = fma(kap * kap, zb.x, s2);              // A2 = -sum kap^2 Re(zb)
-                    const double Mk = cnorm(mft[(size_t)n * a.M + j]);
+                    const double Mk = msq[(size_t)n * a.M + j];
                     S0 = fma(D, Mk, S0);
                     if (scat_on) {
                         const cplx zb2 = cmul(zb, b);

@@ -66,7 +66,7 @@ struct DevBuf {
 struct ModelSlot {
     bool set = false;
     int nchan = 0, nbin = 0, Kt = 0;
-    DevBuf mft, msum, mmax, mdc, kt;
+    DevBuf mft, msum, mmax, mdc, kt, msq;
 };
 
 enum KernelFamily { KF_MODEL = 0, KF_XSPEC, KF_PREP, KF_SEED, KF_ACCUM, KF_EVAL, KF_TAYLOR, KF_STEP, KF_FINAL, KF_SYNTH, KF_FPS, KF_COUNT };
@@ -78,7 +78,7 @@ struct pp_ctx {
     hipStream_t stream = nullptr;
     std::map<int, DevBuf> twiddles;   // by nbin
     ModelSlot slots[PP_MAX_SLOTS];
-    DevBuf mft_table, msum_table, kt_table, mdc_table;   // device arrays of slot base pointers
+    DevBuf mft_table, msum_table, kt_table, mdc_table, msq_table;   // device arrays of slot base pointers
     // work buffers
     DevBuf data, X, sdraw, noise, wts, freqs, errs, mask, P, x0, nufit, nuout, slot, state, csum, partial;
     std::map<const void*, int> occ_cache;   // resident workgroups per CU, by kernel
@@ -156,6 +156,9 @@ extern "C" int pp_create(int device_id, pp_ctx** out) {
     rc = c->mdc_table.reserve(sizeof(void*) * PP_MAX_SLOTS);
     if (rc) return rc;
     HIP_TRY(hipMemset(c->mdc_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
+    rc = c->msq_table.reserve(sizeof(void*) * PP_MAX_SLOTS);
+    if (rc) return rc;
+    HIP_TRY(hipMemset(c->msq_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
     HIP_TRY(hipMemset(c->kt_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
     HIP_TRY(hipMemset(c->mft_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
     HIP_TRY(hipMemset(c->msum_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
@@ -169,9 +172,9 @@ extern "C" int pp_destroy(pp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     resolve_spans(c);
     for (auto& kv : c->twiddles) kv.second.release();
-    for (auto& s : c->slots) { s.mft.release(); s.msum.release(); s.mmax.release(); s.mdc.release(); s.kt.release(); }
+    for (auto& s : c->slots) { s.mft.release(); s.msum.release(); s.mmax.release(); s.mdc.release(); s.kt.release(); s.msq.release(); }
     if (c->o_host) (void)hipHostFree(c->o_host);
-    DevBuf* bufs[] = {&c->o_pack, &c->mft_table, &c->msum_table, &c->kt_table, &c->mdc_table, &c->data, &c->X, &c->sdraw, &c->noise, &c->wts, &c->freqs,
+    DevBuf* bufs[] = {&c->o_pack, &c->mft_table, &c->msum_table, &c->kt_table, &c->mdc_table, &c->msq_table, &c->data, &c->X, &c->sdraw, &c->noise, &c->wts, &c->freqs,
                       &c->errs, &c->mask, &c->P, &c->x0, &c->nufit, &c->nuout, &c->slot, &c->state, &c->csum,
                       &c->partial, &c->o_params, &c->o_errs, &c->o_nu, &c->o_cov, &c->o_chi2, &c->o_rchi2,
                       &c->o_snr, &c->o_nfev, &c->o_rc, &c->o_scales, &c->o_serrs, &c->o_csnr, &c->o_f0, &c->o_g0,
@@ -298,6 +301,7 @@ extern "C" int pp_model_set(pp_ctx* c, int slot, const void* portrait, int dtype
     if ((rc = s.mmax.reserve((size_t)nchan * sizeof(double)))) return rc;
     if ((rc = s.mdc.reserve((size_t)nchan * sizeof(double)))) return rc;
     if ((rc = s.kt.reserve((size_t)nchan * sizeof(int)))) return rc;
+    if ((rc = s.msq.reserve((size_t)nchan * M * sizeof(double)))) return rc;
     const void* dport = portrait;
     if (!on_device) {
         if ((rc = c->data.reserve((size_t)nchan * nbin * esz))) return rc;
@@ -306,7 +310,8 @@ extern "C" int pp_model_set(pp_ctx* c, int slot, const void* portrait, int dtype
     }
     const cplx* tw = nullptr;
     if ((rc = get_twiddles(c, nbin, &tw))) return rc;
-    ModelFftArgs a{dport, s.mft.as<cplx>(), s.msum.as<double>(), s.mmax.as<double>(), s.mdc.as<double>(), tw, nchan};
+    ModelFftArgs a{dport, s.mft.as<cplx>(), s.msum.as<double>(), s.mmax.as<double>(), s.mdc.as<double>(),
+                   s.msq.as<double>(), tw, nchan};
     {
         Prof pr(c, KF_MODEL);
         PP_DISPATCH_M(M, {
@@ -339,6 +344,8 @@ extern "C" int pp_model_set(pp_ctx* c, int slot, const void* portrait, int dtype
     HIP_TRY(hipMemcpy((char*)c->kt_table.p + sizeof(void*) * slot, &pk, sizeof(void*), hipMemcpyHostToDevice));
     void* pd = s.mdc.p;
     HIP_TRY(hipMemcpy((char*)c->mdc_table.p + sizeof(void*) * slot, &pd, sizeof(void*), hipMemcpyHostToDevice));
+    void* pq = s.msq.p;
+    HIP_TRY(hipMemcpy((char*)c->msq_table.p + sizeof(void*) * slot, &pq, sizeof(void*), hipMemcpyHostToDevice));
     return PP_OK;
 }
 
@@ -558,6 +565,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.max_iter = c->max_iter; fa.scat = scat ? 1 : 0;
     fa.X = c->X.as<cplx>();
     fa.mft = (const cplx* const*)c->mft_table.p;
+    fa.msq = (const double* const*)c->msq_table.p;
     fa.msum = (const double* const*)c->msum_table.p;
     fa.ktab = (const int* const*)c->kt_table.p;
     fa.slot = in->model_slot ? c->slot.as<int>() : nullptr;
