@@ -285,13 +285,14 @@ class GetTOAs(object):
                  method='trust-ncg', bounds=None, nu_fits=None, show_plot=False,
                  quiet=None):
         """Same arguments as the reference (pptoas.py:150-156).  Not supported
-        here: tscrunch, add_instrumental_response, show_plot (they raise) -- they
-        live outside the fit path."""
+        here: tscrunch and show_plot (they raise) -- they live in PSRCHIVE / the
+        plotting code."""
         if quiet is None:
             quiet = self.quiet
-        if tscrunch or add_instrumental_response or show_plot:
-            raise NotImplementedError("tscrunch / instrumental response / plots are "
-                                      "outside the accelerated path")
+        if tscrunch or show_plot:
+            raise NotImplementedError("tscrunch / plots are outside the accelerated path")
+        use_ird = bool(add_instrumental_response and
+                       (self.ird['DM'] or len(self.ird['wids'])))
         if method not in ('trust-ncg', 'Newton-CG', 'TNC'):
             print("Method '%s' is not implemented." % method)
             sys.exit()
@@ -350,14 +351,27 @@ class GetTOAs(object):
                 mask[j, ich] = 1
                 freqsx = d.freqs[isub, ich]
                 key = d.freqs[isub].tobytes() + np.float64(d.Ps[isub]).tobytes() \
-                    if fit_scat else d.freqs[isub].tobytes()
+                    if (fit_scat or use_ird) else d.freqs[isub].tobytes()
+                if use_ird:
+                    key += ich.tobytes()    # the smearing width uses the good channels' spacing
                 if key not in slots:
                     if len(slots) >= 64:
-                        raise NotImplementedError("more than 64 distinct frequency rows "
-                                                  "in one archive")
+                        raise NotImplementedError("more than 64 distinct templates in one archive")
                     slots[key] = len(slots)
-                    self._load_template(eng, slots[key], d.freqs[isub], nbin, d.Ps[isub],
-                                        unscattered=fit_scat)
+                    if use_ird:
+                        # template x instrumental response, on the good channels
+                        # (pptoas.py:388-394)
+                        from .pptoaslib import instrumental_response_port_FT
+                        mport = np.array(self._model_for(d.freqs[isub], nbin, d.Ps[isub],
+                                                         unscattered=fit_scat))
+                        resp = instrumental_response_port_FT(nbin, freqsx, self.ird['DM'],
+                                                             d.Ps[isub], self.ird['wids'],
+                                                             self.ird['irf_types'])
+                        mport[ich] = np.fft.irfft(resp * np.fft.rfft(mport[ich], axis=-1), axis=-1)
+                        eng.set_model(mport, slot=slots[key])
+                    else:
+                        self._load_template(eng, slots[key], d.freqs[isub], nbin, d.Ps[isub],
+                                            unscattered=fit_scat)
                 slot_of[j] = slots[key]
                 if nu_fits is None:
                     nu_fit = guess_fit_freq(freqsx, d.SNRs[isub, 0, ich])
@@ -625,13 +639,26 @@ class GetTOAs(object):
                 params[j] = [self.phis[iarch][isub], self.DMs[iarch][isub] / df,
                              self.GMs[iarch][isub] / df ** 3, tau, self.alphas[iarch][isub]]
                 scat = bool(tau != 0.0)
-                key = (d.freqs[isub].tobytes(), scat)
+                use_ird = bool(getattr(self, "add_instrumental_response", False) and
+                               (self.ird['DM'] or len(self.ird['wids'])))
+                key = (d.freqs[isub].tobytes(), scat,
+                       np.float64(d.Ps[isub]).tobytes() if use_ird else b"")
                 if key not in slots:
                     if len(slots) >= 64:
                         raise NotImplementedError("more than 64 distinct templates in one archive")
                     slots[key] = len(slots)
-                    self._load_template(eng, slots[key], d.freqs[isub], nbin, d.Ps.mean(),
-                                        unscattered=scat)
+                    if use_ird:     # show_fit applies it over all channels (pptoas.py:1389-1395)
+                        from .pptoaslib import instrumental_response_port_FT
+                        mport = np.array(self._model_for(d.freqs[isub], nbin, d.Ps.mean(),
+                                                         unscattered=scat))
+                        resp = instrumental_response_port_FT(nbin, d.freqs[isub], self.ird['DM'],
+                                                             d.Ps[isub], self.ird['wids'],
+                                                             self.ird['irf_types'])
+                        eng.set_model(np.fft.irfft(resp * np.fft.rfft(mport, axis=-1), axis=-1),
+                                      slot=slots[key])
+                    else:
+                        self._load_template(eng, slots[key], d.freqs[isub], nbin, d.Ps.mean(),
+                                            unscattered=scat)
                 slot_of[j] = slots[key]
                 scales[j] = self.scales[iarch][isub]
             port = _take_subints(d.subints, ok_isubs)

@@ -89,3 +89,63 @@ def fit_portrait_full_batch(data_ports, model_port, init_params, Ps, freqs,
                          nu_fits=nu_fits, nu_outs=nu_outs, fit_flags=fit_flags,
                          log10_tau=log10_tau, option=option, is_toa=is_toa,
                          chan_mask=chan_mask, model_slot=model_slot)
+
+
+# --------------------------------------------------------------------------
+# instrumental response applied to the template (host-side input preparation of
+# get_TOAs(add_instrumental_response=True); pptoaslib.py:14-50, 112-179)
+# --------------------------------------------------------------------------
+def gaussian_profile_FT(nbin, loc, wid, amp):
+    """Analytic Fourier transform of a Gaussian profile of FWHM wid [rot] at
+    phase loc, sampled at nbin/2 + 1 harmonics, windowing included through the
+    sinc-Gauss convolution formula (pptoaslib.py:14-50)."""
+    from scipy.special import erf
+    nharm = nbin // 2 + 1
+    if wid <= 0.0:
+        return np.zeros(nharm, 'd')
+    sigma = wid / (2 * np.sqrt(2 * np.log(2)))
+    amp = amp * (2 * np.pi * sigma ** 2) ** 0.5
+    sigma = 1.0 / (sigma * 2 * np.pi)
+    k = np.arange(nharm)
+    a = sigma / ((1.0 / np.pi) * 2 ** 0.5)
+    b = k / (sigma * 2 ** 0.5)
+    vals = np.exp(-b ** 2) * (erf(a - b * 1j) + erf(a + b * 1j)) / 2
+    vals = vals * (amp * nbin)
+    if loc != 0.0:
+        vals = vals * np.exp(-k * 2.0j * np.pi * loc)
+    return np.nan_to_num(vals)
+
+
+def instrumental_response_FT(nbin, wid=0.0, irf_type='rect'):
+    """Fourier transform of one instrumental response of width wid [rot]: a
+    rectangle ('rect', a sinc) or a Gaussian of that FWHM ('gauss')
+    (pptoaslib.py:112-143)."""
+    nharm = nbin // 2 + 1
+    if wid == 0.0:
+        return np.ones(nharm)
+    if irf_type == 'rect':
+        return np.sinc(np.arange(nharm) * wid)
+    if irf_type == 'gauss':
+        g = gaussian_profile_FT(nbin, 0.0, wid, 1.0)
+        return g / g[0]
+    print("Unrecognized instrumental response function type '%s'." % irf_type)
+    return 0
+
+
+def instrumental_response_port_FT(nbin, freqs, DM=0.0, P=1.0, wids=[], irf_types=[]):
+    """Combined response per channel: the constant responses times the
+    dispersive smearing of DM across a channel, 8.3e-6 chan_bw / nu_GHz^3 / P
+    rotations wide (pptoaslib.py:145-179)."""
+    nharm = nbin // 2 + 1
+    nchan = len(freqs)
+    if DM == len(wids) == 0.0:
+        return np.ones([nchan, nharm])
+    resp = np.ones([nchan, nharm], dtype=np.complex128)
+    for wid, irf_type in zip(wids, irf_types):
+        resp *= np.asarray(instrumental_response_FT(nbin, wid, irf_type))[None, :]
+    if DM:
+        chan_bw = abs(freqs[1] - freqs[0])
+        for ichan, freq in enumerate(freqs):
+            wid = 8.3e-6 * chan_bw / (freq / 1e3) ** 3 / P
+            resp[ichan] *= instrumental_response_FT(nbin, wid, 'rect')
+    return resp

@@ -130,10 +130,12 @@ def synth_archive(ref, seed, nsub=5, C=32, B=256, DM0=34.56789, sigma=0.05, GM=N
     return data, arrays, scal
 
 
-def run(pptoas, data, **kw):
+def run(pptoas, data, ird=None, **kw):
     pptoas.load_data = lambda *a, **k: data
     gt = pptoas.GetTOAs("fake.fits", os.path.join(mg.REF, "examples", "example.gmodel"),
                         quiet=True)
+    if ird is not None:
+        gt.instrumental_response_dict = gt.ird = ird
     gt.get_TOAs(quiet=True, **kw)
     out = {}
     for name in ("phis", "phi_errs", "DMs", "DM_errs", "GMs", "GM_errs", "taus",
@@ -177,9 +179,22 @@ def main():
              ("gettoas_scat", dict(seed=34, tau_us=20.0),
               dict(fit_scat=True, log10_tau=True, scat_guess=(30e-6, 1500.0, -4.0))),
              ("gettoas_zap", dict(seed=35, corrupt=True), dict(print_flux=True))]
+    cases.append(("gettoas_ird", dict(seed=36), dict(add_instrumental_response=True)))
     for name, skw, gkw in cases:
         data, arrays, scal = synth_archive(ref, **skw)
-        out = run(pptoas, data, **gkw)
+        ird = None
+        if name == "gettoas_ird":
+            ird = {'DM': 34.56789, 'wids': [0.004, 0.003], 'irf_types': ['rect', 'gauss']}
+        out = run(pptoas, data, ird=ird, **gkw)
+        if ird is not None:
+            import pptoaslib as ptl          # the converted reference module
+            out["ird_resp"] = ptl.instrumental_response_port_FT(
+                data.nbin, data.freqs[0][data.ok_ichans[0]], ird['DM'], data.Ps[0], ird['wids'],
+                ird['irf_types'])
+            out["ird_gauss_FT"] = ptl.gaussian_profile_FT(data.nbin, 0.3, 0.02, 1.7)
+            out["ird_DM"] = ird['DM']
+            out["ird_wids"] = np.array(ird['wids'])
+            out["ird_types"] = np.array(ird['irf_types'])
         kwargs = {}
         for k, v in gkw.items():
             kwargs["kw_" + k] = np.asarray(v)

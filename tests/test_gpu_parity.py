@@ -389,7 +389,7 @@ def _check_against_polished_reference(g, gt, isub, kw):
 
 
 @pytest.mark.parametrize("name", ["gettoas_phiDM", "gettoas_phiDM_nurefs", "gettoas_GM",
-                                  "gettoas_scat", "gettoas_zap"])
+                                  "gettoas_scat", "gettoas_zap", "gettoas_ird"])
 def test_get_TOAs_matches_reference_caller(name):
     """Caller level: GetTOAs.get_TOAs on a synthetic archive (ragged channel
     masks, a fully zapped subint, Doppler factors, backend delay) against what
@@ -412,6 +412,10 @@ def test_get_TOAs_matches_reference_caller(name):
             v = g[k]
             kw[k[3:]] = v.item() if v.ndim == 0 else tuple(v.tolist())
     gt = GetTOAs(data, os.path.join(GOLDEN, "example.gmodel"), quiet=True)
+    if "out_ird_DM" in g.files:     # instrumental response: smearing + rect + gauss
+        gt.instrumental_response_dict = gt.ird = {
+            'DM': float(g["out_ird_DM"]), 'wids': [float(v) for v in g["out_ird_wids"]],
+            'irf_types': [str(v) for v in g["out_ird_types"]]}
     gt.get_TOAs(quiet=True, **kw)
     ok = g["out_ok_isubs"]
     np.testing.assert_array_equal(gt.ok_isubs[0], ok)

@@ -104,3 +104,26 @@ def test_spline_model_portraits_match_reference():
     np.testing.assert_allclose(
         splmodel.gen_spline_portrait(mean_prof, g["freqs"], eigvec[:, :0], tck),
         g["port_flat"], rtol=0, atol=0)
+
+
+def test_instrumental_response_matches_reference():
+    """Host-side template preparation of get_TOAs(add_instrumental_response=True):
+    the per-channel response (rect + gauss + dispersive smearing) and the analytic
+    Gaussian transform, against the reference's own arrays (pptoaslib.py:14-50,
+    112-179) stored by make_golden_gettoas.py."""
+    import os
+    import numpy as np
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = np.load(os.path.join(here, "golden", "gettoas_ird.npz"))
+    # the functions are plain NumPy/SciPy; load the module without the HIP library
+    src = open(os.path.join(here, "..", "pulseportraiture_amd", "pptoaslib.py")).read()
+    ns = {"np": np}
+    exec(src[src.index("def gaussian_profile_FT("):], ns)
+    ok = np.where(g["weights"][0] > 0)[0]
+    resp = ns["instrumental_response_port_FT"](
+        g["subints"].shape[-1], g["freqs"][0][ok], float(g["out_ird_DM"]), float(g["Ps"][0]),
+        [float(v) for v in g["out_ird_wids"]], [str(v) for v in g["out_ird_types"]])
+    np.testing.assert_allclose(resp, g["out_ird_resp"], rtol=1e-13, atol=1e-15)
+    gft = ns["gaussian_profile_FT"](g["subints"].shape[-1], 0.3, 0.02, 1.7)
+    np.testing.assert_allclose(gft, g["out_ird_gauss_FT"], rtol=1e-13, atol=1e-13)
