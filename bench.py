@@ -247,8 +247,7 @@ def main():
                                     *np.unique(res["return_code"], return_counts=True))}}}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(data, freqs, P, x0, errs, nu_fit, flags,
-                                                log10_tau, res, args.cpu_sample,
-                                                model if not flags[3] else model)
+                                                log10_tau, res, args.cpu_sample, model)
         print(json.dumps(line))
     if use_dist:
         dist.barrier()
