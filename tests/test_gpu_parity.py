@@ -1062,3 +1062,42 @@ def test_randomised_shapes_and_flags_match_oracle(eng):
                                        rtol=1e-4 if gm else 1e-8)
             ncheck += 1
     assert ncheck >= 20
+
+
+def test_randomised_scattering_fits_sit_at_the_oracle_optimum(eng):
+    """Scattering fits (tau, alpha free or alpha fixed, log10 or linear tau) on
+    randomly drawn small problems: the oracle's exact Newton step at the device
+    answer must vanish within the parity bars, chi^2 must match the oracle's fit, and
+    the parameters agree with its (less converged) answer to 1e-3 of their errors."""
+    from oracle import pptoas_oracle as orc
+    from tests.synth_host import make_inputs, caller_guess, model_portrait
+    rng = np.random.default_rng(77001)
+    for case, (flags, l10) in enumerate([([1, 1, 0, 1, 1], True), ([1, 1, 0, 1, 0], True),
+                                         ([1, 1, 0, 1, 1], False), ([1, 1, 0, 1, 0], False),
+                                         ([1, 1, 0, 1, 1], True)]):
+        C = int(rng.integers(12, 40))
+        nbin = int(2 ** rng.integers(7, 10))
+        tau_us = float(rng.uniform(15.0, 40.0))
+        freqs, model = model_portrait(C, nbin)
+        eng.set_model(model)
+        inp = make_inputs(C, nbin, 500 + case, model=model, tau_us=tau_us, sigma=0.03)
+        g = caller_guess(inp, fit_scat=True, log10_tau=l10,
+                         tau_guess_rot=1.4 * tau_us * 1e-6 / inp["P"])
+        nus = [g["nu_fit"]] * 3
+        r = eng.fit_batch(inp["data"][None], freqs, inp["P"], g["init_params"], errs=inp["errs"],
+                          nu_fits=[nus], fit_flags=flags, log10_tau=l10)
+        o = orc.fit_portrait_full(inp["data"], model, g["init_params"], inp["P"], freqs, nus,
+                                  [None] * 3, inp["errs"], flags, log10_tau=l10)
+        dFT = np.fft.rfft(inp["data"], axis=-1); dFT[:, 0] = 0
+        mFT = np.fft.rfft(model, axis=-1); mFT[:, 0] = 0
+        args = (dFT, mFT, inp["errs"] * np.sqrt(nbin / 2.0), inp["P"], freqs, r["nu_refs"][0, 0],
+                r["nu_refs"][0, 1], r["nu_refs"][0, 2], flags, l10)
+        gr = orc.fit_portrait_full_function_deriv(r["params"][0], *args)
+        hs = orc.fit_portrait_full_function_2deriv(r["params"][0], *args)
+        ii = np.where(flags)[0]
+        step = np.linalg.solve(hs[np.ix_(ii, ii)], gr[ii])
+        assert abs(step[0]) < PHI_BAR and abs(step[1]) < DM_BAR, (case, step)
+        np.testing.assert_allclose(r["chi2"][0], o.chi2, rtol=1e-9)
+        tol = np.maximum(1e-3 * np.asarray(o.param_errs), 1e-9)
+        assert np.all(np.abs(r["params"][0] - np.asarray(o.params))[ii] <= tol[ii] + 5e-9), case
+        np.testing.assert_allclose(r["param_errs"][0][ii], np.asarray(o.param_errs)[ii], rtol=1e-4)
