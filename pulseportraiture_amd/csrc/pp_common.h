@@ -39,14 +39,14 @@ __device__ __forceinline__ const T* as_global(const T* p) {
     return (const T*)(gp_t)(uintptr_t)p;
 }
 
-// 1/x for 1 <= x < 2^1000 (no zeros, denormals, infinities or NaNs to honour): the
+// 1/x for x >= 1 (no zeros or denormals to honour; huge and infinite x give 0): the
 // hardware estimate refined by two Newton steps, ~1 ulp, instead of the dozen
 // instructions of the IEEE division sequence
 __device__ __forceinline__ double recip_ge1(double x) {
     double y = __builtin_amdgcn_rcp(x);
     y = fma(fma(-x, y, 1.0), y, y);
     y = fma(fma(-x, y, 1.0), y, y);
-    return y;
+    return (x < 1e300) ? y : 0.0;      // (the refinement of 1/inf would be inf * 0)
 }
 
 // sin and cos of 2 pi t for |t| <= 1/2 (a little beyond is fine): quarter-turn
