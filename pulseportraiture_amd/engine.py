@@ -267,9 +267,13 @@ class Engine(object):
         d = _f64(np.atleast_2d(data))
         nprof, nbin = d.shape
         m = _f64(np.atleast_2d(model), (nprof, nbin))
-        nz = np.full(nprof, np.nan) if noise is None else _f64(
-            [np.nan if v is None else v for v in
-             np.broadcast_to(np.asarray(noise, dtype=object), (nprof,))])
+        if noise is None:
+            nz = np.full(nprof, np.nan)
+        elif isinstance(noise, np.ndarray) and noise.dtype.kind == "f":
+            nz = _f64(noise, (nprof,))
+        else:
+            nz = _f64([np.nan if v is None else v for v in
+                       np.broadcast_to(np.asarray(noise, dtype=object), (nprof,))])
         out = np.empty((nprof, 7))
         _check(self._lib.pp_fit_phase_shift_batch(
             self._ctx, _dp(d), _dp(m), _dp(nz), nprof, nbin, float(bounds[0]),

@@ -610,6 +610,136 @@ class GetTOAs(object):
             print("Total time: %.2f sec, ~%.4f sec/TOA" %
                   (tot_duration, tot_duration / sum(len(o) for o in self.ok_isubs)))
 
+    def get_narrowband_TOAs(self, datafile=None, tscrunch=False, fit_scat=False,
+                            log10_tau=True, scat_guess=None, print_phase=False,
+                            print_flux=False, print_parangle=False,
+                            add_instrumental_response=False, addtnl_toa_flags={},
+                            method='trust-ncg', bounds=None, show_plot=False, quiet=None):
+        """One TOA per channel (pptoas.py:744-1120): every good channel of every
+        good subint is fitted for a phase shift and an amplitude against its
+        template profile -- fit_phase_shift, bounds [-0.5, 0.5], Ns = 100 -- in one
+        device batch per archive.  As in the reference, scattering fits are not
+        implemented here; print_phase / print_flux cannot work in the reference's
+        narrowband path (it reads fields fit_phase_shift does not return) and raise."""
+        if quiet is None:
+            quiet = self.quiet
+        if fit_scat or tscrunch or show_plot or print_phase or print_flux:
+            raise NotImplementedError("fit_scat / tscrunch / show_plot / print_phase / print_flux "
+                                      "are not available for narrowband TOAs")
+        print("You are using an experimental functionality of pptoas!")
+        self.nfit = 1
+        self.fit_phi, self.fit_tau = True, False
+        self.fit_flags = [1, 0]
+        self.log10_tau = False
+        self.scat_guess = scat_guess
+        self.tscrunch = tscrunch
+        self.add_instrumental_response = add_instrumental_response
+        use_ird = bool(add_instrumental_response and
+                       (self.ird['DM'] or len(self.ird['wids'])))
+        start = time.time()
+        datafiles = self.datafiles if datafile is None else [datafile]
+        eng = default_engine()
+        for iarch, datafile in enumerate(datafiles):
+            try:
+                d, fname = _load(datafile)
+            except RuntimeError:
+                if not quiet:
+                    print("Cannot load_data(%s).  Skipping it." % datafile)
+                continue
+            if not len(d.ok_isubs):
+                if not quiet:
+                    print("No subints to fit for %s.  Skipping it." % fname)
+                continue
+            self.ok_idatafiles.append(iarch)
+            nsub, nchan, nbin = d.nsub, d.nchan, d.nbin
+            ok_isubs = np.asarray(d.ok_isubs, dtype=int)
+            obs = DataBunch(telescope=d.telescope, backend=d.backend, frontend=d.frontend)
+            z2 = lambda dt=np.float64: np.zeros([nsub, nchan], dtype=dt)  # noqa: E731
+            phis, phi_errs, taus, tau_errs = z2(), z2(), z2(), z2()
+            TOAs, TOA_errs = z2("object"), z2("object")
+            scales, scale_errs, channel_snrs = z2(), z2(), z2()
+            profile_fluxes, profile_flux_errs, channel_red_chi2s = z2(), z2(), z2()
+            covariances = np.zeros([nsub, nchan, self.nfit, self.nfit])
+            nfevals, rcs = z2("int"), z2("int")
+            MJDs = np.array([e.in_days() for e in d.epochs], dtype=np.double)
+            # ---- gather every (subint, good channel) profile pair ----
+            profs, mprofs, noises, where = [], [], [], []
+            for isub in ok_isubs:
+                ich = np.asarray(d.ok_ichans[isub], dtype=int)
+                model = np.asarray(self._model_for(d.freqs[isub], nbin, d.Ps[isub]))
+                modelx = model[ich]
+                if use_ird:
+                    from .pptoaslib import instrumental_response_port_FT
+                    resp = instrumental_response_port_FT(nbin, d.freqs[isub, ich], self.ird['DM'],
+                                                         d.Ps[isub], self.ird['wids'],
+                                                         self.ird['irf_types'])
+                    modelx = np.fft.irfft(resp * np.fft.rfft(modelx, axis=-1), axis=-1)
+                profs.append(np.asarray(d.subints)[isub, 0, ich])
+                mprofs.append(modelx)
+                noises.append(np.asarray(d.noise_stds)[isub, 0, ich])
+                where += [(isub, ichan) for ichan in ich]
+            t0 = time.time()
+            out = eng.fit_phase_shift_batch(np.concatenate(profs), np.concatenate(mprofs),
+                                            np.concatenate(noises).astype(np.float64),
+                                            bounds=(-0.5, 0.5), Ns=100)
+            fit_duration = time.time() - t0
+            # ---- TOA bookkeeping (pptoas.py:994-1088) ----
+            for (isub, ichan), r in zip(where, out):
+                phase, phase_err, scale, scale_err, snr, red_chi2 = r[:6]
+                P = d.Ps[isub]
+                TOA_MJD = d.epochs[isub] + MJD(0, (phase * P + d.backend_delay) / (3600 * 24.))
+                TOA_err = phase_err * P * 1e6
+                phis[isub, ichan], phi_errs[isub, ichan] = phase, phase_err
+                TOAs[isub, ichan], TOA_errs[isub, ichan] = TOA_MJD, TOA_err
+                scales[isub, ichan], scale_errs[isub, ichan] = scale, scale_err
+                channel_snrs[isub, ichan] = snr
+                channel_red_chi2s[isub] = red_chi2     # (the reference assigns the whole row)
+                toa_flags = {'be': d.backend, 'fe': d.frontend, 'f': d.frontend + "_" + d.backend,
+                             'nbin': int(nbin), 'bw': abs(d.bw) / nchan, 'subint': int(isub),
+                             'chan': int(ichan), 'tobs': d.subtimes[isub],
+                             'tmplt': self.modelfile if isinstance(self.modelfile, str)
+                             else self.model_name, 'snr': snr, 'gof': red_chi2}
+                if print_parangle:
+                    toa_flags['par_angle'] = d.parallactic_angles[isub]
+                for k, v in addtnl_toa_flags.items():
+                    toa_flags[k] = v
+                self.TOA_list.append(TOA(fname, d.freqs[isub, ichan], TOA_MJD, TOA_err,
+                                         d.telescope, d.telescope_code, None, None, toa_flags))
+            self.order.append(fname)
+            self.obs.append(obs)
+            self.doppler_fs.append(d.doppler_factors)
+            self.ok_isubs.append(ok_isubs)
+            self.epochs.append(d.epochs)
+            self.MJDs.append(MJDs)
+            self.Ps.append(d.Ps)
+            self.phis.append(phis)
+            self.phi_errs.append(phi_errs)
+            self.TOAs.append(TOAs)
+            self.TOA_errs.append(TOA_errs)
+            self.taus.append(taus)
+            self.tau_errs.append(tau_errs)
+            self.scales.append(scales)
+            self.scale_errs.append(scale_errs)
+            self.channel_snrs.append(channel_snrs)
+            self.profile_fluxes.append(profile_fluxes)
+            self.profile_flux_errs.append(profile_flux_errs)
+            self.covariances.append(covariances)
+            self.channel_red_chi2s.append(channel_red_chi2s)
+            self.nfevals.append(nfevals)
+            self.rcs.append(rcs)
+            self.fit_durations.append(fit_duration)
+            if not quiet:
+                print("--------------------------")
+                print(fname)
+                print("~%.4f sec/TOA" % (fit_duration / max(1, len(self.TOA_list))))
+                print("Med. TOA error is %.3f us" % (np.median(phi_errs[ok_isubs]) *
+                                                     d.Ps.mean() * 1e6))
+        tot_duration = time.time() - start
+        if not quiet and len(self.ok_isubs):
+            print("--------------------------")
+            print("Total time: %.2f sec, ~%.4f sec/TOA" %
+                  (tot_duration, tot_duration / max(1, len(self.TOA_list))))
+
     def get_channels_to_zap(self, SNR_threshold=8.0, rchi2_threshold=1.3, iterate=True,
                             show=False):
         """Flag channels by per-channel reduced chi^2 and S/N (pptoas.py:1208-1285;

@@ -200,6 +200,24 @@ def main():
             kwargs["kw_" + k] = np.asarray(v)
         mg.save(name, **arrays, **{"scal_" + k: np.asarray(v) for k, v in scal.items()},
                 **{"out_" + k: v for k, v in out.items()}, **kwargs)
+    # ---- narrowband TOAs (one per channel), same archive as gettoas_phiDM ----
+    data, arrays, scal = synth_archive(ref, seed=31)
+    pptoas.load_data = lambda *a, **k: data
+    gt = pptoas.GetTOAs("fake.fits", os.path.join(mg.REF, "examples", "example.gmodel"), quiet=True)
+    gt.get_narrowband_TOAs(quiet=True)
+    out = {}
+    for name in ("phis", "phi_errs", "scales", "scale_errs", "channel_snrs", "channel_red_chi2s",
+                 "TOA_errs"):
+        out[name] = np.asarray(getattr(gt, name)[0], dtype=np.float64)
+    out["ok_isubs"] = np.asarray(gt.ok_isubs[0])
+    out["TOA_days"] = np.array([[t.d if t != 0 else 0 for t in row] for row in gt.TOAs[0]])
+    out["TOA_fracs"] = np.array([[t.f if t != 0 else 0.0 for t in row] for row in gt.TOAs[0]])
+    out["ntoa"] = len(gt.TOA_list)
+    t0 = gt.TOA_list[0]
+    out["toa0_frequency"] = t0.frequency
+    out["toa0_flag_names"] = np.array(sorted(t0.flags.keys()))
+    mg.save("gettoas_narrowband", **arrays, **{"scal_" + k: np.asarray(v) for k, v in scal.items()},
+            **{"out_" + k: v for k, v in out.items()})
     shutil.rmtree(tmp, ignore_errors=True)
 
 

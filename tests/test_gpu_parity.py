@@ -1101,3 +1101,46 @@ def test_randomised_scattering_fits_sit_at_the_oracle_optimum(eng):
         tol = np.maximum(1e-3 * np.asarray(o.param_errs), 1e-9)
         assert np.all(np.abs(r["params"][0] - np.asarray(o.params))[ii] <= tol[ii] + 5e-9), case
         np.testing.assert_allclose(r["param_errs"][0][ii], np.asarray(o.param_errs)[ii], rtol=1e-4)
+
+
+def test_narrowband_TOAs_match_reference_caller():
+    """One TOA per channel (get_narrowband_TOAs, pptoas.py:744-1120): 120 per-channel
+    fit_phase_shift fits of a synthetic archive in one device batch, against the
+    reference's own narrowband run.  The reference polishes each phase with a simplex
+    to xtol = 1e-4, so phases agree to that level (TOAs to 1e-4 P) and the derived
+    quantities to 2e-4."""
+    from pulseportraiture_amd.pptoas import GetTOAs, MJD, data_from_arrays
+    g = _load("gettoas_narrowband")
+    epochs = [MJD(int(d), float(f)) for d, f in zip(g["epoch_days"], g["epoch_fracs"])]
+    data = data_from_arrays(
+        g["subints"], g["freqs"], g["Ps"], epochs, weights=g["weights"],
+        noise_stds=g["noise_stds"], SNRs=g["SNRs"], DM=float(g["scal_DM"]),
+        doppler_factors=g["doppler_factors"],
+        backend_delay=float(g["scal_backend_delay"]), telescope=str(g["scal_telescope"]),
+        telescope_code=str(g["scal_telescope_code"]), backend=str(g["scal_backend"]),
+        frontend=str(g["scal_frontend"]), bw=float(g["scal_bw"]), nu0=float(g["scal_nu0"]),
+        subtimes=g["subtimes"], source=str(g["scal_source"]), filename="fake.fits")
+    gt = GetTOAs(data, os.path.join(GOLDEN, "example.gmodel"), quiet=True)
+    gt.get_narrowband_TOAs(quiet=True)
+    assert len(gt.TOA_list) == int(g["out_ntoa"])
+    np.testing.assert_array_equal(gt.ok_isubs[0], g["out_ok_isubs"])
+    used = g["weights"] > 0
+    used[[i for i in range(len(used)) if i not in set(g["out_ok_isubs"])]] = False
+    dph = np.abs((gt.phis[0] - g["out_phis"] + 0.5) % 1.0 - 0.5)
+    assert dph[used].max() < 1e-4 and not gt.phis[0][~used].any()
+    for fld in ("phi_errs", "scales", "scale_errs", "channel_snrs", "TOA_errs"):
+        np.testing.assert_allclose(np.asarray(getattr(gt, fld)[0], dtype=float)[used],
+                                   g["out_" + fld][used], rtol=3e-4)
+    np.testing.assert_allclose(gt.channel_red_chi2s[0][g["out_ok_isubs"]],
+                               g["out_channel_red_chi2s"][g["out_ok_isubs"]], rtol=3e-4)
+    for isub, ichan in zip(*np.where(used)):
+        t = gt.TOAs[0][isub, ichan]
+        dt = (t.intday() - g["out_TOA_days"][isub, ichan]) + \
+            (t.fracday() - g["out_TOA_fracs"][isub, ichan])
+        # (a phase at the +-0.5 edge of the search interval may come out one turn
+        # away from the reference's: the same pulse, numbered differently)
+        turns = dt * 86400.0 / g["Ps"][isub]
+        assert abs(turns - round(turns)) < 1e-4 + 1e-9 and abs(round(turns)) <= 1
+    t0 = gt.TOA_list[0]
+    assert sorted(t0.flags.keys()) == list(g["out_toa0_flag_names"])
+    assert t0.frequency == float(g["out_toa0_frequency"]) and t0.DM is None
