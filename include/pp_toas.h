@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 1
+#define PP_ABI_VERSION 2
 
 /* status codes */
 #define PP_OK 0
@@ -50,6 +50,17 @@ extern "C" {
 #define PP_RC_MAXITER 1   /* iteration limit */
 #define PP_RC_STALL 2     /* no predicted reduction left: converged to rounding */
 #define PP_RC_NAN 3       /* NaN / singular objective */
+
+/* minimiser (pp_fit_in.method; the reference's `method` argument,
+ * pptoaslib.py:932, 993-1010).  The reference's answer for GM and scattering
+ * fits is where SciPy's trust-ncg stops with gtol = -1 ("no predicted
+ * reduction" in floating point, after truncated conjugate-gradient steps), up
+ * to ~1.5e-9 rot short of the optimum: PP_METHOD_TRUST_NCG walks that very
+ * iteration (scipy/optimize/_trustregion.py, _trustregion_ncg.py) on the device
+ * and stops where it stops; PP_METHOD_NEWTON converges to the rounding of the
+ * objective in fewer evaluations (what 'Newton-CG' and 'TNC' also aim at). */
+#define PP_METHOD_TRUST_NCG 0
+#define PP_METHOD_NEWTON 1
 
 typedef struct pp_ctx pp_ctx;
 
@@ -133,6 +144,7 @@ typedef struct {
     int32_t log10_tau;
     int32_t option;            /* get_nu_zeros option (pptoaslib.py:734) */
     int32_t is_toa;
+    int32_t method;            /* PP_METHOD_* */
     int32_t seed_ns;           /* > 0: ignore init_params[.][0] and seed the phase on
                                   the device: seed_ns-point grid over [-0.5, 0.5] of
                                   the channel-summed cross-correlation at the guessed

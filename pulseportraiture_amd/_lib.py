@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpptoas_hip.so")
 PP_OK, PP_EINVAL, PP_EHIP, PP_ENOMEM, PP_ESTATE = 0, -1, -2, -3, -4
 PP_F64, PP_F32 = 0, 1
 PP_MAX_SLOTS = 64
-ABI_VERSION = 1
+ABI_VERSION = 2
+PP_METHOD_TRUST_NCG, PP_METHOD_NEWTON = 0, 1
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -30,7 +31,7 @@ class FitIn(C.Structure):
                 ("init_params", c_double_p), ("nu_fits", c_double_p),
                 ("nu_outs", c_double_p), ("fit_flags", C.c_int32 * 5),
                 ("log10_tau", C.c_int32), ("option", C.c_int32),
-                ("is_toa", C.c_int32), ("seed_ns", C.c_int32)]
+                ("is_toa", C.c_int32), ("method", C.c_int32), ("seed_ns", C.c_int32)]
 
 
 class FitOut(C.Structure):

@@ -485,11 +485,30 @@ __device__ __forceinline__ void fps_sums(const cplx* X, int M, double phi, int t
     }
 }
 
+// index of the smallest of the values the threads of a 256-thread block hold
+// (lowest index on ties, like a sequential scan); valid in every thread
+__device__ inline int block_argmin256(double v, int j, double* shv, int* shj) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(v, o, 64);
+        const int oj = __shfl_xor(j, o, 64);
+        if (ov < v || (ov == v && oj < j)) { v = ov; j = oj; }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { shv[threadIdx.x >> 6] = v; shj[threadIdx.x >> 6] = j; }
+    __syncthreads();
+    v = shv[0]; j = shj[0];
+    for (int w = 1; w < 4; ++w)
+        if (shv[w] < v || (shv[w] == v && shj[w] < j)) { v = shv[w]; j = shj[w]; }
+    __syncthreads();
+    return j;
+}
+
 __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
     const int i = blockIdx.x, tid = threadIdx.x, M = a.M;
     __shared__ double scratch[4 * 4];
-    __shared__ double gridf[1024];
-    __shared__ double sh[8];
+    __shared__ double shv[4];
+    __shared__ int shj[4];
     const cplx* d = a.spec + (size_t)(2 * i) * (M + 1);
     const cplx* m = a.spec + (size_t)(2 * i + 1) * (M + 1);
     cplx* X = xwork + (size_t)i * M;
@@ -510,23 +529,21 @@ __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
     const double err2 = sig * sig * (0.5 * B);
     const double dd = v[0] / err2, pp_ = v[1] / err2;
     // brute grid, both ends included (scipy.optimize.brute with complex(Ns))
-    const int Ns = min(a.Ns, 1024);
+    const int Ns = a.Ns;
+    double bestv = INFINITY;
+    int bestj = 0x7fffffff;
     for (int j = tid; j < Ns; j += 256) {
         const double phi = (Ns > 1) ? a.lo + (a.hi - a.lo) * (double)j / (double)(Ns - 1) : a.lo;
         double s0, s1, s2;
         fps_sums(X, M, phi, 0, 1, s0, s1, s2);
-        gridf[j] = -s0 / err2;
+        const double v = -s0 / err2;
+        if (v < bestv) { bestv = v; bestj = j; }
     }
-    __syncthreads();
-    if (tid == 0) {
-        int best = 0;
-        for (int j = 1; j < Ns; ++j) if (gridf[j] < gridf[best]) best = j;
-        sh[0] = (Ns > 1) ? a.lo + (a.hi - a.lo) * (double)best / (double)(Ns - 1) : a.lo;
-    }
-    __syncthreads();
+    const int best = min(block_argmin256(bestv, bestj, shv, shj), Ns - 1);
     // polish: safeguarded Newton on f(phi) = -Re sum X e / err2 inside +-1 grid step
     const double h = (Ns > 1) ? (a.hi - a.lo) / (double)(Ns - 1) : 0.5;
-    double phi = sh[0], lo = phi - h, hi = phi + h;
+    double phi = (Ns > 1) ? a.lo + (a.hi - a.lo) * (double)best / (double)(Ns - 1) : a.lo;
+    double lo = phi - h, hi = phi + h;
     double f = 0.0, f2 = 0.0;
     for (int it = 0; it < 60; ++it) {
         double s[3];
@@ -572,7 +589,7 @@ __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
 //               phase into x0[i][0].
 // --------------------------------------------------------------------------
 #define PP_SEED_KPT 16   // harmonics per lane (one wave per channel): Kt <= 1024
-__global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart) {
+__global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart, int Ks) {
     const int i = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     __shared__ cplx ysh[3 * 64 * PP_SEED_KPT / 4];   // three waves' partial spectra, one quarter at a time
@@ -597,7 +614,7 @@ __global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart) {
         cplx e = unit_phasor((double)(lane + 1), phin);
         const cplx wst = make_double2(__shfl(e.x, 63, 64), __shfl(e.y, 63, 64));
         const cplx* xrow = a.X + ((size_t)i * a.nchan + n) * a.Kt;
-        const int ktn = ktv ? ktv[n] : a.Kt;
+        const int ktn = min(ktv ? ktv[n] : a.Kt, Ks);
         // all of the row's loads first (independent, 1 KB per wave-instruction)
         cplx xv[PP_SEED_KPT];
 #pragma unroll
@@ -616,7 +633,7 @@ __global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart) {
         }
     }
     // sum the four waves' spectra (a quarter of the harmonics per round) and store
-    cplx* yo = ypart + ((size_t)i * a.nchunk + chunk) * a.Kt;
+    cplx* yo = ypart + ((size_t)i * a.nchunk + chunk) * Ks;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         __syncthreads();
@@ -636,17 +653,18 @@ __global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart) {
                     s.x += v.x; s.y += v.y;
                 }
                 const int k = lane + 1 + 64 * jj;
-                if (k <= a.Kt) yo[k - 1] = s;
+                if (k <= Ks) yo[k - 1] = s;
             }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, cplx* ywork, double* x0, int Ns) {
-    const int i = blockIdx.x, tid = threadIdx.x, K = a.Kt;
+__global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, cplx* ywork, double* x0, int Ns,
+                                                  int Ks) {
+    const int i = blockIdx.x, tid = threadIdx.x, K = Ks;
     __shared__ double scratch[4 * 4];
-    __shared__ double gridf[1024];
-    __shared__ double sh[2];
+    __shared__ double shv[4];
+    __shared__ int shj[4];
     cplx* Y = ywork + (size_t)i * K;
     // scattering kernel of the guessed tau at the fit reference frequency
     const double taup = x0[i * 5 + 3];
@@ -664,22 +682,18 @@ __global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, 
         Y[k - 1] = s;
     }
     __syncthreads();
-    Ns = min(max(Ns, 2), 1024);
+    Ns = max(Ns, 2);
+    double bestv = INFINITY;
+    int bestj = 0x7fffffff;
     for (int j = tid; j < Ns; j += 256) {
         const double phi = -0.5 + (double)j / (double)(Ns - 1);
         double s0, s1, s2;
         fps_sums(Y, K, phi, 0, 1, s0, s1, s2);
-        gridf[j] = -s0;
+        if (-s0 < bestv) { bestv = -s0; bestj = j; }
     }
-    __syncthreads();
-    if (tid == 0) {
-        int best = 0;
-        for (int j = 1; j < Ns; ++j) if (gridf[j] < gridf[best]) best = j;
-        sh[0] = -0.5 + (double)best / (double)(Ns - 1);
-    }
-    __syncthreads();
+    const int best = min(block_argmin256(bestv, bestj, shv, shj), Ns - 1);
     const double h = 1.0 / (double)(Ns - 1);
-    double phi = sh[0], lo = phi - h, hi = phi + h;
+    double phi = -0.5 + (double)best / (double)(Ns - 1), lo = phi - h, hi = phi + h;
     for (int it = 0; it < 60; ++it) {
         double s[3];
         fps_sums(Y, K, phi, tid, 256, s[0], s[1], s[2]);

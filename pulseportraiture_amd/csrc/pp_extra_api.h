@@ -4,7 +4,7 @@ extern "C" int pp_fit_phase_shift_batch(pp_ctx* c, const double* data, const dou
                                         int nprof, int nbin, double lo, double hi, int Ns, double* out7) {
     if (!c || !data || !model || !out7) return fail(PP_EINVAL, "pp_fit_phase_shift_batch: null argument");
     if (!nbin_ok(nbin) || nprof < 1) return fail(PP_EINVAL, "pp_fit_phase_shift_batch: bad shape %d x %d", nprof, nbin);
-    if (Ns < 1 || Ns > 1024) return fail(PP_EINVAL, "pp_fit_phase_shift_batch: Ns %d not in [1,1024]", Ns);
+    if (Ns < 1) return fail(PP_EINVAL, "pp_fit_phase_shift_batch: Ns %d", Ns);
     HIP_TRY(hipSetDevice(c->device));
     const int M = nbin / 2;
     int rc;

@@ -60,6 +60,7 @@ struct FitArgs {
     int nsub, nchan, nbin, M, Kt;
     int flags[5];
     int log10_tau, option, is_toa, max_iter, scat;
+    int method;               // PP_METHOD_*: 0 = SciPy trust-ncg, step for step; 1 = Newton to rounding
     const cplx* X;
     const cplx* const* mft;
     const double* const* msq;   // [nslot] |m_nk|^2 tables
@@ -1034,6 +1035,86 @@ __device__ inline void tr_subproblem(int n, const double* g, const double* H, do
 }
 
 // --------------------------------------------------------------------------
+// SciPy's trust-ncg, operation by operation (scipy/optimize/_trustregion_ncg.py
+// CGSteihaugSubproblem.solve and _trustregion.py _minimize_trust_region): what
+// the reference drives with gtol = -1 (pptoaslib.py:1001-1014).  Its exit --
+// "predicted reduction <= 0" in floating point -- and its TRUNCATED conjugate-
+// gradient steps (residual tolerance min(1/2, sqrt|g|) |g|) decide where the
+// reference's answer lands (up to ~1.5e-9 rot short of the optimum for GM and
+// scattering fits); following the same iterates reproduces that answer, not
+// merely the optimum.  Unfitted parameters have zero gradient / Hessian rows in
+// the reference, so working on the fit subspace gives the same numbers.
+// --------------------------------------------------------------------------
+__device__ inline double tr_model_value(int n, double f, const double* g, const double* H, const double* p) {
+    double Hp[5];
+    for (int i = 0; i < n; ++i) Hp[i] = vdot(n, H + i * n, p);
+    return f + vdot(n, g, p) + 0.5 * vdot(n, p, Hp);
+}
+
+__device__ inline void tr_boundaries(int n, const double* z, const double* d, double radius, double* ta,
+                                     double* tb) {
+    const double a = vdot(n, d, d), b = 2.0 * vdot(n, z, d), c = vdot(n, z, z) - radius * radius;
+    const double sq = sqrt(b * b - 4.0 * a * c);
+    const double aux = b + copysign(sq, b);
+    const double t1 = -aux / (2.0 * a), t2 = -2.0 * c / aux;
+    *ta = fmin(t1, t2); *tb = fmax(t1, t2);
+}
+
+__device__ inline void tr_cg_steihaug_scipy(int n, double f, const double* g, const double* H, double radius,
+                                            double* p, int* hits) {
+    *hits = 0;
+    for (int i = 0; i < n; ++i) p[i] = 0.0;
+    const double gmag = sqrt(vdot(n, g, g));
+    const double tol = fmin(0.5, sqrt(gmag)) * gmag;
+    if (gmag < tol) return;
+    double z[5] = {0, 0, 0, 0, 0}, r[5], d[5], Bd[5];
+    for (int i = 0; i < n; ++i) { r[i] = g[i]; d[i] = -g[i]; }
+    for (int it = 0; it < 64; ++it) {
+        for (int i = 0; i < n; ++i) Bd[i] = vdot(n, H + i * n, d);
+        const double dBd = vdot(n, d, Bd);
+        if (dBd <= 0.0) {
+            double ta, tb, pa[5], pb[5];
+            tr_boundaries(n, z, d, radius, &ta, &tb);
+            for (int i = 0; i < n; ++i) { pa[i] = z[i] + ta * d[i]; pb[i] = z[i] + tb * d[i]; }
+            const bool first = tr_model_value(n, f, g, H, pa) < tr_model_value(n, f, g, H, pb);
+            for (int i = 0; i < n; ++i) p[i] = first ? pa[i] : pb[i];
+            *hits = 1;
+            return;
+        }
+        const double rsq = vdot(n, r, r), alpha = rsq / dBd;
+        double zn[5];
+        for (int i = 0; i < n; ++i) zn[i] = z[i] + alpha * d[i];
+        if (sqrt(vdot(n, zn, zn)) >= radius) {
+            double ta, tb;
+            tr_boundaries(n, z, d, radius, &ta, &tb);
+            for (int i = 0; i < n; ++i) p[i] = z[i] + tb * d[i];
+            *hits = 1;
+            return;
+        }
+        double rn[5];
+        for (int i = 0; i < n; ++i) rn[i] = r[i] + alpha * Bd[i];
+        const double rnsq = vdot(n, rn, rn);
+        if (sqrt(rnsq) < tol || !(rnsq == rnsq)) {
+            for (int i = 0; i < n; ++i) p[i] = zn[i];
+            return;
+        }
+        const double beta = rnsq / rsq;
+        for (int i = 0; i < n; ++i) { d[i] = -rn[i] + beta * d[i]; z[i] = zn[i]; r[i] = rn[i]; }
+    }
+    for (int i = 0; i < n; ++i) p[i] = z[i];
+}
+
+// one decision of SciPy's loop after the proposal x + p was evaluated (f_new):
+// radius update and acceptance (eta = 0.15, max radius 1000)
+__device__ inline bool tr_scipy_accept(double f, double f_new, double pred, int hits, bool finite,
+                                       double* radius) {
+    const double rho = finite ? (f - f_new) / pred : -1.0;
+    if (rho < 0.25) *radius *= 0.25;
+    else if (rho > 0.75 && hits) *radius = fmin(2.0 * *radius, 1000.0);
+    return rho > 0.15;
+}
+
+// --------------------------------------------------------------------------
 // One pass over X that makes further passes unnecessary (no scattering): the
 // per-channel cross-correlation C_n(phi_n + d) = Re sum_k X_nk e^{2 pi i k (phi_n + d)}
 // is an entire function of d, so its derivatives at the initial point
@@ -1132,7 +1213,9 @@ __device__ __forceinline__ void taylor_shift(const double* t, double d, double& 
     A0 = a0; A1 = a1; A2 = a2;
 }
 
-// Newton solve on the Taylor model, one 256-thread block per subint.
+// Solve on the Taylor model, one 256-thread block per subint.  method 0 walks
+// SciPy's trust-ncg iteration on the model (every evaluation is O(nchan), no pass
+// over the data), method 1 is plain Newton to the rounding of f.
 __global__ __launch_bounds__(256) void k_taylor_solve(FitArgs a) {
     const int i = blockIdx.x, tid = threadIdx.x;
     SubState& st = a.st[i];
@@ -1147,21 +1230,20 @@ __global__ __launch_bounds__(256) void k_taylor_solve(FitArgs a) {
     const int* fl = a.flags;
     int idx[3], nf = 0;
     for (int j = 0; j < 3; ++j) if (fl[j]) idx[nf++] = j;
-    double dx[3] = {0.0, 0.0, 0.0};      // displacement from x0 in (phi, DM, GM)
-    double fprev = INFINITY, f0 = 0.0;
-    double g[5], H[25];
-    bool ok = true;
-    int it;
-    for (it = 0; it < 24; ++it) {
+    // f, g, H of the model at displacement dx from x0 (identical in every thread);
+    // returns the largest per-channel phase displacement
+    auto evalm = [&](const double* dx, double& f, double* g, double* H) -> double {
         double acc[10];
 #pragma unroll
         for (int j = 0; j < 10; ++j) acc[j] = 0.0;
+        double dmax = 0.0;
         for (int n = tid; n < a.nchan; n += 256) {
             const double w = wts[n];
             if (w == 0.0) continue;
             double p1, p2;
             phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
             const double d = dx[0] + dx[1] * p1 + dx[2] * p2;
+            dmax = fmax(dmax, fabs(d));
             double A0, A1, A2;
             taylor_shift(tay + (size_t)n * PP_TSTRIDE, d, A0, A1, A2);
             const double S0 = msum[n], r = A0 / S0;
@@ -1173,45 +1255,85 @@ __global__ __launch_bounds__(256) void k_taylor_solve(FitArgs a) {
             acc[7] += Lpp * p1 * p1; acc[8] += Lpp * p1 * p2; acc[9] += Lpp * p2 * p2;
         }
         block_sum<10>(acc, scratch);
+        dmax = group_max<64>(dmax);
         __syncthreads();
-        const double f = acc[0];
+        if ((tid & 63) == 0) shx[tid >> 6] = dmax;
+        __syncthreads();
+        dmax = fmax(fmax(shx[0], shx[1]), fmax(shx[2], shx[3]));
+        __syncthreads();
+        f = acc[0];
         for (int j = 0; j < 5; ++j) g[j] = 0.0;
         for (int j = 0; j < 25; ++j) H[j] = 0.0;
         g[0] = fl[0] ? acc[1] : 0.0; g[1] = fl[1] ? acc[2] : 0.0; g[2] = fl[2] ? acc[3] : 0.0;
         const double hh[3][3] = {{acc[4], acc[5], acc[6]}, {acc[5], acc[7], acc[8]}, {acc[6], acc[8], acc[9]}};
         for (int r_ = 0; r_ < 3; ++r_)
             for (int c_ = 0; c_ < 3; ++c_) H[r_ * 5 + c_] = (fl[r_] && fl[c_]) ? hh[r_][c_] : 0.0;
-        if (it == 0) {
-            f0 = f;
-            if (tid == 0) {
-                st.f0 = f;
-                for (int j = 0; j < 5; ++j) st.g0[j] = g[j];
-                for (int j = 0; j < 25; ++j) st.H0[j] = H[j];
-            }
-        }
-        if (!isfinite(f)) { ok = false; break; }
-        // Newton step on the fit subspace (every thread computes the same)
-        double gs[3], Hs[9], p[3];
+        return dmax;
+    };
+    auto subspace = [&](const double* g, const double* H, double* gs, double* Hs) {
         for (int r_ = 0; r_ < nf; ++r_) {
             gs[r_] = g[idx[r_]];
             for (int c_ = 0; c_ < nf; ++c_) Hs[r_ * nf + c_] = H[idx[r_] * 5 + idx[c_]];
         }
-        double mg[3];
-        for (int r_ = 0; r_ < nf; ++r_) mg[r_] = -gs[r_];
-        if (!chol_solve(nf, Hs, mg, p)) { ok = false; break; }
-        double Hp[3];
-        for (int r_ = 0; r_ < nf; ++r_) Hp[r_] = vdot(nf, Hs + r_ * nf, p);
-        const double pred = -(vdot(nf, gs, p) + 0.5 * vdot(nf, p, Hp));
-        if (f > fprev + 1e-9 * fabs(fprev)) { ok = false; break; }   // not descending: leave it to the trust region
-        fprev = f;
-        if (!(pred > 64.0 * 2.220446049250313e-16 * fabs(f))) {
-            // converged to the rounding of f: take the last step and stop
-            for (int r_ = 0; r_ < nf; ++r_) dx[idx[r_]] += p[r_];
-            break;
-        }
-        for (int r_ = 0; r_ < nf; ++r_) dx[idx[r_]] += p[r_];
+    };
+    double dx[3] = {0.0, 0.0, 0.0};      // accepted displacement from x0 in (phi, DM, GM)
+    double f, g[5], H[25];
+    bool ok = true;
+    int it = 0;
+    double dpath = evalm(dx, f, g, H);   // (0 at the expansion point)
+    if (tid == 0) {
+        st.f0 = f;
+        for (int j = 0; j < 5; ++j) st.g0[j] = g[j];
+        for (int j = 0; j < 25; ++j) st.H0[j] = H[j];
     }
-    if (it >= 24) ok = false;
+    if (!isfinite(f)) ok = false;
+    if (ok && a.method == 0) {
+        double radius = 1.0;
+        for (;;) {
+            double gs[3], Hs[9], p[3];
+            subspace(g, H, gs, Hs);
+            int hits = 0;
+            tr_cg_steihaug_scipy(nf, f, gs, Hs, radius, p, &hits);
+            const double pred = f - tr_model_value(nf, f, gs, Hs, p);
+            if (!(pred > 0.0)) break;                 // SciPy's status 2, the reference's normal exit
+            double xt[3] = {dx[0], dx[1], dx[2]};
+            for (int r_ = 0; r_ < nf; ++r_) xt[idx[r_]] += p[r_];
+            double f2, g2[5], H2[25];
+            dpath = fmax(dpath, evalm(xt, f2, g2, H2));
+            bool finite = isfinite(f2);
+            for (int j = 0; j < 3; ++j) finite = finite && isfinite(g2[j]);
+            if (tr_scipy_accept(f, f2, pred, hits, finite, &radius)) {
+                for (int j = 0; j < 3; ++j) dx[j] = xt[j];
+                f = f2;
+                for (int j = 0; j < 5; ++j) g[j] = g2[j];
+                for (int j = 0; j < 25; ++j) H[j] = H2[j];
+            }
+            ++it;
+            if (it >= a.max_iter || !(radius > 1e-300)) { ok = false; break; }
+        }
+    } else if (ok) {
+        double fprev = INFINITY;
+        for (it = 0; it < 24; ++it) {
+            if (it > 0) dpath = fmax(dpath, evalm(dx, f, g, H));
+            if (!isfinite(f)) { ok = false; break; }
+            // Newton step on the fit subspace (every thread computes the same)
+            double gs[3], Hs[9], p[3], mg[3];
+            subspace(g, H, gs, Hs);
+            for (int r_ = 0; r_ < nf; ++r_) mg[r_] = -gs[r_];
+            if (!chol_solve(nf, Hs, mg, p)) { ok = false; break; }
+            double Hp[3];
+            for (int r_ = 0; r_ < nf; ++r_) Hp[r_] = vdot(nf, Hs + r_ * nf, p);
+            const double pred = -(vdot(nf, gs, p) + 0.5 * vdot(nf, p, Hp));
+            if (f > fprev + 1e-9 * fabs(fprev)) { ok = false; break; }   // not descending: leave it to the trust region
+            fprev = f;
+            for (int r_ = 0; r_ < nf; ++r_) dx[idx[r_]] += p[r_];
+            // converged to the rounding of f: that was the last step
+            if (!(pred > 64.0 * 2.220446049250313e-16 * fabs(f))) break;
+        }
+        if (it >= 24) ok = false;
+        // (g, H belong to the point before the last step: the certificate only
+        // needs the curvature scale; the published sums are taken at x0 + dx)
+    }
     // ---- certificate: truncation error of the gradient, in parameter units ----
     double ev[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // err bounds g_phi, g_DM, g_GM; H00; max |d|
     if (ok) {
@@ -1229,15 +1351,9 @@ __global__ __launch_bounds__(256) void k_taylor_solve(FitArgs a) {
             const double r = fabs(t[0] / msum[n]) + 1e-300;
             const double ge = 2.0 * w * r * e1 * 1.5;   // + remainder through A0 (smaller by |d|/PP_TJ)
             ev[0] += ge; ev[1] += ge * fabs(p1); ev[2] += ge * fabs(p2);
-            ev[4] = fmax(ev[4], fabs(d));
         }
-        double mx = ev[4];
-        mx = group_max<64>(mx);
         block_sum<4>(reinterpret_cast<double(&)[4]>(ev), scratch);
         __syncthreads();
-        if ((tid & 63) == 0) shx[tid >> 6] = mx;
-        __syncthreads();
-        mx = fmax(fmax(shx[0], shx[1]), fmax(shx[2], shx[3]));
         // position error <= gradient error / curvature, per fitted parameter
         const double tol[3] = {1e-12, 1e-10, 1e-7};   // turns, pc cm^-3, GM units
         for (int j = 0; j < 3; ++j)
@@ -1245,7 +1361,8 @@ __global__ __launch_bounds__(256) void k_taylor_solve(FitArgs a) {
                 const double hjj = fabs(H[j * 5 + j]);
                 if (!(ev[j] <= tol[j] * hjj)) ok = false;
             }
-        if (!(mx < 0.02)) ok = false;
+        // every point the iteration visited must lie inside the model's range
+        if (!(dpath < 0.02)) ok = false;
     }
     __syncthreads();
     if (ok) {
@@ -1277,8 +1394,8 @@ __global__ __launch_bounds__(256) void k_taylor_solve(FitArgs a) {
         // fall back to evaluations over X, starting from the initial point
         st.fresh = 1;
     }
-    (void)f0;
 }
+
 
 // unpack the 21 accumulators into g[5], H[25] with the fit flags applied
 // (pptoaslib.py:573, 629-630)
@@ -1359,6 +1476,20 @@ __global__ __launch_bounds__(64) void k_step(FitArgs a) {
             for (int c = 0; c < n; ++c) Hs[r * n + c] = s.H[idx[r] * 5 + idx[c]];
         }
         int hits = 0;
+        if (a.method == 0) {
+            // the reference's own iteration (SciPy trust-ncg): truncated CG step, and
+            // the exit where the model predicts no reduction in floating point
+            tr_cg_steihaug_scipy(n, s.f, gs, Hs, s.radius, p, &hits);
+            const double pred = s.f - tr_model_value(n, s.f, gs, Hs, p);
+            if (!(pred > 0.0)) {
+                s.status = PP_RC_STALL; done = true;
+            } else {
+                for (int j = 0; j < 5; ++j) s.xe[j] = s.x[j];
+                for (int r = 0; r < n; ++r) s.xe[idx[r]] = s.x[idx[r]] + p[r];
+                s.pred_red = pred;
+                s.hits_boundary = hits;
+            }
+        } else {
         tr_subproblem(n, gs, Hs, s.radius, p, &hits);
         double Hp[5];
         for (int r = 0; r < n; ++r) Hp[r] = vdot(n, Hs + r * n, p);
@@ -1390,6 +1521,7 @@ __global__ __launch_bounds__(64) void k_step(FitArgs a) {
             for (int r = 0; r < n; ++r) s.xe[idx[r]] = s.x[idx[r]] + p[r];
             s.pred_red = pred;
             s.hits_boundary = hits;
+        }
         }
     }
     if (done) {

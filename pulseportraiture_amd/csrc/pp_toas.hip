@@ -135,33 +135,40 @@ static void resolve_spans(pp_ctx* c) {
 extern "C" int pp_abi_version(void) { return PP_ABI_VERSION; }
 extern "C" const char* pp_last_error(void) { return g_err.c_str(); }
 
+static int ctx_init(pp_ctx* c) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipHostMalloc((void**)&c->nactive_h, sizeof(int) * 4, hipHostMallocDefault));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    DevBuf* tables[] = {&c->mft_table, &c->msum_table, &c->kt_table, &c->mdc_table, &c->msq_table};
+    for (DevBuf* t : tables) {
+        int rc = t->reserve(sizeof(void*) * PP_MAX_SLOTS);
+        if (rc) return rc;
+        HIP_TRY(hipMemset(t->p, 0, sizeof(void*) * PP_MAX_SLOTS));
+    }
+    return PP_OK;
+}
+
+extern "C" int pp_destroy(pp_ctx* c);
+
 extern "C" int pp_create(int device_id, pp_ctx** out) {
     if (!out) return fail(PP_EINVAL, "pp_create: out is NULL");
+    *out = nullptr;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device_id < 0 || device_id >= ndev) return fail(PP_EINVAL, "pp_create: device %d of %d", device_id, ndev);
     HIP_TRY(hipSetDevice(device_id));
     pp_ctx* c = new pp_ctx();
     c->device = device_id;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipHostMalloc((void**)&c->nactive_h, sizeof(int) * 4, hipHostMallocDefault));
-    HIP_TRY(hipEventCreate(&c->ev0));
-    HIP_TRY(hipEventCreate(&c->ev1));
-    int rc = c->mft_table.reserve(sizeof(void*) * PP_MAX_SLOTS);
-    if (rc) return rc;
-    rc = c->msum_table.reserve(sizeof(void*) * PP_MAX_SLOTS);
-    if (rc) return rc;
-    rc = c->kt_table.reserve(sizeof(void*) * PP_MAX_SLOTS);
-    if (rc) return rc;
-    rc = c->mdc_table.reserve(sizeof(void*) * PP_MAX_SLOTS);
-    if (rc) return rc;
-    HIP_TRY(hipMemset(c->mdc_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
-    rc = c->msq_table.reserve(sizeof(void*) * PP_MAX_SLOTS);
-    if (rc) return rc;
-    HIP_TRY(hipMemset(c->msq_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
-    HIP_TRY(hipMemset(c->kt_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
-    HIP_TRY(hipMemset(c->mft_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
-    HIP_TRY(hipMemset(c->msum_table.p, 0, sizeof(void*) * PP_MAX_SLOTS));
+    const int rc = ctx_init(c);
+    if (rc) {
+        // release whatever the half-built context already holds (the error
+        // string of the failing call stays in place)
+        const std::string keep = g_err;
+        (void)pp_destroy(c);
+        g_err = keep;
+        return rc;
+    }
     *out = c;
     return PP_OK;
 }
@@ -563,6 +570,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     for (int j = 0; j < 5; ++j) fa.flags[j] = in->fit_flags[j] ? 1 : 0;
     fa.log10_tau = in->log10_tau ? 1 : 0; fa.option = in->option; fa.is_toa = in->is_toa ? 1 : 0;
     fa.max_iter = c->max_iter; fa.scat = scat ? 1 : 0;
+    fa.method = in->method;
     fa.X = c->X.as<cplx>();
     fa.mft = (const cplx* const*)c->mft_table.p;
     fa.msq = (const double* const*)c->msq_table.p;
@@ -593,14 +601,17 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.o_f0 = c->o_f0.as<double>(); fa.o_g0 = c->o_g0.as<double>(); fa.o_H0 = c->o_H0.as<double>();
 
     if (in->seed_ns > 0) {
-        if (Kt > 64 * PP_SEED_KPT) return fail(PP_EINVAL, "seed: Kt %d too large", Kt);
-        if ((rc = c->seedbuf.reserve(((size_t)ns * nchunk + ns) * Kt * sizeof(cplx)))) return rc;
+        // the coarse seed uses the lowest 64 * PP_SEED_KPT = 1024 harmonics at most
+        // (templates that keep more -- nbin 4096 / 8192 with power out to Nyquist --
+        // lose nothing a 100-point grid could resolve)
+        const int Ks = std::min(Kt, 64 * PP_SEED_KPT);
+        if ((rc = c->seedbuf.reserve(((size_t)ns * nchunk + ns) * Ks * sizeof(cplx)))) return rc;
         cplx* ypart = c->seedbuf.as<cplx>();
-        cplx* ywork = ypart + (size_t)ns * nchunk * Kt;
+        cplx* ywork = ypart + (size_t)ns * nchunk * Ks;
         Prof pr(c, KF_SEED);
-        hipLaunchKernelGGL(k_seed_accum, dim3(nchunk, ns), dim3(256), 0, c->stream, fa, ypart);
+        hipLaunchKernelGGL(k_seed_accum, dim3(nchunk, ns), dim3(256), 0, c->stream, fa, ypart, Ks);
         hipLaunchKernelGGL(k_seed_fit, dim3(ns), dim3(256), 0, c->stream, fa, (const cplx*)ypart, ywork,
-                           c->x0.as<double>(), (int)in->seed_ns);
+                           c->x0.as<double>(), (int)in->seed_ns, Ks);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(k_init_state, dim3((ns + 63) / 64), dim3(64), 0, c->stream, fa);
@@ -696,6 +707,7 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
     if (!in->data || !in->freqs || !in->P || !in->init_params) return fail(PP_EINVAL, "missing input array");
     if (in->data_dtype != PP_F64 && in->data_dtype != PP_F32) return fail(PP_EINVAL, "data_dtype %d", in->data_dtype);
     if (in->freqs_stride != 0 && in->freqs_stride != in->nchan) return fail(PP_EINVAL, "freqs_stride must be 0 or nchan");
+    if (in->method != PP_METHOD_TRUST_NCG && in->method != PP_METHOD_NEWTON) return fail(PP_EINVAL, "method %d", in->method);
     if (!out->params || !out->param_errs || !out->nu_refs || !out->cov || !out->chi2 || !out->red_chi2 ||
         !out->snr || !out->nfeval || !out->return_code)
         return fail(PP_EINVAL, "missing output array");
@@ -717,6 +729,20 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
         for (int i = 0; i < N; ++i) if (in->init_params[(size_t)i * 5 + 3] != 0.0) { scat = true; break; }
     // default reference frequencies: mean of the (unmasked) channel frequencies
     std::vector<double> nufit((size_t)N * 3), nuout((size_t)N * 3);
+    // the masked mean needs the mask on the host: a device-resident mask is
+    // copied back once, and only if some reference frequency was left to default
+    std::vector<uint8_t> mask_h;
+    const uint8_t* mask_host = in->chan_mask;
+    if (in->chan_mask && in->aux_on_device) {
+        bool need = (in->nu_fits == nullptr);
+        for (size_t j = 0; !need && j < (size_t)N * 3; ++j) need = std::isnan(in->nu_fits[j]);
+        mask_host = nullptr;
+        if (need) {
+            mask_h.resize((size_t)N * C);
+            HIP_TRY(hipMemcpy(mask_h.data(), in->chan_mask, mask_h.size(), hipMemcpyDeviceToHost));
+            mask_host = mask_h.data();
+        }
+    }
     for (int i = 0; i < N; ++i) {
         double mean = NAN;
         for (int j = 0; j < 3; ++j) {
@@ -724,7 +750,7 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
             if (std::isnan(v)) {
                 if (std::isnan(mean)) {
                     const double* f = in->freqs + (in->freqs_stride ? (size_t)i * C : 0);
-                    const uint8_t* m = in->chan_mask ? in->chan_mask + (size_t)i * C : nullptr;
+                    const uint8_t* m = mask_host ? mask_host + (size_t)i * C : nullptr;
                     double s = 0.0; long long cnt = 0;
                     for (int n = 0; n < C; ++n) if (!m || m[n]) { s += f[n]; ++cnt; }
                     mean = cnt ? s / (double)cnt : NAN;
@@ -742,7 +768,7 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
                            (double)C * (8.0 * 12 + 2 * 9 * 8.0) + 4096.0;
     double budget = std::min(c->max_work_bytes, 0.85 * ((double)free_b + (double)c->X.cap + (double)c->data.cap + (double)c->csum.cap));
     int cap = (int)std::max(1.0, std::floor(budget / per_sub));
-    cap = std::min(cap, N);
+    cap = std::min(std::min(cap, N), 65535);   // (subints index the grid's y dimension)
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     for (int s0 = 0; s0 < N; s0 += cap) {
         const int ns = std::min(cap, N - s0);

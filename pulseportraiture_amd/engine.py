@@ -9,7 +9,12 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import FitIn, FitOut, PP_F32, PP_F64, c_double_p, c_int32_p, c_uint8_p
+from ._lib import (FitIn, FitOut, PP_F32, PP_F64, PP_METHOD_NEWTON, PP_METHOD_TRUST_NCG,
+                   c_double_p, c_int32_p, c_uint8_p)
+
+# the reference's minimiser names (pptoaslib.py:993-1010) -> device solver
+METHODS = {'trust-ncg': PP_METHOD_TRUST_NCG, 'Newton-CG': PP_METHOD_NEWTON,
+           'TNC': PP_METHOD_NEWTON, 'newton': PP_METHOD_NEWTON}
 
 
 class EngineError(RuntimeError):
@@ -126,13 +131,18 @@ class Engine(object):
     def fit_batch(self, data, freqs, P, init_params, errs=None, nu_fits=None,
                   nu_outs=None, fit_flags=(1, 1, 0, 0, 0), log10_tau=False,
                   option=0, is_toa=True, model_slot=None, chan_mask=None,
-                  per_channel=True, objective=False, seed_ns=0):
+                  per_channel=True, objective=False, seed_ns=0, method='trust-ncg'):
         """Fit nsub subints.  data: [nsub,nchan,nbin] numpy array (f64/f32) or
         CUDA tensor.  freqs: [nchan] or [nsub,nchan].  Returns a dict of arrays
         (see include/pp_toas.h pp_fit_out).  errs / chan_mask may be CUDA
         tensors [nsub,nchan]; per_channel="device" leaves scales, scale_errs and
         channel_snrs in HBM as CUDA tensors instead of copying them out.
-        seed_ns > 0 replaces init_params[:, 0] by a phase seeded on the device."""
+        seed_ns > 0 replaces init_params[:, 0] by a phase seeded on the device.
+        method: 'trust-ncg' follows SciPy's trust-ncg iteration to the very point
+        where the reference stops; 'newton' ('Newton-CG', 'TNC') converges to the
+        rounding of the objective in fewer evaluations."""
+        if method not in METHODS:
+            raise EngineError("unknown method %r" % (method,))
         if _is_device_array(data):
             nsub, nchan, nbin = (int(s) for s in data.shape)
             if not data.is_contiguous():
@@ -205,6 +215,7 @@ class Engine(object):
         fin.log10_tau = int(bool(log10_tau))
         fin.option, fin.is_toa = int(option), int(bool(is_toa))
         fin.seed_ns = int(seed_ns)
+        fin.method = METHODS[method]
 
         res = dict(params=np.empty((nsub, 5)), param_errs=np.empty((nsub, 5)),
                    nu_refs=np.empty((nsub, 3)), cov=np.empty((nsub, 5, 5)),

@@ -216,7 +216,7 @@ def fit_portrait(data, model, init_params, P, freqs, nu_fit=None, nu_out=None,
     from .pptoaslib import fit_portrait_full
     x0 = [init_params[0], init_params[1], 0.0, 0.0, 0.0]
     r = fit_portrait_full(data, model, x0, P, freqs, [nu_fit] * 3, [nu_out] * 3,
-                          errs, [1, 1, 0, 0, 0], log10_tau=False, sub_id=id,
+                          errs, [1, 1, 0, 0, 0], log10_tau=False, sub_id=id, method='TNC',
                           is_toa=True, quiet=quiet)
     with np.errstate(divide='ignore', invalid='ignore'):
         scale_errs = np.abs(r.scales / r.channel_snrs)   # (p_n/sigma_n^2)^-1/2

@@ -191,6 +191,31 @@ def _load(datafile):
                        "DataBunch (data_from_arrays) or an .npz of its fields." % datafile)
 
 
+def _dededisperse(eng, port, d, ok_isubs):
+    """A DataBunch flagged dmc (stored dedispersed) is put back to its dispersed
+    state before fitting, as the reference does by re-loading the archive with
+    dededisperse=True (pptoas.py:256-265): every channel is delayed again by the
+    stored DM relative to the centre frequency (what PSRCHIVE's dedisperse() took
+    out).  Runs on the device (rotate_portraits)."""
+    if not d.dmc:
+        return port
+    isubs = np.asarray(ok_isubs, dtype=int)
+    return eng.rotate_portraits(port, d.freqs[isubs], d.Ps[isubs], DM=-float(d.DM),
+                                nu_DM=float(d.nu0))
+
+
+def _noise_rows(d, isubs):
+    """noise_stds[isubs, 0] of a DataBunch, measured from the power spectrum
+    (pplib.get_noise, what load_data stores: pplib.py:2727-2731) when the bunch was
+    built without them."""
+    isubs = np.asarray(isubs, dtype=int)
+    if d.noise_stds is not None:
+        return np.ascontiguousarray(np.asarray(d.noise_stds)[isubs, 0], dtype=np.float64)
+    from .pplib import get_noise
+    sub = np.asarray(d.subints)
+    return np.array([get_noise(sub[i, 0], chans=True) for i in isubs], dtype=np.float64)
+
+
 def _take_subints(subints, ok_isubs):
     """[nok, nchan, nbin] total-intensity portraits of the good subints, without
     copying the archive when they are a contiguous run (fancy indexing would copy
@@ -410,7 +435,7 @@ class GetTOAs(object):
                 else:
                     fl = list(self.fit_flags)
                 flags_per.append(tuple(fl))
-            port = _take_subints(d.subints, ok_isubs)
+            port = _dededisperse(eng, _take_subints(d.subints, ok_isubs), d, ok_isubs)
             # ---- one device call per distinct flag set (normally one) ----
             res = None
             for fl in sorted(set(flags_per)):
@@ -422,7 +447,7 @@ class GetTOAs(object):
                                   nu_fits=nu_fit_arr[sel], nu_outs=nu_ref_arr[sel],
                                   fit_flags=fl, log10_tau=log10_tau, option=0,
                                   is_toa=True, model_slot=slot_of[sel],
-                                  chan_mask=mask[sel], seed_ns=100)
+                                  chan_mask=mask[sel], seed_ns=100, method=method)
                 if res is None:
                     res = {k: (np.zeros((nok,) + v.shape[1:], dtype=v.dtype)
                                if isinstance(v, np.ndarray) else v) for k, v in r.items()}
@@ -626,7 +651,8 @@ class GetTOAs(object):
         if fit_scat or tscrunch or show_plot or print_phase or print_flux:
             raise NotImplementedError("fit_scat / tscrunch / show_plot / print_phase / print_flux "
                                       "are not available for narrowband TOAs")
-        print("You are using an experimental functionality of pptoas!")
+        if not quiet:
+            print("You are using an experimental functionality of pptoas!")
         self.nfit = 1
         self.fit_phi, self.fit_tau = True, False
         self.fit_flags = [1, 0]
@@ -664,6 +690,10 @@ class GetTOAs(object):
             MJDs = np.array([e.in_days() for e in d.epochs], dtype=np.double)
             # ---- gather every (subint, good channel) profile pair ----
             profs, mprofs, noises, where = [], [], [], []
+            sub_all = np.asarray(d.subints)
+            if d.dmc:
+                sub_all = sub_all.copy()
+                sub_all[ok_isubs, 0] = _dededisperse(eng, _take_subints(sub_all, ok_isubs), d, ok_isubs)
             for isub in ok_isubs:
                 ich = np.asarray(d.ok_ichans[isub], dtype=int)
                 model = np.asarray(self._model_for(d.freqs[isub], nbin, d.Ps[isub]))
@@ -674,9 +704,11 @@ class GetTOAs(object):
                                                          d.Ps[isub], self.ird['wids'],
                                                          self.ird['irf_types'])
                     modelx = np.fft.irfft(resp * np.fft.rfft(modelx, axis=-1), axis=-1)
-                profs.append(np.asarray(d.subints)[isub, 0, ich])
+                profs.append(sub_all[isub, 0, ich])
                 mprofs.append(modelx)
-                noises.append(np.asarray(d.noise_stds)[isub, 0, ich])
+                # (NaN: the device measures the noise from the power spectrum)
+                noises.append(np.full(len(ich), np.nan) if d.noise_stds is None
+                              else np.asarray(d.noise_stds)[isub, 0, ich])
                 where += [(isub, ichan) for ichan in ich]
             t0 = time.time()
             out = eng.fit_phase_shift_batch(np.concatenate(profs), np.concatenate(mprofs),
@@ -791,8 +823,8 @@ class GetTOAs(object):
                                             unscattered=scat)
                 slot_of[j] = slots[key]
                 scales[j] = self.scales[iarch][isub]
-            port = _take_subints(d.subints, ok_isubs)
-            noise = np.ascontiguousarray(np.asarray(d.noise_stds)[ok_isubs, 0], dtype=np.float64)
+            port = _dededisperse(eng, _take_subints(d.subints, ok_isubs), d, ok_isubs)
+            noise = _noise_rows(d, ok_isubs)
             nu_refs = np.array([self.nu_refs[iarch][isub] for isub in ok_isubs], dtype=np.float64)
             with np.errstate(divide="ignore", invalid="ignore"):
                 rchi2 = eng.channel_red_chi2(port, d.freqs[ok_isubs], d.Ps[ok_isubs], params,

@@ -37,10 +37,12 @@ def fit_portrait_full(data_port, model_port, init_params, P, freqs,
                       quiet=True):
     """Fit phase, DM, GM, tau and alpha between a data and a model portrait.
 
-    Same arguments and result fields as the reference.  `method` selects
-    nothing on the device (one trust-region Newton solver serves the three
-    reference method names; `bounds` are not applied); an unknown method exits
-    like the reference does (pptoaslib.py:1008-1010)."""
+    Same arguments and result fields as the reference.  method='trust-ncg' (the
+    reference's default) walks SciPy's trust-ncg iteration on the device and stops
+    where the reference stops; 'Newton-CG' and 'TNC' both run the device's Newton
+    solver to the rounding of the objective (`bounds` are not applied: the
+    reference drops them too unless TNC, pptoaslib.py:995-997); an unknown method
+    exits like the reference does (pptoaslib.py:1008-1010)."""
     if method not in _METHODS:
         print("Method '%s' is not implemented." % method)
         sys.exit()
@@ -51,7 +53,8 @@ def fit_portrait_full(data_port, model_port, init_params, P, freqs,
     res = eng.fit_batch(data[None] if data.ndim == 2 else data, freqs, P,
                         init_params, errs=errs, nu_fits=[list(nu_fits)],
                         nu_outs=[list(nu_outs)], fit_flags=flags,
-                        log10_tau=log10_tau, option=option, is_toa=is_toa)
+                        log10_tau=log10_tau, option=option, is_toa=is_toa,
+                        method=method)
     r = _bunch(res, 0, flags)
     if r.return_code not in (0, 1, 2, 4):
         rcs = "NaN or singular objective"
@@ -79,7 +82,7 @@ def fit_portrait_full_batch(data_ports, model_port, init_params, Ps, freqs,
                             nu_fits=None, nu_outs=None, errs=None,
                             fit_flags=[1, 1, 0, 0, 0], log10_tau=False, option=0,
                             is_toa=True, chan_mask=None, model_slot=None,
-                            engine=None):
+                            engine=None, method='trust-ncg'):
     """Batched form: data_ports[nsub,nchan,nbin] against one model (or several
     pre-loaded slots); returns the dict of result arrays of Engine.fit_batch."""
     eng = engine or default_engine()
@@ -88,7 +91,7 @@ def fit_portrait_full_batch(data_ports, model_port, init_params, Ps, freqs,
     return eng.fit_batch(data_ports, freqs, Ps, init_params, errs=errs,
                          nu_fits=nu_fits, nu_outs=nu_outs, fit_flags=fit_flags,
                          log10_tau=log10_tau, option=option, is_toa=is_toa,
-                         chan_mask=chan_mask, model_slot=model_slot)
+                         chan_mask=chan_mask, model_slot=model_slot, method=method)
 
 
 # --------------------------------------------------------------------------
