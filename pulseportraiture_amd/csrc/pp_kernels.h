@@ -1543,10 +1543,13 @@ __device__ inline double pick_poly_root(const double* cin, int deg, double targe
     while (n > 0 && cin[off + n] == 0.0) --n;   // roots at zero are never selected
     for (int j = 0; j <= n; ++j) c[j] = cin[off + j] / cin[off];
     if (n <= 0) return NAN;
-    // Cauchy bound for the starting circle
+    // Fujiwara's bound on the root moduli, 2 max_j |c_j|^(1/j): within a factor of
+    // two of the largest root however the coefficients are scaled (the nu_zero
+    // polynomials in nu^2 have coefficient ratios of 1e17..1e31; Cauchy's bound
+    // 1 + max|c_j| would start the iteration 25 decades away)
     double rad = 0.0;
-    for (int j = 1; j <= n; ++j) rad = fmax(rad, fabs(c[j]));
-    rad = 1.0 + rad;
+    for (int j = 1; j <= n; ++j) rad = fmax(rad, pow(fabs(c[j]), 1.0 / (double)j));
+    rad *= 2.0;
     double zr[6], zi[6];
     for (int j = 0; j < n; ++j) {
         double s, co;
@@ -1554,8 +1557,9 @@ __device__ inline double pick_poly_root(const double* cin, int deg, double targe
         zr[j] = 0.5 * rad * co; zi[j] = 0.5 * rad * s;
     }
     // (stops a few ulp short: every selected root is polished by Newton below, and
-    // a step that hovers at the rounding level would otherwise never meet a tighter test)
-    for (int it = 0; it < 64; ++it) {
+    // a step that hovers at the rounding level would otherwise never meet a tighter
+    // test; roots that are zero to rounding are measured against the bound instead)
+    for (int it = 0; it < 200; ++it) {
         double maxstep = 0.0;
         for (int j = 0; j < n; ++j) {
             // p(z), p'(z) by Horner
@@ -1580,7 +1584,7 @@ __device__ inline double pick_poly_root(const double* cin, int deg, double targe
             const double qr = 1.0 - (wr * sr - wi * si), qi = -(wr * si + wi * sr), qn = qr * qr + qi * qi;
             const double stx = (wr * qr + wi * qi) / qn, sty = (wi * qr - wr * qi) / qn;
             zr[j] -= stx; zi[j] -= sty;
-            maxstep = fmax(maxstep, (fabs(stx) + fabs(sty)) / (fabs(zr[j]) + fabs(zi[j]) + 1e-300));
+            maxstep = fmax(maxstep, (fabs(stx) + fabs(sty)) / (fabs(zr[j]) + fabs(zi[j]) + 1e-10 * rad));
         }
         if (maxstep < 8e-16) break;
     }
