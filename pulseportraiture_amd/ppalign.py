@@ -83,7 +83,7 @@ def align_subints(ports, freqs, Ps, noise_stds, model_port, weights=None, SNRs=N
         # ppalign.py:183-186
         res = eng.fit_batch(ports, f2, Ps, x0, errs=errs, chan_mask=mask,
                             nu_fits=np.repeat(nu_fit[:, None], 3, axis=1), fit_flags=flags,
-                            log10_tau=False, seed_ns=nbin)
+                            log10_tau=False, seed_ns=nbin, method='newton')
         scales = np.where(mask > 0, res["scales"], 0.0)
         w_acc = np.where(mask > 0, scales / errs ** 2.0, 0.0)
         aligned, totw = eng.align_accumulate(ports, f2, Ps, res["params"][:, 0],

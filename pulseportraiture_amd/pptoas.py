@@ -311,7 +311,13 @@ class GetTOAs(object):
                  quiet=None):
         """Same arguments as the reference (pptoas.py:150-156).  Not supported
         here: tscrunch and show_plot (they raise) -- they live in PSRCHIVE / the
-        plotting code."""
+        plotting code.  Every `method` runs the device's Newton solver to the
+        rounding of the objective: the phase seed is formed on the device (the exact
+        maximum of the channel-summed cross-correlation, where the reference polishes
+        a 100-point grid with a simplex to 1e-4), so SciPy's iterates from the
+        reference's own starting point cannot be retraced here, and the optimum is
+        the point closest to wherever they stop (fit_portrait_full, given the same
+        init_params as the reference, does retrace them)."""
         if quiet is None:
             quiet = self.quiet
         if tscrunch or show_plot:
@@ -447,7 +453,7 @@ class GetTOAs(object):
                                   nu_fits=nu_fit_arr[sel], nu_outs=nu_ref_arr[sel],
                                   fit_flags=fl, log10_tau=log10_tau, option=0,
                                   is_toa=True, model_slot=slot_of[sel],
-                                  chan_mask=mask[sel], seed_ns=100, method=method)
+                                  chan_mask=mask[sel], seed_ns=100, method='newton')
                 if res is None:
                     res = {k: (np.zeros((nok,) + v.shape[1:], dtype=v.dtype)
                                if isinstance(v, np.ndarray) else v) for k, v in r.items()}

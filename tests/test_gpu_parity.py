@@ -1102,7 +1102,13 @@ def test_randomised_shapes_and_flags_match_oracle(eng):
                 assert _dphi(r["params"][i, 0], o.phi) < 1e-6, (case, i)
             else:
                 assert _dphi(r["params"][i, 0], o.phi) < PHI_BAR, (case, i)
-            raw = _dphi(rn["params"][i, 0], o.phi)
+            # (phases compared at the SAME reference frequencies: with a non-dedispersed
+            # DM or a large GM a 1e-7 relative difference of the zero-covariance
+            # frequency alone moves the phase by more than the bar)
+            Kd, Kg = orc.Dconst * rn["params"][i, 1] / Ps[i], orc.Dconst ** 2 * rn["params"][i, 2] / Ps[i]
+            phi_rn = rn["params"][i, 0] + Kd * (o.nu_DM ** -2 - rn["nu_refs"][i, 0] ** -2) + \
+                Kg * (o.nu_GM ** -4 - rn["nu_refs"][i, 1] ** -4)
+            raw = _dphi(phi_rn, o.phi)
             if raw >= PHI_BAR:
                 # A marginal exit: SciPy's last accepted step was worth about one ulp
                 # of f, so whether it is taken depends on the rounding of f itself (the
