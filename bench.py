@@ -6,10 +6,18 @@ resident in HBM (BASELINE.json metric), one process per GPU.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the whole fit (rFFT, cross-spectrum, trust-region
-solve, zero-covariance frequency, errors, S/N, chi2) over one batch of
-`nsub` subints per GPU; the batch is generated on the device before the timed
-region.  Rank 0 prints ONE JSON line.
+A "step" is one pass of the whole fit (rFFT, cross-spectrum, solve, zero-covariance
+frequency, errors, S/N, chi2) over one batch of `nsub` subints per GPU; the batch is
+generated on the device and its phase guesses are formed the way pptoas forms them
+(dedispersed mean profile -> fit_phase_shift -> phase_transform, pptoas.py:421-457)
+before the timed region.  The TOA records of every step stay in HBM and are gathered
+ONCE, at the end of the timed region (RCCL gather of device tensors).  Rank 0 prints
+ONE JSON line; at N = 1 it also carries the other workloads (3 steps each, same
+process) and the CPU baseline (1 core and a one-worker-per-core pool).
+
+    --total-nsub 100000   configs[4] as written: the subints are dealt in contiguous
+                          shards to the ranks (strong scaling) and fitted in
+                          device-generated sub-batches of --nsub
 """
 import argparse
 import json
@@ -49,6 +57,66 @@ def algorithmic_bytes_per_fit(C, B, s, n_share):
     return C * B * s + C * B * s / n_share + 40 * C + 512
 
 
+# --------------------------------------------------------------------------
+# CPU baseline workers (spawned BEFORE this process touches the GPU; they import
+# NumPy/SciPy and the oracle only)
+# --------------------------------------------------------------------------
+def _cpu_fit(job):
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[v] = "1"
+    path, model_path, x0, P, freqs, nu_fit, err, flags, log10_tau = job
+    from oracle import pptoas_oracle as orc
+    data = np.load(path)
+    model = np.load(model_path)
+    t0 = time.perf_counter()
+    o = orc.fit_portrait_full(data, model, x0, P, freqs, [nu_fit] * 3, [None] * 3, err,
+                              flags, log10_tau=log10_tau)
+    return o.phi, o.DM, time.perf_counter() - t0
+
+
+def _cpu_warm(_):
+    from oracle import pptoas_oracle  # noqa: F401
+    return os.getpid()
+
+
+def start_cpu_pool():
+    """One worker per physical core (psutil; half the logical cores otherwise),
+    single-threaded BLAS/FFT in each."""
+    import multiprocessing as mp
+    try:
+        import psutil
+        workers = psutil.cpu_count(logical=False) or 0
+    except ImportError:
+        workers = 0
+    avail = len(os.sched_getaffinity(0))
+    if workers <= 0:
+        workers = max(1, avail // 2)
+    workers = max(1, min(workers, avail))
+    # memory: ~0.7 GB per worker at 4096 x 2048 (measured); stay under 40 % of what
+    # the host (or the container's cgroup) has free
+    free_b = None
+    try:
+        import psutil
+        free_b = psutil.virtual_memory().available
+    except ImportError:
+        pass
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        cur = int(open("/sys/fs/cgroup/memory.current").read().strip())
+        if lim != "max":
+            free_b = min(free_b, int(lim) - cur) if free_b is not None else int(lim) - cur
+    except (OSError, ValueError):
+        pass
+    if free_b is not None:
+        workers = max(1, min(workers, int(0.4 * free_b / 1.0e9)))
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(v, "1")
+    pool = mp.get_context("spawn").Pool(workers)
+    pool.map(_cpu_warm, range(workers), chunksize=1)     # imports done before the clock
+    return pool, workers
+
+
+# --------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,19 +125,34 @@ def main():
     ap.add_argument("--workload", default="toa-4096x2048-phiDM",
                     choices=sorted(WORKLOADS))
     ap.add_argument("--nsub", type=int, default=0, help="subints per GPU per step")
+    ap.add_argument("--total-nsub", type=int, default=0,
+                    help="> 0: strong scaling -- this many subints in all, dealt to the ranks in "
+                         "contiguous shards and fitted in device-generated sub-batches of --nsub")
     ap.add_argument("--input-dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--method", default="trust-ncg", choices=["trust-ncg", "newton"])
     ap.add_argument("--dm0", type=float, default=34.56789)
     ap.add_argument("--sigma", type=float, default=0.05)
     ap.add_argument("--seed", type=int, default=20260101)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0,
-                    help="subints the CPU baseline fits (0 = as many as fit in ~12 s, at most 64)")
+                    help="subints the 1-core CPU leg fits (0 = as many as fit in ~10 s)")
     ap.add_argument("--seed-ns", type=int, default=0,
                     help="> 0: ignore the phase guesses and seed the phase on the device "
                          "with an N-point grid (the whole pptoas preamble + fit)")
+    ap.add_argument("--truth-guesses", action="store_true",
+                    help="phase guesses = injected phase + 1e-4 rot of noise instead of the "
+                         "fit_phase_shift seed (experiments)")
     ap.add_argument("--harm-eps", type=float, default=None,
                     help="override the harmonic-truncation threshold (experiments)")
     args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    pool = None
+    if world == 1 and not args.no_cpu_baseline:
+        pool = start_cpu_pool()         # before anything initialises the GPU
 
     import torch
     import torch.distributed as dist
@@ -78,9 +161,6 @@ def main():
     from pulseportraiture_amd.engine import Engine
     from pulseportraiture_amd.pplib import guess_fit_freq
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d"
@@ -106,64 +186,9 @@ def main():
             os.dup2(saved, 1)
             os.close(saved)
 
-    C, B, flags, log10_tau, nsub_def, note = WORKLOADS[args.workload]
-    nsub = args.nsub or nsub_def
-    tdtype = torch.float64 if args.input_dtype == "f64" else torch.float32
-    s_bytes = 8 if args.input_dtype == "f64" else 4
-
     eng = Engine(local_rank)
     if args.harm_eps is not None:
         eng.set_option("harm_eps", args.harm_eps)
-    freqs, model, P0 = gmodel.example_model(C, B)
-    nharm = eng.set_model(model)
-    # ---- synthetic batch, generated on the device (weak scaling: every rank
-    # owns nsub subints; global subint index keys the RNG) ----
-    rng = np.random.default_rng([args.seed, rank])
-    first = rank * nsub
-    P = np.full(nsub, P0)
-    inj = np.zeros((nsub, 3))
-    inj[:, 0] = rng.uniform(-0.5, 0.5, nsub)
-    inj[:, 1] = args.dm0 + rng.normal(3e-4, 2e-4, nsub)
-    tau_rot = 0.0
-    if flags[2]:
-        inj[:, 2] = rng.normal(0.25, 0.05, nsub)
-    data = torch.empty((nsub, C, B), dtype=tdtype, device=device)
-    if flags[3]:
-        # scattered template: tau = 20 us at 1500 MHz, alpha = -4
-        tau_rot = 20e-6 / P0
-        taus = tau_rot * (freqs / 1500.0) ** -4.0
-        k = np.arange(B // 2 + 1)
-        smodel = np.fft.irfft(np.fft.rfft(model, axis=-1) /
-                              (1.0 + 2j * np.pi * np.outer(taus, k)), axis=-1)
-        eng.set_model(smodel, slot=1)
-        eng.synth_portraits(data, freqs, P, inj, args.sigma, args.seed, first, slot=1)
-    else:
-        eng.synth_portraits(data, freqs, P, inj, args.sigma, args.seed, first)
-    # ---- initial guesses as the caller forms them (pptoas.py:399-460): DM =
-    # header DM, phase from the 1-D seed fit (good to ~1e-4 rot), at nu_fit ----
-    nu_fit = float(guess_fit_freq(freqs))
-    x0 = np.zeros((nsub, 5))
-    phi_true = inj[:, 0] + DCONST * inj[:, 1] / P / nu_fit ** 2 + \
-        DCONST ** 2 * inj[:, 2] / P / nu_fit ** 4
-    x0[:, 0] = (phi_true + 1e-4 * rng.standard_normal(nsub) + 0.5) % 1.0 - 0.5
-    x0[:, 1] = args.dm0
-    if flags[3]:
-        x0[:, 3] = np.log10(1.5 * tau_rot * (nu_fit / 1500.0) ** -4.0) \
-            if log10_tau else 1.5 * tau_rot * (nu_fit / 1500.0) ** -4.0
-        x0[:, 4] = -4.0
-    errs = np.full((nsub, C), args.sigma)
-    errs_dev = torch.full((nsub, C), args.sigma, dtype=torch.float64, device=device)
-    nu_fits = np.full((nsub, 3), nu_fit)
-    # per-channel inputs and outputs stay in HBM (inputs resident before the timed
-    # region; the fitted TOA records are what leaves the GPU)
-    kw = dict(errs=errs_dev, nu_fits=nu_fits, fit_flags=flags, log10_tau=log10_tau,
-              per_channel="device", seed_ns=args.seed_ns)
-
-    def step():
-        res = eng.fit_batch(data, freqs, P, x0, **kw)
-        rec = ppdist.pack_records(res)
-        out = ppdist.gather_records(rec, device=device)   # one RCCL gather
-        return res, out
 
     def fence():
         eng.synchronize()
@@ -172,33 +197,157 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    eng.set_option("profile", 1)
-    eng.kernel_times(reset=True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res, gathered = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    eng.set_option("profile", 0)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ktimes = eng.kernel_times()
+    # ----------------------------------------------------------------------
+    class Batch(object):
+        """One workload's template, device-resident synthetic subints and guesses."""
 
-    if rank == 0:
-        total_fits = nsub * world * args.steps
-        value = total_fits / elapsed
-        # ---- roofline of the dominant kernel family (HIP events on the
-        # engine's own stream, recorded inside the timed region) ----
+        def __init__(self, workload, nsub, input_dtype, first_subint, seed_ns=0):
+            self.workload = workload
+            C, B, flags, log10_tau, nsub_def, note = WORKLOADS[workload]
+            self.C, self.B, self.flags, self.log10_tau, self.note = C, B, flags, log10_tau, note
+            self.nsub = nsub or nsub_def
+            self.input_dtype, self.seed_ns = input_dtype, seed_ns
+            self.s_bytes = 8 if input_dtype == "f64" else 4
+            self.freqs, self.model, self.P0 = gmodel.example_model(C, B)
+            self.nharm = eng.set_model(self.model)
+            self.gen_slot, self.tau_rot = 0, 0.0
+            if flags[3]:
+                # scattered template: tau = 20 us at 1500 MHz, alpha = -4 (SURVEY 8d)
+                self.tau_rot = 20e-6 / self.P0
+                taus = self.tau_rot * (self.freqs / 1500.0) ** -4.0
+                k = np.arange(B // 2 + 1)
+                smodel = np.fft.irfft(np.fft.rfft(self.model, axis=-1) /
+                                      (1.0 + 2j * np.pi * np.outer(taus, k)), axis=-1)
+                eng.set_model(smodel, slot=1)
+                self.gen_slot = 1
+            self.nu_fit = float(guess_fit_freq(self.freqs))
+            # template profile of the 1-D seed fit: the mean profile, scattered with the
+            # GUESSED tau at nu_fit when scattering is fitted (pptoas.py:430-452)
+            self.seed_prof = self.model.mean(axis=0)
+            if flags[3]:
+                tg = 1.5 * self.tau_rot * (self.nu_fit / 1500.0) ** -4.0
+                k = np.arange(B // 2 + 1)
+                self.seed_prof = np.fft.irfft(np.fft.rfft(self.seed_prof) / (1.0 + 2j * np.pi * k * tg))
+            self.data = torch.empty((self.nsub, C, B), device=device,
+                                    dtype=torch.float64 if input_dtype == "f64" else torch.float32)
+            self.errs_dev = torch.full((self.nsub, C), args.sigma, dtype=torch.float64, device=device)
+            self.P = np.full(self.nsub, self.P0)
+            self.generate(first_subint)
+
+        def generate(self, first_subint):
+            """Fill the device buffer with subints [first, first + nsub) of the job
+            (RNG keyed on the global subint index) and form their guesses."""
+            nsub, flags = self.nsub, self.flags
+            rng = np.random.default_rng([args.seed, first_subint])
+            inj = np.zeros((nsub, 3))
+            inj[:, 0] = rng.uniform(-0.5, 0.5, nsub)
+            inj[:, 1] = args.dm0 + rng.normal(3e-4, 2e-4, nsub)
+            if flags[2]:
+                inj[:, 2] = rng.normal(0.25, 0.05, nsub)
+            self.inj = inj
+            eng.synth_portraits(self.data, self.freqs, self.P, inj, args.sigma, args.seed,
+                                first_subint, slot=self.gen_slot)
+            x0 = np.zeros((nsub, 5))
+            x0[:, 1] = args.dm0
+            if args.truth_guesses:
+                phi_true = inj[:, 0] + DCONST * inj[:, 1] / self.P / self.nu_fit ** 2 + \
+                    DCONST ** 2 * inj[:, 2] / self.P / self.nu_fit ** 4
+                x0[:, 0] = (phi_true + 1e-4 * rng.standard_normal(nsub) + 0.5) % 1.0 - 0.5
+                self.guess = "injected phase + 1e-4 rot noise"
+            elif self.seed_ns > 0:
+                self.guess = "device seed inside the timed fit (seed_ns=%d)" % self.seed_ns
+            else:
+                x0[:, 0] = self.pptoas_phase_guess()
+                self.guess = "pptoas preamble (rotate to nu_mean, mean profile, fit_phase_shift Ns=100)"
+            if flags[3]:
+                t0 = 1.5 * self.tau_rot * (self.nu_fit / 1500.0) ** -4.0
+                x0[:, 3] = np.log10(t0) if self.log10_tau else t0
+                x0[:, 4] = -4.0
+            self.x0 = x0
+
+        def pptoas_phase_guess(self):
+            """pptoas.py:421-457 on the device: dedisperse every subint at the header
+            DM to the mean frequency, average over channels, 1-D FFTFIT against the
+            template's mean profile (Ns = 100), move the phase to nu_fit."""
+            nu_mean = float(self.freqs.mean())
+            profs = np.empty((self.nsub, self.B))
+            step = max(1, min(self.nsub, int(8e9 // (self.C * self.B * 8))))
+            for s0 in range(0, self.nsub, step):
+                chunk = self.data[s0:s0 + step].to(torch.float64).clone()
+                n = chunk.shape[0]
+                eng.rotate_portraits(chunk, self.freqs, self.P[s0:s0 + n], DM=np.full(n, args.dm0),
+                                     nu_DM=nu_mean)
+                profs[s0:s0 + n] = chunk.mean(dim=1).cpu().numpy()
+                del chunk
+            out = eng.fit_phase_shift_batch(profs, self.seed_prof, Ns=100)
+            phi = out[:, 0] + DCONST * args.dm0 / self.P * (self.nu_fit ** -2 - nu_mean ** -2)
+            return (phi + 0.5) % 1.0 - 0.5
+
+        def fit(self, records=None, method=None):
+            return eng.fit_batch(self.data, self.freqs, self.P, self.x0, errs=self.errs_dev,
+                                 nu_fits=np.full((self.nsub, 3), self.nu_fit), fit_flags=self.flags,
+                                 log10_tau=self.log10_tau, per_channel="device",
+                                 seed_ns=self.seed_ns, method=method or args.method, records=records)
+
+        def free(self):
+            del self.data, self.errs_dev
+            torch.cuda.empty_cache()
+
+    def timed(batch, steps, warmup, method=None):
+        """`steps` passes over the resident batch; records of all steps stay on the
+        device and are gathered once before the clock stops."""
+        recs = torch.zeros((steps, batch.nsub, ppdist.RECORD_WIDTH), dtype=torch.float64, device=device)
+        for _ in range(warmup):
+            batch.fit(method=method)
+        eng.set_option("profile", 1)
+        eng.kernel_times(reset=True)
+        fence()
+        t0 = time.perf_counter()
+        res = None
+        for k in range(steps):
+            res = batch.fit(records=recs[k], method=method)
+        gathered = ppdist.gather_records(recs.view(-1, ppdist.RECORD_WIDTH))   # one RCCL gather
+        fence()
+        elapsed = time.perf_counter() - t0
+        eng.set_option("profile", 0)
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return res, gathered, elapsed, eng.kernel_times()
+
+    def summary(batch, res, elapsed, ktimes, steps, nfits):
         fam = max((k for k in ktimes if ktimes[k][1] > 0), key=lambda k: ktimes[k][0])
-        fam_s, fam_n = ktimes[fam]
-        per_step_s = fam_s / args.steps
-        abytes = algorithmic_bytes_per_fit(C, B, s_bytes, nsub)
-        achieved = abytes * nsub / per_step_s / 1e9
+        per_step_s = ktimes[fam][0] / steps
+        abytes = algorithmic_bytes_per_fit(batch.C, batch.B, batch.s_bytes, batch.nsub)
+        achieved = abytes * batch.nsub / per_step_s / 1e9
+        return fam, per_step_s, abytes, achieved, {
+            "fits_per_s": round(nfits / elapsed, 2),
+            "ms_per_step": round(1e3 * elapsed / steps, 3),
+            "dominant_kernel": fam,
+            "hbm_frac_of_8TBps": round(achieved / HBM_PEAK_GBPS, 4),
+            "kernels_ms_per_step": {k: round(1e3 * v[0] / steps, 4) for k, v in ktimes.items() if v[1] > 0},
+            "nfeval_mean": float(np.mean(res["nfeval"])), "nfeval_max": int(np.max(res["nfeval"])),
+            "return_codes": {str(k): int(v) for k, v in zip(*np.unique(res["return_code"],
+                                                                      return_counts=True))}}
+
+    # ======================================================================
+    if args.total_nsub > 0:
+        strong_scaling(args, eng, Batch, fence, ppdist, dist, torch, device, rank, world, use_dist)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    batch = Batch(args.workload, args.nsub, args.input_dtype, rank * (args.nsub or WORKLOADS[args.workload][4]),
+                  seed_ns=args.seed_ns)
+    res, gathered, elapsed, ktimes = timed(batch, args.steps, args.warmup)
+
+    line = None
+    if rank == 0:
+        nsub, C, B = batch.nsub, batch.C, batch.B
+        fam, per_step_s, abytes, achieved, summ = summary(batch, res, elapsed, ktimes, args.steps,
+                                                          nsub * world * args.steps)
         # HBM bytes per launch of that kernel from the PMC passes (FETCH_SIZE x2 +
         # WRITE_SIZE, collected separately with rocprofv3 --pmc and committed under
         # profiles/); null when no matching profile exists
@@ -209,7 +358,6 @@ def main():
                     and tp["kernel"] == fam):
                 traffic = tp["hbm_bytes_per_fit"] * nsub
                 if "valu_issue_frac_per_wave" in tp:
-                    # what actually limits the kernel (counter passes under profiles/)
                     co_limit = {"resource": "f64 VALU issue",
                                 "busy_frac": round(tp["valu_issue_frac_per_wave"] *
                                                    tp.get("waves_per_simd", 1), 3),
@@ -223,64 +371,197 @@ def main():
                     "algorithmic_bytes_per_launch": abytes * nsub,
                     "algorithmic_bytes_per_fit": abytes,
                     "fits_per_launch_group": nsub,
-                    "launches_per_step": fam_n / args.steps,
+                    "launches_per_step": ktimes[fam][1] / args.steps,
                     "ms_per_step_in_kernel": round(1e3 * per_step_s, 4),
-                    "all_kernels_ms_per_step": {
-                        k: round(1e3 * v[0] / args.steps, 4) for k, v in ktimes.items()
-                        if v[1] > 0}}
-        line = {"metric": "subint_fits_per_sec", "value": round(value, 2),
+                    "all_kernels_ms_per_step": summ["kernels_ms_per_step"]}
+        rec = gathered.cpu().numpy() if hasattr(gathered, "cpu") else np.asarray(gathered)
+        line = {"metric": "subint_fits_per_sec", "value": summ["fits_per_s"],
                 "unit": "fits/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+                "warmup": args.warmup, "ms_per_step": summ["ms_per_step"],
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f64", "data": "synthetic",
-                "config": {"workload": args.workload, "note": note,
+                "config": {"workload": args.workload, "note": batch.note,
                            "nsub_per_gpu_per_step": nsub, "nchan": C, "nbin": B,
-                           "fit_flags": flags, "input_dtype": args.input_dtype,
-                           "bytes_per_sample_resident": s_bytes, "dm0": args.dm0,
-                           "sigma": args.sigma, "model_harmonics_kept": nharm,
+                           "fit_flags": batch.flags, "input_dtype": args.input_dtype,
+                           "bytes_per_sample_resident": batch.s_bytes, "dm0": args.dm0,
+                           "sigma": args.sigma, "model_harmonics_kept": batch.nharm,
+                           "method": args.method, "phase_guesses": batch.guess,
                            "device_phase_seed_ns": args.seed_ns,
-                           "parallelism": "subint shards, %d rank(s), 1 gather" % world},
+                           "parallelism": "subint shards, %d rank(s), records kept in HBM, "
+                                          "1 gather at the end" % world},
                 "roofline": roofline,
-                "convergence": {"nfeval_mean": float(np.mean(res["nfeval"])),
-                                "nfeval_max": int(np.max(res["nfeval"])),
-                                "return_codes": {str(k): int(v) for k, v in zip(
-                                    *np.unique(res["return_code"], return_counts=True))}}}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(data, freqs, P, x0, errs, nu_fit, flags,
-                                                log10_tau, res, args.cpu_sample, model)
+                "convergence": {"nfeval_mean": summ["nfeval_mean"], "nfeval_max": summ["nfeval_max"],
+                                "return_codes": summ["return_codes"]},
+                "gathered_records": {"rows": int(rec.shape[0]),
+                                     "checksum": ppdist.records_checksum(rec)["column_sums"][:3]}}
+    # ---- the other workloads, same process, 3 steps each (N = 1 only) ----
+    if world == 1 and not args.no_other_workloads:
+        keep = dict(data=batch.data[:64].cpu().numpy() if pool is not None else None)
+        main_x0, main_P, main_res = batch.x0, batch.P, res
+        main_model, main_freqs, main_nu_fit = batch.model, batch.freqs, batch.nu_fit
+        main_flags, main_l10 = batch.flags, batch.log10_tau
+        batch.free()
+        others = {}
+        plan = [("seeded", args.workload, args.input_dtype, 100, None),
+                ("f32", args.workload, "f32", 0, None),
+                ("cfg2-512x1024-phiDM", "cfg2-512x1024-phiDM", "f64", 0, None),
+                ("cfg3-4096x2048-phiDMGM", "cfg3-4096x2048-phiDMGM", "f64", 0, None),
+                ("cfg4-2048x2048-scat", "cfg4-2048x2048-scat", "f64", 0, None),
+                ("cfg4-2048x2048-scat-newton", "cfg4-2048x2048-scat", "f64", 0, "newton")]
+        for key, wl, dt, sns, meth in plan:
+            if wl == args.workload and dt == args.input_dtype and sns == args.seed_ns and meth is None:
+                continue
+            try:
+                b = Batch(wl, 0, dt, 0, seed_ns=sns)
+                r, _, el, kt = timed(b, 3, 1, method=meth)
+                _, _, _, _, sm = summary(b, r, el, kt, 3, b.nsub * 3)
+                sm.update(workload=wl, input_dtype=dt, seed_ns=sns, nsub=b.nsub,
+                          method=meth or args.method, phase_guesses=b.guess)
+                # recovered values against the injected ones, in units of the errors
+                sm["max_abs_dDM_over_err"] = float(np.max(np.abs(r["params"][:, 1] - b.inj[:, 1]) /
+                                                          r["param_errs"][:, 1]))
+                others[key] = sm
+                b.free()
+            except Exception as exc:      # a secondary workload must not lose the headline
+                others[key] = {"error": repr(exc)}
+        line["other_workloads"] = others
+        if pool is not None:
+            line["cpu_baseline"] = cpu_baseline(pool, keep["data"], main_model, main_freqs, main_P, main_x0,
+                                                args.sigma, main_nu_fit, main_flags, main_l10, main_res,
+                                                args.cpu_sample)
+    elif pool is not None and rank == 0:
+        line["cpu_baseline"] = cpu_baseline(pool, batch.data[:64].cpu().numpy(), batch.model, batch.freqs,
+                                            batch.P, batch.x0, args.sigma, batch.nu_fit, batch.flags,
+                                            batch.log10_tau, res, args.cpu_sample)
+    if pool is not None:
+        pool[0].close()
+        pool[0].join()
+    if rank == 0:
         print(json.dumps(line))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(data, freqs, P, x0, errs, nu_fit, flags, log10_tau, res, nsample, model):
-    """Time the CPU oracle (a NumPy/SciPy port of the reference algorithm) on a
-    bounded sample of the very batch the GPU fitted, and report parity on it."""
+def strong_scaling(args, eng, Batch, fence, ppdist, dist, torch, device, rank, world, use_dist):
+    """configs[4] as written: --total-nsub subints in all, rank r owns the contiguous
+    shard shard_range(total, r, world) and fits it in device-generated sub-batches
+    of --nsub (a sub-batch is generated, the clock runs only while it is fitted:
+    inputs are resident when their timed region starts); every record stays in HBM
+    and ONE gather at the end brings them to rank 0."""
+    C, B, flags, log10_tau, nsub_def, note = WORKLOADS[args.workload]
+    nsub = args.nsub or nsub_def
+    lo, hi = ppdist.shard_range(args.total_nsub, rank, world)
+    counts = [b - a for a, b in (ppdist.shard_range(args.total_nsub, r, world) for r in range(world))]
+    recs = torch.zeros((hi - lo, ppdist.RECORD_WIDTH), dtype=torch.float64, device=device)
+    batch = Batch(args.workload, nsub, args.input_dtype, lo, seed_ns=args.seed_ns)
+    batch.fit()                                  # warm-up (untimed)
+    fit_s, done = 0.0, 0
+    worst = 0.0
+    while done < hi - lo:
+        n = min(nsub, hi - lo - done)
+        if done:
+            batch.generate(lo + done)
+        eng.synchronize(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if n == nsub:
+            res = batch.fit(records=recs[done:done + n])
+        else:      # ragged tail: fit the whole buffer, keep the first n records
+            tmp = torch.zeros((nsub, ppdist.RECORD_WIDTH), dtype=torch.float64, device=device)
+            res = batch.fit(records=tmp)
+            recs[done:done + n] = tmp[:n]
+        eng.synchronize(); torch.cuda.synchronize()
+        fit_s += time.perf_counter() - t0
+        worst = max(worst, float(np.max(np.abs(res["params"][:n, 1] - batch.inj[:n, 1]) /
+                                        res["param_errs"][:n, 1])))
+        done += n
+    fence()
+    t0 = time.perf_counter()
+    gathered = ppdist.gather_records(recs, counts=counts)
+    fence()
+    gather_s = time.perf_counter() - t0
+    total_s = fit_s + gather_s
+    if use_dist:
+        t = torch.tensor([total_s, worst], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        total_s, worst = float(t[0].item()), float(t[1].item())
+    if rank == 0:
+        rec = gathered.cpu().numpy() if hasattr(gathered, "cpu") else np.asarray(gathered)
+        cs = ppdist.records_checksum(rec)
+        print(json.dumps({
+            "metric": "subint_fits_per_sec", "value": round(args.total_nsub / total_s, 2),
+            "unit": "fits/s", "n_gpus": world, "steps": 1, "warmup": 1,
+            "ms_per_step": round(1e3 * total_s, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "note": note, "total_nsub": args.total_nsub,
+                       "fits_per_rank": counts, "sub_batch": nsub, "nchan": C, "nbin": B,
+                       "fit_flags": flags, "input_dtype": args.input_dtype, "method": args.method,
+                       "phase_guesses": batch.guess,
+                       "timed": "fit of every sub-batch (inputs resident, generation excluded) + "
+                                "the one gather of all records",
+                       "parallelism": "contiguous subint shards over %d rank(s), records kept in "
+                                      "HBM, 1 gather at the end" % world},
+            "gather_ms": round(1e3 * gather_s, 3),
+            "gathered_records": {"rows": cs["rows"], "checksum": cs["column_sums"][:3],
+                                 "return_code_sum": cs["column_sums"][17]},
+            "max_abs_dDM_over_err": worst}))
+
+
+def cpu_baseline(pool, data64, model, freqs, P, x0, sigma, nu_fit, flags, log10_tau, res, nsample):
+    """The CPU oracle (a NumPy/SciPy restatement of the reference algorithm) on a
+    bounded sample of the very batch the GPU fitted: (i) one process, one core;
+    (ii) a pool with one single-threaded worker per physical core, every worker one
+    subint.  Parity of the GPU answers on the distinct subints."""
+    import tempfile
     from oracle import pptoas_oracle as orc
-    budget_s, cap = 12.0, min(64, data.shape[0])
-    want = cap if nsample <= 0 else max(1, min(nsample, data.shape[0]))
+    pool, workers = pool
+    errs = np.full(len(freqs), sigma)
+    # ---- (i) one core ----
+    budget_s, cap = 10.0, min(32, data64.shape[0])
+    want = cap if nsample <= 0 else max(1, min(nsample, data64.shape[0]))
     t0 = time.perf_counter()
     outs = []
     for i in range(want):
-        host = data[i].cpu().numpy().astype(np.float64)
-        outs.append(orc.fit_portrait_full(host, model, x0[i], P[i], freqs,
-                                          [nu_fit] * 3, [None] * 3, errs[i], flags,
+        outs.append(orc.fit_portrait_full(data64[i].astype(np.float64), model, x0[i], P[i], freqs,
+                                          [nu_fit] * 3, [None] * 3, errs, flags,
                                           log10_tau=log10_tau))
-        # bounded sample: stop when the next fit would overrun the time budget
         el = time.perf_counter() - t0
         if nsample <= 0 and el + el / (i + 1) > budget_s:
             break
-    nsample = len(outs)
-    dt = time.perf_counter() - t0
-    dphi = max(abs(((o.phi - res["params"][i, 0]) + 0.5) % 1.0 - 0.5)
-               for i, o in enumerate(outs))
+    n1 = len(outs)
+    dt1 = time.perf_counter() - t0
+    dphi = max(abs(((o.phi - res["params"][i, 0]) + 0.5) % 1.0 - 0.5) for i, o in enumerate(outs))
     dDM = max(abs(o.DM - res["params"][i, 1]) for i, o in enumerate(outs))
-    return {"value": round(nsample / dt, 5), "unit": "fits/s", "cores": 1,
-            "kind": "port", "host_cpu_count": os.cpu_count(),
-            "sample": "%d subint(s) of the timed batch, whole fit_portrait_full "
-                      "(oracle/pptoas_oracle.py), %.1f s" % (nsample, dt),
-            "parity_on_sample": {"max_abs_dphi": dphi, "max_abs_dDM": dDM}}
+    # ---- (ii) one worker per physical core, n = max(8, workers) fits ----
+    ndistinct = min(16, data64.shape[0])
+    njobs = max(8, workers)
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=shm) as tmp:
+        mpath = os.path.join(tmp, "model.npy")
+        np.save(mpath, model)
+        paths = []
+        for i in range(ndistinct):
+            paths.append(os.path.join(tmp, "sub%d.npy" % i))
+            np.save(paths[-1], data64[i].astype(np.float64))
+        jobs = [(paths[j % ndistinct], mpath, x0[j % ndistinct], P[j % ndistinct], freqs, nu_fit, errs,
+                 flags, log10_tau) for j in range(njobs)]
+        t0 = time.perf_counter()
+        pres = pool.map(_cpu_fit, jobs, chunksize=1)
+        dtp = time.perf_counter() - t0
+    for j, (phi, DM, _) in enumerate(pres):
+        i = j % ndistinct
+        dphi = max(dphi, abs(((phi - res["params"][i, 0]) + 0.5) % 1.0 - 0.5))
+        dDM = max(dDM, abs(DM - res["params"][i, 1]))
+    return {"value": round(njobs / dtp, 4), "unit": "fits/s", "cores": workers, "kind": "port",
+            "workers": workers, "host_cpu_count": os.cpu_count(),
+            "sample": "%d fits (%d distinct subints of the timed batch, one per worker, "
+                      "single-threaded NumPy/SciPy each), whole fit_portrait_full "
+                      "(oracle/pptoas_oracle.py), %.1f s wall; mean %.1f s per fit inside a worker"
+                      % (njobs, ndistinct, dtp, float(np.mean([p[2] for p in pres]))),
+            "one_core": {"value": round(n1 / dt1, 5), "unit": "fits/s", "cores": 1,
+                         "sample": "%d subint(s), %.1f s" % (n1, dt1)},
+            "parity_on_sample": {"max_abs_dphi": dphi, "max_abs_dDM": dDM,
+                                 "subints": max(n1, ndistinct)}}
 
 
 if __name__ == "__main__":

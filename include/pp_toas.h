@@ -170,7 +170,13 @@ typedef struct {
     double* obj_grad;     /* [nsub][5]   its gradient, or NULL */
     double* obj_hess;     /* [nsub][25]  its Hessian, or NULL */
     double* duration;     /* [1] seconds of device time for the whole call */
+    double* records_dev;  /* DEVICE pointer [nsub][PP_RECORD_WIDTH] or NULL: one fixed-size
+                             TOA record per subint left in HBM -- phi, DM, GM, tau, alpha,
+                             their five errors, nu_DM, nu_GM, nu_tau, chi2, red_chi2, snr,
+                             nfeval, return_code -- what the ranks of a multi-GPU job
+                             gather (one RCCL gather at the end of the job) */
 } pp_fit_out;
+#define PP_RECORD_WIDTH 18
 
 /* Fit every subint of the batch: rFFT, cross-spectrum, trust-region Newton
  * solve, zero-covariance frequencies, errors, S/N, chi2.  One call replaces

@@ -86,6 +86,7 @@ struct FitArgs {
     double* o_chi2; double* o_rchi2; double* o_snr; int* o_nfev; int* o_rc;
     double* o_scales; double* o_scale_errs; double* o_csnr;
     double* o_f0; double* o_g0; double* o_H0;
+    double* o_rec;            // [nsub][PP_RECORD_WIDTH] TOA records left on the device, or nullptr
 };
 
 // --------------------------------------------------------------------------
@@ -1904,6 +1905,13 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs a) {
         a.o_snr[i] = sqrt(m[30]);
         a.o_nfev[i] = s.nfev;
         a.o_rc[i] = s.status;
+        if (a.o_rec) {
+            double* rec = a.o_rec + (size_t)i * PP_RECORD_WIDTH;
+            for (int j = 0; j < 5; ++j) { rec[j] = op[j]; rec[5 + j] = oe[j]; }
+            rec[10] = noDM; rec[11] = noGM; rec[12] = notau;
+            rec[13] = chi2; rec[14] = chi2 / dof; rec[15] = sqrt(m[30]);
+            rec[16] = (double)s.nfev; rec[17] = (double)s.status;
+        }
         if (a.o_f0) a.o_f0[i] = s.f0;
         if (a.o_g0) for (int j = 0; j < 5; ++j) a.o_g0[(size_t)i * 5 + j] = s.g0[j];
         if (a.o_H0) for (int j = 0; j < 25; ++j) a.o_H0[(size_t)i * 25 + j] = s.H0[j];

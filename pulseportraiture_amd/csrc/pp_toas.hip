@@ -599,6 +599,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         fa.o_csnr = out->channel_snrs ? c->o_csnr.as<double>() : nullptr;
     }
     fa.o_f0 = c->o_f0.as<double>(); fa.o_g0 = c->o_g0.as<double>(); fa.o_H0 = c->o_H0.as<double>();
+    fa.o_rec = out->records_dev ? out->records_dev + (size_t)s0 * PP_RECORD_WIDTH : nullptr;
 
     if (in->seed_ns > 0) {
         // the coarse seed uses the lowest 64 * PP_SEED_KPT = 1024 harmonics at most

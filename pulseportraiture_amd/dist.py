@@ -43,8 +43,10 @@ def unpack_records(rec):
 
 def gather_records(rec, counts=None, device=None, dst=0):
     """Gather per-rank record blocks on rank `dst`; returns the concatenated
-    [sum(counts), RECORD_WIDTH] array there and None elsewhere.  Without an
-    initialised process group this is the identity."""
+    [sum(counts), RECORD_WIDTH] array there and None elsewhere.  `rec` is a NumPy
+    array or a torch tensor (a CUDA tensor is gathered as it is: device buffers
+    over RCCL, no host staging; the result is then a tensor on the same device).
+    Without an initialised process group this is the identity."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
@@ -53,11 +55,28 @@ def gather_records(rec, counts=None, device=None, dst=0):
     if counts is None:
         counts = [rec.shape[0]] * world
     nmax = max(counts)
-    dev = device if device is not None else "cpu"
-    buf = torch.zeros((nmax, RECORD_WIDTH), dtype=torch.float64, device=dev)
-    buf[:rec.shape[0]] = torch.from_numpy(np.ascontiguousarray(rec)).to(dev)
+    as_tensor = torch.is_tensor(rec)
+    if as_tensor:
+        dev = rec.device
+        src = rec.to(torch.float64)
+    else:
+        dev = device if device is not None else "cpu"
+        src = torch.from_numpy(np.ascontiguousarray(rec, dtype=np.float64)).to(dev)
+    if src.shape[0] == nmax:
+        buf = src.contiguous()
+    else:
+        buf = torch.zeros((nmax, RECORD_WIDTH), dtype=torch.float64, device=dev)
+        buf[:src.shape[0]] = src
     outs = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
     dist.gather(buf, gather_list=outs, dst=dst)
     if rank != dst:
         return None
-    return np.concatenate([o[:c].cpu().numpy() for o, c in zip(outs, counts)])
+    cat = torch.cat([o[:c] for o, c in zip(outs, counts)])
+    return cat if as_tensor else cat.cpu().numpy()
+
+
+def records_checksum(rec):
+    """Order-independent digest of a block of records (sum of every column and the
+    number of rows): what a multi-GPU job prints so that runs can be compared."""
+    a = rec.detach().cpu().numpy() if hasattr(rec, "detach") else np.asarray(rec)
+    return {"rows": int(a.shape[0]), "column_sums": [float(v) for v in a.sum(axis=0)]}

@@ -131,18 +131,26 @@ class Engine(object):
     def fit_batch(self, data, freqs, P, init_params, errs=None, nu_fits=None,
                   nu_outs=None, fit_flags=(1, 1, 0, 0, 0), log10_tau=False,
                   option=0, is_toa=True, model_slot=None, chan_mask=None,
-                  per_channel=True, objective=False, seed_ns=0, method='trust-ncg'):
+                  per_channel=True, objective=False, seed_ns=0, method='trust-ncg',
+                  records=None):
         """Fit nsub subints.  data: [nsub,nchan,nbin] numpy array (f64/f32) or
         CUDA tensor.  freqs: [nchan] or [nsub,nchan].  Returns a dict of arrays
         (see include/pp_toas.h pp_fit_out).  errs / chan_mask may be CUDA
         tensors [nsub,nchan]; per_channel="device" leaves scales, scale_errs and
-        channel_snrs in HBM as CUDA tensors instead of copying them out.
+        channel_snrs in HBM as CUDA tensors instead of copying them out;
+        records (a float64 CUDA tensor [nsub, 18]) receives one TOA record per
+        subint on the device (dist.RECORD_FIELDS).
         seed_ns > 0 replaces init_params[:, 0] by a phase seeded on the device.
         method: 'trust-ncg' follows SciPy's trust-ncg iteration to the very point
         where the reference stops; 'newton' ('Newton-CG', 'TNC') converges to the
         rounding of the objective in fewer evaluations."""
         if method not in METHODS:
             raise EngineError("unknown method %r" % (method,))
+        if records is not None and not (
+                _is_device_array(records) and records.is_contiguous() and
+                records.element_size() == 8 and tuple(records.shape)[-1] == _lib.PP_RECORD_WIDTH):
+            raise EngineError("records must be a contiguous float64 CUDA tensor [nsub, %d]"
+                              % _lib.PP_RECORD_WIDTH)
         if _is_device_array(data):
             nsub, nchan, nbin = (int(s) for s in data.shape)
             if not data.is_contiguous():
@@ -238,8 +246,12 @@ class Engine(object):
                        obj_hess=np.empty((nsub, 5, 5)))
         fout = FitOut()
         fout.chan_on_device = int(chan_dev)
+        if records is not None:
+            if int(records.shape[0]) != nsub:
+                raise EngineError("records has %d rows for %d subints" % (records.shape[0], nsub))
+            fout.records_dev = C.cast(records.data_ptr(), c_double_p)
         for name, _ in FitOut._fields_:
-            if name == "chan_on_device":
+            if name in ("chan_on_device", "records_dev"):
                 continue
             arr = res.get(name)
             if arr is None:

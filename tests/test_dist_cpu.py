@@ -68,3 +68,59 @@ def test_gather_records_world2_gloo():
     f = ppdist.unpack_records(out)
     np.testing.assert_array_equal(f["DM"], np.arange(n) * 2.0)
     assert set(f) == set(ppdist.RECORD_FIELDS)
+
+
+def _worker_tensor(rank, world, port, n, q):
+    """The bench's N > 1 data path with the shapes Engine.fit_batch(records=...)
+    produces: every rank keeps [steps][nsub][RECORD_WIDTH] float64 tensors and ONE
+    gather at the end brings them to rank 0 (torch tensors in, tensor out)."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        counts = [b - a for a, b in (ppdist.shard_range(n, r, world) for r in range(world))]
+        lo, hi = ppdist.shard_range(n, rank, world)
+        rec = torch.from_numpy(ppdist.pack_records(_fake_result(lo, hi)))
+        assert rec.dtype == torch.float64 and rec.shape == (hi - lo, ppdist.RECORD_WIDTH)
+        out = ppdist.gather_records(rec, counts=counts)
+        if rank == 0:
+            assert torch.is_tensor(out)
+            q.put((out.numpy(), ppdist.records_checksum(out)))
+        else:
+            assert out is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gather_tensor_records_world2_gloo():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n, world = 13, 2
+    procs = [ctx.Process(target=_worker_tensor, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out, cs = q.get(timeout=90)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = ppdist.pack_records(_fake_result(0, n))
+    np.testing.assert_array_equal(out, want)
+    assert cs["rows"] == n
+    np.testing.assert_allclose(cs["column_sums"], want.sum(axis=0))
+
+
+def test_record_layout_matches_the_c_abi():
+    """RECORD_FIELDS is the layout k_finalize writes into pp_fit_out.records_dev
+    (include/pp_toas.h PP_RECORD_WIDTH)."""
+    import re
+    from pulseportraiture_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include",
+                            "pp_toas.h")).read()
+    assert int(re.search(r"#define PP_RECORD_WIDTH (\d+)", hdr).group(1)) == ppdist.RECORD_WIDTH
+    assert _lib.PP_RECORD_WIDTH == ppdist.RECORD_WIDTH == 18
