@@ -84,6 +84,9 @@ void* pp_stream(pp_ctx* ctx);
  *   "max_work_bytes"  cap on device scratch per call (larger batches are split)
  *   "taylor"       1 (default) = fits without scattering first try the
  *                  per-channel Taylor-model solve; 0 = always iterate
+ *   "paired_split" 1 (default) = 2048-bin rows whose template keeps fewer than 512
+ *                  harmonics take the transform kernel that does the last FFT stage
+ *                  and the even/odd split in registers; 0 = the generic kernel
  *   "moments_in_xspec"  1 (default) = the Taylor moments are accumulated inside
  *                  the transform kernel and no cross-spectrum is stored; 0 = store
  *                  the cross-spectrum and take the moments in a second pass

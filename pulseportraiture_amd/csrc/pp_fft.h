@@ -191,7 +191,7 @@ __device__ __forceinline__ void stage_load_lds(cplx (&v)[PER][R], const cplx* ld
 // butterflies + inter-stage twiddles + in-place write + LDS sync.
 // tw[i] = W_M^(t - t%S) of this thread's i-th butterfly (unused in the last
 // stage): loop-invariant per thread, so callers hoist it out of their row loop.
-template <int M, int T, int R, int S, int PADLOG, int PER, typename TW>
+template <int M, int T, int R, int S, int PADLOG, int PER, typename TW, bool TREE = false>
 __device__ __forceinline__ void stage_finish(cplx (&v)[PER][R], cplx* lds, const TW& tw, int tid,
                                              double* power = nullptr) {
     constexpr int NBF = StageGeom<M, T, R>::NBF;
@@ -205,6 +205,26 @@ __device__ __forceinline__ void stage_finish(cplx (&v)[PER][R], cplx* lds, const
             const int q = t & (S - 1);
             const int ob = q + S * R * (t / S);
             if constexpr (!LAST) {
+#ifndef PP_TWIDDLE_TREE
+#define PP_TWIDDLE_TREE 1
+#endif
+                if (PP_TWIDDLE_TREE && TREE) {
+                    // v[j] *= w^j with every power formed once, w^j = (w^(j/2))^2 or
+                    // w^(j-1) w: R - 2 products for the powers + R - 1 for the elements
+                    // (29 for R = 16 where the bitwise scheme below takes 35), at most
+                    // log2(R) + 1 roundings per power; a few powers live at a time
+                    cplx wq[R];
+                    wq[1] = tw[i];
+#pragma unroll
+                    for (int j = 2; j < R; ++j) {
+                        if (j % 2 == 0) {
+                            const cplx h = wq[j / 2];
+                            wq[j] = make_double2(fma(h.x, h.x, -h.y * h.y), 2.0 * h.x * h.y);
+                        } else wq[j] = cmul(wq[j - 1], wq[1]);
+                    }
+#pragma unroll
+                    for (int j = 1; j < R; ++j) v[i][j] = cmul(v[i][j], wq[j]);
+                } else {
                 // v[j] *= w^j as the product of w^(2^b) over the set bits of j:
                 // one twiddle power live at a time (register pressure), at most
                 // log2(R) roundings per element
@@ -215,6 +235,7 @@ __device__ __forceinline__ void stage_finish(cplx (&v)[PER][R], cplx* lds, const
                     for (int j = 1; j < R; ++j)
                         if (j & b) v[i][j] = cmul(v[i][j], wp);
                     if (2 * b < R) wp = cmul(wp, wp);
+                }
                 }
             }
             if (LAST && power) {
@@ -232,10 +253,22 @@ __device__ __forceinline__ void stage_finish(cplx (&v)[PER][R], cplx* lds, const
             // pad(ob) + j
             cplx* wbase = lds + lds_pad<PADLOG>(ob);
             constexpr int JSTEP = (S % (1 << PADLOG) == 0) ? S + (S >> PADLOG) : ((S == 1 && R == (1 << PADLOG)) ? 1 : 0);
+#ifndef PP_ABL_LDSW
+#define PP_ABL_LDSW 0     // timing experiments: 1 = no stores in the last stage, 2 = every stage's stores twice
+#endif
+            if (PP_ABL_LDSW == 1 && LAST) continue;
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 if (JSTEP) wbase[j * JSTEP] = v[i][j];
                 else lds[lds_pad<PADLOG>(ob + S * j)] = v[i][j];
+            }
+            if (PP_ABL_LDSW == 2) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    if (JSTEP) wbase[j * JSTEP] = v[i][j];
+                    else lds[lds_pad<PADLOG>(ob + S * j)] = v[i][j];
+                }
             }
         }
     }
@@ -325,13 +358,14 @@ __device__ __forceinline__ void opaque_twiddles(RowTwiddles<M>& tw) {
     }
 }
 
-// first stage from registers
-template <int M, int PER1_, int R1_>
+// first stage from registers (TREE: twiddle powers by the product tree -- fewer
+// multiplications, a few more registers; for callers with registers to spare there)
+template <int M, bool TREE = false, int PER1_, int R1_>
 __device__ __forceinline__ void fft_first_stage(cplx* lds, cplx (&v)[PER1_][R1_], const RowTwiddles<M>& tw,
                                                 int tid) {
     typedef FftPlan<M> P;
     static_assert(PER1_ == P::PER1 && R1_ == P::R1, "first-stage tile mismatch");
-    stage_finish<M, P::T, P::R1, 1, P::PADLOG>(v, lds, tw.t1, tid);
+    stage_finish<M, P::T, P::R1, 1, P::PADLOG, PER1_, decltype(tw.t1), TREE>(v, lds, tw.t1, tid);
 }
 
 // the remaining stages, LDS to LDS

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                 for (int k = 0; k < R1; ++k) keep += v[ii][k].x * v[ii][k].y;
             if (keep == 1.2345e300) a.sdraw[0] = keep;
 #else
-            fft_first_stage<M>(lds, v, tw, tid);
+            fft_first_stage<M, M2>(lds, v, tw, tid);
 #endif
         }
 #if PP_SB_PREFETCH
@@ -505,6 +505,10 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         lds_sync<T>();
     }
 }
+
+}  // namespace pp
+#include "pp_xspec1024.h"
+namespace pp {
 
 // plain rFFT of rows (parity hook): out[row][0..M] complex
 template <int M, typename Tin>

@@ -95,6 +95,7 @@ struct pp_ctx {
     int check_every = 1;
     int use_taylor = 1;
     int moments_in_xspec = 1;   // fold the Taylor moments into k_xspec (mode 2) when it applies
+    int paired_split = 1;       // 2048-bin rows: last FFT stage + split in registers (k_xspec_p1024)
     double max_work_bytes = 96e9;
     // profiling
     struct Span { int fam; hipEvent_t a, b; };
@@ -213,6 +214,7 @@ extern "C" int pp_set_option(pp_ctx* c, const char* name, double value) {
     else if (n == "max_work_bytes") c->max_work_bytes = value;
     else if (n == "taylor") c->use_taylor = (int)value;
     else if (n == "moments_in_xspec") c->moments_in_xspec = (int)value;
+    else if (n == "paired_split") c->paired_split = (int)value;
     else return fail(PP_EINVAL, "pp_set_option: unknown option '%s'", name);
     return PP_OK;
 }
@@ -436,6 +438,23 @@ static void launch_xspec(pp_ctx* c, const XspecArgs& xa, bool tail, int mode) {
     const int T = FftPlan<MM>::T;
     const long long nrows = (long long)xa.nsub * xa.nchan;
     const dim3 blk(T);
+    if constexpr (MM == 1024 && sizeof(TIN) == 4) {
+        // 2048-bin rows whose template keeps fewer than 512 harmonics: last stage
+        // and split in registers (pp_xspec1024.h)
+        // (f32 portraits only: with f64 rows the 64 prefetch registers on top of the
+        // 16 held outputs push the kernel over 256 VGPRs -- it spills and loses)
+        if (c->paired_split && 2 * xa.Kt < MM && mode <= 2) {
+#define PP_XP(TL, MD)                                                                                  \
+    do {                                                                                               \
+        const dim3 grid(resident_grid(c, k_xspec_p1024<TIN, TL, MD>, T, nrows, fft_grid(T, nrows)));   \
+        hipLaunchKernelGGL((k_xspec_p1024<TIN, TL, MD>), grid, blk, 0, c->stream, xa);                 \
+    } while (0)
+            if (tail) { if (mode == 2) PP_XP(true, 2); else if (mode == 1) PP_XP(true, 1); else PP_XP(true, 0); }
+            else { if (mode == 2) PP_XP(false, 2); else if (mode == 1) PP_XP(false, 1); else PP_XP(false, 0); }
+#undef PP_XP
+            return;
+        }
+    }
 #define PP_XS(TL, MD)                                                                                  \
     do {                                                                                               \
         const dim3 grid(resident_grid(c, k_xspec<MM, TIN, TL, MD>, T, nrows, fft_grid(T, nrows)));     \
