@@ -84,6 +84,12 @@ void* pp_stream(pp_ctx* ctx);
  *   "max_work_bytes"  cap on device scratch per call (larger batches are split)
  *   "taylor"       1 (default) = fits without scattering first try the
  *                  per-channel Taylor-model solve; 0 = always iterate
+ *   "seed_chan_stride"  device phase seed (seed_ns > 0) of fits without scattering:
+ *                  the seed is formed in a pilot pass over every n-th channel (default
+ *                  8; 1 = from all channels, with the cross-spectrum stored), then the
+ *                  usual single pass runs at the seeded phase
+ *   "seed_min_snr" pilot seeds whose correlation peak stands less than this many rms
+ *                  above the mean of the grid (default 8) are redone from all channels
  *   "paired_split" 1 (default) = 2048-bin rows whose template keeps fewer than 512
  *                  harmonics take the transform kernel that does the last FFT stage
  *                  and the even/odd split in registers; 0 = the generic kernel

@@ -580,6 +580,29 @@ __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
 }
 
 // --------------------------------------------------------------------------
+// The subints that still need work, listed in index order (one 256-thread block):
+// seedq != nullptr selects those whose seed quality is below qmin, else those whose
+// solver state is not done.  act[0..*count) receives the indices.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_list_active(const SubState* st, const double* seedq, double qmin, int nsub,
+                                                     int* act, int* count) {
+    __shared__ int offs[257];
+    const int tid = threadIdx.x;
+    const int per = (nsub + 255) / 256, lo = min(nsub, tid * per), hi = min(nsub, lo + per);
+    auto want = [&](int i) { return seedq ? !(seedq[i] >= qmin) : (st[i].done == 0); };
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += want(i) ? 1 : 0;
+    offs[tid + 1] = c;
+    if (tid == 0) offs[0] = 0;
+    __syncthreads();
+    if (tid == 0) for (int t = 1; t <= 256; ++t) offs[t] += offs[t - 1];
+    __syncthreads();
+    int o = offs[tid];
+    for (int i = lo; i < hi; ++i) if (want(i)) act[o++] = i;
+    if (tid == 0) *count = offs[256];
+}
+
+// --------------------------------------------------------------------------
 // Phase seed on the device (role of pptoas.py:421-457).  With the guessed
 // DM/GM the per-channel cross-correlations are aligned and summed:
 //   Y_k = sum_n w_n X_nk e^{2 pi i k (phi_n - phi)},   CCF(phi) = Re sum_k Y_k B_k^* e^{2 pi i k phi}
@@ -590,7 +613,7 @@ __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
 // --------------------------------------------------------------------------
 #define PP_SEED_KPT 16   // harmonics per lane (one wave per channel): Kt <= 1024
 __global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart, int Ks) {
-    const int i = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int jx = blockIdx.y, i = sub_of(a.act, jx), chunk = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     __shared__ cplx ysh[3 * 64 * PP_SEED_KPT / 4];   // three waves' partial spectra, one quarter at a time
     const double P = a.P[i];
@@ -604,8 +627,9 @@ __global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart, int 
     cplx y[PP_SEED_KPT];
 #pragma unroll
     for (int j = 0; j < PP_SEED_KPT; ++j) y[j] = make_double2(0.0, 0.0);
-    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan);
-    for (int n = n0 + wave; n < n1; n += 4) {
+    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan_x);
+    for (int nn = n0 + wave; nn < n1; nn += 4) {
+        const int n = a.coff + nn * a.cstep;
         const double w = wts[n];
         if (w == 0.0) continue;
         double p1, p2;
@@ -613,7 +637,7 @@ __global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart, int 
         const double phin = DM * p1 + GM * p2;
         cplx e = unit_phasor((double)(lane + 1), phin);
         const cplx wst = make_double2(__shfl(e.x, 63, 64), __shfl(e.y, 63, 64));
-        const cplx* xrow = a.X + ((size_t)i * a.nchan + n) * a.Kt;
+        const cplx* xrow = a.X + ((size_t)jx * a.nchan_x + nn) * a.Kt;
         const int ktn = min(ktv ? ktv[n] : a.Kt, Ks);
         // all of the row's loads first (independent, 1 KB per wave-instruction)
         cplx xv[PP_SEED_KPT];
@@ -633,7 +657,7 @@ __global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart, int 
         }
     }
     // sum the four waves' spectra (a quarter of the harmonics per round) and store
-    cplx* yo = ypart + ((size_t)i * a.nchunk + chunk) * Ks;
+    cplx* yo = ypart + ((size_t)jx * a.nchunk + chunk) * Ks;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         __syncthreads();
@@ -659,20 +683,23 @@ __global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart, int 
     }
 }
 
+// seedq (optional): significance of the grid's maximum, (max - mean) / rms of the
+// cross-correlation over the grid -- what tells a seed formed from a subset of the
+// channels apart from a noise peak
 __global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, cplx* ywork, double* x0, int Ns,
-                                                  int Ks) {
-    const int i = blockIdx.x, tid = threadIdx.x, K = Ks;
+                                                  int Ks, double* seedq) {
+    const int jx = blockIdx.x, i = sub_of(a.act, jx), tid = threadIdx.x, K = Ks;
     __shared__ double scratch[4 * 4];
     __shared__ double shv[4];
     __shared__ int shj[4];
-    cplx* Y = ywork + (size_t)i * K;
+    cplx* Y = ywork + (size_t)jx * K;
     // scattering kernel of the guessed tau at the fit reference frequency
     const double taup = x0[i * 5 + 3];
     const double tau = a.scat ? (a.log10_tau ? pow(10.0, taup) : taup) : 0.0;
     for (int k = tid + 1; k <= K; k += 256) {
         cplx s = make_double2(0.0, 0.0);
         for (int c = 0; c < a.nchunk; ++c) {
-            const cplx v = ypart[((size_t)i * a.nchunk + c) * K + k - 1];
+            const cplx v = ypart[((size_t)jx * a.nchunk + c) * K + k - 1];
             s.x += v.x; s.y += v.y;
         }
         if (tau != 0.0) {   // times conj(B_k) = (1 + i u)/(1 + u^2)
@@ -685,13 +712,29 @@ __global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, 
     Ns = max(Ns, 2);
     double bestv = INFINITY;
     int bestj = 0x7fffffff;
+    double gs[2] = {0.0, 0.0};           // sum and sum of squares of the CCF over this thread's points
     for (int j = tid; j < Ns; j += 256) {
         const double phi = -0.5 + (double)j / (double)(Ns - 1);
         double s0, s1, s2;
         fps_sums(Y, K, phi, 0, 1, s0, s1, s2);
         if (-s0 < bestv) { bestv = -s0; bestj = j; }
+        gs[0] += s0; gs[1] += s0 * s0;
     }
     const int best = min(block_argmin256(bestv, bestj, shv, shj), Ns - 1);
+    if (seedq) {
+        double pk = group_max<64>(-bestv);      // maximum of the CCF over the grid
+        __syncthreads();
+        if ((tid & 63) == 0) shv[tid >> 6] = pk;
+        __syncthreads();
+        pk = fmax(fmax(shv[0], shv[1]), fmax(shv[2], shv[3]));
+        __syncthreads();
+        double g2[2] = {gs[0], gs[1]};
+        block_sum<2>(g2, scratch);
+        __syncthreads();
+        const double mean = g2[0] / (double)Ns;
+        const double var = fmax(g2[1] / (double)Ns - mean * mean, 0.0);
+        if (tid == 0) seedq[i] = (var > 0.0) ? (pk - mean) / sqrt(var) : 0.0;
+    }
     const double h = 1.0 / (double)(Ns - 1);
     double phi = -0.5 + (double)best / (double)(Ns - 1), lo = phi - h, hi = phi + h;
     for (int it = 0; it < 60; ++it) {

@@ -54,6 +54,13 @@ struct XspecArgs {
     double* csum0;            // [nsub][nchan][3]: A0 A1 A2 at x0 (csum buffer 0)
     double* tay;              // [nsub][nchan][PP_TSTRIDE]: Taylor model at x0 (MODE 2)
     const double* ph0;        // [nsub][nchan]: phi_n at x0 (k_phase0), MODE 1 and 2
+    // Subsets (pilot pass over every cstep-th channel; re-transform of the subints
+    // that need evaluations): `nsub` x `nchan` is the set of rows PROCESSED, row
+    // (nn, j) being channel coff + nn*cstep of subint act[j] (act == nullptr: j).
+    // X is indexed by the compact (j, nn); every other array by the true
+    // (subint, channel) with row pitch nchan_full.
+    const int* act;
+    int cstep, coff, nchan_full;
 };
 
 struct FitArgs {
@@ -87,7 +94,13 @@ struct FitArgs {
     double* o_scales; double* o_scale_errs; double* o_csnr;
     double* o_f0; double* o_g0; double* o_H0;
     double* o_rec;            // [nsub][PP_RECORD_WIDTH] TOA records left on the device, or nullptr
+    // subsets for the kernels that read X (see XspecArgs): blockIdx.y = j walks
+    // act[0..nact), channels coff + nn*cstep for nn < nchan_x; X is compact in (j, nn)
+    const int* act;
+    int nact, nchan_x, cstep, coff;
 };
+
+__device__ __forceinline__ int sub_of(const int* act, int j) { return act ? act[j] : j; }
 
 // --------------------------------------------------------------------------
 // model rFFT
@@ -218,7 +231,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
     if (row < rend) {
         n = __builtin_amdgcn_readfirstlane((int)(row / a.nsub));
         i = __builtin_amdgcn_readfirstlane((int)(row % a.nsub));
-        const size_t rc = (size_t)i * a.nchan + n;
+        const size_t rc = (size_t)sub_of(a.act, i) * a.nchan_full + (a.coff + n * a.cstep);
         stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rc * (2 * M), tid);
     }
     // MODE 2 keeps this thread's harmonics of the template row in registers; they
@@ -243,13 +256,15 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             opaque_twiddles<M>(tw);
             asm volatile("" : "+v"(wb0.x), "+v"(wb0.y));   // or all of wb0 wbT^j are hoisted
         }
-        const size_t rc = (size_t)i * a.nchan + n;
+        const int ia = sub_of(a.act, i), ne = a.coff + n * a.cstep;   // true subint, channel
+        const size_t rc = (size_t)ia * a.nchan_full + ne;
+        const size_t rx = (size_t)i * a.nchan + n;                    // compact row of X
         // Issue, BEFORE anything waits, every load of this row whose result is
         // needed late: vector-memory results return in order, so these must be
         // older than the prefetch of the next row or consuming them would drain it.
-        const cplx* mrow = as_global(a.slot ? a.mft[a.slot[i]] : a.mft0) + (size_t)n * M;
+        const cplx* mrow = as_global(a.slot ? a.mft[a.slot[ia]] : a.mft0) + (size_t)ne * M;
         // harmonics this channel's template keeps (multiple of 64)
-        const int ktn = a.ktab ? as_global(a.slot ? a.ktab[a.slot[i]] : a.kt0)[n] : a.Kt;
+        const int ktn = a.ktab ? as_global(a.slot ? a.ktab[a.slot[ia]] : a.kt0)[ne] : a.Kt;
         if (M2 && mrow != mheld) {
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
@@ -296,7 +311,8 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         // every use of an earlier load, because on the path without it no younger
         // loads exist)
         {
-            const size_t rn = (row + 1 < rend) ? (size_t)i_nx * a.nchan + n_nx : rc;
+            const size_t rn = (row + 1 < rend)
+                ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
             stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);
         }
 #if PP_SB_PREFETCH
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         __builtin_amdgcn_sched_barrier(0);
 #endif
         // ---- cross-spectrum (and the first evaluation's sums) ----
-        cplx* xrow = a.X + rc * a.Kt;
+        cplx* xrow = a.X + rx * a.Kt;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         cplx e = make_double2(1.0, 0.0), wst = make_double2(1.0, 0.0);
         auto setup_phasors = [&]() {
@@ -667,7 +683,7 @@ __device__ __forceinline__ void accumulate_channel(const Local& L, const ChanGeo
 template <bool SCAT>
 __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
     constexpr int LPC = 16;
-    const int i = blockIdx.y, chunk = blockIdx.x;
+    const int jx = blockIdx.y, i = sub_of(a.act, jx), chunk = blockIdx.x;
     SubState& st = a.st[i];
     if (st.done) return;
     __shared__ double red[(256 / LPC) * PP_NACC];
@@ -685,8 +701,9 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
     const int trial = 1 - st.cur;
     double* csum = a.csum + ((size_t)trial * a.nsub + i) * a.nchan * a.ncs;
     double accA = 0.0, accB = 0.0;   // lane l of a group owns sums l and 16+l of the 21
-    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan);
-    for (int n = n0 + g; n < n1; n += 256 / LPC) {
+    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan_x);
+    for (int nn = n0 + g; nn < n1; nn += 256 / LPC) {
+        const int n = a.coff + nn * a.cstep;
         const double w = wts[n];
         ChanGeom cg;
         chan_geom(freqs[n], P, nuDM, nuGM, nutau, tau, alpha, a.log10_tau, scat_on, cg);
@@ -695,7 +712,7 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
         cplx e = unit_phasor((double)(l + 1), phin);
         const int src = ((tid & 63) & ~(LPC - 1)) | (LPC - 1);
         const cplx wst = make_double2(__shfl(e.x, src, 64), __shfl(e.y, src, 64));
-        const cplx* xrow = a.X + ((size_t)i * a.nchan + n) * a.Kt;
+        const cplx* xrow = a.X + ((size_t)jx * a.nchan_x + nn) * a.Kt;
         double s0 = 0, s1 = 0, s2 = 0, t1 = 0, t2 = 0, a1t = 0, S0 = 0, S1 = 0, S2 = 0;
         double k = (double)(l + 1);
         // harmonics beyond the template's kept range carry |m_nk|^2 < 2^-100 of
@@ -790,7 +807,7 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
 // First evaluation when k_xspec already produced the per-channel sums (FUSE):
 // only the O(nchan) chain rule + reduction remains.  grid = (nchunk, nsub).
 __global__ __launch_bounds__(256) void k_accum(FitArgs a) {
-    const int i = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int i = sub_of(a.act, blockIdx.y), chunk = blockIdx.x, tid = threadIdx.x;
     SubState& st = a.st[i];
     if (st.done) return;
     __shared__ double scratch[4 * PP_NACC];
@@ -804,8 +821,9 @@ __global__ __launch_bounds__(256) void k_accum(FitArgs a) {
     double acc[PP_NACC];
 #pragma unroll
     for (int j = 0; j < PP_NACC; ++j) acc[j] = 0.0;
-    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan);
-    for (int n = n0 + tid; n < n1; n += 256) {
+    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan_x);
+    for (int nn = n0 + tid; nn < n1; nn += 256) {
+        const int n = a.coff + nn * a.cstep;
         const double w = wts[n];
         if (w == 0.0) continue;
         double cs[PP_NCS];
@@ -834,7 +852,7 @@ __global__ __launch_bounds__(256) void k_accum(FitArgs a) {
 // only two of the 21 per-subint accumulators.
 __global__ __launch_bounds__(256) void k_eval_fast(FitArgs a) {
     constexpr int LPC = 16;
-    const int i = blockIdx.y, chunk = blockIdx.x;
+    const int jx = blockIdx.y, i = sub_of(a.act, jx), chunk = blockIdx.x;
     SubState& st = a.st[i];
     if (st.done) return;
     __shared__ double red[(256 / LPC) * PP_NACC];
@@ -849,9 +867,10 @@ __global__ __launch_bounds__(256) void k_eval_fast(FitArgs a) {
     const int trial = 1 - st.cur;
     double* csum = a.csum + ((size_t)trial * a.nsub + i) * a.nchan * a.ncs;
     double accA = 0.0;
-    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan);
+    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan_x);
     const int src = ((tid & 63) & ~(LPC - 1)) | (LPC - 1);
-    for (int n = n0 + g; n < n1; n += 256 / LPC) {
+    for (int nn = n0 + g; nn < n1; nn += 256 / LPC) {
+        const int n = a.coff + nn * a.cstep;
         const double w = wts[n];
         double p1, p2;
         phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
@@ -859,7 +878,7 @@ __global__ __launch_bounds__(256) void k_eval_fast(FitArgs a) {
         cplx e0 = unit_phasor((double)(l + 1), phin);
         const cplx w1 = make_double2(__shfl(e0.x, src, 64), __shfl(e0.y, src, 64));
         const cplx w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
-        const cplx* xrow = a.X + ((size_t)i * a.nchan + n) * a.Kt;
+        const cplx* xrow = a.X + ((size_t)jx * a.nchan_x + nn) * a.Kt;
         double s0a = 0, s1a = 0, s2a = 0, s0b = 0, s1b = 0, s2b = 0;
         double k = (double)(l + 1);
         const int ktn = ktv ? ktv[n] : a.Kt;
@@ -1133,7 +1152,7 @@ __device__ inline bool tr_scipy_accept(double f, double f_new, double pred, int 
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_eval_moments(FitArgs a) {
     constexpr int LPC = 16;
-    const int i = blockIdx.y, chunk = blockIdx.x;
+    const int jx = blockIdx.y, i = sub_of(a.act, jx), chunk = blockIdx.x;
     const SubState& st = a.st[i];
     const int tid = threadIdx.x, g = tid / LPC, l = tid % LPC;
     const double phi = st.xe[0], DM = st.xe[1], GM = st.xe[2];
@@ -1143,9 +1162,10 @@ __global__ __launch_bounds__(256) void k_eval_moments(FitArgs a) {
     const double* wts = a.wts + (size_t)i * a.nchan;
     const int* ktv = a.ktab ? as_global(a.ktab[a.slot ? a.slot[i] : 0]) : nullptr;
     double* tay = a.tay + (size_t)i * a.nchan * PP_TSTRIDE;
-    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan);
+    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan_x);
     const int src = ((tid & 63) & ~(LPC - 1)) | (LPC - 1);
-    for (int n = n0 + g; n < n1; n += 256 / LPC) {
+    for (int nn = n0 + g; nn < n1; nn += 256 / LPC) {
+        const int n = a.coff + nn * a.cstep;
         const double w = wts[n];
         double p1, p2;
         phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
@@ -1153,7 +1173,7 @@ __global__ __launch_bounds__(256) void k_eval_moments(FitArgs a) {
         cplx e0 = unit_phasor((double)(l + 1), phin);
         const cplx w1 = make_double2(__shfl(e0.x, src, 64), __shfl(e0.y, src, 64));
         const cplx w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
-        const cplx* xrow = a.X + ((size_t)i * a.nchan + n) * a.Kt;
+        const cplx* xrow = a.X + ((size_t)jx * a.nchan_x + nn) * a.Kt;
         const int ktn = ktv ? ktv[n] : a.Kt;
         double s[PP_TSTRIDE];
 #pragma unroll
@@ -1419,7 +1439,7 @@ __device__ inline void unpack_acc(const double* acc, const int* flags, double& f
 
 // one trust-region iteration per subint (64 threads, lane 0 decides)
 __global__ __launch_bounds__(64) void k_step(FitArgs a) {
-    const int i = blockIdx.x, tid = threadIdx.x;
+    const int i = sub_of(a.act, blockIdx.x), tid = threadIdx.x;
     SubState& s = a.st[i];
     if (s.done) return;
     __shared__ double acc[PP_NACC];

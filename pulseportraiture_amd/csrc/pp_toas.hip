@@ -86,7 +86,7 @@ struct pp_ctx {
     DevBuf o_pack;   // per-subint scalar outputs, one allocation -> one D2H copy
     void* o_host = nullptr; size_t o_host_cap = 0;   // pinned staging of o_pack
     DevBuf o_params, o_errs, o_nu, o_cov, o_chi2, o_rchi2, o_snr, o_nfev, o_rc, o_scales, o_serrs, o_csnr,
-        o_f0, o_g0, o_H0, misc, seedbuf, tay, ph0;
+        o_f0, o_g0, o_H0, misc, seedbuf, tay, ph0, act, seedq;
     int* nactive_h = nullptr;   // pinned
     // options
     double harm_eps = 8.8817841970012523e-16;  // 2^-50
@@ -96,6 +96,8 @@ struct pp_ctx {
     int use_taylor = 1;
     int moments_in_xspec = 1;   // fold the Taylor moments into k_xspec (mode 2) when it applies
     int paired_split = 1;       // 2048-bin rows: last FFT stage + split in registers (k_xspec_p1024)
+    int seed_chan_stride = 8;   // device phase seed: pilot pass over every n-th channel (1 = all channels)
+    double seed_min_snr = 8.0;  // pilot seeds below this peak significance are redone from all channels
     double max_work_bytes = 96e9;
     // profiling
     struct Span { int fam; hipEvent_t a, b; };
@@ -186,7 +188,7 @@ extern "C" int pp_destroy(pp_ctx* c) {
                       &c->errs, &c->mask, &c->P, &c->x0, &c->nufit, &c->nuout, &c->slot, &c->state, &c->csum,
                       &c->partial, &c->o_params, &c->o_errs, &c->o_nu, &c->o_cov, &c->o_chi2, &c->o_rchi2,
                       &c->o_snr, &c->o_nfev, &c->o_rc, &c->o_scales, &c->o_serrs, &c->o_csnr, &c->o_f0, &c->o_g0,
-                      &c->o_H0, &c->misc, &c->seedbuf, &c->tay, &c->ph0};
+                      &c->o_H0, &c->misc, &c->seedbuf, &c->tay, &c->ph0, &c->act, &c->seedq};
     for (DevBuf* b : bufs) b->release();
     if (c->nactive_h) (void)hipHostFree(c->nactive_h);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -215,6 +217,8 @@ extern "C" int pp_set_option(pp_ctx* c, const char* name, double value) {
     else if (n == "taylor") c->use_taylor = (int)value;
     else if (n == "moments_in_xspec") c->moments_in_xspec = (int)value;
     else if (n == "paired_split") c->paired_split = (int)value;
+    else if (n == "seed_chan_stride") c->seed_chan_stride = std::max(1, (int)value);
+    else if (n == "seed_min_snr") c->seed_min_snr = value;
     else return fail(PP_EINVAL, "pp_set_option: unknown option '%s'", name);
     return PP_OK;
 }
@@ -443,7 +447,7 @@ static void launch_xspec(pp_ctx* c, const XspecArgs& xa, bool tail, int mode) {
         // and split in registers (pp_xspec1024.h)
         // (f32 portraits only: with f64 rows the 64 prefetch registers on top of the
         // 16 held outputs push the kernel over 256 VGPRs -- it spills and loses)
-        if (c->paired_split && 2 * xa.Kt < MM && mode <= 2) {
+        if (c->paired_split && 2 * xa.Kt < MM && mode <= 2 && !xa.act && xa.cstep == 1) {
 #define PP_XP(TL, MD)                                                                                  \
     do {                                                                                               \
         const dim3 grid(resident_grid(c, k_xspec_p1024<TIN, TL, MD>, T, nrows, fft_grid(T, nrows)));   \
@@ -502,21 +506,34 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     if ((rc = upload(c, c->nuout, nuout_h.data() + (size_t)s0 * 3, (size_t)ns * 24))) return rc;
     if (in->model_slot) if ((rc = upload(c, c->slot, in->model_slot + s0, (size_t)ns * 4))) return rc;
     // ---- work ----
-    // no scattering: one moments pass over X + a Taylor-model solve replace the
-    // evaluation loop (fallback: the loop below); otherwise evaluate as usual
+    // no scattering: one pass over the data that leaves a Taylor model of every
+    // channel + a solve on it replace the evaluation loop (fallback: the loop below,
+    // on the subints that need it); otherwise evaluate as usual
     const bool taylor = !scat && c->max_iter > 0 && c->use_taylor;
-    const bool fuse = !scat && !taylor && in->seed_ns <= 0;   // first evaluation folded into k_xspec
-    // k_xspec mode: 2/3 = Taylor model only, no cross-spectrum stored (the seed
-    // needs X at a phase not known yet, so it keeps mode 0 + k_eval_moments);
+    const bool seeded = in->seed_ns > 0;
+    // Phase seed.  The Taylor flow wants the phase BEFORE its single pass, so the seed
+    // comes from a pilot pass over every cstep-th channel (1/cstep of the rows and of
+    // the bytes), certified by the significance of its correlation peak; subints whose
+    // pilot seed is not convincing are seeded from all their channels.  Scattering
+    // fits store the whole cross-spectrum anyway and seed from it.
+    const int cstep = std::max(1, c->seed_chan_stride);
+    const bool pilot = seeded && taylor && c->moments_in_xspec && cstep > 1 && C / cstep >= 16;
+    const bool seed_full = seeded && !pilot;
+    const bool fuse = !scat && !taylor && !seeded;   // first evaluation folded into k_xspec
+    // k_xspec mode: 2/3 = Taylor model only, no cross-spectrum stored;
     // 2 while every thread owns single harmonics (2 Kt < M), else 3 (pairs k, M-k)
-    const bool xmom = taylor && c->moments_in_xspec && in->seed_ns <= 0;
+    const bool xmom = taylor && c->moments_in_xspec && !seed_full;
     const int xmode = xmom ? (2 * Kt < M ? 2 : 3) : (fuse ? 1 : 0);
     const bool xstore = (xmode < 2);
     const int ncs = scat ? PP_NCS : 3;
-    int nchunk = std::min(std::max(1, C / 64), std::max(1, (4096 + ns - 1) / ns));
-    int cpc = (C + nchunk - 1) / nchunk;
-    cpc = ((cpc + 15) / 16) * 16;
-    nchunk = (C + cpc - 1) / cpc;
+    auto chunking = [&](int nch, int nsu, int& nchunk_, int& cpc_) {
+        nchunk_ = std::min(std::max(1, nch / 64), std::max(1, (4096 + nsu - 1) / nsu));
+        cpc_ = (nch + nchunk_ - 1) / nchunk_;
+        cpc_ = ((cpc_ + 15) / 16) * 16;
+        nchunk_ = (nch + cpc_ - 1) / cpc_;
+    };
+    int nchunk, cpc;
+    chunking(C, ns, nchunk, cpc);
     if (xstore) if ((rc = c->X.reserve(nc * Kt * sizeof(cplx)))) return rc;
     if ((rc = c->sdraw.reserve(nc * 8))) return rc;
     if ((rc = c->noise.reserve(nc * 8))) return rc;
@@ -527,6 +544,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     if (taylor) if ((rc = c->tay.reserve(nc * PP_TSTRIDE * 8))) return rc;
     if (xmode != 0) if ((rc = c->ph0.reserve(nc * 8))) return rc;
     if ((rc = c->misc.reserve(256))) return rc;
+    if ((rc = c->act.reserve((size_t)ns * 4))) return rc;
     // per-subint scalar outputs: blocks of one allocation (params 5, errs 5, nu 3,
     // cov 25, chi2, red_chi2, snr doubles; nfeval, return_code ints) = 336 B / subint
     const size_t o_bytes = (size_t)ns * 336;
@@ -548,7 +566,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         if (out->channel_snrs) if ((rc = c->o_csnr.reserve(nc * 8))) return rc;
     }
 
-    // ---- rFFT + cross-spectrum ----
+    // ---- argument blocks ----
     const bool tail = (in->errs == nullptr);
     XspecArgs xa;
     memset(&xa, 0, sizeof xa);
@@ -564,25 +582,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     xa.csum0 = c->csum.as<double>();
     xa.tay = c->tay.as<double>();
     xa.ph0 = c->ph0.as<double>();
-    if (xmode != 0) {
-        Prof pr(c, KF_PREP);
-        hipLaunchKernelGGL(k_phase0, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, ns, C,
-                           xa.x0, xa.P, xa.nu_fit, xa.freqs, xa.freqs_stride, c->ph0.as<double>());
-    }
-    {
-        Prof pr(c, KF_XSPEC);
-        PP_DISPATCH_M(M, {
-            if (in->data_dtype == PP_F64) launch_xspec<MM, double>(c, xa, tail, xmode);
-            else launch_xspec<MM, float>(c, xa, tail, xmode);
-        });
-    }
-    HIP_TRY(hipGetLastError());
-    {
-        Prof pr(c, KF_PREP);
-        hipLaunchKernelGGL(k_prep, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, ns, C, B,
-                           d_errs, c->noise.as<double>(), d_mask, c->wts.as<double>());
-    }
-    HIP_TRY(hipGetLastError());
+    xa.act = nullptr; xa.cstep = 1; xa.coff = 0; xa.nchan_full = C;
     FitArgs fa;
     memset(&fa, 0, sizeof fa);
     fa.nsub = ns; fa.nchan = C; fa.nbin = B; fa.M = M; fa.Kt = Kt;
@@ -619,20 +619,104 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     }
     fa.o_f0 = c->o_f0.as<double>(); fa.o_g0 = c->o_g0.as<double>(); fa.o_H0 = c->o_H0.as<double>();
     fa.o_rec = out->records_dev ? out->records_dev + (size_t)s0 * PP_RECORD_WIDTH : nullptr;
+    fa.act = nullptr; fa.nact = ns; fa.nchan_x = C; fa.cstep = 1; fa.coff = 0;
 
-    if (in->seed_ns > 0) {
-        // the coarse seed uses the lowest 64 * PP_SEED_KPT = 1024 harmonics at most
-        // (templates that keep more -- nbin 4096 / 8192 with power out to Nyquist --
-        // lose nothing a 100-point grid could resolve)
-        const int Ks = std::min(Kt, 64 * PP_SEED_KPT);
-        if ((rc = c->seedbuf.reserve(((size_t)ns * nchunk + ns) * Ks * sizeof(cplx)))) return rc;
-        cplx* ypart = c->seedbuf.as<cplx>();
-        cplx* ywork = ypart + (size_t)ns * nchunk * Ks;
-        Prof pr(c, KF_SEED);
-        hipLaunchKernelGGL(k_seed_accum, dim3(nchunk, ns), dim3(256), 0, c->stream, fa, ypart, Ks);
-        hipLaunchKernelGGL(k_seed_fit, dim3(ns), dim3(256), 0, c->stream, fa, (const cplx*)ypart, ywork,
-                           c->x0.as<double>(), (int)in->seed_ns, Ks);
+    auto run_xspec = [&](const XspecArgs& x, int mode) -> int {
+        Prof pr(c, KF_XSPEC);
+        PP_DISPATCH_M(M, {
+            if (in->data_dtype == PP_F64) launch_xspec<MM, double>(c, x, tail, mode);
+            else launch_xspec<MM, float>(c, x, tail, mode);
+        });
         HIP_TRY(hipGetLastError());
+        return PP_OK;
+    };
+    auto run_prep = [&]() -> int {
+        Prof pr(c, KF_PREP);
+        hipLaunchKernelGGL(k_prep, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, ns, C, B,
+                           d_errs, c->noise.as<double>(), d_mask, c->wts.as<double>());
+        HIP_TRY(hipGetLastError());
+        return PP_OK;
+    };
+    // the coarse seed uses the lowest 64 * PP_SEED_KPT = 1024 harmonics at most
+    // (templates that keep more -- nbin 4096 / 8192 with power out to Nyquist --
+    // lose nothing a 100-point grid could resolve)
+    const int Ks = std::min(Kt, 64 * PP_SEED_KPT);
+    // seed the subints f lists (f.act / f.nact, channels f.coff + nn f.cstep) from the
+    // cross-spectrum in f.X; seedq (optional) receives the peak significance
+    auto run_seed = [&](const FitArgs& f, double* seedq) -> int {
+        if ((rc = c->seedbuf.reserve(((size_t)f.nact * f.nchunk + f.nact) * Ks * sizeof(cplx)))) return rc;
+        cplx* ypart = c->seedbuf.as<cplx>();
+        cplx* ywork = ypart + (size_t)f.nact * f.nchunk * Ks;
+        Prof pr(c, KF_SEED);
+        hipLaunchKernelGGL(k_seed_accum, dim3(f.nchunk, f.nact), dim3(256), 0, c->stream, f, ypart, Ks);
+        hipLaunchKernelGGL(k_seed_fit, dim3(f.nact), dim3(256), 0, c->stream, f, (const cplx*)ypart, ywork,
+                           c->x0.as<double>(), (int)in->seed_ns, Ks, seedq);
+        HIP_TRY(hipGetLastError());
+        return PP_OK;
+    };
+    // list the subints that need more work into c->act; returns their number
+    auto list_active = [&](const double* seedq, double qmin, int* count) -> int {
+        hipLaunchKernelGGL(k_list_active, dim3(1), dim3(256), 0, c->stream, (const SubState*)c->state.p, seedq, qmin,
+                           ns, c->act.as<int>(), c->misc.as<int>() + 1);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(c->nactive_h + 1, c->misc.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        *count = c->nactive_h[1];
+        return PP_OK;
+    };
+    // transform every channel of the listed subints again with the cross-spectrum
+    // stored (compact in the list index), and point the evaluators at the list
+    auto store_x_for_list = [&](int count) -> int {
+        if ((rc = c->X.reserve((size_t)count * C * Kt * sizeof(cplx)))) return rc;
+        XspecArgs xl = xa;
+        xl.X = c->X.as<cplx>(); xl.act = c->act.as<int>(); xl.nsub = count;
+        if ((rc = run_xspec(xl, 0))) return rc;
+        fa.X = c->X.as<cplx>(); fa.act = c->act.as<int>(); fa.nact = count;
+        chunking(C, count, fa.nchunk, fa.cpc);
+        if ((rc = c->partial.reserve((size_t)ns * fa.nchunk * PP_NACC * 8))) return rc;
+        fa.partial = c->partial.as<double>();
+        return PP_OK;
+    };
+
+    // ---- phase seed from a pilot pass ----
+    if (pilot) {
+        const int Cp = (C + cstep - 1) / cstep;
+        if ((rc = c->X.reserve((size_t)ns * Cp * Kt * sizeof(cplx)))) return rc;
+        if ((rc = c->seedq.reserve((size_t)ns * 8))) return rc;
+        XspecArgs xp = xa;
+        xp.X = c->X.as<cplx>(); xp.nchan = Cp; xp.cstep = cstep;
+        if ((rc = run_xspec(xp, 0))) return rc;
+        if ((rc = run_prep())) return rc;      // (rows not transformed yet have no measured noise: unused here)
+        FitArgs fp = fa;
+        fp.X = c->X.as<cplx>(); fp.nchan_x = Cp; fp.cstep = cstep;
+        chunking(Cp, ns, fp.nchunk, fp.cpc);
+        if ((rc = run_seed(fp, c->seedq.as<double>()))) return rc;
+        int nweak = 0;
+        if ((rc = list_active(c->seedq.as<double>(), c->seed_min_snr, &nweak))) return rc;
+        if (nweak > 0) {
+            // not convincing on a subset: seed these from all their channels
+            if ((rc = store_x_for_list(nweak))) return rc;
+            if ((rc = run_prep())) return rc;
+            if ((rc = run_seed(fa, nullptr))) return rc;
+            fa.act = nullptr; fa.nact = ns; fa.nchunk = nchunk; fa.cpc = cpc;
+        }
+    }
+
+    // ---- rFFT + cross-spectrum (or the Taylor model) of every row ----
+    if (xmode != 0) {
+        Prof pr(c, KF_PREP);
+        hipLaunchKernelGGL(k_phase0, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, ns, C,
+                           xa.x0, xa.P, xa.nu_fit, xa.freqs, xa.freqs_stride, c->ph0.as<double>());
+    }
+    if (seed_full) {
+        // the seed needs the cross-spectrum at a phase not known yet: store it, seed,
+        // then take the Taylor moments (or iterate) in a second pass over it
+        if ((rc = run_xspec(xa, 0))) return rc;
+        if ((rc = run_prep())) return rc;
+        if ((rc = run_seed(fa, nullptr))) return rc;
+    } else {
+        if ((rc = run_xspec(xa, xmode))) return rc;
+        if ((rc = run_prep())) return rc;
     }
     hipLaunchKernelGGL(k_init_state, dim3((ns + 63) / 64), dim3(64), 0, c->stream, fa);
     HIP_TRY(hipGetLastError());
@@ -651,16 +735,11 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         HIP_TRY(hipStreamSynchronize(c->stream));
         all_done = (c->nactive_h[0] <= 0);
         if (!all_done && !xstore) {
-            // some subints failed the certificate: they need evaluations over the
-            // cross-spectrum, which was not stored -- transform the batch again
-            if ((rc = c->X.reserve(nc * Kt * sizeof(cplx)))) return rc;
-            xa.X = c->X.as<cplx>(); fa.X = c->X.as<cplx>();
-            Prof pr(c, KF_XSPEC);
-            PP_DISPATCH_M(M, {
-                if (in->data_dtype == PP_F64) launch_xspec<MM, double>(c, xa, tail, 0);
-                else launch_xspec<MM, float>(c, xa, tail, 0);
-            });
-            HIP_TRY(hipGetLastError());
+            // some subints failed the certificate (poor guesses): they need evaluations
+            // over the cross-spectrum, which was not stored -- transform THOSE again
+            int nleft = 0;
+            if ((rc = list_active(nullptr, 0.0, &nleft))) return rc;
+            if ((rc = store_x_for_list(nleft))) return rc;
         }
     }
     // ---- trust-region iterations: evaluation + step, until every subint is done
@@ -668,15 +747,15 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     for (int it = 0; it < max_evals; ++it) {
         if (it == 0 && fuse) {
             Prof pr(c, KF_ACCUM);
-            hipLaunchKernelGGL(k_accum, dim3(nchunk, ns), dim3(256), 0, c->stream, fa);
+            hipLaunchKernelGGL(k_accum, dim3(fa.nchunk, fa.nact), dim3(256), 0, c->stream, fa);
         } else {
             Prof pr(c, KF_EVAL);
-            if (scat) hipLaunchKernelGGL(k_eval<true>, dim3(nchunk, ns), dim3(256), 0, c->stream, fa);
-            else hipLaunchKernelGGL(k_eval_fast, dim3(nchunk, ns), dim3(256), 0, c->stream, fa);
+            if (scat) hipLaunchKernelGGL(k_eval<true>, dim3(fa.nchunk, fa.nact), dim3(256), 0, c->stream, fa);
+            else hipLaunchKernelGGL(k_eval_fast, dim3(fa.nchunk, fa.nact), dim3(256), 0, c->stream, fa);
         }
         {
             Prof pr(c, KF_STEP);
-            hipLaunchKernelGGL(k_step, dim3(ns), dim3(64), 0, c->stream, fa);
+            hipLaunchKernelGGL(k_step, dim3(fa.nact), dim3(64), 0, c->stream, fa);
         }
         HIP_TRY(hipGetLastError());
         if (it >= 2 && ((it - 2) % c->check_every) == 0) {
@@ -685,6 +764,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             if (c->nactive_h[0] <= 0) break;
         }
     }
+    fa.act = nullptr; fa.nact = ns;
     {
         Prof pr(c, KF_FINAL);
         hipLaunchKernelGGL(k_finalize, dim3(ns), dim3(256), 0, c->stream, fa);

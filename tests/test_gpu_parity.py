@@ -1463,3 +1463,86 @@ def test_callers_measure_the_noise_when_the_bunch_has_none():
     nb = GetTOAs(_gettoas_bunch(g, noise_stds=None), os.path.join(GOLDEN, "example.gmodel"), quiet=True)
     nb.get_narrowband_TOAs(quiet=True)
     assert len(nb.TOA_list) == int((g["weights"][ok] > 0).sum())
+
+
+def _medium_batch(eng, nsub, C=512, B=2048, seed=11):
+    import torch
+    from pulseportraiture_amd import gmodel
+    from pulseportraiture_amd.pplib import guess_fit_freq, Dconst
+    freqs, model, P0 = gmodel.example_model(C, B)
+    eng.set_model(model)
+    rng = np.random.default_rng(seed)
+    P = np.full(nsub, P0)
+    inj = np.zeros((nsub, 3))
+    inj[:, 0] = rng.uniform(-0.5, 0.5, nsub)
+    inj[:, 1] = 34.56789 + rng.normal(3e-4, 2e-4, nsub)
+    data = torch.empty((nsub, C, B), dtype=torch.float64, device="cuda:0")
+    eng.synth_portraits(data, freqs, P, inj, 0.05, 777, 0)
+    nu_fit = float(guess_fit_freq(freqs))
+    x0 = np.zeros((nsub, 5))
+    x0[:, 0] = (inj[:, 0] + Dconst * inj[:, 1] / P / nu_fit ** 2 + 1e-4 * rng.standard_normal(nsub) + 0.5) % 1 - 0.5
+    x0[:, 1] = 34.56789
+    kw = dict(errs=np.full((nsub, C), 0.05), nu_fits=np.full((nsub, 3), nu_fit), fit_flags=[1, 1, 0, 0, 0])
+    return data, freqs, P, x0, kw
+
+
+def test_mixed_batch_re_transforms_only_the_poor_guesses(eng):
+    """A batch in which 1 % of the phase guesses are poor (0.03 rot off: outside the
+    Taylor model's certificate): only those subints are transformed again with their
+    cross-spectrum stored and iterated; the rest keep their one-pass answers, and the
+    batch costs about what the all-good batch costs."""
+    nsub = 400
+    data, freqs, P, x0, kw = _medium_batch(eng, nsub)
+    good = eng.fit_batch(data, freqs, P, x0, **kw)
+    t_good = min(eng.fit_batch(data, freqs, P, x0, **kw)["duration"] for _ in range(3))
+    bad = [17, 123, 256, 399]
+    x1 = x0.copy()
+    x1[bad, 0] = (x1[bad, 0] + 0.03 + 0.5) % 1 - 0.5
+    mixed = eng.fit_batch(data, freqs, P, x1, **kw)
+    t_mixed = min(eng.fit_batch(data, freqs, P, x1, **kw)["duration"] for _ in range(3))
+    ok = np.setdiff1d(np.arange(nsub), bad)
+    assert (mixed["nfeval"][ok] == 1).all() and (mixed["nfeval"][bad] >= 3).all()
+    for k in ("params", "param_errs", "chi2", "nu_refs"):
+        np.testing.assert_array_equal(mixed[k][ok], good[k][ok])
+    assert np.max(np.abs((mixed["params"][bad, 0] - good["params"][bad, 0] + 0.5) % 1 - 0.5)) < PHI_BAR
+    assert np.max(np.abs(mixed["params"][bad, 1] - good["params"][bad, 1])) < DM_BAR
+    np.testing.assert_allclose(mixed["chi2"][bad], good["chi2"][bad], rtol=1e-10)
+    assert (mixed["return_code"] == 2).all()
+    assert t_mixed < 1.25 * t_good, (t_mixed, t_good)     # (was ~2.5x: the whole batch re-transformed)
+
+
+def test_pilot_seed_matches_full_seed(eng):
+    """The device phase seed formed from every 8th channel (pilot pass) leads to the
+    same fit as the seed formed from all channels; seeds that fail the pilot's
+    significance test (forced here for every subint) are redone from all channels."""
+    nsub = 64
+    data, freqs, P, x0, kw = _medium_batch(eng, nsub, seed=12)
+    x0 = x0.copy()
+    x0[:, 0] = 0.123           # ignored by the seed
+    try:
+        eng.set_option("seed_chan_stride", 1)
+        full = eng.fit_batch(data, freqs, P, x0, seed_ns=100, **kw)
+        eng.set_option("seed_chan_stride", 8)
+        pilot = eng.fit_batch(data, freqs, P, x0, seed_ns=100, **kw)
+        eng.set_option("seed_min_snr", 1e30)      # every pilot seed "weak"
+        weak = eng.fit_batch(data, freqs, P, x0, seed_ns=100, **kw)
+    finally:
+        eng.set_option("seed_chan_stride", 8)
+        eng.set_option("seed_min_snr", 8.0)
+    for r in (pilot, weak):
+        assert np.max(np.abs((r["params"][:, 0] - full["params"][:, 0] + 0.5) % 1 - 0.5)) < 1e-11
+        assert np.max(np.abs(r["params"][:, 1] - full["params"][:, 1])) < 1e-9
+        np.testing.assert_allclose(r["chi2"], full["chi2"], rtol=1e-11)
+        assert (r["return_code"] == 2).all() and (r["nfeval"] == 1).all()
+    # a third of the channels masked, measured noise: same agreement
+    import torch
+    mask = np.ones((nsub, len(freqs)), dtype=np.uint8)
+    mask[:, ::3] = 0
+    kw2 = dict(kw, errs=None, chan_mask=mask)
+    eng.set_option("seed_chan_stride", 1)
+    full = eng.fit_batch(data, freqs, P, x0, seed_ns=100, **kw2)
+    eng.set_option("seed_chan_stride", 8)
+    pilot = eng.fit_batch(data, freqs, P, x0, seed_ns=100, **kw2)
+    assert np.max(np.abs((pilot["params"][:, 0] - full["params"][:, 0] + 0.5) % 1 - 0.5)) < 1e-11
+    np.testing.assert_allclose(pilot["chi2"], full["chi2"], rtol=1e-11)
+    del torch
