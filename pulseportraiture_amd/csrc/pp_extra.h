@@ -683,9 +683,10 @@ __global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart, int 
     }
 }
 
-// seedq (optional): significance of the grid's maximum, (max - mean) / rms of the
-// cross-correlation over the grid -- what tells a seed formed from a subset of the
-// channels apart from a noise peak
+// seedq (optional): significance of the grid's maximum, (max - mean over the grid) /
+// (noise rms of the correlation, from the weights and the template power) -- the
+// matched-filter S/N of the channels used, which tells a seed formed from a subset
+// of the channels apart from a noise peak
 __global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, cplx* ywork, double* x0, int Ns,
                                                   int Ks, double* seedq) {
     const int jx = blockIdx.x, i = sub_of(a.act, jx), tid = threadIdx.x, K = Ks;
@@ -712,13 +713,13 @@ __global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, 
     Ns = max(Ns, 2);
     double bestv = INFINITY;
     int bestj = 0x7fffffff;
-    double gs[2] = {0.0, 0.0};           // sum and sum of squares of the CCF over this thread's points
+    double gs[1] = {0.0};                // sum of the CCF over this thread's points
     for (int j = tid; j < Ns; j += 256) {
         const double phi = -0.5 + (double)j / (double)(Ns - 1);
         double s0, s1, s2;
         fps_sums(Y, K, phi, 0, 1, s0, s1, s2);
         if (-s0 < bestv) { bestv = -s0; bestj = j; }
-        gs[0] += s0; gs[1] += s0 * s0;
+        gs[0] += s0;
     }
     const int best = min(block_argmin256(bestv, bestj, shv, shj), Ns - 1);
     if (seedq) {
@@ -728,12 +729,22 @@ __global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, 
         __syncthreads();
         pk = fmax(fmax(shv[0], shv[1]), fmax(shv[2], shv[3]));
         __syncthreads();
-        double g2[2] = {gs[0], gs[1]};
+        // noise of the correlation: Var = sum_n w_n^2 sigma_Fn^2 sum_k |m_nk|^2 = sum_n w_n S_n
+        // over the channels that went into Y (S_n over all harmonics: a slight
+        // overestimate, on the safe side)
+        const double* wts = a.wts + (size_t)i * a.nchan;
+        const double* msum = as_global(a.msum[a.slot ? a.slot[i] : 0]);
+        double nz = 0.0;
+        for (int nn = tid; nn < a.nchan_x; nn += 256) {
+            const int n = a.coff + nn * a.cstep;
+            const double w = wts[n];
+            if (w != 0.0) nz += w * msum[n];
+        }
+        double g2[2] = {gs[0], nz};
         block_sum<2>(g2, scratch);
         __syncthreads();
         const double mean = g2[0] / (double)Ns;
-        const double var = fmax(g2[1] / (double)Ns - mean * mean, 0.0);
-        if (tid == 0) seedq[i] = (var > 0.0) ? (pk - mean) / sqrt(var) : 0.0;
+        if (tid == 0) seedq[i] = (g2[1] > 0.0) ? (pk - mean) / sqrt(g2[1]) : 0.0;
     }
     const double h = 1.0 / (double)(Ns - 1);
     double phi = -0.5 + (double)best / (double)(Ns - 1), lo = phi - h, hi = phi + h;

@@ -1508,7 +1508,9 @@ def test_mixed_batch_re_transforms_only_the_poor_guesses(eng):
     assert np.max(np.abs(mixed["params"][bad, 1] - good["params"][bad, 1])) < DM_BAR
     np.testing.assert_allclose(mixed["chi2"][bad], good["chi2"][bad], rtol=1e-10)
     assert (mixed["return_code"] == 2).all()
-    assert t_mixed < 1.25 * t_good, (t_mixed, t_good)     # (was ~2.5x: the whole batch re-transformed)
+    # (fixed costs of the fallback -- a host check, a dozen small launches -- are ~2 ms;
+    # before, the whole batch was transformed again: 2.5x)
+    assert t_mixed < 1.25 * t_good + 3e-3, (t_mixed, t_good)
 
 
 def test_pilot_seed_matches_full_seed(eng):
