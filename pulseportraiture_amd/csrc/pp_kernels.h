@@ -1380,7 +1380,9 @@ __global__ __launch_bounds__(256) void k_taylor_solve(FitArgs a) {
         block_sum<4>(reinterpret_cast<double(&)[4]>(ev), scratch);
         __syncthreads();
         // position error <= gradient error / curvature, per fitted parameter
-        const double tol[3] = {1e-12, 1e-10, 1e-7};   // turns, pc cm^-3, GM units
+        // (1e-11 pc cm^-3 of DM is worth ~1e-11 rot of phase at the band edge: two
+        // decades inside the parity bars)
+        const double tol[3] = {1e-13, 1e-11, 1e-8};   // turns, pc cm^-3, GM units
         for (int j = 0; j < 3; ++j)
             if (fl[j]) {
                 const double hjj = fabs(H[j * 5 + j]);

@@ -1465,6 +1465,16 @@ def test_callers_measure_the_noise_when_the_bunch_has_none():
     assert len(nb.TOA_list) == int((g["weights"][ok] > 0).sum())
 
 
+def _dphi_common(r, ref, P):
+    """Largest phase difference of two batch results with r's phases moved to ref's
+    output frequencies (with a non-dedispersed DM the phase at the zero-covariance
+    frequency moves by 1e-10 rot for a 2e-12 relative change of that frequency)."""
+    from pulseportraiture_amd.pplib import Dconst
+    phi = r["params"][:, 0] + Dconst * r["params"][:, 1] / P * (ref["nu_refs"][:, 0] ** -2 -
+                                                                 r["nu_refs"][:, 0] ** -2)
+    return np.max(np.abs((phi - ref["params"][:, 0] + 0.5) % 1 - 0.5))
+
+
 def _medium_batch(eng, nsub, C=512, B=2048, seed=11):
     import torch
     from pulseportraiture_amd import gmodel
@@ -1516,35 +1526,39 @@ def test_mixed_batch_re_transforms_only_the_poor_guesses(eng):
 def test_pilot_seed_matches_full_seed(eng):
     """The device phase seed formed from every 8th channel (pilot pass) leads to the
     same fit as the seed formed from all channels; seeds that fail the pilot's
-    significance test (forced here for every subint) are redone from all channels."""
+    significance test (forced here for every subint) are redone from all channels.
+    With the Newton solver the answers agree to rounding; SciPy's iteration, walked
+    from two different seeds, stops at two different points ~1e-10 rot apart (the
+    reference's own scatter with its starting point)."""
     nsub = 64
     data, freqs, P, x0, kw = _medium_batch(eng, nsub, seed=12)
     x0 = x0.copy()
     x0[:, 0] = 0.123           # ignored by the seed
+    mask = np.ones((nsub, len(freqs)), dtype=np.uint8)
+    mask[:, ::3] = 0
     try:
+        for method, tol in (("newton", 1e-12), ("trust-ncg", PHI_BAR)):
+            eng.set_option("seed_chan_stride", 1)
+            full = eng.fit_batch(data, freqs, P, x0, seed_ns=100, method=method, **kw)
+            eng.set_option("seed_chan_stride", 8)
+            pilot = eng.fit_batch(data, freqs, P, x0, seed_ns=100, method=method, **kw)
+            eng.set_option("seed_min_snr", 1e30)      # every pilot seed "weak"
+            weak = eng.fit_batch(data, freqs, P, x0, seed_ns=100, method=method, **kw)
+            eng.set_option("seed_min_snr", 8.0)
+            for name, r in (("pilot", pilot), ("weak", weak)):
+                dphi = _dphi_common(r, full, P)
+                assert dphi < tol, (method, name, dphi)
+                assert np.max(np.abs(r["params"][:, 1] - full["params"][:, 1])) < 1e3 * tol
+                np.testing.assert_allclose(r["chi2"], full["chi2"], rtol=1e-11)
+                assert (r["return_code"] == 2).all() and (r["nfeval"] == 1).all()
+        # a third of the channels masked, measured noise: same agreement
+        kw2 = dict(kw, errs=None, chan_mask=mask)
         eng.set_option("seed_chan_stride", 1)
-        full = eng.fit_batch(data, freqs, P, x0, seed_ns=100, **kw)
+        full = eng.fit_batch(data, freqs, P, x0, seed_ns=100, method="newton", **kw2)
         eng.set_option("seed_chan_stride", 8)
-        pilot = eng.fit_batch(data, freqs, P, x0, seed_ns=100, **kw)
-        eng.set_option("seed_min_snr", 1e30)      # every pilot seed "weak"
-        weak = eng.fit_batch(data, freqs, P, x0, seed_ns=100, **kw)
+        pilot = eng.fit_batch(data, freqs, P, x0, seed_ns=100, method="newton", **kw2)
+        assert _dphi_common(pilot, full, P) < 1e-12
+        np.testing.assert_allclose(pilot["chi2"], full["chi2"], rtol=1e-11)
     finally:
         eng.set_option("seed_chan_stride", 8)
         eng.set_option("seed_min_snr", 8.0)
-    for r in (pilot, weak):
-        assert np.max(np.abs((r["params"][:, 0] - full["params"][:, 0] + 0.5) % 1 - 0.5)) < 1e-11
-        assert np.max(np.abs(r["params"][:, 1] - full["params"][:, 1])) < 1e-9
-        np.testing.assert_allclose(r["chi2"], full["chi2"], rtol=1e-11)
-        assert (r["return_code"] == 2).all() and (r["nfeval"] == 1).all()
-    # a third of the channels masked, measured noise: same agreement
-    import torch
-    mask = np.ones((nsub, len(freqs)), dtype=np.uint8)
-    mask[:, ::3] = 0
-    kw2 = dict(kw, errs=None, chan_mask=mask)
-    eng.set_option("seed_chan_stride", 1)
-    full = eng.fit_batch(data, freqs, P, x0, seed_ns=100, **kw2)
-    eng.set_option("seed_chan_stride", 8)
-    pilot = eng.fit_batch(data, freqs, P, x0, seed_ns=100, **kw2)
-    assert np.max(np.abs((pilot["params"][:, 0] - full["params"][:, 0] + 0.5) % 1 - 0.5)) < 1e-11
-    np.testing.assert_allclose(pilot["chi2"], full["chi2"], rtol=1e-11)
-    del torch
