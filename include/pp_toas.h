@@ -86,7 +86,7 @@ void* pp_stream(pp_ctx* ctx);
  *                  per-channel Taylor-model solve; 0 = always iterate
  *   "seed_chan_stride"  device phase seed (seed_ns > 0) of fits without scattering:
  *                  the seed is formed in a pilot pass over every n-th channel (default
- *                  8; 1 = from all channels, with the cross-spectrum stored), then the
+ *                  16; 1 = from all channels, with the cross-spectrum stored), then the
  *                  usual single pass runs at the seeded phase
  *   "seed_min_snr" pilot seeds whose correlation peak stands less than this many rms
  *                  above the mean of the grid (default 8) are redone from all channels
@@ -130,6 +130,34 @@ int pp_model_set_gaussian(pp_ctx* ctx, int slot, int nchan, int nbin,
                           const double* freqs, const char* code, double nu_ref,
                           double dc, double tau_rot, double alpha, int ngauss,
                           const double* comps);
+
+/* Spline (PCA + B-spline) template portraits synthesised on the device (.spl files:
+ * read_spline_model / gen_spline_portrait, pplib.py:2955-2987, 932-956): row n =
+ * basis[0] + sum_c splev(freqs[n]; t, coefs[c], degree) * basis[1 + c], where basis
+ * [ncomp + 1][nbin] holds the mean profile and the eigenvectors (resampled to nbin
+ * on the host when the model's own resolution differs), t[nknots] the knots and
+ * coefs[ncomp][nknots] the B-spline coefficients of scipy's `tck` (FITPACK layout).
+ * The curve is evaluated like scipy.interpolate.splev(..., ext=0).  pp_spline_portrait
+ * writes the [nchan][nbin] f64 portrait (host or device pointer);
+ * pp_model_set_spline loads it straight into a model slot. */
+int pp_spline_portrait(pp_ctx* ctx, int nchan, int nbin, const double* freqs, int ncomp,
+                       const double* basis, int nknots, const double* t,
+                       const double* coefs, int degree, double* portrait,
+                       int out_on_device);
+int pp_model_set_spline(pp_ctx* ctx, int slot, int nchan, int nbin, const double* freqs,
+                        int ncomp, const double* basis, int nknots, const double* t,
+                        const double* coefs, int degree);
+
+/* Instrumental response applied to the template resident in `slot`, in the Fourier
+ * domain on the device (instrumental_response_port_FT, pptoaslib.py:145-179, as
+ * get_TOAs(add_instrumental_response=True) uses it, pptoas.py:388-394):
+ * m_nk <- m_nk * rconst[k] * sinc(k smear_wid[n]).  rconst: host [nbin/2 + 1]
+ * interleaved (re, im), the product of the constant responses, or NULL; smear_wid:
+ * host [nchan], the dispersive smearing width of every channel in rotations
+ * (8.3e-6 chan_bw / nu_GHz^3 / P as the reference forms it; 0 = none), or NULL.  The
+ * harmonic truncation of the slot is re-derived. */
+int pp_model_apply_response(pp_ctx* ctx, int slot, const double* rconst,
+                            const double* smear_wid);
 
 /* ---- the batched fit ----------------------------------------------------- */
 typedef struct {

@@ -80,6 +80,11 @@ SYMBOLS = {
     "pp_model_set_gaussian": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p,
                                         C.c_char_p, C.c_double, C.c_double, C.c_double,
                                         C.c_double, C.c_int, c_double_p]),
+    "pp_spline_portrait": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, C.c_int, c_double_p,
+                                     C.c_int, c_double_p, c_double_p, C.c_int, C.c_void_p, C.c_int]),
+    "pp_model_set_spline": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p, C.c_int,
+                                      c_double_p, C.c_int, c_double_p, c_double_p, C.c_int]),
+    "pp_model_apply_response": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p]),
     "pp_align_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, c_double_p, C.c_int64, c_double_p,
                                       c_double_p, c_double_p, c_double_p, c_double_p]),

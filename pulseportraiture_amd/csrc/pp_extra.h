@@ -299,6 +299,112 @@ __global__ __launch_bounds__(FftPlan<M>::T) void k_gauss_portrait(GaussArgs a) {
 }
 
 // --------------------------------------------------------------------------
+// Spline (PCA + B-spline) template portraits on the device:
+// gen_spline_portrait (pplib.py:932-956) = mean profile + (B-spline curve of the
+// PCA coordinates evaluated at the channel frequency) x eigenvectors.  The curve
+// is evaluated the way scipy.interpolate.splev does (FITPACK splev / fpbspl,
+// ext = 0: the boundary pieces extrapolate): interval search, the k+1 non-zero
+// B-splines by the Cox-de Boor recurrence, dot product with the coefficients.
+// One workgroup per channel; basis = [mean_prof; eigvec_0; ...; eigvec_{nc-1}]
+// rows of nbin (already resampled to nbin on the host when the model's own
+// resolution differs: resampling is linear, so it commutes with the sum).
+// --------------------------------------------------------------------------
+#define PP_MAX_SPLINE_DEG 5
+#define PP_MAX_SPLINE_COMP 32
+struct SplineArgs {
+    const double* freqs;   // [nchan]
+    const double* basis;   // [ncomp + 1][nbin]
+    const double* t;       // [nk] knots
+    const double* c;       // [ncomp][nk] coefficients (FITPACK layout: the last k+1 unused)
+    double* out;           // [nchan][nbin]
+    int nchan, nbin, ncomp, nk, k;
+};
+
+__device__ inline double splev_one(const double* t, int n, const double* c, int k, double x) {
+    // FITPACK splev (1-based indices kept as in the source)
+    const int k1 = k + 1, k2 = k1 + 1, nk1 = n - k1;
+    int l = k1, l1 = l + 1;
+    while (x < t[l - 1] && l1 != k2) { l1 = l; l = l - 1; }
+    while (x >= t[l1 - 1] && l != nk1) { l = l1; l1 = l + 1; }
+    // fpbspl
+    double h[PP_MAX_SPLINE_DEG + 2], hh[PP_MAX_SPLINE_DEG + 1];
+    h[0] = 1.0;
+    for (int j = 1; j <= k; ++j) {
+        for (int i = 0; i < j; ++i) hh[i] = h[i];
+        h[0] = 0.0;
+        for (int i = 1; i <= j; ++i) {
+            const int li = l + i, lj = li - j;
+            if (t[li - 1] != t[lj - 1]) {
+                const double f = hh[i - 1] / (t[li - 1] - t[lj - 1]);
+                h[i - 1] = h[i - 1] + f * (t[li - 1] - x);
+                h[i] = f * (x - t[lj - 1]);
+            } else h[i] = 0.0;
+        }
+    }
+    double sp = 0.0;
+    int ll = l - k1;
+    for (int j = 1; j <= k1; ++j) { ll = ll + 1; sp = sp + c[ll - 1] * h[j - 1]; }
+    return sp;
+}
+
+__global__ __launch_bounds__(256) void k_spline_portrait(SplineArgs a) {
+    __shared__ double proj[PP_MAX_SPLINE_COMP];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    if (tid < a.ncomp) proj[tid] = splev_one(a.t, a.nk, a.c + (size_t)tid * a.nk, a.k, a.freqs[n]);
+    __syncthreads();
+    double* out = a.out + (size_t)n * a.nbin;
+    for (int b = tid; b < a.nbin; b += 256) {
+        // numpy.dot(proj, eigvec.T) + mean_prof: the products summed in component order
+        double s = 0.0;
+        for (int cidx = 0; cidx < a.ncomp; ++cidx)
+            s = __dadd_rn(s, __dmul_rn(proj[cidx], a.basis[(size_t)(cidx + 1) * a.nbin + b]));
+        out[b] = __dadd_rn(s, a.basis[b]);
+    }
+}
+
+// --------------------------------------------------------------------------
+// Instrumental response applied to a resident template in the Fourier domain
+// (instrumental_response_port_FT, pptoaslib.py:145-179; get_TOAs(add_instrumental_
+// response=True), pptoas.py:388-394): m_nk <- m_nk rconst_k sinc(k wid_n), with
+// rconst the product of the constant responses (host, nbin/2 + 1 complex values)
+// and wid_n the dispersive smearing of channel n in rotations (0 = none).  Re-forms
+// |m_nk|^2, its sum and maximum per channel, and the DC term.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_model_response(cplx* mft, double* msq, double* msum, double* mmax,
+                                                        double* mdc, const cplx* rconst, const double* wid,
+                                                        int nchan, int M) {
+    __shared__ double scratch[8];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const double wn = wid ? wid[n] : 0.0;
+    double s = 0.0, mx = 0.0;
+    for (int k = 1 + tid; k <= M; k += 256) {
+        cplx r = rconst ? rconst[k] : make_double2(1.0, 0.0);
+        if (wn != 0.0) {
+            // numpy.sinc: sin(pi x) / (pi x)
+            const double y = 3.141592653589793 * ((double)k * wn);
+            const double sc = sin(y) / y;
+            r.x *= sc; r.y *= sc;
+        }
+        const cplx m = cmul(mft[(size_t)n * M + (k - 1)], r);
+        mft[(size_t)n * M + (k - 1)] = m;
+        const double p = cnorm(m);
+        msq[(size_t)n * M + (k - 1)] = p;
+        s += p;
+        mx = fmax(mx, p);
+    }
+    s = group_sum<64>(s);
+    mx = group_max<64>(mx);
+    if ((tid & 63) == 0) { scratch[2 * (tid >> 6)] = s; scratch[2 * (tid >> 6) + 1] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        s = 0.0; mx = 0.0;
+        for (int w = 0; w < 4; ++w) { s += scratch[2 * w]; mx = fmax(mx, scratch[2 * w + 1]); }
+        msum[n] = s; mmax[n] = mx;
+        if (rconst) mdc[n] *= rconst[0].x;
+    }
+}
+
+// --------------------------------------------------------------------------
 // ppalign's accumulation (ppalign.py:199-206): aligned[n] = sum_i w_in *
 // rotate_data(data_in, phase_i, DM_i, P_i, freqs, nu_ref_i), totw[n] = sum_i w_in.
 // Rotation is linear, so the weighted harmonics of all subints of a channel are

@@ -281,3 +281,92 @@ extern "C" int pp_model_set_gaussian(pp_ctx* c, int slot, int nchan, int nbin, c
         return rc;
     return pp_model_set(c, slot, c->X.p, PP_F64, 1, nchan, nbin);
 }
+
+// ---- spline (PCA + B-spline) templates on the device --------------------------
+static int spline_generate(pp_ctx* c, int nchan, int nbin, const double* freqs, int ncomp, const double* basis,
+                           int nknots, const double* t, const double* coefs, int degree, double* dev_out) {
+    if (!freqs || !basis || (ncomp > 0 && (!t || !coefs))) return fail(PP_EINVAL, "spline portrait: null argument");
+    if (nbin < 2 || nchan < 1) return fail(PP_EINVAL, "spline portrait: bad shape");
+    if (ncomp < 0 || ncomp > PP_MAX_SPLINE_COMP) return fail(PP_EINVAL, "spline portrait: 0..%d components", PP_MAX_SPLINE_COMP);
+    if (ncomp > 0 && (degree < 1 || degree > PP_MAX_SPLINE_DEG || nknots < 2 * (degree + 1)))
+        return fail(PP_EINVAL, "spline portrait: degree %d with %d knots", degree, nknots);
+    int rc;
+    if ((rc = upload(c, c->freqs, freqs, (size_t)nchan * 8))) return rc;
+    const size_t nb = (size_t)(ncomp + 1) * nbin, nt = (size_t)std::max(nknots, 1), ncf = (size_t)std::max(ncomp, 1) * nt;
+    if ((rc = c->seedbuf.reserve((nb + nt + ncf) * 8))) return rc;
+    double* dbasis = c->seedbuf.as<double>();
+    double* dt = dbasis + nb;
+    double* dc = dt + nt;
+    HIP_TRY(hipMemcpyAsync(dbasis, basis, nb * 8, hipMemcpyHostToDevice, c->stream));
+    if (ncomp > 0) {
+        HIP_TRY(hipMemcpyAsync(dt, t, (size_t)nknots * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(dc, coefs, (size_t)ncomp * nknots * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    SplineArgs a{c->freqs.as<double>(), dbasis, dt, dc, dev_out, nchan, nbin, ncomp, nknots, degree};
+    {
+        Prof pr(c, KF_MODEL);
+        hipLaunchKernelGGL(k_spline_portrait, dim3(nchan), dim3(256), 0, c->stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return PP_OK;
+}
+
+extern "C" int pp_spline_portrait(pp_ctx* c, int nchan, int nbin, const double* freqs, int ncomp,
+                                  const double* basis, int nknots, const double* t, const double* coefs,
+                                  int degree, double* portrait, int out_on_device) {
+    if (!c || !portrait) return fail(PP_EINVAL, "pp_spline_portrait: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    double* dout = portrait;
+    if (!out_on_device) {
+        if ((rc = c->data.reserve((size_t)nchan * nbin * 8))) return rc;
+        dout = c->data.as<double>();
+    }
+    if ((rc = spline_generate(c, nchan, nbin, freqs, ncomp, basis, nknots, t, coefs, degree, dout))) return rc;
+    if (!out_on_device)
+        HIP_TRY(hipMemcpyAsync(portrait, dout, (size_t)nchan * nbin * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PP_OK;
+}
+
+extern "C" int pp_model_set_spline(pp_ctx* c, int slot, int nchan, int nbin, const double* freqs, int ncomp,
+                                   const double* basis, int nknots, const double* t, const double* coefs,
+                                   int degree) {
+    if (!c) return fail(PP_EINVAL, "pp_model_set_spline: null context");
+    if (!nbin_ok(nbin)) return fail(PP_EINVAL, "pp_model_set_spline: nbin %d must be a power of two in [32,8192]", nbin);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->X.reserve((size_t)nchan * nbin * 8))) return rc;     // scratch for the portrait
+    if ((rc = spline_generate(c, nchan, nbin, freqs, ncomp, basis, nknots, t, coefs, degree, c->X.as<double>())))
+        return rc;
+    return pp_model_set(c, slot, c->X.p, PP_F64, 1, nchan, nbin);
+}
+
+// ---- instrumental response applied to a resident template ---------------------
+extern "C" int pp_model_apply_response(pp_ctx* c, int slot, const double* rconst, const double* smear_wid) {
+    if (!c || slot < 0 || slot >= PP_MAX_SLOTS || !c->slots[slot].set)
+        return fail(PP_ESTATE, "pp_model_apply_response: slot not set");
+    if (!rconst && !smear_wid) return PP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    ModelSlot& s = c->slots[slot];
+    const int M = s.nbin / 2;
+    int rc;
+    const cplx* drc = nullptr;
+    const double* dwid = nullptr;
+    if (rconst) {
+        if ((rc = upload(c, c->seedbuf, rconst, (size_t)(M + 1) * 16))) return rc;
+        drc = c->seedbuf.as<cplx>();
+    }
+    if (smear_wid) {
+        if ((rc = upload(c, c->errs, smear_wid, (size_t)s.nchan * 8))) return rc;
+        dwid = c->errs.as<double>();
+    }
+    {
+        Prof pr(c, KF_MODEL);
+        hipLaunchKernelGGL(k_model_response, dim3(s.nchan), dim3(256), 0, c->stream, s.mft.as<cplx>(),
+                           s.msq.as<double>(), s.msum.as<double>(), s.mmax.as<double>(), s.mdc.as<double>(), drc,
+                           dwid, s.nchan, M);
+    }
+    HIP_TRY(hipGetLastError());
+    return model_publish(c, slot);
+}

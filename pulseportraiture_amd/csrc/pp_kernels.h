@@ -1225,7 +1225,15 @@ __global__ __launch_bounds__(256) void k_eval_moments(FitArgs a) {
 }
 
 // Horner evaluation of the shifted sums A0', A1', A2' from the Taylor model
-__device__ __forceinline__ void taylor_shift(const double* t, double d, double& A0, double& A1, double& A2) {
+// (the channel's 12 doubles are fetched as six 16-byte loads: rows are 96 B apart)
+__device__ __forceinline__ void taylor_shift(const double* tg, double d, double& A0, double& A1, double& A2) {
+    static_assert(PP_TSTRIDE % 2 == 0, "rows of the Taylor model are read in pairs");
+    double t[PP_TSTRIDE];
+#pragma unroll
+    for (int j = 0; j < PP_TSTRIDE / 2; ++j) {
+        const double2 v = reinterpret_cast<const double2*>(tg)[j];
+        t[2 * j] = v.x; t[2 * j + 1] = v.y;
+    }
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
     for (int j = PP_TJ; j >= 0; --j) {

@@ -96,7 +96,7 @@ struct pp_ctx {
     int use_taylor = 1;
     int moments_in_xspec = 1;   // fold the Taylor moments into k_xspec (mode 2) when it applies
     int paired_split = 1;       // 2048-bin rows: last FFT stage + split in registers (k_xspec_p1024)
-    int seed_chan_stride = 8;   // device phase seed: pilot pass over every n-th channel (1 = all channels)
+    int seed_chan_stride = 16;  // device phase seed: pilot pass over every n-th channel (1 = all channels)
     double seed_min_snr = 8.0;  // pilot seeds below this peak significance are redone from all channels
     double max_work_bytes = 96e9;
     // profiling
@@ -297,6 +297,33 @@ static int fft_grid(int T, long long nrows) {
 // --------------------------------------------------------------------------
 // model
 // --------------------------------------------------------------------------
+// harmonic truncation of a slot whose spectrum is in place (per-channel kept
+// harmonics kt[n] and their maximum) and its entry in the device pointer tables
+static int model_publish(pp_ctx* c, int slot) {
+    ModelSlot& s = c->slots[slot];
+    const int nchan = s.nchan, M = s.nbin / 2;
+    int rc;
+    int Kt = M;
+    {
+        if ((rc = c->misc.reserve(256))) return rc;
+        HIP_TRY(hipMemsetAsync(c->misc.p, 0, sizeof(int), c->stream));
+        // eps = 0 keeps everything: threshold -1 makes every harmonic "significant"
+        const double eps2 = c->harm_eps > 0.0 ? c->harm_eps * c->harm_eps : -1.0;
+        hipLaunchKernelGGL(k_model_kcut, dim3(nchan), dim3(64), 0, c->stream, s.mft.as<cplx>(), s.mmax.as<double>(),
+                           nchan, M, eps2, s.kt.as<int>(), c->misc.as<int>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&Kt, c->misc.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        Kt = std::min(M, std::max(64, Kt));
+    }
+    s.set = true; s.Kt = Kt;
+    void* ptrs[5] = {s.mft.p, s.msum.p, s.kt.p, s.mdc.p, s.msq.p};
+    DevBuf* tables[5] = {&c->mft_table, &c->msum_table, &c->kt_table, &c->mdc_table, &c->msq_table};
+    for (int j = 0; j < 5; ++j)
+        HIP_TRY(hipMemcpy((char*)tables[j]->p + sizeof(void*) * slot, &ptrs[j], sizeof(void*), hipMemcpyHostToDevice));
+    return PP_OK;
+}
+
 extern "C" int pp_model_set(pp_ctx* c, int slot, const void* portrait, int dtype, int on_device, int nchan,
                             int nbin) {
     if (!c || !portrait) return fail(PP_EINVAL, "pp_model_set: null argument");
@@ -334,32 +361,8 @@ extern "C" int pp_model_set(pp_ctx* c, int slot, const void* portrait, int dtype
         });
     }
     HIP_TRY(hipGetLastError());
-    // harmonic truncation: per-channel kept harmonics kt[n] and their maximum
-    int Kt = M;
-    {
-        if ((rc = c->misc.reserve(256))) return rc;
-        HIP_TRY(hipMemsetAsync(c->misc.p, 0, sizeof(int), c->stream));
-        // eps = 0 keeps everything: threshold -1 makes every harmonic "significant"
-        const double eps2 = c->harm_eps > 0.0 ? c->harm_eps * c->harm_eps : -1.0;
-        hipLaunchKernelGGL(k_model_kcut, dim3(nchan), dim3(64), 0, c->stream, s.mft.as<cplx>(), s.mmax.as<double>(),
-                           nchan, M, eps2, s.kt.as<int>(), c->misc.as<int>());
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(&Kt, c->misc.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        Kt = std::min(M, std::max(64, Kt));
-    }
-    s.set = true; s.nchan = nchan; s.nbin = nbin; s.Kt = Kt;
-    void* pm = s.mft.p;
-    void* ps = s.msum.p;
-    HIP_TRY(hipMemcpy((char*)c->mft_table.p + sizeof(void*) * slot, &pm, sizeof(void*), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy((char*)c->msum_table.p + sizeof(void*) * slot, &ps, sizeof(void*), hipMemcpyHostToDevice));
-    void* pk = s.kt.p;
-    HIP_TRY(hipMemcpy((char*)c->kt_table.p + sizeof(void*) * slot, &pk, sizeof(void*), hipMemcpyHostToDevice));
-    void* pd = s.mdc.p;
-    HIP_TRY(hipMemcpy((char*)c->mdc_table.p + sizeof(void*) * slot, &pd, sizeof(void*), hipMemcpyHostToDevice));
-    void* pq = s.msq.p;
-    HIP_TRY(hipMemcpy((char*)c->msq_table.p + sizeof(void*) * slot, &pq, sizeof(void*), hipMemcpyHostToDevice));
-    return PP_OK;
+    s.nchan = nchan; s.nbin = nbin;
+    return model_publish(c, slot);
 }
 
 extern "C" int pp_model_dc(pp_ctx* c, int slot, double* dc) {

@@ -374,6 +374,47 @@ class Engine(object):
         self._digests.pop(int(slot), None)
         return int(self._lib.pp_model_nharm(self._ctx, int(slot)))
 
+    def _spline_args(self, mean_prof, eigvec, tck, nbin):
+        from .splmodel import spline_device_args
+        basis, t, coefs, k = spline_device_args(mean_prof, eigvec, tck, nbin)
+        ncomp = basis.shape[0] - 1
+        return basis, t, coefs, k, ncomp
+
+    def spline_portrait(self, mean_prof, eigvec, tck, freqs, nbin=None):
+        """nchan x nbin portrait of a spline model (gen_spline_portrait, pplib.py:932-956)
+        built on the device; returns a NumPy array."""
+        freqs = _f64(freqs)
+        basis, t, coefs, k, ncomp = self._spline_args(mean_prof, eigvec, tck, nbin)
+        out = np.empty((len(freqs), basis.shape[1]))
+        _check(self._lib.pp_spline_portrait(self._ctx, len(freqs), basis.shape[1], _dp(freqs), ncomp,
+                                            _dp(basis), len(t), _dp(t), _dp(coefs), k,
+                                            C.c_void_p(out.ctypes.data), 0), "pp_spline_portrait")
+        return out
+
+    def set_model_spline(self, mean_prof, eigvec, tck, freqs, nbin=None, slot=0):
+        """Synthesise a spline (.spl) template on the device straight into a model
+        slot (no host portrait); returns the number of harmonics kept."""
+        freqs = _f64(freqs)
+        basis, t, coefs, k, ncomp = self._spline_args(mean_prof, eigvec, tck, nbin)
+        _check(self._lib.pp_model_set_spline(self._ctx, int(slot), len(freqs), basis.shape[1], _dp(freqs),
+                                             ncomp, _dp(basis), len(t), _dp(t), _dp(coefs), k),
+               "pp_model_set_spline")
+        self._digests.pop(int(slot), None)
+        return int(self._lib.pp_model_nharm(self._ctx, int(slot)))
+
+    def apply_response(self, slot, rconst=None, smear_wid=None):
+        """Multiply the template resident in `slot` by an instrumental response in the
+        Fourier domain, on the device: rconst[nbin/2 + 1] (complex, the product of the
+        constant responses) and/or smear_wid[nchan] (dispersive smearing width of each
+        channel in rotations).  pptoaslib.py:145-179."""
+        rc = None if rconst is None else np.ascontiguousarray(
+            np.asarray(rconst, dtype=np.complex128)).view(np.float64)
+        wd = None if smear_wid is None else _f64(smear_wid)
+        _check(self._lib.pp_model_apply_response(self._ctx, int(slot), _dp(rc), _dp(wd)),
+               "pp_model_apply_response")
+        self._digests.pop(int(slot), None)
+        return int(self._lib.pp_model_nharm(self._ctx, int(slot)))
+
     def model_means(self, slot, nchan, nbin):
         """Mean over phase of every channel of the template in `slot` (its DC
         harmonic / nbin)."""

@@ -293,6 +293,16 @@ class GetTOAs(object):
         Gaussian-component models are synthesised on the device, spline models are
         evaluated on the host and uploaded."""
         mdl = self._gmodel()
+        if mdl is None:
+            # spline (.spl) template: B-spline curve x eigenvectors evaluated on the
+            # device straight into the slot (no host portrait)
+            from .splmodel import read_spline_model
+            name, _, _, mean_prof, eigvec, tck = read_spline_model(self.modelfile, quiet=True)
+            self.model_name = name
+            if np.asarray(eigvec).reshape(len(mean_prof), -1).shape[1] <= 32 and \
+                    (not np.asarray(eigvec).size or int(tck[2]) <= 5):
+                eng.set_model_spline(mean_prof, eigvec, tck, freqs_row, nbin, slot=slot)
+                return
         if mdl is None or mdl["ngauss"] > 64:
             eng.set_model(self._model_for(freqs_row, nbin, P, unscattered), slot=slot)
             return
@@ -389,20 +399,17 @@ class GetTOAs(object):
                     if len(slots) >= 64:
                         raise NotImplementedError("more than 64 distinct templates in one archive")
                     slots[key] = len(slots)
+                    self._load_template(eng, slots[key], d.freqs[isub], nbin, d.Ps[isub],
+                                        unscattered=fit_scat)
                     if use_ird:
-                        # template x instrumental response, on the good channels
-                        # (pptoas.py:388-394)
-                        from .pptoaslib import instrumental_response_port_FT
-                        mport = np.array(self._model_for(d.freqs[isub], nbin, d.Ps[isub],
-                                                         unscattered=fit_scat))
-                        resp = instrumental_response_port_FT(nbin, freqsx, self.ird['DM'],
-                                                             d.Ps[isub], self.ird['wids'],
-                                                             self.ird['irf_types'])
-                        mport[ich] = np.fft.irfft(resp * np.fft.rfft(mport[ich], axis=-1), axis=-1)
-                        eng.set_model(mport, slot=slots[key])
-                    else:
-                        self._load_template(eng, slots[key], d.freqs[isub], nbin, d.Ps[isub],
-                                            unscattered=fit_scat)
+                        # template x instrumental response of the good channels
+                        # (pptoas.py:388-394), multiplied in the Fourier domain on the
+                        # device: constant responses x per-channel dispersive smearing
+                        from .pptoaslib import instrumental_response_device_args
+                        rconst, smear = instrumental_response_device_args(
+                            nbin, freqsx, self.ird['DM'], d.Ps[isub], self.ird['wids'],
+                            self.ird['irf_types'], nchan=nchan, ichans=ich)
+                        eng.apply_response(slots[key], rconst, smear)
                 slot_of[j] = slots[key]
                 if nu_fits is None:
                     nu_fit = guess_fit_freq(freqsx, d.SNRs[isub, 0, ich])
@@ -815,18 +822,14 @@ class GetTOAs(object):
                     if len(slots) >= 64:
                         raise NotImplementedError("more than 64 distinct templates in one archive")
                     slots[key] = len(slots)
+                    self._load_template(eng, slots[key], d.freqs[isub], nbin, d.Ps.mean(),
+                                        unscattered=scat)
                     if use_ird:     # show_fit applies it over all channels (pptoas.py:1389-1395)
-                        from .pptoaslib import instrumental_response_port_FT
-                        mport = np.array(self._model_for(d.freqs[isub], nbin, d.Ps.mean(),
-                                                         unscattered=scat))
-                        resp = instrumental_response_port_FT(nbin, d.freqs[isub], self.ird['DM'],
-                                                             d.Ps[isub], self.ird['wids'],
-                                                             self.ird['irf_types'])
-                        eng.set_model(np.fft.irfft(resp * np.fft.rfft(mport, axis=-1), axis=-1),
-                                      slot=slots[key])
-                    else:
-                        self._load_template(eng, slots[key], d.freqs[isub], nbin, d.Ps.mean(),
-                                            unscattered=scat)
+                        from .pptoaslib import instrumental_response_device_args
+                        rconst, smear = instrumental_response_device_args(
+                            nbin, d.freqs[isub], self.ird['DM'], d.Ps[isub], self.ird['wids'],
+                            self.ird['irf_types'])
+                        eng.apply_response(slots[key], rconst, smear)
                 slot_of[j] = slots[key]
                 scales[j] = self.scales[iarch][isub]
             port = _dededisperse(eng, _take_subints(d.subints, ok_isubs), d, ok_isubs)

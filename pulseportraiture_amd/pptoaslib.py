@@ -152,3 +152,30 @@ def instrumental_response_port_FT(nbin, freqs, DM=0.0, P=1.0, wids=[], irf_types
             wid = 8.3e-6 * chan_bw / (freq / 1e3) ** 3 / P
             resp[ichan] *= instrumental_response_FT(nbin, wid, 'rect')
     return resp
+
+
+def instrumental_response_device_args(nbin, freqs, DM=0.0, P=1.0, wids=[], irf_types=[], nchan=None,
+                                      ichans=None):
+    """The two factors of instrumental_response_port_FT as Engine.apply_response takes
+    them: the product of the constant responses (nbin/2 + 1 complex values, or None)
+    and the dispersive smearing width of every channel in rotations (or None).
+    `freqs` are the channels the response applies to (pptoas.py:388-394 passes the good
+    channels: the smearing uses THEIR spacing); with ichans / nchan the widths are
+    scattered into a full-length array, zero (no response) elsewhere."""
+    nharm = nbin // 2 + 1
+    rconst = None
+    if len(wids):
+        rconst = np.ones(nharm, dtype=np.complex128)
+        for wid, irf_type in zip(wids, irf_types):
+            rconst = rconst * np.asarray(instrumental_response_FT(nbin, wid, irf_type))
+    smear = None
+    if DM:
+        freqs = np.asarray(freqs, dtype=np.float64)
+        chan_bw = abs(freqs[1] - freqs[0])
+        w = 8.3e-6 * chan_bw / (freqs / 1e3) ** 3 / P
+        if ichans is not None:
+            smear = np.zeros(int(nchan))
+            smear[np.asarray(ichans, dtype=int)] = w
+        else:
+            smear = w
+    return rconst, smear

@@ -46,3 +46,30 @@ def read_spline_model(modelfile, freqs=None, nbin=None, quiet=False):
     if freqs is None:
         return (modelname, source, datafile, mean_prof, eigvec, tck)
     return (modelname, gen_spline_portrait(mean_prof, freqs, eigvec, tck, nbin))
+
+
+def spline_device_args(mean_prof, eigvec, tck, nbin=None):
+    """What the device synthesis needs (Engine.set_model_spline): the basis
+    [ncomp + 1, nbin] = mean profile and eigenvectors -- resampled to nbin exactly
+    as gen_spline_portrait resamples the finished portrait (the operation is linear
+    along phase, so it commutes with the sum over components) --, the knots, the
+    [ncomp, nknots] coefficients and the degree of `tck`."""
+    mean_prof = np.asarray(mean_prof, dtype=np.float64)
+    eigvec = np.asarray(eigvec, dtype=np.float64).reshape(len(mean_prof), -1)
+    basis = np.vstack([mean_prof[None, :], eigvec.T])
+    if nbin is not None and len(mean_prof) != nbin:
+        shift = 0.5 * (nbin ** -1 - len(mean_prof) ** -1)
+        basis = ss.resample(basis, nbin, axis=1)
+        bFT = np.fft.rfft(basis, axis=1)
+        bFT *= np.exp(np.arange(bFT.shape[1]) * 2.0j * np.pi * shift)
+        basis = np.fft.irfft(bFT)
+    ncomp = eigvec.shape[1]
+    if ncomp:
+        t = np.ascontiguousarray(tck[0], dtype=np.float64)
+        coefs = np.ascontiguousarray(np.array([np.asarray(cj, dtype=np.float64) for cj in tck[1]]))
+        if coefs.shape[1] < len(t):       # scipy >= 1.? may trim the unused tail
+            coefs = np.hstack([coefs, np.zeros((ncomp, len(t) - coefs.shape[1]))])
+        k = int(tck[2])
+    else:
+        t, coefs, k = np.zeros(1), np.zeros((1, 1)), 3
+    return np.ascontiguousarray(basis), t, np.ascontiguousarray(coefs[:, :len(t)]), k

@@ -1560,5 +1560,67 @@ def test_pilot_seed_matches_full_seed(eng):
         assert _dphi_common(pilot, full, P) < 1e-12
         np.testing.assert_allclose(pilot["chi2"], full["chi2"], rtol=1e-11)
     finally:
-        eng.set_option("seed_chan_stride", 8)
+        eng.set_option("seed_chan_stride", 16)
         eng.set_option("seed_min_snr", 8.0)
+
+
+def test_device_spline_portrait_matches_reference(eng):
+    """Spline (.spl) templates synthesised on the device -- FITPACK-style B-spline
+    evaluation of the PCA coordinates x eigenvectors + mean profile -- against the
+    reference's own gen_spline_portrait output (golden spline_model_256: native
+    resolution, resampled to 512 bins, and a model without eigenvectors), and the
+    slot it loads against an uploaded host portrait."""
+    from pulseportraiture_amd import splmodel
+    g = _load("spline_model_256")
+    name, src, dfile, mean_prof, eigvec, tck = splmodel.read_spline_model(
+        os.path.join(GOLDEN, "example.spl"), quiet=True)
+    f = g["freqs"]
+    port = eng.spline_portrait(mean_prof, eigvec, tck, f)
+    scale = np.abs(g["port"]).max()
+    assert np.abs(port - g["port"]).max() < 1e-14 * scale
+    port512 = eng.spline_portrait(mean_prof, eigvec, tck, f, nbin=512)
+    assert np.abs(port512 - g["port_512"]).max() < 1e-13 * scale
+    flat = eng.spline_portrait(mean_prof, np.asarray(eigvec)[:, :0], tck, f)
+    np.testing.assert_array_equal(flat, g["port_flat"])
+    # frequencies outside the knot range extrapolate like scipy's splev(ext=0)
+    fx = np.array([900.0, 1105.0, 1500.0, 1895.0, 2100.0])
+    np.testing.assert_allclose(eng.spline_portrait(mean_prof, eigvec, tck, fx),
+                               splmodel.gen_spline_portrait(mean_prof, fx, eigvec, tck), rtol=0,
+                               atol=1e-13 * scale)
+    # the slot filled on the device fits like the slot filled from the host portrait
+    C, B = len(f), 256
+    rng = np.random.default_rng(3)
+    data = g["port"] * 1.7 + rng.normal(0, 0.02, (C, B))
+    kw = dict(errs=np.full(C, 0.02), nu_fits=[[1500.0] * 3], fit_flags=[1, 1, 0, 0, 0], method="newton")
+    eng.set_model(g["port"])
+    a = eng.fit_batch(data[None], f, 0.003, [0.0, 0.0, 0, 0, 0], **kw)
+    eng.set_model_spline(mean_prof, eigvec, tck, f, 256)
+    b = eng.fit_batch(data[None], f, 0.003, [0.0, 0.0, 0, 0, 0], **kw)
+    assert abs(a["params"][0, 0] - b["params"][0, 0]) < 1e-12
+    np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-11)
+
+
+def test_device_instrumental_response_matches_host(eng):
+    """apply_response (constant responses x per-channel dispersive smearing, multiplied
+    into the resident template's spectrum on the device) against the same template
+    multiplied on the host with instrumental_response_port_FT (pptoaslib.py:145-179)."""
+    from pulseportraiture_amd.pptoaslib import (instrumental_response_port_FT,
+                                                instrumental_response_device_args)
+    g = _load("fpf_64x256_phiDM")
+    C, B = g["model"].shape
+    P = float(g["P"])
+    wids, types, DM = [0.011, 0.004], ["rect", "gauss"], 30.0
+    resp = instrumental_response_port_FT(B, g["freqs"], DM, P, wids, types)
+    host = np.fft.irfft(resp * np.fft.rfft(g["model"], axis=-1), axis=-1)
+    kw = dict(errs=g["errs"], nu_fits=[list(g["nu_fits"])], fit_flags=[1, 1, 0, 0, 0], method="newton")
+    eng.set_model(host)
+    a = eng.fit_batch(g["data"][None], g["freqs"], P, g["init_params"], **kw)
+    eng.set_model(g["model"])
+    rconst, smear = instrumental_response_device_args(B, g["freqs"], DM, P, wids, types)
+    eng.apply_response(0, rconst, smear)
+    b = eng.fit_batch(g["data"][None], g["freqs"], P, g["init_params"], **kw)
+    assert _dphi(a["params"][0, 0], b["params"][0, 0]) < 1e-12
+    assert abs(a["params"][0, 1] - b["params"][0, 1]) < 1e-10
+    np.testing.assert_allclose(a["scales"], b["scales"], rtol=1e-10)
+    np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-11)
+    np.testing.assert_allclose(a["param_errs"], b["param_errs"], rtol=1e-9)
