@@ -1226,14 +1226,23 @@ __global__ __launch_bounds__(256) void k_eval_moments(FitArgs a) {
 
 // Horner evaluation of the shifted sums A0', A1', A2' from the Taylor model
 // (the channel's 12 doubles are fetched as six 16-byte loads: rows are 96 B apart)
-__device__ __forceinline__ void taylor_shift(const double* tg, double d, double& A0, double& A1, double& A2) {
+__device__ __forceinline__ void taylor_load(const double* tg, double (&t)[PP_TSTRIDE]) {
     static_assert(PP_TSTRIDE % 2 == 0, "rows of the Taylor model are read in pairs");
-    double t[PP_TSTRIDE];
 #pragma unroll
     for (int j = 0; j < PP_TSTRIDE / 2; ++j) {
         const double2 v = reinterpret_cast<const double2*>(tg)[j];
         t[2 * j] = v.x; t[2 * j + 1] = v.y;
     }
+}
+__device__ __forceinline__ void taylor_shift_reg(const double (&t)[PP_TSTRIDE], double d, double& A0, double& A1,
+                                                 double& A2);
+__device__ __forceinline__ void taylor_shift(const double* tg, double d, double& A0, double& A1, double& A2) {
+    double t[PP_TSTRIDE];
+    taylor_load(tg, t);
+    taylor_shift_reg(t, d, A0, A1, A2);
+}
+__device__ __forceinline__ void taylor_shift_reg(const double (&t)[PP_TSTRIDE], double d, double& A0, double& A1,
+                                                 double& A2) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
     for (int j = PP_TJ; j >= 0; --j) {
@@ -1249,10 +1258,18 @@ __device__ __forceinline__ void taylor_shift(const double* tg, double d, double&
 // Solve on the Taylor model, one 256-thread block per subint.  method 0 walks
 // SciPy's trust-ncg iteration on the model (every evaluation is O(nchan), no pass
 // over the data), method 1 is plain Newton to the rounding of f.
-__global__ __launch_bounds__(256) void k_taylor_solve(FitArgs a) {
+// CPT > 0: 512 threads, each keeps the Taylor rows of its CPT channels (nchan <= 512 CPT)
+// in registers, so the ~8 passes of the solve read them from HBM once; CPT = 0: 256
+// threads re-reading the rows on every pass (any nchan).
+#ifndef PP_TAYLOR_WAVES
+#define PP_TAYLOR_WAVES 2     // waves per SIMD the generic variant is compiled for (register cap 512 / n)
+#endif
+template <int CPT>
+__global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a) {
+    constexpr int NT = CPT ? 512 : 256, NWV = NT / 64;
     const int i = blockIdx.x, tid = threadIdx.x;
     SubState& st = a.st[i];
-    __shared__ double scratch[4 * 12];
+    __shared__ double scratch[NWV * 12];
     __shared__ double shx[8];
     const double P = a.P[i];
     const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1];
@@ -1263,6 +1280,34 @@ __global__ __launch_bounds__(256) void k_taylor_solve(FitArgs a) {
     const int* fl = a.flags;
     int idx[3], nf = 0;
     for (int j = 0; j < 3; ++j) if (fl[j]) idx[nf++] = j;
+    double treg[CPT ? CPT : 1][PP_TSTRIDE];
+    if constexpr (CPT > 0) {
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int n = tid + NT * q;
+            if (n < a.nchan) taylor_load(tay + (size_t)n * PP_TSTRIDE, treg[q]);
+            else {
+#pragma unroll
+                for (int j = 0; j < PP_TSTRIDE; ++j) treg[q][j] = 0.0;
+            }
+        }
+    }
+    // this thread's channels: body(n, row of the Taylor model)
+    auto for_channels = [&](auto&& body) {
+        if constexpr (CPT > 0) {
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                const int n = tid + NT * q;
+                if (n < a.nchan) body(n, treg[q]);
+            }
+        } else {
+            for (int n = tid; n < a.nchan; n += NT) {
+                double t[PP_TSTRIDE];
+                taylor_load(tay + (size_t)n * PP_TSTRIDE, t);
+                body(n, t);
+            }
+        }
+    };
     // f, g, H of the model at displacement dx from x0 (identical in every thread);
     // returns the largest per-channel phase displacement
     auto evalm = [&](const double* dx, double& f, double* g, double* H) -> double {
@@ -1270,15 +1315,15 @@ __global__ __launch_bounds__(256) void k_taylor_solve(FitArgs a) {
 #pragma unroll
         for (int j = 0; j < 10; ++j) acc[j] = 0.0;
         double dmax = 0.0;
-        for (int n = tid; n < a.nchan; n += 256) {
+        for_channels([&](int n, const double (&t)[PP_TSTRIDE]) {
             const double w = wts[n];
-            if (w == 0.0) continue;
+            if (w == 0.0) return;
             double p1, p2;
             phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
             const double d = dx[0] + dx[1] * p1 + dx[2] * p2;
             dmax = fmax(dmax, fabs(d));
             double A0, A1, A2;
-            taylor_shift(tay + (size_t)n * PP_TSTRIDE, d, A0, A1, A2);
+            taylor_shift_reg(t, d, A0, A1, A2);
             const double S0 = msum[n], r = A0 / S0;
             const double F = -w * A0 * r, Gp = -2.0 * w * r * A1;
             const double Lpp = -2.0 * w * (A1 * A1 / S0 + r * A2);
@@ -1286,38 +1331,44 @@ __global__ __launch_bounds__(256) void k_taylor_solve(FitArgs a) {
             acc[1] += Gp; acc[2] += Gp * p1; acc[3] += Gp * p2;
             acc[4] += Lpp; acc[5] += Lpp * p1; acc[6] += Lpp * p2;
             acc[7] += Lpp * p1 * p1; acc[8] += Lpp * p1 * p2; acc[9] += Lpp * p2 * p2;
-        }
+        });
         block_sum<10>(acc, scratch);
         dmax = group_max<64>(dmax);
         __syncthreads();
         if ((tid & 63) == 0) shx[tid >> 6] = dmax;
         __syncthreads();
-        dmax = fmax(fmax(shx[0], shx[1]), fmax(shx[2], shx[3]));
+        {
+            double m = shx[0];
+            for (int w_ = 1; w_ < NWV; ++w_) m = fmax(m, shx[w_]);
+            dmax = m;
+        }
         __syncthreads();
         f = acc[0];
-        for (int j = 0; j < 5; ++j) g[j] = 0.0;
-        for (int j = 0; j < 25; ++j) H[j] = 0.0;
+        // (phi, DM, GM) block only: 3 + 9 numbers per thread instead of 5 + 25
         g[0] = fl[0] ? acc[1] : 0.0; g[1] = fl[1] ? acc[2] : 0.0; g[2] = fl[2] ? acc[3] : 0.0;
         const double hh[3][3] = {{acc[4], acc[5], acc[6]}, {acc[5], acc[7], acc[8]}, {acc[6], acc[8], acc[9]}};
+#pragma unroll
         for (int r_ = 0; r_ < 3; ++r_)
-            for (int c_ = 0; c_ < 3; ++c_) H[r_ * 5 + c_] = (fl[r_] && fl[c_]) ? hh[r_][c_] : 0.0;
+#pragma unroll
+            for (int c_ = 0; c_ < 3; ++c_) H[r_ * 3 + c_] = (fl[r_] && fl[c_]) ? hh[r_][c_] : 0.0;
         return dmax;
     };
     auto subspace = [&](const double* g, const double* H, double* gs, double* Hs) {
         for (int r_ = 0; r_ < nf; ++r_) {
             gs[r_] = g[idx[r_]];
-            for (int c_ = 0; c_ < nf; ++c_) Hs[r_ * nf + c_] = H[idx[r_] * 5 + idx[c_]];
+            for (int c_ = 0; c_ < nf; ++c_) Hs[r_ * nf + c_] = H[idx[r_] * 3 + idx[c_]];
         }
     };
     double dx[3] = {0.0, 0.0, 0.0};      // accepted displacement from x0 in (phi, DM, GM)
-    double f, g[5], H[25];
+    double f, g[3], H[9];
     bool ok = true;
     int it = 0;
     double dpath = evalm(dx, f, g, H);   // (0 at the expansion point)
     if (tid == 0) {
         st.f0 = f;
-        for (int j = 0; j < 5; ++j) st.g0[j] = g[j];
-        for (int j = 0; j < 25; ++j) st.H0[j] = H[j];
+        for (int j = 0; j < 5; ++j) st.g0[j] = j < 3 ? g[j] : 0.0;
+        for (int r_ = 0; r_ < 5; ++r_)
+            for (int c_ = 0; c_ < 5; ++c_) st.H0[r_ * 5 + c_] = (r_ < 3 && c_ < 3) ? H[r_ * 3 + c_] : 0.0;
     }
     if (!isfinite(f)) ok = false;
     if (ok && a.method == 0) {
@@ -1331,15 +1382,15 @@ __global__ __launch_bounds__(256) void k_taylor_solve(FitArgs a) {
             if (!(pred > 0.0)) break;                 // SciPy's status 2, the reference's normal exit
             double xt[3] = {dx[0], dx[1], dx[2]};
             for (int r_ = 0; r_ < nf; ++r_) xt[idx[r_]] += p[r_];
-            double f2, g2[5], H2[25];
+            double f2, g2[3], H2[9];
             dpath = fmax(dpath, evalm(xt, f2, g2, H2));
             bool finite = isfinite(f2);
             for (int j = 0; j < 3; ++j) finite = finite && isfinite(g2[j]);
             if (tr_scipy_accept(f, f2, pred, hits, finite, &radius)) {
                 for (int j = 0; j < 3; ++j) dx[j] = xt[j];
                 f = f2;
-                for (int j = 0; j < 5; ++j) g[j] = g2[j];
-                for (int j = 0; j < 25; ++j) H[j] = H2[j];
+                for (int j = 0; j < 3; ++j) g[j] = g2[j];
+                for (int j = 0; j < 9; ++j) H[j] = H2[j];
             }
             ++it;
             if (it >= a.max_iter || !(radius > 1e-300)) { ok = false; break; }
@@ -1367,25 +1418,34 @@ __global__ __launch_bounds__(256) void k_taylor_solve(FitArgs a) {
         // (g, H belong to the point before the last step: the certificate only
         // needs the curvature scale; the published sums are taken at x0 + dx)
     }
-    // ---- certificate: truncation error of the gradient, in parameter units ----
-    double ev[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // err bounds g_phi, g_DM, g_GM; H00; max |d|
+    // ---- certificate (truncation error of the gradient, in parameter units) and the
+    // sums of the accepted point x0 + dx for the post-fit stage, in ONE pass over the
+    // model (they go to the buffer that only becomes current if the certificate holds)
+    const int buf = 1 - st.cur;
     if (ok) {
+        double* csum = a.csum + ((size_t)buf * a.nsub + i) * a.nchan * a.ncs;
+        double ev[4] = {0.0, 0.0, 0.0, 0.0};   // err bounds g_phi, g_DM, g_GM; f at the accepted point
         double jf = 1.0;
         for (int j = 2; j <= PP_TJ; ++j) jf *= (double)j;   // PP_TJ!
-        for (int n = tid; n < a.nchan; n += 256) {
+        for_channels([&](int n, const double (&t)[PP_TSTRIDE]) {
             const double w = wts[n];
-            if (w == 0.0) continue;
             double p1, p2;
             phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
             const double d = dx[0] + dx[1] * p1 + dx[2] * p2;
-            const double* t = tay + (size_t)n * PP_TSTRIDE;
+            double A0, A1, A2;
+            taylor_shift_reg(t, d, A0, A1, A2);
+            csum[(size_t)n * 3] = A0; csum[(size_t)n * 3 + 1] = A1; csum[(size_t)n * 3 + 2] = A2;
+            if (w == 0.0) return;
+            ev[3] += -w * A0 * A0 / msum[n];
             // remainder of A1's series (one derivative): Bn |d|^PP_TJ / PP_TJ!
-            const double e1 = t[PP_TJ + 1] * pow(fabs(d), (double)PP_TJ) / jf;
+            const double d2 = d * d, d4 = d2 * d2, d10 = d4 * d4 * d2;
+            static_assert(PP_TJ == 10, "remainder power written for order 10");
+            const double e1 = t[PP_TJ + 1] * d10 / jf;
             const double r = fabs(t[0] / msum[n]) + 1e-300;
             const double ge = 2.0 * w * r * e1 * 1.5;   // + remainder through A0 (smaller by |d|/PP_TJ)
             ev[0] += ge; ev[1] += ge * fabs(p1); ev[2] += ge * fabs(p2);
-        }
-        block_sum<4>(reinterpret_cast<double(&)[4]>(ev), scratch);
+        });
+        block_sum<4>(ev, scratch);
         __syncthreads();
         // position error <= gradient error / curvature, per fitted parameter
         // (1e-11 pc cm^-3 of DM is worth ~1e-11 rot of phase at the band edge: two
@@ -1393,44 +1453,26 @@ __global__ __launch_bounds__(256) void k_taylor_solve(FitArgs a) {
         const double tol[3] = {1e-13, 1e-11, 1e-8};   // turns, pc cm^-3, GM units
         for (int j = 0; j < 3; ++j)
             if (fl[j]) {
-                const double hjj = fabs(H[j * 5 + j]);
+                const double hjj = fabs(H[j * 3 + j]);
                 if (!(ev[j] <= tol[j] * hjj)) ok = false;
             }
         // every point the iteration visited must lie inside the model's range
         if (!(dpath < 0.02)) ok = false;
-    }
-    __syncthreads();
-    if (ok) {
-        // accepted point = x0 + dx; publish its sums for the post-fit stage
-        const int buf = 1 - st.cur;
-        double* csum = a.csum + ((size_t)buf * a.nsub + i) * a.nchan * a.ncs;
-        double fsum = 0.0;
-        for (int n = tid; n < a.nchan; n += 256) {
-            double p1, p2;
-            phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
-            const double d = dx[0] + dx[1] * p1 + dx[2] * p2;
-            double A0, A1, A2;
-            taylor_shift(tay + (size_t)n * PP_TSTRIDE, d, A0, A1, A2);
-            csum[(size_t)n * 3] = A0; csum[(size_t)n * 3 + 1] = A1; csum[(size_t)n * 3 + 2] = A2;
-            if (wts[n] != 0.0) fsum += -wts[n] * A0 * A0 / msum[n];
-        }
-        double fv[1] = {fsum};
-        block_sum<1>(fv, scratch);
-        if (tid == 0) {
+        if (ok && tid == 0) {
             for (int j = 0; j < 3; ++j) st.x[j] = st.xe[j] + dx[j];
             st.x[3] = st.xe[3]; st.x[4] = st.xe[4];
-            st.f = fv[0];
-            for (int j = 0; j < 5; ++j) st.g[j] = g[j];
-            for (int j = 0; j < 25; ++j) st.H[j] = H[j];
+            st.f = ev[3];
+            for (int j = 0; j < 5; ++j) st.g[j] = j < 3 ? g[j] : 0.0;
+            for (int r_ = 0; r_ < 5; ++r_)
+                for (int c_ = 0; c_ < 5; ++c_) st.H[r_ * 5 + c_] = (r_ < 3 && c_ < 3) ? H[r_ * 3 + c_] : 0.0;
             st.cur = buf; st.nfev = 1; st.iter = it; st.status = PP_RC_STALL; st.done = 1; st.fresh = 0;
             atomicSub(a.nactive, 1);
         }
-    } else if (tid == 0) {
-        // fall back to evaluations over X, starting from the initial point
-        st.fresh = 1;
     }
+    // (not ok: fall back to evaluations over X, starting from the initial point;
+    // k_init_state left fresh = 1)
+    if (!ok && tid == 0) st.fresh = 1;
 }
-
 
 // unpack the 21 accumulators into g[5], H[25] with the fit flags applied
 // (pptoaslib.py:573, 629-630)

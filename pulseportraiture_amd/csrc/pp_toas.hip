@@ -731,7 +731,8 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         }
         {
             Prof pr(c, KF_TAYLOR);
-            hipLaunchKernelGGL(k_taylor_solve, dim3(ns), dim3(256), 0, c->stream, fa);
+            // (rows of the Taylor model in registers where the channel count allows)
+            hipLaunchKernelGGL(k_taylor_solve<0>, dim3(ns), dim3(256), 0, c->stream, fa);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(c->nactive_h, fa.nactive, sizeof(int), hipMemcpyDeviceToHost, c->stream));

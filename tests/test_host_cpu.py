@@ -127,3 +127,48 @@ def test_instrumental_response_matches_reference():
     np.testing.assert_allclose(resp, g["out_ird_resp"], rtol=1e-13, atol=1e-15)
     gft = ns["gaussian_profile_FT"](g["subints"].shape[-1], 0.3, 0.02, 1.7)
     np.testing.assert_allclose(gft, g["out_ird_gauss_FT"], rtol=1e-13, atol=1e-13)
+
+
+def test_tim_lines_match_the_hand_derived_fixture(tmp_path):
+    """The .tim line format of write_TOAs (pplib.py:3445-3503), byte for byte against
+    tests/golden/toa_lines.tim -- lines written out by hand from the reference's format
+    strings (15-decimal MJD fraction spliced onto the integer day, three spaces, %.3f
+    error, two spaces, the telescope code; -pp_dm / -pp_dme with 7 decimals; flags in
+    insertion order with the per-type formats; None flags skipped; 0.0 for an infinite
+    frequency).  Also through a file, append and overwrite."""
+    import collections
+    import json
+    from pulseportraiture_amd.pptoas import MJD, TOA, toa_string, write_TOAs
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    want = [ln.rstrip("\n") for ln in open(os.path.join(here, "toa_lines.tim")) if not ln.startswith("#")]
+    recs = json.load(open(os.path.join(here, "toa_lines.json")))
+    toas = []
+    for r in recs:
+        flags = collections.OrderedDict((k, v) for k, v in r["flags"])
+        freq = np.inf if r["frequency"] == "inf" else r["frequency"]
+        toas.append(TOA(r["archive"], freq, MJD(r["mjd_day"], r["mjd_frac"]), r["TOA_error"], r["telescope"],
+                        r["telescope_code"], r["DM"], r["DM_error"], flags))
+    assert [toa_string(t) for t in toas] == want
+    # inf_is_zero=False writes "inf" like Python's %f would
+    assert toa_string(toas[1], inf_is_zero=False).startswith("fake.fits inf 56001.000000000000001")
+    out = tmp_path / "t.tim"
+    write_TOAs(toas, outfile=str(out), append=False)
+    write_TOAs(toas[0], outfile=str(out), append=True)
+    assert open(out).read() == "\n".join(want + [want[0]]) + "\n"
+    # the S/N cut drops the second TOA (snr 9.5) and any TOA without an snr flag
+    write_TOAs(toas, SNR_cutoff=10.0, outfile=str(out), append=False)
+    assert open(out).read() == want[0] + "\n"
+
+
+def test_get_TOAs_flag_order_is_the_reference_insertion_order():
+    """The flag dictionary get_TOAs builds follows the statement order of the reference
+    (pptoas.py:607-657), which is the order the .tim line lists them in."""
+    import inspect
+    from pulseportraiture_amd import pptoas
+    src = inspect.getsource(pptoas.GetTOAs.get_TOAs)
+    order = ["'gm'", "'gm_err'", "'scat_time'", "'scat_ref_freq'", "'scat_ind'", "'scat_ind_err'", "'be'",
+             "'fe'", "'f'", "'nbin'", "'nch'", "'nchx'", "'bw'", "'chbw'", "'subint'", "'tobs'", "'fratio'",
+             "'tmplt'", "'snr'", "'phi_DM_cov'", "'gof'", "'phs'", "'phs_err'", "'flux'", "'flux_err'",
+             "'flux_ref_freq'", "'par_angle'"]
+    pos = [src.index("toa_flags[%s]" % k) for k in order]
+    assert pos == sorted(pos), [k for k, a, b in zip(order[1:], pos, pos[1:]) if b < a]
