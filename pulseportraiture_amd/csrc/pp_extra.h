@@ -719,7 +719,7 @@ __global__ __launch_bounds__(256) void k_list_active(const SubState* st, const d
 // --------------------------------------------------------------------------
 #define PP_SEED_KPT 16   // harmonics per lane (one wave per channel): Kt <= 1024
 __global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart, int Ks) {
-    const int jx = blockIdx.y, i = sub_of(a.act, jx), chunk = blockIdx.x, tid = threadIdx.x;
+    const int jx = blockIdx.x, i = sub_of(a.act, jx), chunk = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     __shared__ cplx ysh[3 * 64 * PP_SEED_KPT / 4];   // three waves' partial spectra, one quarter at a time
     const double P = a.P[i];

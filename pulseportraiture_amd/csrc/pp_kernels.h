@@ -670,7 +670,10 @@ __device__ __forceinline__ void accumulate_channel(const Local& L, const ChanGeo
 }
 
 // --------------------------------------------------------------------------
-// chi^2 evaluator.  grid = (nchunk, nsub), 256 threads; 16 lanes per channel.
+// chi^2 evaluator.  grid = (nsub, nchunk) -- the subint runs fastest, so the
+// workgroups in flight together work on the SAME channels of different subints and
+// share the template's |m_nk|^2 rows in their XCD's L2 --, 256 threads; 16 lanes per
+// channel.
 // Each lane owns harmonics k = l+1, l+17, ... and advances its phasor by
 // e^{2 pi i 16 phi_n} (taken from lane 15's start phasor, k = 16).
 // --------------------------------------------------------------------------
@@ -683,7 +686,7 @@ __device__ __forceinline__ void accumulate_channel(const Local& L, const ChanGeo
 template <bool SCAT>
 __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
     constexpr int LPC = 16;
-    const int jx = blockIdx.y, i = sub_of(a.act, jx), chunk = blockIdx.x;
+    const int jx = blockIdx.x, i = sub_of(a.act, jx), chunk = blockIdx.y;
     SubState& st = a.st[i];
     if (st.done) return;
     __shared__ double red[(256 / LPC) * PP_NACC];
@@ -807,7 +810,7 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
 // First evaluation when k_xspec already produced the per-channel sums (FUSE):
 // only the O(nchan) chain rule + reduction remains.  grid = (nchunk, nsub).
 __global__ __launch_bounds__(256) void k_accum(FitArgs a) {
-    const int i = sub_of(a.act, blockIdx.y), chunk = blockIdx.x, tid = threadIdx.x;
+    const int i = sub_of(a.act, blockIdx.x), chunk = blockIdx.y, tid = threadIdx.x;
     SubState& st = a.st[i];
     if (st.done) return;
     __shared__ double scratch[4 * PP_NACC];
@@ -852,7 +855,7 @@ __global__ __launch_bounds__(256) void k_accum(FitArgs a) {
 // only two of the 21 per-subint accumulators.
 __global__ __launch_bounds__(256) void k_eval_fast(FitArgs a) {
     constexpr int LPC = 16;
-    const int jx = blockIdx.y, i = sub_of(a.act, jx), chunk = blockIdx.x;
+    const int jx = blockIdx.x, i = sub_of(a.act, jx), chunk = blockIdx.y;
     SubState& st = a.st[i];
     if (st.done) return;
     __shared__ double red[(256 / LPC) * PP_NACC];
@@ -1152,7 +1155,7 @@ __device__ inline bool tr_scipy_accept(double f, double f_new, double pred, int 
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_eval_moments(FitArgs a) {
     constexpr int LPC = 16;
-    const int jx = blockIdx.y, i = sub_of(a.act, jx), chunk = blockIdx.x;
+    const int jx = blockIdx.x, i = sub_of(a.act, jx), chunk = blockIdx.y;
     const SubState& st = a.st[i];
     const int tid = threadIdx.x, g = tid / LPC, l = tid % LPC;
     const double phi = st.xe[0], DM = st.xe[1], GM = st.xe[2];

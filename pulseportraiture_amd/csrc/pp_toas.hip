@@ -651,7 +651,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         cplx* ypart = c->seedbuf.as<cplx>();
         cplx* ywork = ypart + (size_t)f.nact * f.nchunk * Ks;
         Prof pr(c, KF_SEED);
-        hipLaunchKernelGGL(k_seed_accum, dim3(f.nchunk, f.nact), dim3(256), 0, c->stream, f, ypart, Ks);
+        hipLaunchKernelGGL(k_seed_accum, dim3(f.nact, f.nchunk), dim3(256), 0, c->stream, f, ypart, Ks);
         hipLaunchKernelGGL(k_seed_fit, dim3(f.nact), dim3(256), 0, c->stream, f, (const cplx*)ypart, ywork,
                            c->x0.as<double>(), (int)in->seed_ns, Ks, seedq);
         HIP_TRY(hipGetLastError());
@@ -727,7 +727,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     if (taylor) {
         if (xstore) {
             Prof pr(c, KF_EVAL);
-            hipLaunchKernelGGL(k_eval_moments, dim3(nchunk, ns), dim3(256), 0, c->stream, fa);
+            hipLaunchKernelGGL(k_eval_moments, dim3(ns, nchunk), dim3(256), 0, c->stream, fa);
         }
         {
             Prof pr(c, KF_TAYLOR);
@@ -751,11 +751,11 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     for (int it = 0; it < max_evals; ++it) {
         if (it == 0 && fuse) {
             Prof pr(c, KF_ACCUM);
-            hipLaunchKernelGGL(k_accum, dim3(fa.nchunk, fa.nact), dim3(256), 0, c->stream, fa);
+            hipLaunchKernelGGL(k_accum, dim3(fa.nact, fa.nchunk), dim3(256), 0, c->stream, fa);
         } else {
             Prof pr(c, KF_EVAL);
-            if (scat) hipLaunchKernelGGL(k_eval<true>, dim3(fa.nchunk, fa.nact), dim3(256), 0, c->stream, fa);
-            else hipLaunchKernelGGL(k_eval_fast, dim3(fa.nchunk, fa.nact), dim3(256), 0, c->stream, fa);
+            if (scat) hipLaunchKernelGGL(k_eval<true>, dim3(fa.nact, fa.nchunk), dim3(256), 0, c->stream, fa);
+            else hipLaunchKernelGGL(k_eval_fast, dim3(fa.nact, fa.nchunk), dim3(256), 0, c->stream, fa);
         }
         {
             Prof pr(c, KF_STEP);
