@@ -1,23 +1,28 @@
 #!/bin/bash
-# usage (on the MI355X box, repo root):  ./tools_profile.sh r01
+# usage (on the MI355X box, repo root):  ./tools_profile.sh r02
 # Runs every profiling pass behind profiles/<round>_* and writes the summaries to
 # gpurun_out/profiles_<round>/ (copy them into profiles/ afterwards).
 # Counter passes are separate runs with --kernel-trace only (no sys/hip traces).
 set -u
 export TMPDIR=/tmp
-R=${1:-r01}
+R=${1:-r02}
 O=gpurun_out/profiles_$R
 rm -rf $O; mkdir -p $O/raw
+# the driver's command: headline + other workloads + CPU baseline in one line
 python3 bench.py > $O/${R}_bench.json 2> $O/raw/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${R}_bench_under_rocprof.json 2> $O/raw/trace.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $O/raw/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $O/raw/write.err
-./tools_pmc.sh $R > $O/${R}_sq_counters.txt 2>&1
-for w in cfg2-512x1024-phiDM cfg3-4096x2048-phiDMGM cfg4-2048x2048-scat; do
-  python3 bench.py --workload $w > $O/raw/bench_$w.json 2>> $O/raw/bench.err
-done
-python3 bench.py --input-dtype f32 --no-cpu-baseline > $O/raw/bench_f32.json 2>> $O/raw/bench.err
-python3 bench.py --seed-ns 100 --no-cpu-baseline > $O/raw/bench_seeded.json 2>> $O/raw/bench.err
+# profiled passes: headline only (no CPU pool: nothing may be spawned under rocprofv3)
+B="python3 bench.py --no-cpu-baseline --no-other-workloads"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/trace -- $B --steps 3 --warmup 1 > $O/${R}_bench_under_rocprof.json 2> $O/raw/trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_fetch -- $B --steps 1 --warmup 0 > /dev/null 2> $O/raw/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_write -- $B --steps 1 --warmup 0 > /dev/null 2> $O/raw/write.err
+./tools_pmc.sh $R --no-other-workloads > $O/${R}_sq_counters.txt 2>&1
+# configs[3] (scattering): kernel stats and HBM counters of its own
+W4="--workload cfg4-2048x2048-scat"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/trace_cfg4 -- $B $W4 --steps 3 --warmup 1 > $O/raw/bench_cfg4_under_rocprof.json 2> $O/raw/trace4.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_fetch_cfg4 -- $B $W4 --steps 1 --warmup 0 > /dev/null 2> $O/raw/fetch4.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_write_cfg4 -- $B $W4 --steps 1 --warmup 0 > /dev/null 2> $O/raw/write4.err
+# the seeded (get_TOAs) flow
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/trace_seeded -- $B --seed-ns 100 --steps 3 --warmup 1 > $O/raw/bench_seeded_under_rocprof.json 2> $O/raw/trace_s.err
 python3 - $O $R <<'PY'
 import csv, glob, json, sys, collections, os
 O, R = sys.argv[1], sys.argv[2]
@@ -63,16 +68,34 @@ if fb > 0:
     except Exception as ex:
         print("no SQ counters for the co-limit:", ex)
     json.dump(tl, open(f"{O}/traffic_latest.json", "w"), indent=1)
-allw = {}
-for tag, fn in [("plain", f"{O}/{R}_bench.json")] + [(os.path.basename(f)[6:-5], f) for f in sorted(glob.glob(O + "/raw/bench_*.json"))]:
+# configs[3]: per-launch traffic of the evaluator and of the transform
+def first(pat):
+    fs = glob.glob(pat)
+    return fs[0] if fs else None
+for tag in ("cfg4", "seeded"):
+    f = first(f"{O}/raw/trace_{tag}/*/*_kernel_stats.csv")
+    if f:
+        open(f"{O}/{R}_{tag}_kernel_stats.csv", "w").write(open(f).read())
+f4, w4 = counters("pmc_fetch_cfg4", "FETCH_SIZE"), counters("pmc_write_cfg4", "WRITE_SIZE")
+if f4:
     try:
-        d = json.loads(open(fn).read().strip().splitlines()[-1])
+        b4 = json.loads(open(f"{O}/raw/bench_cfg4_under_rocprof.json").read().strip().splitlines()[-1])
+        n4 = b4["config"]["nsub_per_gpu_per_step"]
+        alg = b4["roofline"]["algorithmic_bytes_per_fit"]
+        rows = {}
+        for kn in ("k_eval", "k_xspec", "k_step", "k_finalize"):
+            fb = sum(v["sum_KiB"] for k, v in f4.items() if kn in k) * 2048
+            wb = sum(v["sum_KiB"] for k, v in w4.items() if kn in k) * 1024
+            nd = sum(v["dispatches"] for k, v in f4.items() if kn in k)
+            rows[kn] = {"dispatches_per_step": nd, "hbm_bytes_per_fit": (fb + wb) / n4,
+                        "hbm_bytes_per_fit_per_dispatch": (fb + wb) / n4 / max(nd, 1)}
+        tot = sum(r["hbm_bytes_per_fit"] for r in rows.values())
+        json.dump({"workload": b4["config"]["workload"], "method": b4["config"]["method"], "nsub": n4,
+                   "fits_per_s_under_profiler": b4["value"], "algorithmic_bytes_per_fit": alg,
+                   "hbm_bytes_per_fit_all_kernels": tot, "traffic_over_algorithmic": tot / alg,
+                   "kernels": rows, "note": "FETCH_SIZE x2 + WRITE_SIZE of one step (separate --pmc passes)"},
+                  open(f"{O}/{R}_cfg4_traffic.json", "w"), indent=1)
     except Exception as ex:
-        allw[tag] = {"error": str(ex)}; continue
-    allw[tag] = {"value": d["value"], "ms_per_step": d["ms_per_step"], "nsub": d["config"]["nsub_per_gpu_per_step"],
-                 "kernels_ms": d["roofline"]["all_kernels_ms_per_step"], "frac": d["roofline"]["frac"],
-                 "conv": d.get("convergence"), "cpu": d.get("cpu_baseline")}
-json.dump(allw, open(f"{O}/{R}_all_workloads.json", "w"), indent=1)
-print(json.dumps({k: (v.get("value"), v.get("kernels_ms")) for k, v in allw.items()}, indent=1))
+        print("cfg4 traffic summary failed:", ex)
 PY
 ls -la $O
