@@ -718,13 +718,16 @@ __global__ __launch_bounds__(256) void k_list_active(const SubState* st, const d
 //               phase into x0[i][0].
 // --------------------------------------------------------------------------
 #define PP_SEED_KPT 16   // harmonics per lane (one wave per channel): Kt <= 1024
-__global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart, int Ks) {
+// dm_off: trial offset added to the guessed DM (the DM axis of the coarse (phi, DM)
+// grid: one accumulation + phase search per trial value, the best correlation peak wins)
+__global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart, int Ks, const double* xbase,
+                                                    double dm_off) {
     const int jx = blockIdx.x, i = sub_of(a.act, jx), chunk = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     __shared__ cplx ysh[3 * 64 * PP_SEED_KPT / 4];   // three waves' partial spectra, one quarter at a time
     const double P = a.P[i];
     const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1];
-    const double DM = a.x0[i * 5 + 1], GM = a.x0[i * 5 + 2];
+    const double DM = xbase[i * 5 + 1] + dm_off, GM = xbase[i * 5 + 2];
     const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
     const double* wts = a.wts + (size_t)i * a.nchan;
     const int* ktv = a.ktab ? a.ktab[a.slot ? a.slot[i] : 0] : nullptr;
@@ -793,15 +796,18 @@ __global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart, int 
 // (noise rms of the correlation, from the weights and the template power) -- the
 // matched-filter S/N of the channels used, which tells a seed formed from a subset
 // of the channels apart from a noise peak
+// bestpk (optional, DM trials): the seed is written only if this trial's peak beats the
+// best so far (trial 0 always writes); xbase / dm_off as in k_seed_accum.
 __global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, cplx* ywork, double* x0, int Ns,
-                                                  int Ks, double* seedq) {
+                                                  int Ks, double* seedq, const double* xbase, double dm_off,
+                                                  double* bestpk, int trial) {
     const int jx = blockIdx.x, i = sub_of(a.act, jx), tid = threadIdx.x, K = Ks;
     __shared__ double scratch[4 * 4];
     __shared__ double shv[4];
     __shared__ int shj[4];
     cplx* Y = ywork + (size_t)jx * K;
     // scattering kernel of the guessed tau at the fit reference frequency
-    const double taup = x0[i * 5 + 3];
+    const double taup = xbase[i * 5 + 3];
     const double tau = a.scat ? (a.log10_tau ? pow(10.0, taup) : taup) : 0.0;
     for (int k = tid + 1; k <= K; k += 256) {
         cplx s = make_double2(0.0, 0.0);
@@ -828,13 +834,20 @@ __global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, 
         gs[0] += s0;
     }
     const int best = min(block_argmin256(bestv, bestj, shv, shj), Ns - 1);
-    if (seedq) {
-        double pk = group_max<64>(-bestv);      // maximum of the CCF over the grid
+    double pk = group_max<64>(-bestv);          // maximum of the CCF over the grid
+    __syncthreads();
+    if ((tid & 63) == 0) shv[tid >> 6] = pk;
+    __syncthreads();
+    pk = fmax(fmax(shv[0], shv[1]), fmax(shv[2], shv[3]));
+    __syncthreads();
+    // DM trials: a trial that does not beat the best peak so far changes nothing
+    bool take = true;
+    if (bestpk) {
+        take = (trial == 0) || (pk > bestpk[i]);
         __syncthreads();
-        if ((tid & 63) == 0) shv[tid >> 6] = pk;
-        __syncthreads();
-        pk = fmax(fmax(shv[0], shv[1]), fmax(shv[2], shv[3]));
-        __syncthreads();
+        if (take && tid == 0) bestpk[i] = pk;
+    }
+    if (seedq && take) {
         // noise of the correlation: Var = sum_n w_n^2 sigma_Fn^2 sum_k |m_nk|^2 = sum_n w_n S_n
         // over the channels that went into Y (S_n over all harmonics: a slight
         // overestimate, on the safe side)
@@ -867,11 +880,12 @@ __global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, 
         phi = nxt;
         if (step < 1e-13) break;
     }
-    if (tid == 0) {
+    if (tid == 0 && take) {
         // wrap to [-0.5, 0.5) like phase_transform(..., mod=True)
         if (fabs(phi) >= 0.5) { phi = fmod(phi, 1.0); if (phi < 0.0) phi += 1.0; }
         if (phi >= 0.5) phi -= 1.0;
         x0[i * 5] = phi;
+        x0[i * 5 + 1] = xbase[i * 5 + 1] + dm_off;
     }
 }
 

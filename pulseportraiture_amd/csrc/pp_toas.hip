@@ -86,7 +86,7 @@ struct pp_ctx {
     DevBuf o_pack;   // per-subint scalar outputs, one allocation -> one D2H copy
     void* o_host = nullptr; size_t o_host_cap = 0;   // pinned staging of o_pack
     DevBuf o_params, o_errs, o_nu, o_cov, o_chi2, o_rchi2, o_snr, o_nfev, o_rc, o_scales, o_serrs, o_csnr,
-        o_f0, o_g0, o_H0, misc, seedbuf, tay, ph0, act, seedq;
+        o_f0, o_g0, o_H0, misc, seedbuf, tay, ph0, act, seedq, xbase;
     int* nactive_h = nullptr;   // pinned
     // options
     double harm_eps = 8.8817841970012523e-16;  // 2^-50
@@ -98,6 +98,8 @@ struct pp_ctx {
     int paired_split = 1;       // 2048-bin rows: last FFT stage + split in registers (k_xspec_p1024)
     int seed_chan_stride = 16;  // device phase seed: pilot pass over every n-th channel (1 = all channels)
     double seed_min_snr = 8.0;  // pilot seeds below this peak significance are redone from all channels
+    int seed_ndm = 1;           // DM trials of the coarse (phi, DM) seed grid (1 = phase only, at the guessed DM)
+    double seed_dm_step = 0.0;  // their spacing [pc cm^-3]
     double max_work_bytes = 96e9;
     // profiling
     struct Span { int fam; hipEvent_t a, b; };
@@ -188,7 +190,7 @@ extern "C" int pp_destroy(pp_ctx* c) {
                       &c->errs, &c->mask, &c->P, &c->x0, &c->nufit, &c->nuout, &c->slot, &c->state, &c->csum,
                       &c->partial, &c->o_params, &c->o_errs, &c->o_nu, &c->o_cov, &c->o_chi2, &c->o_rchi2,
                       &c->o_snr, &c->o_nfev, &c->o_rc, &c->o_scales, &c->o_serrs, &c->o_csnr, &c->o_f0, &c->o_g0,
-                      &c->o_H0, &c->misc, &c->seedbuf, &c->tay, &c->ph0, &c->act, &c->seedq};
+                      &c->o_H0, &c->misc, &c->seedbuf, &c->tay, &c->ph0, &c->act, &c->seedq, &c->xbase};
     for (DevBuf* b : bufs) b->release();
     if (c->nactive_h) (void)hipHostFree(c->nactive_h);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -219,6 +221,8 @@ extern "C" int pp_set_option(pp_ctx* c, const char* name, double value) {
     else if (n == "paired_split") c->paired_split = (int)value;
     else if (n == "seed_chan_stride") c->seed_chan_stride = std::max(1, (int)value);
     else if (n == "seed_min_snr") c->seed_min_snr = value;
+    else if (n == "seed_ndm") c->seed_ndm = std::max(1, (int)value);
+    else if (n == "seed_dm_step") c->seed_dm_step = value;
     else return fail(PP_EINVAL, "pp_set_option: unknown option '%s'", name);
     return PP_OK;
 }
@@ -646,14 +650,30 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     const int Ks = std::min(Kt, 64 * PP_SEED_KPT);
     // seed the subints f lists (f.act / f.nact, channels f.coff + nn f.cstep) from the
     // cross-spectrum in f.X; seedq (optional) receives the peak significance
+    // The coarse grid is (phi, DM): seed_ns phases x seed_ndm trial DMs spaced
+    // seed_dm_step about the guess (1 trial = the reference's behaviour, whose seed
+    // trusts the header DM, pptoas.py:421-457); the best correlation peak wins.
+    const int ndm = (c->seed_ndm > 1 && c->seed_dm_step > 0.0) ? c->seed_ndm : 1;
     auto run_seed = [&](const FitArgs& f, double* seedq) -> int {
         if ((rc = c->seedbuf.reserve(((size_t)f.nact * f.nchunk + f.nact) * Ks * sizeof(cplx)))) return rc;
         cplx* ypart = c->seedbuf.as<cplx>();
         cplx* ywork = ypart + (size_t)f.nact * f.nchunk * Ks;
+        const double* xbase = c->x0.as<double>();
+        double* bestpk = nullptr;
+        if (ndm > 1) {
+            if ((rc = c->xbase.reserve((size_t)ns * 40 + (size_t)ns * 8))) return rc;
+            HIP_TRY(hipMemcpyAsync(c->xbase.p, c->x0.p, (size_t)ns * 40, hipMemcpyDeviceToDevice, c->stream));
+            xbase = c->xbase.as<double>();
+            bestpk = c->xbase.as<double>() + (size_t)ns * 5;
+        }
         Prof pr(c, KF_SEED);
-        hipLaunchKernelGGL(k_seed_accum, dim3(f.nact, f.nchunk), dim3(256), 0, c->stream, f, ypart, Ks);
-        hipLaunchKernelGGL(k_seed_fit, dim3(f.nact), dim3(256), 0, c->stream, f, (const cplx*)ypart, ywork,
-                           c->x0.as<double>(), (int)in->seed_ns, Ks, seedq);
+        for (int t = 0; t < ndm; ++t) {
+            const double off = (ndm > 1) ? (t - (ndm - 1) / 2) * c->seed_dm_step : 0.0;
+            hipLaunchKernelGGL(k_seed_accum, dim3(f.nact, f.nchunk), dim3(256), 0, c->stream, f, ypart, Ks, xbase,
+                               off);
+            hipLaunchKernelGGL(k_seed_fit, dim3(f.nact), dim3(256), 0, c->stream, f, (const cplx*)ypart, ywork,
+                               c->x0.as<double>(), (int)in->seed_ns, Ks, seedq, xbase, off, bestpk, t);
+        }
         HIP_TRY(hipGetLastError());
         return PP_OK;
     };

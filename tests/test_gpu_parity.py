@@ -1624,3 +1624,31 @@ def test_device_instrumental_response_matches_host(eng):
     np.testing.assert_allclose(a["scales"], b["scales"], rtol=1e-10)
     np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-11)
     np.testing.assert_allclose(a["param_errs"], b["param_errs"], rtol=1e-9)
+
+
+def test_coarse_phase_dm_grid_recovers_a_poor_dm_guess(eng):
+    """The coarse seed grid with a DM axis (seed_ndm trial DMs about the guess): a DM
+    guess 0.02 pc cm^-3 off leaves the phase-only seed outside the one-pass model's
+    certificate (the fit then iterates over the cross-spectrum), while the (phi, DM)
+    grid lands close enough for the one-pass flow; both reach the same optimum."""
+    nsub = 24
+    data, freqs, P, x0, kw = _medium_batch(eng, nsub, seed=21)
+    x0 = x0.copy()
+    x0[:, 0] = 0.0
+    x0[:, 1] += 0.02
+    kw = dict(kw, method="newton")
+    try:
+        one = eng.fit_batch(data, freqs, P, x0, seed_ns=100, **kw)
+        eng.set_option("seed_ndm", 41)
+        eng.set_option("seed_dm_step", 1e-3)
+        grid = eng.fit_batch(data, freqs, P, x0, seed_ns=100, **kw)
+    finally:
+        eng.set_option("seed_ndm", 1)
+        eng.set_option("seed_dm_step", 0.0)
+    assert (one["nfeval"] > 1).all() and (grid["nfeval"] == 1).all()
+    assert (one["return_code"] == 2).all() and (grid["return_code"] == 2).all()
+    assert _dphi_common(grid, one, P) < 1e-11
+    assert np.max(np.abs(grid["params"][:, 1] - one["params"][:, 1])) < 1e-9
+    np.testing.assert_allclose(grid["chi2"], one["chi2"], rtol=1e-11)
+    # and the injected DM is what both recover
+    assert np.all(np.abs(grid["params"][:, 1] - 34.56789) < 2e-3)
