@@ -92,8 +92,9 @@ void* pp_stream(pp_ctx* ctx);
  *                  above the mean of the grid (default 8) are redone from all channels
  *   "seed_ndm", "seed_dm_step"  the coarse seed grid is (phi, DM): seed_ns phases x
  *                  seed_ndm trial DMs spaced seed_dm_step [pc cm^-3] about the guessed DM
- *                  (centred; an odd count keeps the guess itself); the trial with the
- *                  highest correlation peak seeds both phase and DM.  Default 1 trial:
+ *                  (centred; an odd count keeps the guess itself); the DM of the highest
+ *                  correlation peak, refined by the parabola through it and its
+ *                  neighbours, seeds the DM, and the phase is seeded at it.  Default 1 trial:
  *                  the reference's seed trusts the header DM (pptoas.py:421-457)
  *   "paired_split" 1 (default) = 2048-bin rows whose template keeps fewer than 512
  *                  harmonics take the transform kernel that does the last FFT stage

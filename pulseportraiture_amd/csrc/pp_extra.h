@@ -685,6 +685,25 @@ __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
     }
 }
 
+// DM axis of the coarse grid: per subint the trial with the highest correlation peak,
+// refined by the parabola through it and its neighbours; xout[i] = xbase[i] with that DM
+__global__ void k_seed_dm_pick(const int* act, int nact, const double* pk, int ntrial, double step,
+                               const double* xbase, double* xout) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nact) return;
+    const int i = sub_of(act, j);
+    const double* p = pk + (size_t)i * ntrial;
+    int b = 0;
+    for (int t = 1; t < ntrial; ++t) if (p[t] > p[b]) b = t;
+    double frac = 0.0;
+    if (b > 0 && b < ntrial - 1) {
+        const double den = p[b - 1] - 2.0 * p[b] + p[b + 1];
+        if (den < 0.0) frac = fmin(0.5, fmax(-0.5, 0.5 * (p[b - 1] - p[b + 1]) / den));
+    }
+    for (int q = 0; q < 5; ++q) xout[i * 5 + q] = xbase[i * 5 + q];
+    xout[i * 5 + 1] = xbase[i * 5 + 1] + ((double)(b - (ntrial - 1) / 2) + frac) * step;
+}
+
 // --------------------------------------------------------------------------
 // The subints that still need work, listed in index order (one 256-thread block):
 // seedq != nullptr selects those whose seed quality is below qmin, else those whose
@@ -796,11 +815,13 @@ __global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart, int 
 // (noise rms of the correlation, from the weights and the template power) -- the
 // matched-filter S/N of the channels used, which tells a seed formed from a subset
 // of the channels apart from a noise peak
-// bestpk (optional, DM trials): the seed is written only if this trial's peak beats the
-// best so far (trial 0 always writes); xbase / dm_off as in k_seed_accum.
+// pkout (optional, DM trials): only the height of the correlation peak is recorded,
+// pkout[i * ntrial + trial]; nothing is written to x0 (k_seed_dm_pick then chooses the
+// DM and a last accumulation + fit at it writes the seed).  xbase / dm_off as in
+// k_seed_accum.
 __global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, cplx* ywork, double* x0, int Ns,
                                                   int Ks, double* seedq, const double* xbase, double dm_off,
-                                                  double* bestpk, int trial) {
+                                                  double* pkout, int trial, int ntrial) {
     const int jx = blockIdx.x, i = sub_of(a.act, jx), tid = threadIdx.x, K = Ks;
     __shared__ double scratch[4 * 4];
     __shared__ double shv[4];
@@ -840,13 +861,11 @@ __global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, 
     __syncthreads();
     pk = fmax(fmax(shv[0], shv[1]), fmax(shv[2], shv[3]));
     __syncthreads();
-    // DM trials: a trial that does not beat the best peak so far changes nothing
-    bool take = true;
-    if (bestpk) {
-        take = (trial == 0) || (pk > bestpk[i]);
-        __syncthreads();
-        if (take && tid == 0) bestpk[i] = pk;
+    if (pkout) {
+        if (tid == 0) pkout[(size_t)i * ntrial + trial] = pk;
+        return;
     }
+    const bool take = true;
     if (seedq && take) {
         // noise of the correlation: Var = sum_n w_n^2 sigma_Fn^2 sum_k |m_nk|^2 = sum_n w_n S_n
         // over the channels that went into Y (S_n over all harmonics: a slight

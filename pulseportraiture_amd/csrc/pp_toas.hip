@@ -658,22 +658,32 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         if ((rc = c->seedbuf.reserve(((size_t)f.nact * f.nchunk + f.nact) * Ks * sizeof(cplx)))) return rc;
         cplx* ypart = c->seedbuf.as<cplx>();
         cplx* ywork = ypart + (size_t)f.nact * f.nchunk * Ks;
-        const double* xbase = c->x0.as<double>();
-        double* bestpk = nullptr;
-        if (ndm > 1) {
-            if ((rc = c->xbase.reserve((size_t)ns * 40 + (size_t)ns * 8))) return rc;
-            HIP_TRY(hipMemcpyAsync(c->xbase.p, c->x0.p, (size_t)ns * 40, hipMemcpyDeviceToDevice, c->stream));
-            xbase = c->xbase.as<double>();
-            bestpk = c->xbase.as<double>() + (size_t)ns * 5;
-        }
         Prof pr(c, KF_SEED);
-        for (int t = 0; t < ndm; ++t) {
-            const double off = (ndm > 1) ? (t - (ndm - 1) / 2) * c->seed_dm_step : 0.0;
-            hipLaunchKernelGGL(k_seed_accum, dim3(f.nact, f.nchunk), dim3(256), 0, c->stream, f, ypart, Ks, xbase,
-                               off);
-            hipLaunchKernelGGL(k_seed_fit, dim3(f.nact), dim3(256), 0, c->stream, f, (const cplx*)ypart, ywork,
-                               c->x0.as<double>(), (int)in->seed_ns, Ks, seedq, xbase, off, bestpk, t);
+        const double* xbase = c->x0.as<double>();
+        if (ndm > 1) {
+            // trial DMs: peak heights only, then the refined DM of every subint, then
+            // the seed proper at that DM
+            if ((rc = c->xbase.reserve((size_t)ns * 80 + (size_t)ns * ndm * 8))) return rc;
+            double* xb = c->xbase.as<double>();          // [ns][5] guesses as given
+            double* xr = xb + (size_t)ns * 5;            // [ns][5] with the chosen DM
+            double* pk = xr + (size_t)ns * 5;            // [ns][ndm]
+            HIP_TRY(hipMemcpyAsync(xb, c->x0.p, (size_t)ns * 40, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(xr, c->x0.p, (size_t)ns * 40, hipMemcpyDeviceToDevice, c->stream));
+            for (int t = 0; t < ndm; ++t) {
+                const double off = (t - (ndm - 1) / 2) * c->seed_dm_step;
+                hipLaunchKernelGGL(k_seed_accum, dim3(f.nact, f.nchunk), dim3(256), 0, c->stream, f, ypart, Ks,
+                                   (const double*)xb, off);
+                hipLaunchKernelGGL(k_seed_fit, dim3(f.nact), dim3(256), 0, c->stream, f, (const cplx*)ypart, ywork,
+                                   c->x0.as<double>(), (int)in->seed_ns, Ks, (double*)nullptr, (const double*)xb, off,
+                                   pk, t, ndm);
+            }
+            hipLaunchKernelGGL(k_seed_dm_pick, dim3((f.nact + 63) / 64), dim3(64), 0, c->stream, f.act, f.nact,
+                               (const double*)pk, ndm, c->seed_dm_step, (const double*)xb, xr);
+            xbase = xr;
         }
+        hipLaunchKernelGGL(k_seed_accum, dim3(f.nact, f.nchunk), dim3(256), 0, c->stream, f, ypart, Ks, xbase, 0.0);
+        hipLaunchKernelGGL(k_seed_fit, dim3(f.nact), dim3(256), 0, c->stream, f, (const cplx*)ypart, ywork,
+                           c->x0.as<double>(), (int)in->seed_ns, Ks, seedq, xbase, 0.0, (double*)nullptr, 0, 1);
         HIP_TRY(hipGetLastError());
         return PP_OK;
     };
