@@ -855,18 +855,37 @@ __global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, 
         gs[0] += s0;
     }
     const int best = min(block_argmin256(bestv, bestj, shv, shj), Ns - 1);
-    double pk = group_max<64>(-bestv);          // maximum of the CCF over the grid
-    __syncthreads();
-    if ((tid & 63) == 0) shv[tid >> 6] = pk;
-    __syncthreads();
-    pk = fmax(fmax(shv[0], shv[1]), fmax(shv[2], shv[3]));
-    __syncthreads();
+    // polish: safeguarded Newton on f(phi) = -CCF inside +-1 grid step of the best point
+    const double h = 1.0 / (double)(Ns - 1);
+    double phi = -0.5 + (double)best / (double)(Ns - 1), lo = phi - h, hi = phi + h;
+    for (int it = 0; it < 60; ++it) {
+        double s[3];
+        fps_sums(Y, K, phi, tid, 256, s[0], s[1], s[2]);
+        block_sum<3>(s, scratch);
+        __syncthreads();
+        const double f1 = s[1], f2 = s[2];     // signs of df/dphi, d2f/dphi2 of f = -sum
+        if (f1 > 0.0) hi = phi; else lo = phi;
+        double nxt = (f2 > 0.0) ? phi - f1 / (PP_TWO_PI * f2) : 0.5 * (lo + hi);
+        if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);
+        const double step = fabs(nxt - phi);
+        phi = nxt;
+        if (step < 1e-13) break;
+    }
+    // height of the correlation at the polished maximum (the grid alone samples a
+    // narrow peak too coarsely to compare DM trials or to quote an S/N)
+    double pk = 0.0;
+    if (pkout || seedq) {
+        double s[3];
+        fps_sums(Y, K, phi, tid, 256, s[0], s[1], s[2]);
+        block_sum<3>(s, scratch);
+        __syncthreads();
+        pk = s[0];
+    }
     if (pkout) {
         if (tid == 0) pkout[(size_t)i * ntrial + trial] = pk;
         return;
     }
-    const bool take = true;
-    if (seedq && take) {
+    if (seedq) {
         // noise of the correlation: Var = sum_n w_n^2 sigma_Fn^2 sum_k |m_nk|^2 = sum_n w_n S_n
         // over the channels that went into Y (S_n over all harmonics: a slight
         // overestimate, on the safe side)
@@ -884,22 +903,7 @@ __global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, 
         const double mean = g2[0] / (double)Ns;
         if (tid == 0) seedq[i] = (g2[1] > 0.0) ? (pk - mean) / sqrt(g2[1]) : 0.0;
     }
-    const double h = 1.0 / (double)(Ns - 1);
-    double phi = -0.5 + (double)best / (double)(Ns - 1), lo = phi - h, hi = phi + h;
-    for (int it = 0; it < 60; ++it) {
-        double s[3];
-        fps_sums(Y, K, phi, tid, 256, s[0], s[1], s[2]);
-        block_sum<3>(s, scratch);
-        __syncthreads();
-        const double f1 = s[1], f2 = s[2];     // signs of df/dphi, d2f/dphi2 of f = -sum
-        if (f1 > 0.0) hi = phi; else lo = phi;
-        double nxt = (f2 > 0.0) ? phi - f1 / (PP_TWO_PI * f2) : 0.5 * (lo + hi);
-        if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);
-        const double step = fabs(nxt - phi);
-        phi = nxt;
-        if (step < 1e-13) break;
-    }
-    if (tid == 0 && take) {
+    if (tid == 0) {
         // wrap to [-0.5, 0.5) like phase_transform(..., mod=True)
         if (fabs(phi) >= 0.5) { phi = fmod(phi, 1.0); if (phi < 0.0) phi += 1.0; }
         if (phi >= 0.5) phi -= 1.0;
