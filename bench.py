@@ -286,9 +286,10 @@ def main():
             phi = out[:, 0] + DCONST * args.dm0 / self.P * (self.nu_fit ** -2 - nu_mean ** -2)
             return (phi + 0.5) % 1.0 - 0.5
 
-        def fit(self, records=None, method=None):
-            return eng.fit_batch(self.data, self.freqs, self.P, self.x0, errs=self.errs_dev,
-                                 nu_fits=np.full((self.nsub, 3), self.nu_fit), fit_flags=self.flags,
+        def fit(self, records=None, method=None, n=None):
+            n = self.nsub if n is None else n         # (a ragged last sub-batch fits its first n)
+            return eng.fit_batch(self.data[:n], self.freqs, self.P[:n], self.x0[:n], errs=self.errs_dev[:n],
+                                 nu_fits=np.full((n, 3), self.nu_fit), fit_flags=self.flags,
                                  log10_tau=self.log10_tau, per_channel="device",
                                  seed_ns=self.seed_ns, method=method or args.method, records=records)
 
@@ -467,12 +468,7 @@ def strong_scaling(args, eng, Batch, fence, ppdist, dist, torch, device, rank, w
             batch.generate(lo + done)
         eng.synchronize(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if n == nsub:
-            res = batch.fit(records=recs[done:done + n])
-        else:      # ragged tail: fit the whole buffer, keep the first n records
-            tmp = torch.zeros((nsub, ppdist.RECORD_WIDTH), dtype=torch.float64, device=device)
-            res = batch.fit(records=tmp)
-            recs[done:done + n] = tmp[:n]
+        res = batch.fit(records=recs[done:done + n], n=n)
         eng.synchronize(); torch.cuda.synchronize()
         fit_s += time.perf_counter() - t0
         worst = max(worst, float(np.max(np.abs(res["params"][:n, 1] - batch.inj[:n, 1]) /
