@@ -146,6 +146,8 @@ def main():
     ap.add_argument("--truth-guesses", action="store_true",
                     help="phase guesses = injected phase + 1e-4 rot of noise instead of the "
                          "fit_phase_shift seed (experiments)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="engine option (pp_set_option), e.g. scat_model=0; repeatable")
     ap.add_argument("--harm-eps", type=float, default=None,
                     help="override the harmonic-truncation threshold (experiments)")
     args = ap.parse_args()
@@ -192,6 +194,9 @@ def main():
     eng = Engine(local_rank)
     if args.harm_eps is not None:
         eng.set_option("harm_eps", args.harm_eps)
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        eng.set_option(name, float(val))
 
     def fence():
         eng.synchronize()

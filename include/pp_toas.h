@@ -99,6 +99,15 @@ void* pp_stream(pp_ctx* ctx);
  *   "paired_split" 1 (default) = 2048-bin rows whose template keeps fewer than 512
  *                  harmonics take the transform kernel that does the last FFT stage
  *                  and the even/odd split in registers; 0 = the generic kernel
+ *   "scat_model"   scattering fits: 1 (default) = once the trust-ncg iteration is
+ *                  predicted to stay within its range, ONE more pass over the
+ *                  cross-spectrum leaves a degree-8 polynomial model of every channel's
+ *                  sums in (phi_n, tau_n) and the remaining evaluations are made on it,
+ *                  each with a truncation certificate (DESIGN.md "Scattering fits");
+ *                  2 = also for method 'newton' (whose few closing iterations do not
+ *                  repay the pass); 0 = every evaluation is a pass over the cross-spectrum
+ *   "scat_model_tol"  predicted relative truncation below which that pass is asked
+ *                  for (default 1e-10; the certificate guards the result either way)
  *   "moments_in_xspec"  1 (default) = the Taylor moments are accumulated inside
  *                  the transform kernel and no cross-spectrum is stored; 0 = store
  *                  the cross-spectrum and take the moments in a second pass

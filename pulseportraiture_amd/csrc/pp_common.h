@@ -202,6 +202,9 @@ struct SubState {
     int hits_boundary;
     int iter, nfev, status, done, cur;  // cur: csum buffer of the accepted point
     int fresh;         // the next evaluation is 1: an initial one, 2: the closing one (no ratio test)
+    int model;         // scattering model of the closing iterations: 0 not yet, 1 the next evaluation
+                       // is the model pass, 3 not (again) for this subint
+    double geo[4];     // max |d phi_n/d DM|, |d phi_n/d GM|, |ln(nu_n/nu_tau)| over the channels; template keff
 };
 
 // number of per-subint accumulators of one evaluation: f, g[5], H upper[15]

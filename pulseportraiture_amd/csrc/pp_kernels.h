@@ -98,6 +98,10 @@ struct FitArgs {
     // act[0..nact), channels coff + nn*cstep for nn < nchan_x; X is compact in (j, nn)
     const int* act;
     int nact, nchan_x, cstep, coff;
+    // scattering fits: per-channel model of the closing iterations (pp_scatmodel.h)
+    double* mdl;              // [nsub][nchan][PP_MROW]
+    int use_model;
+    double model_tol;         // predicted relative truncation below which the model pass is asked for
 };
 
 __device__ __forceinline__ int sub_of(const int* act, int j) { return act ? act[j] : j; }
@@ -569,6 +573,7 @@ __global__ void k_init_state(FitArgs a) {
     s.pred_red = 0.0;
     s.hits_boundary = 0;
     s.iter = 0; s.nfev = 0; s.status = PP_RC_MAXITER; s.done = 0; s.cur = 1; s.fresh = 1;
+    s.model = 0; s.geo[0] = s.geo[1] = s.geo[2] = s.geo[3] = 0.0;
     if (i == 0) *a.nactive = a.nsub;
 }
 
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
     constexpr int LPC = 16;
     const int jx = blockIdx.x, i = sub_of(a.act, jx), chunk = blockIdx.y;
     SubState& st = a.st[i];
-    if (st.done) return;
+    if (st.done || st.model == 1) return;    // (model == 1: this evaluation is k_scat_model's)
     __shared__ double red[(256 / LPC) * PP_NACC];
     const int tid = threadIdx.x, g = tid / LPC, l = tid % LPC;
     const double phi = st.xe[0], DM = st.xe[1], GM = st.xe[2], alpha = st.xe[4];
@@ -950,7 +955,8 @@ __global__ __launch_bounds__(256) void k_eval_fast(FitArgs a) {
 // --------------------------------------------------------------------------
 // small dense linear algebra on the fit subspace (n <= 5), one thread
 // --------------------------------------------------------------------------
-__device__ inline bool chol_solve(int n, const double* A, const double* b, double* x) {
+template <int n>
+__device__ inline bool chol_solve(const double* A, const double* b, double* x) {
     double Lm[25];
     for (int i = 0; i < n; ++i)
         for (int j = 0; j <= i; ++j) {
@@ -1004,7 +1010,8 @@ __device__ inline bool mat_inverse(int n, double* A) {
     return true;
 }
 
-__device__ inline double vdot(int n, const double* a, const double* b) {
+template <int n>
+__device__ inline double vdot(const double* a, const double* b) {
     double s = 0.0;
     for (int i = 0; i < n; ++i) s += a[i] * b[i];
     return s;
@@ -1013,40 +1020,41 @@ __device__ inline double vdot(int n, const double* a, const double* b) {
 // trust-region subproblem: Newton step if H is positive definite and the step
 // is inside the region, else Steihaug conjugate gradients to the boundary
 // (scipy/optimize/_trustregion_ncg.py is what the reference drives).
-__device__ inline void tr_subproblem(int n, const double* g, const double* H, double radius, double* p,
+template <int n>
+__device__ inline void tr_subproblem(const double* g, const double* H, double radius, double* p,
                                      int* hits) {
     *hits = 0;
     double mg[5];
     for (int i = 0; i < n; ++i) mg[i] = -g[i];
-    if (chol_solve(n, H, mg, p)) {
-        if (sqrt(vdot(n, p, p)) < radius) return;
+    if (chol_solve<n>(H, mg, p)) {
+        if (sqrt(vdot<n>(p, p)) < radius) return;
     }
     double z[5] = {0, 0, 0, 0, 0}, r[5], d[5], Bd[5];
     for (int i = 0; i < n; ++i) { r[i] = g[i]; d[i] = -g[i]; }
-    const double gnorm = sqrt(vdot(n, g, g));
+    const double gnorm = sqrt(vdot<n>(g, g));
     const double tol = 1e-14 * gnorm;
     for (int it = 0; it < 4 * n + 4; ++it) {
-        for (int i = 0; i < n; ++i) Bd[i] = vdot(n, H + i * n, d);
-        const double dBd = vdot(n, d, Bd);
-        const double dd = vdot(n, d, d), zd = vdot(n, z, d), zz = vdot(n, z, z);
+        for (int i = 0; i < n; ++i) Bd[i] = vdot<n>(H + i * n, d);
+        const double dBd = vdot<n>(d, Bd);
+        const double dd = vdot<n>(d, d), zd = vdot<n>(z, d), zz = vdot<n>(z, z);
         // intersections of z + t d with the boundary
         const double disc = sqrt(fmax(zd * zd - dd * (zz - radius * radius), 0.0));
         const double ta = (-zd - disc) / dd, tb = (-zd + disc) / dd;
         if (dBd <= 0.0) {
             double pa[5], pb[5], Hp[5];
             for (int i = 0; i < n; ++i) { pa[i] = z[i] + ta * d[i]; pb[i] = z[i] + tb * d[i]; }
-            for (int i = 0; i < n; ++i) Hp[i] = vdot(n, H + i * n, pa);
-            const double ma = vdot(n, g, pa) + 0.5 * vdot(n, pa, Hp);
-            for (int i = 0; i < n; ++i) Hp[i] = vdot(n, H + i * n, pb);
-            const double mb = vdot(n, g, pb) + 0.5 * vdot(n, pb, Hp);
+            for (int i = 0; i < n; ++i) Hp[i] = vdot<n>(H + i * n, pa);
+            const double ma = vdot<n>(g, pa) + 0.5 * vdot<n>(pa, Hp);
+            for (int i = 0; i < n; ++i) Hp[i] = vdot<n>(H + i * n, pb);
+            const double mb = vdot<n>(g, pb) + 0.5 * vdot<n>(pb, Hp);
             for (int i = 0; i < n; ++i) p[i] = (ma < mb) ? pa[i] : pb[i];
             *hits = 1;
             return;
         }
-        const double rr = vdot(n, r, r), al = rr / dBd;
+        const double rr = vdot<n>(r, r), al = rr / dBd;
         double zn[5];
         for (int i = 0; i < n; ++i) zn[i] = z[i] + al * d[i];
-        if (sqrt(vdot(n, zn, zn)) >= radius) {
+        if (sqrt(vdot<n>(zn, zn)) >= radius) {
             for (int i = 0; i < n; ++i) p[i] = z[i] + tb * d[i];
             *hits = 1;
             return;
@@ -1072,55 +1080,58 @@ __device__ inline void tr_subproblem(int n, const double* g, const double* H, do
 // merely the optimum.  Unfitted parameters have zero gradient / Hessian rows in
 // the reference, so working on the fit subspace gives the same numbers.
 // --------------------------------------------------------------------------
-__device__ inline double tr_model_value(int n, double f, const double* g, const double* H, const double* p) {
+template <int n>
+__device__ inline double tr_model_value(double f, const double* g, const double* H, const double* p) {
     double Hp[5];
-    for (int i = 0; i < n; ++i) Hp[i] = vdot(n, H + i * n, p);
-    return f + vdot(n, g, p) + 0.5 * vdot(n, p, Hp);
+    for (int i = 0; i < n; ++i) Hp[i] = vdot<n>(H + i * n, p);
+    return f + vdot<n>(g, p) + 0.5 * vdot<n>(p, Hp);
 }
 
-__device__ inline void tr_boundaries(int n, const double* z, const double* d, double radius, double* ta,
+template <int n>
+__device__ inline void tr_boundaries(const double* z, const double* d, double radius, double* ta,
                                      double* tb) {
-    const double a = vdot(n, d, d), b = 2.0 * vdot(n, z, d), c = vdot(n, z, z) - radius * radius;
+    const double a = vdot<n>(d, d), b = 2.0 * vdot<n>(z, d), c = vdot<n>(z, z) - radius * radius;
     const double sq = sqrt(b * b - 4.0 * a * c);
     const double aux = b + copysign(sq, b);
     const double t1 = -aux / (2.0 * a), t2 = -2.0 * c / aux;
     *ta = fmin(t1, t2); *tb = fmax(t1, t2);
 }
 
-__device__ inline void tr_cg_steihaug_scipy(int n, double f, const double* g, const double* H, double radius,
+template <int n>
+__device__ inline void tr_cg_steihaug_scipy(double f, const double* g, const double* H, double radius,
                                             double* p, int* hits) {
     *hits = 0;
     for (int i = 0; i < n; ++i) p[i] = 0.0;
-    const double gmag = sqrt(vdot(n, g, g));
+    const double gmag = sqrt(vdot<n>(g, g));
     const double tol = fmin(0.5, sqrt(gmag)) * gmag;
     if (gmag < tol) return;
     double z[5] = {0, 0, 0, 0, 0}, r[5], d[5], Bd[5];
     for (int i = 0; i < n; ++i) { r[i] = g[i]; d[i] = -g[i]; }
     for (int it = 0; it < 64; ++it) {
-        for (int i = 0; i < n; ++i) Bd[i] = vdot(n, H + i * n, d);
-        const double dBd = vdot(n, d, Bd);
+        for (int i = 0; i < n; ++i) Bd[i] = vdot<n>(H + i * n, d);
+        const double dBd = vdot<n>(d, Bd);
         if (dBd <= 0.0) {
             double ta, tb, pa[5], pb[5];
-            tr_boundaries(n, z, d, radius, &ta, &tb);
+            tr_boundaries<n>(z, d, radius, &ta, &tb);
             for (int i = 0; i < n; ++i) { pa[i] = z[i] + ta * d[i]; pb[i] = z[i] + tb * d[i]; }
-            const bool first = tr_model_value(n, f, g, H, pa) < tr_model_value(n, f, g, H, pb);
+            const bool first = tr_model_value<n>(f, g, H, pa) < tr_model_value<n>(f, g, H, pb);
             for (int i = 0; i < n; ++i) p[i] = first ? pa[i] : pb[i];
             *hits = 1;
             return;
         }
-        const double rsq = vdot(n, r, r), alpha = rsq / dBd;
+        const double rsq = vdot<n>(r, r), alpha = rsq / dBd;
         double zn[5];
         for (int i = 0; i < n; ++i) zn[i] = z[i] + alpha * d[i];
-        if (sqrt(vdot(n, zn, zn)) >= radius) {
+        if (sqrt(vdot<n>(zn, zn)) >= radius) {
             double ta, tb;
-            tr_boundaries(n, z, d, radius, &ta, &tb);
+            tr_boundaries<n>(z, d, radius, &ta, &tb);
             for (int i = 0; i < n; ++i) p[i] = z[i] + tb * d[i];
             *hits = 1;
             return;
         }
         double rn[5];
         for (int i = 0; i < n; ++i) rn[i] = r[i] + alpha * Bd[i];
-        const double rnsq = vdot(n, rn, rn);
+        const double rnsq = vdot<n>(rn, rn);
         if (sqrt(rnsq) < tol || !(rnsq == rnsq)) {
             for (int i = 0; i < n; ++i) p[i] = zn[i];
             return;
@@ -1129,6 +1140,35 @@ __device__ inline void tr_cg_steihaug_scipy(int n, double f, const double* g, co
         for (int i = 0; i < n; ++i) { d[i] = -rn[i] + beta * d[i]; z[i] = zn[i]; r[i] = rn[i]; }
     }
     for (int i = 0; i < n; ++i) p[i] = z[i];
+}
+
+// the same, for a subspace dimension only known at run time
+#define PP_FOR_N(n_, EXPR)            \
+    switch (n_) {                     \
+        case 1: { constexpr int N_ = 1; EXPR; } break; \
+        case 2: { constexpr int N_ = 2; EXPR; } break; \
+        case 3: { constexpr int N_ = 3; EXPR; } break; \
+        case 4: { constexpr int N_ = 4; EXPR; } break; \
+        default: { constexpr int N_ = 5; EXPR; } break; \
+    }
+__device__ inline bool chol_solve(int n, const double* A, const double* b, double* x) {
+    bool ok = false;
+    PP_FOR_N(n, ok = chol_solve<N_>(A, b, x));
+    return ok;
+}
+__device__ inline double vdot(int n, const double* a, const double* b) {
+    double v = 0.0;
+    PP_FOR_N(n, v = vdot<N_>(a, b));
+    return v;
+}
+__device__ inline double tr_model_value(int n, double f, const double* g, const double* H, const double* p) {
+    double v = 0.0;
+    PP_FOR_N(n, v = tr_model_value<N_>(f, g, H, p));
+    return v;
+}
+__device__ inline void tr_cg_steihaug_scipy(int n, double f, const double* g, const double* H, double radius,
+                                            double* p, int* hits) {
+    PP_FOR_N(n, tr_cg_steihaug_scipy<N_>(f, g, H, radius, p, hits));
 }
 
 // one decision of SciPy's loop after the proposal x + p was evaluated (f_new):
@@ -1492,21 +1532,72 @@ __device__ inline void unpack_acc(const double* acc, const int* flags, double& f
         }
 }
 
-// one trust-region iteration per subint (64 threads, lane 0 decides)
-__global__ __launch_bounds__(64) void k_step(FitArgs a) {
-    const int i = sub_of(a.act, blockIdx.x), tid = threadIdx.x;
-    SubState& s = a.st[i];
-    if (s.done) return;
-    __shared__ double acc[PP_NACC];
-    if (tid < PP_NACC) {
-        double v = 0.0;
-        for (int c = 0; c < a.nchunk; ++c) v += a.partial[((size_t)i * a.nchunk + c) * PP_NACC + tid];
-        acc[tid] = v;
-    }
-    __syncthreads();
-    if (tid != 0) return;
-    double f, g[5], H[25];
-    unpack_acc(acc, a.flags, f, g, H);
+// the next proposal from the accepted point's g, H on the fit subspace (dimension n,
+// parameters idx[0..n)); returns true when the iteration ends here
+template <int n>
+__device__ inline bool step_propose(const FitArgs& a, SubState& s, const int* idx) {
+    bool done = false;
+        double gs[n], Hs[n * n], p[n];
+        for (int r = 0; r < n; ++r) {
+            gs[r] = s.g[idx[r]];
+            for (int c = 0; c < n; ++c) Hs[r * n + c] = s.H[idx[r] * 5 + idx[c]];
+        }
+        int hits = 0;
+        if (a.method == 0) {
+            // the reference's own iteration (SciPy trust-ncg): truncated CG step, and
+            // the exit where the model predicts no reduction in floating point
+            tr_cg_steihaug_scipy<n>(s.f, gs, Hs, s.radius, p, &hits);
+            const double pred = s.f - tr_model_value<n>(s.f, gs, Hs, p);
+            if (!(pred > 0.0)) {
+                s.status = PP_RC_STALL; done = true;
+            } else {
+                for (int j = 0; j < 5; ++j) s.xe[j] = s.x[j];
+                for (int r = 0; r < n; ++r) s.xe[idx[r]] = s.x[idx[r]] + p[r];
+                s.pred_red = pred;
+                s.hits_boundary = hits;
+            }
+        } else {
+        tr_subproblem<n>(gs, Hs, s.radius, p, &hits);
+        double Hp[n];
+        for (int r = 0; r < n; ++r) Hp[r] = vdot<n>(Hs + r * n, p);
+        const double pred = -(vdot<n>(gs, p) + 0.5 * vdot<n>(p, Hp));
+        // scipy: predicted_reduction <= 0 -> status 2 (the reference's normal exit)
+        const double fpred = s.f - pred;     // what scipy compares: m(p) vs m(0)
+        const double noise = 2.220446049250313e-16 * fabs(s.f);
+        if (!(pred > 0.0) || !(fpred < s.f) || pred <= 64.0 * noise) {
+            // The predicted reduction is below the rounding noise of f itself, so
+            // the ratio test can no longer see it (scipy stops here with status 2,
+            // the reference's normal exit, up to ~1e-9 rot short of the optimum).
+            // Finish with the full Newton step when that step too is worth no more
+            // than noise in f -- this close the quadratic model is exact to working
+            // precision -- which lands at least as close to the optimum.
+            double pn[n], Hpn[n];
+            int hn = 0;
+            tr_subproblem<n>(gs, Hs, 1e150, pn, &hn);
+            for (int r = 0; r < n; ++r) Hpn[r] = vdot<n>(Hs + r * n, pn);
+            const double predn = -(vdot<n>(gs, pn) + 0.5 * vdot<n>(pn, Hpn));
+            if (!hn && predn >= 0.0 && predn <= 4096.0 * noise && s.iter + 1 < a.max_iter) {
+                for (int j = 0; j < 5; ++j) s.xe[j] = s.x[j];
+                for (int r = 0; r < n; ++r) s.xe[idx[r]] = s.x[idx[r]] + pn[r];
+                s.fresh = 2;
+            } else {
+                s.status = PP_RC_STALL; done = true;
+            }
+        } else {
+            for (int j = 0; j < 5; ++j) s.xe[j] = s.x[j];
+            for (int r = 0; r < n; ++r) s.xe[idx[r]] = s.x[idx[r]] + p[r];
+            s.pred_red = pred;
+            s.hits_boundary = hits;
+        }
+        }
+    return done;
+}
+
+// One decision of the trust-region loop for one subint, given the objective, gradient
+// and Hessian just evaluated at s.xe: the ratio test on the pending proposal (or the
+// bookkeeping of an initial / closing evaluation), then the next proposal into s.xe.
+// Returns true when the subint is finished (s.status set).  One thread.
+__device__ inline bool step_logic(const FitArgs& a, SubState& s, double f, const double* g, const double* H) {
     bool finite = isfinite(f);
     for (int j = 0; j < 5; ++j) finite = finite && isfinite(g[j]);
     for (int j = 0; j < 25; ++j) finite = finite && isfinite(H[j]);
@@ -1550,63 +1641,35 @@ __global__ __launch_bounds__(64) void k_step(FitArgs a) {
     if (!done) {
         int idx[5], n = 0;
         for (int j = 0; j < 5; ++j) if (a.flags[j]) idx[n++] = j;
-        double gs[5], Hs[25], p[5];
-        for (int r = 0; r < n; ++r) {
-            gs[r] = s.g[idx[r]];
-            for (int c = 0; c < n; ++c) Hs[r * n + c] = s.H[idx[r] * 5 + idx[c]];
-        }
-        int hits = 0;
-        if (a.method == 0) {
-            // the reference's own iteration (SciPy trust-ncg): truncated CG step, and
-            // the exit where the model predicts no reduction in floating point
-            tr_cg_steihaug_scipy(n, s.f, gs, Hs, s.radius, p, &hits);
-            const double pred = s.f - tr_model_value(n, s.f, gs, Hs, p);
-            if (!(pred > 0.0)) {
-                s.status = PP_RC_STALL; done = true;
-            } else {
-                for (int j = 0; j < 5; ++j) s.xe[j] = s.x[j];
-                for (int r = 0; r < n; ++r) s.xe[idx[r]] = s.x[idx[r]] + p[r];
-                s.pred_red = pred;
-                s.hits_boundary = hits;
-            }
-        } else {
-        tr_subproblem(n, gs, Hs, s.radius, p, &hits);
-        double Hp[5];
-        for (int r = 0; r < n; ++r) Hp[r] = vdot(n, Hs + r * n, p);
-        const double pred = -(vdot(n, gs, p) + 0.5 * vdot(n, p, Hp));
-        // scipy: predicted_reduction <= 0 -> status 2 (the reference's normal exit)
-        const double fpred = s.f - pred;     // what scipy compares: m(p) vs m(0)
-        const double noise = 2.220446049250313e-16 * fabs(s.f);
-        if (!(pred > 0.0) || !(fpred < s.f) || pred <= 64.0 * noise) {
-            // The predicted reduction is below the rounding noise of f itself, so
-            // the ratio test can no longer see it (scipy stops here with status 2,
-            // the reference's normal exit, up to ~1e-9 rot short of the optimum).
-            // Finish with the full Newton step when that step too is worth no more
-            // than noise in f -- this close the quadratic model is exact to working
-            // precision -- which lands at least as close to the optimum.
-            double pn[5], Hpn[5];
-            int hn = 0;
-            tr_subproblem(n, gs, Hs, 1e150, pn, &hn);
-            for (int r = 0; r < n; ++r) Hpn[r] = vdot(n, Hs + r * n, pn);
-            const double predn = -(vdot(n, gs, pn) + 0.5 * vdot(n, pn, Hpn));
-            if (!hn && predn >= 0.0 && predn <= 4096.0 * noise && s.iter + 1 < a.max_iter) {
-                for (int j = 0; j < 5; ++j) s.xe[j] = s.x[j];
-                for (int r = 0; r < n; ++r) s.xe[idx[r]] = s.x[idx[r]] + pn[r];
-                s.fresh = 2;
-            } else {
-                s.status = PP_RC_STALL; done = true;
-            }
-        } else {
-            for (int j = 0; j < 5; ++j) s.xe[j] = s.x[j];
-            for (int r = 0; r < n; ++r) s.xe[idx[r]] = s.x[idx[r]] + p[r];
-            s.pred_red = pred;
-            s.hits_boundary = hits;
-        }
-        }
+        PP_FOR_N(n, done = step_propose<N_>(a, s, idx));
     }
+    return done;
+}
+
+#include "pp_scatmodel.h"
+
+// one trust-region iteration per subint (64 threads, lane 0 decides)
+__global__ __launch_bounds__(64) void k_step(FitArgs a) {
+    const int i = sub_of(a.act, blockIdx.x), tid = threadIdx.x;
+    SubState& s = a.st[i];
+    if (s.done || s.model == 1) return;      // (model == 1: k_scat_model_solve owns this evaluation)
+    __shared__ double acc[PP_NACC];
+    if (tid < PP_NACC) {
+        double v = 0.0;
+        for (int c = 0; c < a.nchunk; ++c) v += a.partial[((size_t)i * a.nchunk + c) * PP_NACC + tid];
+        acc[tid] = v;
+    }
+    __syncthreads();
+    if (s.fresh == 1 && a.scat && a.use_model) scat_model_geometry(a, i, s);   // (all 64 lanes)
+    if (tid != 0) return;
+    double f, g[5], H[25];
+    unpack_acc(acc, a.flags, f, g, H);
+    const bool done = step_logic(a, s, f, g, H);
     if (done) {
         s.done = 1;
         atomicSub(a.nactive, 1);
+    } else if (a.scat && a.use_model && s.model == 0) {
+        scat_model_request(a, s);
     }
 }
 

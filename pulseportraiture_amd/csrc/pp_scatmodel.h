@@ -1,0 +1,400 @@
+// Scattering fits: the closing iterations without passes over the cross-spectrum.
+//
+// (included from pp_kernels.h, inside namespace pp, after step_logic)
+//
+// With scattering, one evaluation of the objective (pptoaslib.py:495-640) is a pass
+// over X_nk.  The reference's minimiser spends most of its evaluations within a
+// hair of the optimum (SciPy's trust-ncg: ~15 evaluations, the last ~8 of them
+// moving phi_n by < 1e-4 rot and tau_n by < 1 %).  There the per-channel sums are
+// an analytic function of the two per-channel quantities the parameters act
+// through, the phase phi_n and the scattering time tau_n:
+//
+//   C_n(phi_n + d, tau_n + e) = Re sum_k z_k e^{i kap d} b_k / (1 - i kap e b_k)
+//                             = sum_{a,c} d^a/a! e^c G[a+c][c],
+//   G[q][c] = Re sum_k (i kap)^q z_k b_k^(c+1),   z_k = X_nk e^{i kap phi_n},
+//   b_k = conj(B_nk) = 1/(1 - i kap tau_n),  kap = 2 pi k,
+//   S_n(tau_n + e) = sum_k |m_nk|^2 Re(b_k / (1 - i kap e b_k)) = sum_c e^c Sc[c],
+//   Sc[c] = sum_k |m_nk|^2 kap^c Re(i^c b_k^(c+1))
+//
+// (|B|^2 = Re conj(B) for B = 1/(1 + i kap tau)).  k_scat_model takes these
+// coefficients to total degree PP_MP in ONE pass over X -- that pass is also an exact
+// evaluation at its centre, so it takes the place of an ordinary one -- and
+// k_scat_model_solve then walks the remaining iterations of the same minimiser
+// (step_logic, the code the ordinary path runs) on the polynomial, each evaluation
+// O(nchan).  Every evaluation is certified: the dropped terms are bounded by
+//   sum_k |z_k||b_k| sum_{a+c > P} (kap|d|)^a/a! (kap|e||b_k|)^c
+//     <= W_0 e^{kap_max |d|} sum_{a+c > P} (keff|d|)^a/a! rho^c,
+//   W_a = sum_k |z_k||b_k| kap^a,  keff = (W_(P+1)/W_0)^(1/(P+1))  (W_a <= W_0 keff^a for
+//   a <= P+1 by the log-convexity of moments),  rho = |e| max_k kap|b_k|,
+// and turned into a bound on the position of the optimum (gradient error /
+// curvature) that must stay below 1e-13 rot of phase (and matching bars on the other
+// parameters); an evaluation that fails the certificate is simply made over X again
+// (the state is that of the ordinary path at every moment).
+#pragma once
+
+#ifndef PP_MP
+#define PP_MP 8                 // total degree of the per-channel model
+#endif
+#define PP_MNG ((PP_MP + 1) * (PP_MP + 2) / 2)       // G[q][c], c <= q <= P, at q(q+1)/2 + c
+#define PP_MROW ((PP_MNG + PP_MP + 4 + 1) & ~1)       // + Sc[0..P], W_0, tau_n, W_(P+1) (even)
+static_assert(PP_MROW % 2 == 0, "rows of the scattering model are moved in pairs");
+static_assert(PP_MROW <= 64, "one reduce-scatter of 64 values per channel");
+
+// sum over a + c >= m of x^a/a! rho^c  (x >= 0, 0 <= rho < 1), from above
+__device__ inline double series_tail(int m, double x, double rho) {
+    double xf[PP_MP + 2];       // x^j / j!
+    xf[0] = 1.0;
+    for (int j = 1; j <= m; ++j) xf[j] = xf[j - 1] * x / (double)j;
+    double total = 0.0, rc = 1.0;
+    for (int c = 0; c <= m; ++c) { total += rc * xf[m - c]; rc *= rho; }
+    return exp(x) * (total + rc / (1.0 - rho));
+}
+
+// Sum 64 per-lane values over an aligned group of 16 lanes, leaving lane l of the
+// group with the totals of v[4l .. 4l+3] (in v[0..3]): every xor step halves what a
+// lane carries (it keeps the half its lane bit selects and adds the partner's copy of
+// it), 60 exchanges instead of 256.
+__device__ __forceinline__ void group16_reduce_scatter64(double (&v)[64], int lane) {
+#define PP_RS_STEP(HALF, BIT)                                             \
+    {                                                                    \
+        const bool up = (lane & (BIT)) != 0;                             \
+        _Pragma("unroll") for (int j = 0; j < (HALF); ++j) {             \
+            const double keep = up ? v[(HALF) + j] : v[j];               \
+            const double send = up ? v[j] : v[(HALF) + j];               \
+            v[j] = keep + __shfl_xor(send, (BIT), 64);                   \
+        }                                                                \
+    }
+    PP_RS_STEP(32, 8)
+    PP_RS_STEP(16, 4)
+    PP_RS_STEP(8, 2)
+    PP_RS_STEP(4, 1)
+#undef PP_RS_STEP
+}
+
+// largest |d phi_n / d DM|, |d phi_n / d GM|, |ln(nu_n / nu_tau)| of a subint's
+// channels, and the effective harmonic scale keff of the template (from |m_nk|, the
+// weighting of a noise-dominated cross-spectrum, on every 32nd channel) -- 64 lanes;
+// kept in the state for the switch criterion
+__device__ inline void scat_model_geometry(const FitArgs& a, int i, SubState& s) {
+    const double P = a.P[i];
+    const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1], nutau = a.nu_fit[i * 3 + 2];
+    const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
+    const double* wts = a.wts + (size_t)i * a.nchan;
+    double m1 = 0.0, m2 = 0.0, m3 = 0.0;
+    for (int n = threadIdx.x; n < a.nchan; n += 64) {
+        if (wts[n] == 0.0) continue;
+        double p1, p2;
+        phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
+        m1 = fmax(m1, fabs(p1)); m2 = fmax(m2, fabs(p2));
+        m3 = fmax(m3, fabs(log(freqs[n] / nutau)));
+    }
+    m1 = group_max<64>(m1); m2 = group_max<64>(m2); m3 = group_max<64>(m3);
+    const int slot = a.slot ? a.slot[i] : 0;
+    const double* msq = as_global(a.msq[slot]);
+    const int* ktv = a.ktab ? as_global(a.ktab[slot]) : nullptr;
+    double keff = 0.0;
+    for (int n = 0; n < a.nchan; n += 32) {
+        if (wts[n] == 0.0) continue;
+        const int ktn = ktv ? ktv[n] : a.Kt;
+        double w0 = 0.0, wp = 0.0;
+        for (int k = threadIdx.x; k < ktn; k += 64) {
+            const double m = sqrt(msq[(size_t)n * a.M + k]), kap = PP_TWO_PI * (double)(k + 1);
+            double kp = kap;
+            for (int q = 0; q < PP_MP; ++q) kp *= kap;
+            w0 += m; wp = fma(m, kp, wp);
+        }
+        w0 = group_sum<64>(w0); wp = group_sum<64>(wp);
+        if (w0 > 0.0) keff = fmax(keff, exp(log(wp / w0) / (double)(PP_MP + 1)));
+    }
+    if (threadIdx.x == 0) { s.geo[0] = m1; s.geo[1] = m2; s.geo[2] = m3; s.geo[3] = keff; }
+}
+
+// After a proposal: will the rest of the iteration stay where a degree-PP_MP model
+// about the proposed point holds?  The Newton step of the current quadratic model
+// estimates how far the optimum is; that + the proposal must keep the dropped terms
+// below model_tol (1e-10) of the kept ones (a prediction only: the certificate of every model
+// evaluation is what guards the result).  Marks the next evaluation as the model pass.
+__device__ inline void scat_model_request(const FitArgs& a, SubState& s) {
+    if (s.fresh != 0) return;            // (closing evaluation pending: nothing follows it)
+    const double tau = a.log10_tau ? pow(10.0, s.xe[3]) : s.xe[3];
+    if (!(tau > 0.0)) return;
+    int idx[5], n = 0;
+    for (int j = 0; j < 5; ++j) if (a.flags[j]) idx[n++] = j;
+    double gs[5], Hs[25], mg[5], pn[5];
+    for (int r = 0; r < n; ++r) {
+        gs[r] = s.g[idx[r]]; mg[r] = -gs[r];
+        for (int c = 0; c < n; ++c) Hs[r * n + c] = s.H[idx[r] * 5 + idx[c]];
+    }
+    if (!chol_solve(n, Hs, mg, pn)) return;
+    double D[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int r = 0; r < n; ++r) D[idx[r]] = fabs(pn[r]);
+    for (int j = 0; j < 5; ++j) D[j] += fabs(s.xe[j] - s.x[j]);
+    const double dphi = D[0] + D[1] * s.geo[0] + D[2] * s.geo[1];
+    const double rel = (a.log10_tau ? PP_LN10 * D[3] : D[3] / tau) + D[4] * s.geo[2];
+    const double x = 1.25 * s.geo[3] * dphi, rho = 2.0 * rel;
+    if (!(x < 0.5) || !(rho < 0.2) || !(PP_TWO_PI * (double)a.Kt * dphi < 1.0)) return;
+    if (series_tail(PP_MP, x, rho) * (PP_MP + 1) <= a.model_tol) s.model = 1;
+}
+
+// --------------------------------------------------------------------------
+// The model pass.  Same work layout as k_eval<true> (grid (nsub, nchunk), 16 lanes
+// per channel), for the subints whose state asks for it.  Leaves the PP_MROW
+// coefficients of every channel in a.mdl and the nine sums of the centre in the
+// trial csum buffer, exactly as k_eval would.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scat_model(FitArgs a) {
+    constexpr int LPC = 16, P_ = PP_MP;
+    const int jx = blockIdx.x, i = sub_of(a.act, jx), chunk = blockIdx.y;
+    const SubState& st = a.st[i];
+    if (st.done || st.model != 1) return;
+    const int tid = threadIdx.x, g = tid / LPC, l = tid % LPC;
+    const double phi = st.xe[0], DM = st.xe[1], GM = st.xe[2], alpha = st.xe[4];
+    const double tau = a.log10_tau ? pow(10.0, st.xe[3]) : st.xe[3];
+    const double P = a.P[i];
+    const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1], nutau = a.nu_fit[i * 3 + 2];
+    const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
+    const double* wts = a.wts + (size_t)i * a.nchan;
+    const int slot = a.slot ? a.slot[i] : 0;
+    const double* msq = as_global(a.msq[slot]);
+    double* mdl = a.mdl + (size_t)i * a.nchan * PP_MROW;
+    double* csum = a.csum + ((size_t)(1 - st.cur) * a.nsub + i) * a.nchan * a.ncs;
+    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan_x);
+    const int src = ((tid & 63) & ~(LPC - 1)) | (LPC - 1);
+    for (int nn = n0 + g; nn < n1; nn += 256 / LPC) {
+        const int n = a.coff + nn * a.cstep;
+        const double w = wts[n];
+        ChanGeom cg;
+        chan_geom(freqs[n], P, nuDM, nuGM, nutau, tau, alpha, a.log10_tau, true, cg);
+        const double phin = phi + DM * cg.p1 + GM * cg.p2;
+        cplx e = unit_phasor((double)(l + 1), phin);
+        const cplx wst = make_double2(__shfl(e.x, src, 64), __shfl(e.y, src, 64));
+        const cplx* xrow = a.X + ((size_t)jx * a.nchan_x + nn) * a.Kt;
+        const int ktn = a.ktab ? as_global(a.ktab[slot])[n] : a.Kt;
+        double G[PP_MNG], Sc[P_ + 1], An = 0.0, Wp = 0.0;
+#pragma unroll
+        for (int j = 0; j < PP_MNG; ++j) G[j] = 0.0;
+#pragma unroll
+        for (int j = 0; j <= P_; ++j) Sc[j] = 0.0;
+        double k = (double)(l + 1);
+        if (w != 0.0 && l < ktn) {
+            // the next harmonic's loads are issued before this one's arithmetic
+            const double* mrow = msq + (size_t)n * a.M;
+            cplx xn = xrow[l];
+            double Mn = mrow[l];
+#pragma unroll 1
+            for (int j = l; j < ktn; j += LPC) {
+                const cplx x = xn;
+                const double Mk = Mn;
+                if (j + LPC < ktn) { xn = xrow[j + LPC]; Mn = mrow[j + LPC]; }
+                const cplx z = cmul(x, e);
+                const double kap = PP_TWO_PI * k, u = kap * cg.taun;
+                const double D = recip_ge1(fma(u, u, 1.0));
+                const cplx b = make_double2(D, u * D);
+                double kp[P_ + 1];
+                kp[0] = 1.0;
+#pragma unroll
+                for (int q = 1; q <= P_; ++q) kp[q] = kp[q - 1] * kap;
+                cplx zb = cmul(z, b);                           // z b^(c+1)
+                cplx bp = make_double2(Mk * b.x, Mk * b.y);     // |m_nk|^2 b^(c+1)
+#pragma unroll
+                for (int c = 0; c <= P_; ++c) {
+                    if (c > 0) { zb = cmul(zb, b); bp = cmul(bp, b); }
+                    // Re(i^q v): +Re, -Im, -Re, +Im; the sign goes on at the end
+#pragma unroll
+                    for (int q = c; q <= P_; ++q)
+                        G[q * (q + 1) / 2 + c] = fma(kp[q], (q & 1) ? zb.y : zb.x, G[q * (q + 1) / 2 + c]);
+                    Sc[c] = fma(kp[c], (c & 1) ? bp.y : bp.x, Sc[c]);
+                }
+                // |b_k| from above: a single-precision rsqrt, widened by its error
+                const float rs = __builtin_amdgcn_rsqf((float)fma(u, u, 1.0)) * 1.0001f;
+                const double ax = (fabs(x.x) + fabs(x.y)) * (double)rs;
+                An += ax;
+                Wp = fma(ax, kp[P_] * kap, Wp);
+                e = cmul(e, wst);
+                k += (double)LPC;
+            }
+        }
+        // signs of Re(i^q v), then one reduce-scatter of the whole row over the 16 lanes
+        double V[64];
+#pragma unroll
+        for (int q = 0; q <= P_; ++q)
+#pragma unroll
+            for (int c = 0; c <= q; ++c) {
+                const int j = q * (q + 1) / 2 + c;
+                V[j] = ((q & 3) == 1 || (q & 3) == 2) ? -G[j] : G[j];
+            }
+#pragma unroll
+        for (int c = 0; c <= P_; ++c) V[PP_MNG + c] = ((c & 3) == 1 || (c & 3) == 2) ? -Sc[c] : Sc[c];
+        V[PP_MNG + P_ + 1] = An;
+        V[PP_MNG + P_ + 2] = 0.0;                 // (tau_n goes here)
+        V[PP_MNG + P_ + 3] = Wp;
+#pragma unroll
+        for (int j = PP_MNG + P_ + 4; j < 64; ++j) V[j] = 0.0;
+        group16_reduce_scatter64(V, l);
+        constexpr int JT = PP_MNG + P_ + 2;       // tau_n's place in the row
+        if (l == JT / 4) V[JT % 4] = cg.taun;
+        double* row = mdl + (size_t)n * PP_MROW;
+        if (4 * l + 1 < PP_MROW) reinterpret_cast<double2*>(row)[2 * l] = make_double2(V[0], V[1]);
+        if (4 * l + 3 < PP_MROW) reinterpret_cast<double2*>(row)[2 * l + 1] = make_double2(V[2], V[3]);
+        // the nine sums of the centre for the post-fit stage:
+        // A0 = G00, A1 = G10, T1 = G11, A2 = G20, A1T = G21, T2 = 2 G22; S0, S1 = Sc1, S2 = 2 Sc2
+        double* co = csum + (size_t)n * a.ncs;
+        if (l == 0) { co[0] = V[0]; co[1] = V[1]; co[3] = V[2]; co[2] = V[3]; }
+        if (l == 1) { co[5] = V[0]; co[4] = 2.0 * V[1]; }
+        static_assert(PP_MNG % 4 == 1 || PP_MNG % 4 == 0, "Sc[0..2] sit in one lane's quartet");
+        if (l == PP_MNG / 4) {
+            constexpr int o = PP_MNG % 4;
+            co[6] = V[o]; co[7] = V[o + 1]; co[8] = 2.0 * V[o + 2];
+        }
+    }
+}
+
+// the nine sums at (phi_n + d, tau_n + e) from a channel's row
+__device__ __forceinline__ void scat_model_sums(const double* row, double d, double e, double* cs) {
+    constexpr int P_ = PP_MP;
+    // Horner in e over c = P .. 0 of h_c(d), h_c'(d), h_c''(d), each a series in d
+    double v = 0.0, v1 = 0.0, v2 = 0.0;      // C, dC/de, (1/2) d2C/de2
+    double u = 0.0, u1 = 0.0;                // dC/dd, d2C/(dd de)
+    double t = 0.0;                          // d2C/dd2
+#pragma unroll
+    for (int c = P_; c >= 0; --c) {
+        double h0 = 0.0, h1 = 0.0, h2 = 0.0;
+#pragma unroll
+        for (int aa = P_ - c; aa >= 0; --aa) {
+            const double G = row[(aa + c) * (aa + c + 1) / 2 + c];
+            h0 = fma(h0, d * (1.0 / (double)(aa + 1)), G);
+            if (aa >= 1) h1 = fma(h1, d * (1.0 / (double)aa), G);
+            if (aa >= 2) h2 = fma(h2, d * (1.0 / (double)(aa - 1)), G);
+        }
+        v2 = fma(v2, e, v1); v1 = fma(v1, e, v); v = fma(v, e, h0);
+        u1 = fma(u1, e, u); u = fma(u, e, h1);
+        t = fma(t, e, h2);
+    }
+    cs[0] = v; cs[1] = u; cs[2] = t; cs[3] = v1; cs[4] = 2.0 * v2; cs[5] = u1;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int c = P_; c >= 0; --c) {
+        s2 = fma(s2, e, s1); s1 = fma(s1, e, s0); s0 = fma(s0, e, row[PP_MNG + c]);
+    }
+    cs[6] = s0; cs[7] = s1; cs[8] = 2.0 * s2;
+}
+
+// --------------------------------------------------------------------------
+// The iterations on the model: one 256-thread block per subint whose model pass
+// just ran.  Every round evaluates f, g, H at the pending proposal s.xe from the
+// rows (the first round at the centre itself: exact), checks the certificate, and
+// lets thread 0 run the same step_logic as k_step.  An evaluation that fails the
+// certificate is left to the ordinary path (model = 3: no further model passes for
+// this subint).
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scat_model_solve(FitArgs a) {
+    const int i = sub_of(a.act, blockIdx.x), tid = threadIdx.x;
+    SubState& st = a.st[i];
+    if (st.done || st.model != 1) return;
+    __shared__ SubState ss;
+    __shared__ double scratch[4 * (PP_NACC + 5)];
+    __shared__ int flag;
+    if (tid == 0) ss = st;
+    __syncthreads();
+    const double P = a.P[i];
+    const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1], nutau = a.nu_fit[i * 3 + 2];
+    const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
+    const double* wts = a.wts + (size_t)i * a.nchan;
+    const double* mdl = a.mdl + (size_t)i * a.nchan * PP_MROW;
+    double xc[5];                                   // the centre
+    for (int j = 0; j < 5; ++j) xc[j] = ss.xe[j];
+    const double tau_c = a.log10_tau ? pow(10.0, xc[3]) : xc[3];
+    const double kmax = PP_TWO_PI * (double)a.Kt;
+    const double tol[5] = {1e-13, 1e-11, 1e-8, a.log10_tau ? 4e-11 : 1e-10 * tau_c, 1e-9};
+    for (int round = 0;; ++round) {
+        double xe[5];
+        for (int j = 0; j < 5; ++j) xe[j] = ss.xe[j];
+        const int trial = 1 - ss.cur;
+        __syncthreads();
+        const double tau_e = a.log10_tau ? pow(10.0, xe[3]) : xe[3];
+        const double dlnt = a.log10_tau ? PP_LN10 * (xe[3] - xc[3]) : log(tau_e / tau_c);
+        const double dal = xe[4] - xc[4];
+        const double dph = xe[0] - xc[0], dDM = xe[1] - xc[1], dGM = xe[2] - xc[2];
+        double* csum = a.csum + ((size_t)trial * a.nsub + i) * a.nchan * a.ncs;
+        double acc[PP_NACC + 5];
+#pragma unroll
+        for (int j = 0; j < PP_NACC + 5; ++j) acc[j] = 0.0;
+        bool inside = (tau_e > 0.0);
+        for (int n = tid; n < a.nchan; n += 256) {
+            const double w = wts[n];
+            const double* rg = mdl + (size_t)n * PP_MROW;
+            double row[PP_MROW];
+#pragma unroll
+            for (int j = 0; j < PP_MROW / 2; ++j) {
+                const double2 v2 = reinterpret_cast<const double2*>(rg)[j];
+                row[2 * j] = v2.x; row[2 * j + 1] = v2.y;
+            }
+            ChanGeom cg;
+            phase_geom(freqs[n], P, nuDM, nuGM, cg.p1, cg.p2);
+            const double lnf = log(freqs[n] / nutau);
+            const double taun_c = row[PP_MNG + PP_MP + 2];
+            const double eps = taun_c * expm1(dlnt + dal * lnf);
+            const double taun = taun_c + eps;
+            cg.lnf = lnf; cg.taun = taun;
+            if (!a.log10_tau) {
+                cg.q1 = taun / tau_e; cg.q2 = lnf * taun; cg.q11 = 0.0; cg.q12 = cg.q2 / tau_e;
+            } else {
+                cg.q1 = PP_LN10 * taun; cg.q2 = lnf * taun; cg.q11 = PP_LN10 * cg.q1; cg.q12 = PP_LN10 * cg.q2;
+            }
+            cg.q22 = lnf * cg.q2;
+            const double d = dph + dDM * cg.p1 + dGM * cg.p2;
+            double cs[PP_NCS];
+            scat_model_sums(row, d, eps, cs);
+            if (round > 0) {
+#pragma unroll
+                for (int j = 0; j < PP_NCS; ++j) csum[(size_t)n * a.ncs + j] = cs[j];
+            }
+            if (w == 0.0) continue;
+            const Local L = local_terms(cs, w);
+            double c[PP_NACC];
+            accumulate_channel(L, cg, c);
+#pragma unroll
+            for (int j = 0; j < PP_NACC; ++j) acc[j] += c[j];
+            if (round > 0) {
+                // certificate: dropped terms of the first derivatives
+                const double kb = kmax / sqrt(fma(kmax * taun_c, kmax * taun_c, 1.0));
+                const double W0 = row[PP_MNG + PP_MP + 1], Wp = row[PP_MNG + PP_MP + 3];
+                const double keff = (W0 > 0.0) ? exp(log(Wp / W0) * (1.0 / (PP_MP + 1))) : 0.0;
+                const double x = keff * fabs(d), rho = 2.0 * fabs(eps) * kb;
+                if (!(x < 0.5) || !(rho < 0.5) || !(kmax * fabs(d) < 1.0)) { inside = false; continue; }
+                const double e1 = W0 * series_tail(PP_MP, x, rho) * exp(kmax * fabs(d));
+                const double r = fabs(cs[0] / cs[6]) + 1e-300;
+                const double gp = 3.0 * w * r * e1 * kmax, gt = 3.0 * w * r * e1 * kb;
+                acc[PP_NACC] += gp; acc[PP_NACC + 1] += gp * fabs(cg.p1); acc[PP_NACC + 2] += gp * fabs(cg.p2);
+                acc[PP_NACC + 3] += gt * fabs(cg.q1); acc[PP_NACC + 4] += gt * fabs(cg.q2);
+            }
+        }
+        block_sum<PP_NACC + 5>(acc, scratch);
+        if (tid == 0) flag = 0;
+        __syncthreads();
+        if (!inside) flag = 1;               // (any thread)
+        __syncthreads();
+        if (tid == 0) {
+            double f, g[5], H[25];
+            unpack_acc(acc, a.flags, f, g, H);
+            bool ok = (flag == 0);
+            for (int j = 0; j < 5 && ok; ++j)
+                if (a.flags[j] && !(acc[PP_NACC + j] <= tol[j] * fabs(H[j * 5 + j]))) ok = false;
+            if (!ok) {
+                ss.model = 3;                // the ordinary path evaluates this proposal over X
+                flag = 2;
+            } else {
+                ss.model = 2;
+                const bool done = step_logic(a, ss, f, g, H);
+                ss.model = 1;
+                if (done) { ss.done = 1; flag = 3; }
+            }
+        }
+        __syncthreads();
+        if (flag >= 2) break;
+    }
+    if (tid == 0) {
+        if (ss.done) { ss.model = 3; atomicSub(a.nactive, 1); }
+        st = ss;
+    }
+}

@@ -69,9 +69,9 @@ struct ModelSlot {
     DevBuf mft, msum, mmax, mdc, kt, msq;
 };
 
-enum KernelFamily { KF_MODEL = 0, KF_XSPEC, KF_PREP, KF_SEED, KF_ACCUM, KF_EVAL, KF_TAYLOR, KF_STEP, KF_FINAL, KF_SYNTH, KF_FPS, KF_COUNT };
+enum KernelFamily { KF_MODEL = 0, KF_XSPEC, KF_PREP, KF_SEED, KF_ACCUM, KF_EVAL, KF_TAYLOR, KF_STEP, KF_FINAL, KF_SYNTH, KF_FPS, KF_SCATMODEL, KF_COUNT };
 static const char* kFamilyNames[KF_COUNT] = {"model_fft", "xspec", "prep", "seed", "accum", "eval", "taylor_solve", "step", "finalize",
-                                            "synth", "fit_phase_shift"};
+                                            "synth", "fit_phase_shift", "scat_model"};
 
 struct pp_ctx {
     int device = 0;
@@ -86,7 +86,7 @@ struct pp_ctx {
     DevBuf o_pack;   // per-subint scalar outputs, one allocation -> one D2H copy
     void* o_host = nullptr; size_t o_host_cap = 0;   // pinned staging of o_pack
     DevBuf o_params, o_errs, o_nu, o_cov, o_chi2, o_rchi2, o_snr, o_nfev, o_rc, o_scales, o_serrs, o_csnr,
-        o_f0, o_g0, o_H0, misc, seedbuf, tay, ph0, act, seedq, xbase;
+        o_f0, o_g0, o_H0, misc, seedbuf, tay, ph0, act, seedq, xbase, mdl;
     int* nactive_h = nullptr;   // pinned
     // options
     double harm_eps = 8.8817841970012523e-16;  // 2^-50
@@ -95,6 +95,8 @@ struct pp_ctx {
     int check_every = 1;
     int use_taylor = 1;
     int moments_in_xspec = 1;   // fold the Taylor moments into k_xspec (mode 2) when it applies
+    int scat_model = 1;         // scattering fits: closing iterations on the per-channel model (pp_scatmodel.h)
+    double scat_model_tol = 1e-10;
     int paired_split = 1;       // 2048-bin rows: last FFT stage + split in registers (k_xspec_p1024)
     int seed_chan_stride = 16;  // device phase seed: pilot pass over every n-th channel (1 = all channels)
     double seed_min_snr = 8.0;  // pilot seeds below this peak significance are redone from all channels
@@ -219,6 +221,8 @@ extern "C" int pp_set_option(pp_ctx* c, const char* name, double value) {
     else if (n == "taylor") c->use_taylor = (int)value;
     else if (n == "moments_in_xspec") c->moments_in_xspec = (int)value;
     else if (n == "paired_split") c->paired_split = (int)value;
+    else if (n == "scat_model") c->scat_model = (int)value;
+    else if (n == "scat_model_tol") c->scat_model_tol = value;
     else if (n == "seed_chan_stride") c->seed_chan_stride = std::max(1, (int)value);
     else if (n == "seed_min_snr") c->seed_min_snr = value;
     else if (n == "seed_ndm") c->seed_ndm = std::max(1, (int)value);
@@ -549,6 +553,10 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     if ((rc = c->csum.reserve(2 * nc * ncs * 8))) return rc;
     if ((rc = c->partial.reserve((size_t)ns * nchunk * PP_NACC * 8))) return rc;
     if (taylor) if ((rc = c->tay.reserve(nc * PP_TSTRIDE * 8))) return rc;
+    // (SciPy's trust-ncg spends ~8 of its ~15 evaluations inside the model's range;
+    // the Newton iteration only 2-3 of 6, less than the model pass costs)
+    const bool smodel = scat && c->max_iter > 0 && (c->scat_model >= 2 || (c->scat_model == 1 && in->method == PP_METHOD_TRUST_NCG));
+    if (smodel) if ((rc = c->mdl.reserve(nc * PP_MROW * 8))) return rc;
     if (xmode != 0) if ((rc = c->ph0.reserve(nc * 8))) return rc;
     if ((rc = c->misc.reserve(256))) return rc;
     if ((rc = c->act.reserve((size_t)ns * 4))) return rc;
@@ -627,6 +635,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.o_f0 = c->o_f0.as<double>(); fa.o_g0 = c->o_g0.as<double>(); fa.o_H0 = c->o_H0.as<double>();
     fa.o_rec = out->records_dev ? out->records_dev + (size_t)s0 * PP_RECORD_WIDTH : nullptr;
     fa.act = nullptr; fa.nact = ns; fa.nchan_x = C; fa.cstep = 1; fa.coff = 0;
+    fa.mdl = c->mdl.as<double>(); fa.use_model = smodel ? 1 : 0; fa.model_tol = c->scat_model_tol;
 
     auto run_xspec = [&](const XspecArgs& x, int mode) -> int {
         Prof pr(c, KF_XSPEC);
@@ -787,6 +796,13 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             if (scat) hipLaunchKernelGGL(k_eval<true>, dim3(fa.nact, fa.nchunk), dim3(256), 0, c->stream, fa);
             else hipLaunchKernelGGL(k_eval_fast, dim3(fa.nact, fa.nchunk), dim3(256), 0, c->stream, fa);
         }
+        if (smodel && it >= 2) {
+            // subints whose last proposal asked for it: this evaluation is the model
+            // pass, and the rest of their iterations run on the model
+            Prof pr(c, KF_SCATMODEL);
+            hipLaunchKernelGGL(k_scat_model, dim3(fa.nact, fa.nchunk), dim3(256), 0, c->stream, fa);
+            hipLaunchKernelGGL(k_scat_model_solve, dim3(fa.nact), dim3(256), 0, c->stream, fa);
+        }
         {
             Prof pr(c, KF_STEP);
             hipLaunchKernelGGL(k_step, dim3(fa.nact), dim3(64), 0, c->stream, fa);
@@ -899,7 +915,8 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const double per_sub = (double)C * Kt * 16.0 + (in->data_on_device ? 0.0 : (double)C * B * (in->data_dtype == PP_F64 ? 8 : 4)) +
-                           (double)C * (8.0 * 12 + 2 * 9 * 8.0) + 4096.0;
+                           (double)C * (8.0 * 12 + 2 * 9 * 8.0) + 4096.0 +
+                           ((scat && c->scat_model) ? (double)C * PP_MROW * 8.0 : 0.0);
     double budget = std::min(c->max_work_bytes, 0.85 * ((double)free_b + (double)c->X.cap + (double)c->data.cap + (double)c->csum.cap));
     int cap = (int)std::max(1.0, std::floor(budget / per_sub));
     cap = std::min(std::min(cap, N), 65535);   // (subints index the grid's y dimension)

@@ -1652,3 +1652,100 @@ def test_coarse_phase_dm_grid_recovers_a_poor_dm_guess(eng):
     np.testing.assert_allclose(grid["chi2"], one["chi2"], rtol=1e-11)
     # and the injected DM is what both recover
     assert np.all(np.abs(grid["params"][:, 1] - 34.56789) < 2e-3)
+
+
+def _dphi_arr(a, b):
+    d = np.abs(np.asarray(a) - np.asarray(b))
+    return np.minimum(d, np.abs(d - 1.0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("l10,flags", [(True, [1, 1, 0, 1, 1]), (True, [1, 1, 0, 1, 0]),
+                                       (False, [1, 1, 0, 1, 0]), (True, [1, 0, 0, 1, 1])])
+def test_scattering_model_of_the_closing_iterations_walks_the_same_iteration(l10, flags):
+    """Scattering fits finish their trust-ncg iteration on a per-channel polynomial
+    model of the sums (pp_scatmodel.h) instead of passes over the cross-spectrum: the
+    same iterates (evaluation counts identical), the same answer to rounding, the same
+    errors and chi^2 -- and fewer passes."""
+    e, data, freqs, model, P, x0, errs, nu_fit, kw = _full_shape_case(256, 1024, flags, l10, nsub=24,
+                                                                      tau_us=30.0, seed=9)
+    mask = np.ones((24, 256), dtype=np.uint8)
+    mask[:, 17] = 0; mask[3, 100:140] = 0
+    res, evals, passes = {}, {}, {}
+    e.set_option("profile", 1)
+    for sm in (0, 1):
+        e.set_option("scat_model", sm)
+        e.kernel_times(reset=True)
+        # (phases referred to a fixed frequency, so that they compare across runs)
+        res[sm] = e.fit_batch(data, freqs, P, x0, chan_mask=mask, nu_outs=np.full((24, 3), nu_fit), **kw)
+        kt = e.kernel_times(reset=True)
+        evals[sm] = kt["eval"][1]
+        passes[sm] = kt.get("scat_model", (0.0, 0))[1]
+    e.set_option("profile", 0)
+    a, b = res[0], res[1]
+    assert passes[0] == 0 and passes[1] > 0
+    assert evals[1] < evals[0], (evals, "the model never took over")
+    assert (b["return_code"] == 2).all()
+    # Identical iterates wherever the evaluation counts agree.  They need not: SciPy's
+    # exit -- predicted reduction <= 0 in floating point -- hangs on the last bit of f
+    # once the optimum is reached, so ANY change of rounding (the reference's own on
+    # another BLAS included) can add a final no-op evaluation, or send the iteration
+    # into / spare it the tail of rejected steps with shrinking radius; both ends sit at
+    # the optimum to ~1e-9 rot.
+    same = a["nfeval"] == b["nfeval"]
+    assert same.mean() >= 0.75, (a["nfeval"], b["nfeval"])
+    if flags == [1, 1, 0, 1, 1] or flags == [1, 1, 0, 1, 0] and l10:
+        assert same.all(), (a["nfeval"], b["nfeval"])      # (no marginal exits in these draws)
+    ne = ~same
+    assert _dphi_arr(a["params"][ne, 0], b["params"][ne, 0]).max(initial=0.0) < 5e-8
+    np.testing.assert_allclose(a["chi2"][ne], b["chi2"][ne], rtol=1e-11)
+    one = np.abs(a["nfeval"] - b["nfeval"]) == 1           # a final evaluation that moved nothing
+    assert _dphi_arr(a["params"][one, 0], b["params"][one, 0]).max(initial=0.0) < 2e-12
+    a = {k: v[same] for k, v in a.items() if isinstance(v, np.ndarray) and len(v) == len(same)}
+    b = {k: v[same] for k, v in b.items() if isinstance(v, np.ndarray) and len(v) == len(same)}
+    # (linear tau: the badly scaled parameter set also flips accept/reject decisions
+    # inside runs of equal length; those end within 1e-9 rot of each other)
+    t = 1.0 if l10 else 1e3
+    assert np.abs(_dphi_arr(a["params"][:, 0], b["params"][:, 0])).max() < 2e-12 * t
+    assert np.abs(a["params"][:, 1] - b["params"][:, 1]).max() < 1e-11 * t
+    np.testing.assert_allclose(a["params"][:, 3:], b["params"][:, 3:], rtol=1e-10 * t, atol=1e-12)
+    ii = np.where(flags)[0]
+    np.testing.assert_allclose(a["param_errs"][:, ii], b["param_errs"][:, ii], rtol=1e-9 * t)
+    np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-12)
+    np.testing.assert_allclose(a["scales"], b["scales"], rtol=1e-9 * t, atol=1e-12)
+    np.testing.assert_allclose(a["snr"], b["snr"], rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_scattering_model_evaluations_that_fail_their_certificate_are_made_over_the_data():
+    """Ask for the model pass as early as the request allows (scat_model_tol = inf): the
+    iteration then leaves the model's range, the certificate of those evaluations
+    fails, and they are made over the cross-spectrum like any other -- same iterates,
+    same answer.  Also the Newton iteration on the model (scat_model = 2)."""
+    flags, l10 = [1, 1, 0, 1, 1], True
+    e, data, freqs, model, P, x0, errs, nu_fit, kw = _full_shape_case(256, 1024, flags, l10, nsub=16,
+                                                                      tau_us=30.0, seed=10)
+    e.set_option("scat_model", 0)
+    ref = e.fit_batch(data, freqs, P, x0, **kw)
+    refn = e.fit_batch(data, freqs, P, x0, method='newton', **kw)
+    e.set_option("scat_model", 1)
+    e.set_option("scat_model_tol", 1e300)
+    e.set_option("profile", 1)
+    e.kernel_times(reset=True)
+    r = e.fit_batch(data, freqs, P, x0, **kw)
+    kt = e.kernel_times(reset=True)
+    e.set_option("profile", 0)
+    e.set_option("scat_model_tol", 1e-10)
+    np.testing.assert_array_equal(ref["nfeval"], r["nfeval"])
+    assert np.abs(_dphi_arr(ref["params"][:, 0], r["params"][:, 0])).max() < 2e-12
+    np.testing.assert_allclose(ref["params"][:, 3:], r["params"][:, 3:], rtol=1e-10)
+    np.testing.assert_allclose(ref["chi2"], r["chi2"], rtol=1e-12)
+    # early model passes were abandoned: more passes over the data than evaluations the
+    # default setting needs, yet the model still ran
+    assert kt["scat_model"][1] > 0
+    e.set_option("scat_model", 2)
+    rn = e.fit_batch(data, freqs, P, x0, method='newton', **kw)
+    e.set_option("scat_model", 1)
+    np.testing.assert_array_equal(refn["nfeval"], rn["nfeval"])
+    assert np.abs(_dphi_arr(refn["params"][:, 0], rn["params"][:, 0])).max() < 2e-12
+    np.testing.assert_allclose(refn["params"][:, 3:], rn["params"][:, 3:], rtol=1e-10)
