@@ -99,7 +99,7 @@ struct FitArgs {
     const int* act;
     int nact, nchan_x, cstep, coff;
     // scattering fits: per-channel model of the closing iterations (pp_scatmodel.h)
-    double* mdl;              // [nsub][nchan][PP_MROW]
+    double* mdl;              // [nsub][PP_MROW][nchan]
     int use_model;
     double model_tol;         // predicted relative truncation below which the model pass is asked for
 };

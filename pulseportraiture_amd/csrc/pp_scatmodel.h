@@ -40,14 +40,16 @@
 static_assert(PP_MROW % 2 == 0, "rows of the scattering model are moved in pairs");
 static_assert(PP_MROW <= 64, "one reduce-scatter of 64 values per channel");
 
-// sum over a + c >= m of x^a/a! rho^c  (x >= 0, 0 <= rho < 1), from above
+// sum over a + c >= m of x^a/a! rho^c  (0 <= x <= 1/2, 0 <= rho <= 1/2), from above:
+// sum_c rho^c R_(m-c)(x) with R_j(x) = sum_{a >= j} x^a/a! <= e^x x^j/j!, and the
+// cheap majorants e^x <= 1 + x + x^2, 1/(1 - rho) <= 1 + 2 rho on that range
 __device__ inline double series_tail(int m, double x, double rho) {
     double xf[PP_MP + 2];       // x^j / j!
     xf[0] = 1.0;
-    for (int j = 1; j <= m; ++j) xf[j] = xf[j - 1] * x / (double)j;
+    for (int j = 1; j <= m; ++j) xf[j] = xf[j - 1] * x * (1.0 / (double)j);
     double total = 0.0, rc = 1.0;
     for (int c = 0; c <= m; ++c) { total += rc * xf[m - c]; rc *= rho; }
-    return exp(x) * (total + rc / (1.0 - rho));
+    return fma(x, x, 1.0 + x) * fma(rc, fma(2.0, rho, 1.0), total);
 }
 
 // Sum 64 per-lane values over an aligned group of 16 lanes, leaving lane l of the
@@ -73,7 +75,7 @@ __device__ __forceinline__ void group16_reduce_scatter64(double (&v)[64], int la
 
 // largest |d phi_n / d DM|, |d phi_n / d GM|, |ln(nu_n / nu_tau)| of a subint's
 // channels, and the effective harmonic scale keff of the template (from |m_nk|, the
-// weighting of a noise-dominated cross-spectrum, on every 32nd channel) -- 64 lanes;
+// weighting of a noise-dominated cross-spectrum, on 16 channels across the band) -- 64 lanes;
 // kept in the state for the switch criterion
 __device__ inline void scat_model_geometry(const FitArgs& a, int i, SubState& s) {
     const double P = a.P[i];
@@ -93,7 +95,7 @@ __device__ inline void scat_model_geometry(const FitArgs& a, int i, SubState& s)
     const double* msq = as_global(a.msq[slot]);
     const int* ktv = a.ktab ? as_global(a.ktab[slot]) : nullptr;
     double keff = 0.0;
-    for (int n = 0; n < a.nchan; n += 32) {
+    for (int n = 0; n < a.nchan; n += max(1, a.nchan / 16)) {
         if (wts[n] == 0.0) continue;
         const int ktn = ktv ? ktv[n] : a.Kt;
         double w0 = 0.0, wp = 0.0;
@@ -233,9 +235,11 @@ __global__ __launch_bounds__(256) void k_scat_model(FitArgs a) {
         group16_reduce_scatter64(V, l);
         constexpr int JT = PP_MNG + P_ + 2;       // tau_n's place in the row
         if (l == JT / 4) V[JT % 4] = cg.taun;
-        double* row = mdl + (size_t)n * PP_MROW;
-        if (4 * l + 1 < PP_MROW) reinterpret_cast<double2*>(row)[2 * l] = make_double2(V[0], V[1]);
-        if (4 * l + 3 < PP_MROW) reinterpret_cast<double2*>(row)[2 * l + 1] = make_double2(V[2], V[3]);
+        // coefficient j of channel n goes to mdl[j * nchan + n] (the 16 channels a
+        // workgroup has in flight are neighbours: 128 B per coefficient)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (4 * l + q < PP_MROW) mdl[(size_t)(4 * l + q) * a.nchan + n] = V[q];
         // the nine sums of the centre for the post-fit stage:
         // A0 = G00, A1 = G10, T1 = G11, A2 = G20, A1T = G21, T2 = 2 G22; S0, S1 = Sc1, S2 = 2 Sc2
         double* co = csum + (size_t)n * a.ncs;
@@ -249,8 +253,8 @@ __global__ __launch_bounds__(256) void k_scat_model(FitArgs a) {
     }
 }
 
-// the nine sums at (phi_n + d, tau_n + e) from a channel's row
-__device__ __forceinline__ void scat_model_sums(const double* row, double d, double e, double* cs) {
+// the nine sums at (phi_n + d, tau_n + e) from a channel's coefficients (row[j * rs])
+__device__ __forceinline__ void scat_model_sums(const double* row, size_t rs, double d, double e, double* cs) {
     constexpr int P_ = PP_MP;
     // Horner in e over c = P .. 0 of h_c(d), h_c'(d), h_c''(d), each a series in d
     double v = 0.0, v1 = 0.0, v2 = 0.0;      // C, dC/de, (1/2) d2C/de2
@@ -261,7 +265,7 @@ __device__ __forceinline__ void scat_model_sums(const double* row, double d, dou
         double h0 = 0.0, h1 = 0.0, h2 = 0.0;
 #pragma unroll
         for (int aa = P_ - c; aa >= 0; --aa) {
-            const double G = row[(aa + c) * (aa + c + 1) / 2 + c];
+            const double G = row[(size_t)((aa + c) * (aa + c + 1) / 2 + c) * rs];
             h0 = fma(h0, d * (1.0 / (double)(aa + 1)), G);
             if (aa >= 1) h1 = fma(h1, d * (1.0 / (double)aa), G);
             if (aa >= 2) h2 = fma(h2, d * (1.0 / (double)(aa - 1)), G);
@@ -274,7 +278,7 @@ __device__ __forceinline__ void scat_model_sums(const double* row, double d, dou
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int c = P_; c >= 0; --c) {
-        s2 = fma(s2, e, s1); s1 = fma(s1, e, s0); s0 = fma(s0, e, row[PP_MNG + c]);
+        s2 = fma(s2, e, s1); s1 = fma(s1, e, s0); s0 = fma(s0, e, row[(size_t)(PP_MNG + c) * rs]);
     }
     cs[6] = s0; cs[7] = s1; cs[8] = 2.0 * s2;
 }
@@ -306,6 +310,9 @@ __global__ __launch_bounds__(256) void k_scat_model_solve(FitArgs a) {
     const double tau_c = a.log10_tau ? pow(10.0, xc[3]) : xc[3];
     const double kmax = PP_TWO_PI * (double)a.Kt;
     const double tol[5] = {1e-13, 1e-11, 1e-8, a.log10_tau ? 4e-11 : 1e-10 * tau_c, 1e-9};
+#ifdef PP_SOLVE_TIMING
+    long long tA = 0, tB = 0, tC = 0, t0 = clock64(), t1;
+#endif
     for (int round = 0;; ++round) {
         double xe[5];
         for (int j = 0; j < 5; ++j) xe[j] = ss.xe[j];
@@ -322,17 +329,17 @@ __global__ __launch_bounds__(256) void k_scat_model_solve(FitArgs a) {
         bool inside = (tau_e > 0.0);
         for (int n = tid; n < a.nchan; n += 256) {
             const double w = wts[n];
-            const double* rg = mdl + (size_t)n * PP_MROW;
+            // coefficient j of channel n sits at mdl[j * nchan + n]: neighbouring threads
+            // read neighbouring words.  All of them are requested before the first is
+            // used (one memory latency per channel, not one per Horner step)
             double row[PP_MROW];
 #pragma unroll
-            for (int j = 0; j < PP_MROW / 2; ++j) {
-                const double2 v2 = reinterpret_cast<const double2*>(rg)[j];
-                row[2 * j] = v2.x; row[2 * j + 1] = v2.y;
-            }
+            for (int j = 0; j < PP_MROW; ++j) row[j] = mdl[(size_t)j * a.nchan + n];
+            constexpr size_t rs = 1;
             ChanGeom cg;
             phase_geom(freqs[n], P, nuDM, nuGM, cg.p1, cg.p2);
             const double lnf = log(freqs[n] / nutau);
-            const double taun_c = row[PP_MNG + PP_MP + 2];
+            const double taun_c = row[(size_t)(PP_MNG + PP_MP + 2) * rs];
             const double eps = taun_c * expm1(dlnt + dal * lnf);
             const double taun = taun_c + eps;
             cg.lnf = lnf; cg.taun = taun;
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(256) void k_scat_model_solve(FitArgs a) {
             cg.q22 = lnf * cg.q2;
             const double d = dph + dDM * cg.p1 + dGM * cg.p2;
             double cs[PP_NCS];
-            scat_model_sums(row, d, eps, cs);
+            scat_model_sums(row, rs, d, eps, cs);
             if (round > 0) {
 #pragma unroll
                 for (int j = 0; j < PP_NCS; ++j) csum[(size_t)n * a.ncs + j] = cs[j];
@@ -357,28 +364,42 @@ __global__ __launch_bounds__(256) void k_scat_model_solve(FitArgs a) {
             for (int j = 0; j < PP_NACC; ++j) acc[j] += c[j];
             if (round > 0) {
                 // certificate: dropped terms of the first derivatives
-                const double kb = kmax / sqrt(fma(kmax * taun_c, kmax * taun_c, 1.0));
-                const double W0 = row[PP_MNG + PP_MP + 1], Wp = row[PP_MNG + PP_MP + 3];
-                const double keff = (W0 > 0.0) ? exp(log(Wp / W0) * (1.0 / (PP_MP + 1))) : 0.0;
+                // (single-precision hardware rsqrt / log2 / exp2, widened by their error)
+                const double ut = kmax * taun_c;
+                const double kb = kmax * (double)(__builtin_amdgcn_rsqf((float)fma(ut, ut, 1.0)) * 1.0001f);
+                const double W0 = row[(size_t)(PP_MNG + PP_MP + 1) * rs], Wp = row[(size_t)(PP_MNG + PP_MP + 3) * rs];
+                int ex = 0;
+                const float mant = (float)frexp((W0 > 0.0) ? Wp / W0 : 0.0, &ex);   // (the ratio can exceed the f32 range)
+                const double keff = (W0 > 0.0)
+                    ? (double)(__builtin_amdgcn_exp2f((__builtin_amdgcn_logf(mant) + (float)ex) * (1.0f / (PP_MP + 1))) * 1.0001f)
+                    : 0.0;
+                const double y = kmax * fabs(d);
                 const double x = keff * fabs(d), rho = 2.0 * fabs(eps) * kb;
-                if (!(x < 0.5) || !(rho < 0.5) || !(kmax * fabs(d) < 1.0)) { inside = false; continue; }
-                const double e1 = W0 * series_tail(PP_MP, x, rho) * exp(kmax * fabs(d));
+                if (!(x < 0.5) || !(rho < 0.5) || !(y < 1.0)) { inside = false; continue; }
+                const double e1 = W0 * series_tail(PP_MP, x, rho) * fma(y, y, 1.0 + y);   // (e^y <= 1 + y + y^2)
                 const double r = fabs(cs[0] / cs[6]) + 1e-300;
                 const double gp = 3.0 * w * r * e1 * kmax, gt = 3.0 * w * r * e1 * kb;
                 acc[PP_NACC] += gp; acc[PP_NACC + 1] += gp * fabs(cg.p1); acc[PP_NACC + 2] += gp * fabs(cg.p2);
                 acc[PP_NACC + 3] += gt * fabs(cg.q1); acc[PP_NACC + 4] += gt * fabs(cg.q2);
             }
         }
+#ifdef PP_SOLVE_TIMING
+        t1 = clock64(); tA += t1 - t0; t0 = t1;
+#endif
         block_sum<PP_NACC + 5>(acc, scratch);
         if (tid == 0) flag = 0;
         __syncthreads();
         if (!inside) flag = 1;               // (any thread)
         __syncthreads();
+#ifdef PP_SOLVE_TIMING
+        t1 = clock64(); tB += t1 - t0; t0 = t1;
+#endif
         if (tid == 0) {
             double f, g[5], H[25];
             unpack_acc(acc, a.flags, f, g, H);
             bool ok = (flag == 0);
-            for (int j = 0; j < 5 && ok; ++j)
+#pragma unroll
+            for (int j = 0; j < 5; ++j)      // (static indices: acc stays in registers)
                 if (a.flags[j] && !(acc[PP_NACC + j] <= tol[j] * fabs(H[j * 5 + j]))) ok = false;
             if (!ok) {
                 ss.model = 3;                // the ordinary path evaluates this proposal over X
@@ -391,6 +412,10 @@ __global__ __launch_bounds__(256) void k_scat_model_solve(FitArgs a) {
             }
         }
         __syncthreads();
+#ifdef PP_SOLVE_TIMING
+        t1 = clock64(); tC += t1 - t0; t0 = t1;
+        if (flag >= 2 && tid == 0 && i == 0) printf("solve i=0 rounds %d: loop %lld  sum %lld  logic %lld cycles\n", round + 1, tA, tB, tC);
+#endif
         if (flag >= 2) break;
     }
     if (tid == 0) {
