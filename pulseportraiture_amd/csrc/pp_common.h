@@ -201,6 +201,7 @@ struct SubState {
     double pred_red;   // predicted reduction of the pending proposal
     int hits_boundary;
     int iter, nfev, status, done, cur;  // cur: csum buffer of the accepted point
+    double xl[5], fl, gl[5], Hl[25];   // the point evaluated last and its f, g, H (SciPy's cache of one point)
     int fresh;         // the next evaluation is 1: an initial one, 2: the closing one (no ratio test)
     int model;         // scattering model of the closing iterations: 0 not yet, 1 the next evaluation
                        // is the model pass, 3 not (again) for this subint

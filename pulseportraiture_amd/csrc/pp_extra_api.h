@@ -1,5 +1,15 @@
 // host entry points for pp_extra.h (included at the end of pp_toas.hip)
 
+// Host-resident inputs larger than the work-memory budget go through the device in
+// runs of whole subints (every operation here is independent per subint, or a sum
+// over them): how many subints of `per_sub` device bytes fit
+static int aux_chunk_cap(pp_ctx* c, double per_sub, int nsub) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return nsub;
+    const double budget = std::min(c->max_work_bytes, 0.85 * ((double)free_b + (double)c->data.cap + (double)c->X.cap));
+    return (int)std::min<double>(nsub, std::max(1.0, std::floor(budget / std::max(per_sub, 1.0))));
+}
+
 extern "C" int pp_fit_phase_shift_batch(pp_ctx* c, const double* data, const double* model, const double* noise,
                                         int nprof, int nbin, double lo, double hi, int Ns, double* out7) {
     if (!c || !data || !model || !out7) return fail(PP_EINVAL, "pp_fit_phase_shift_batch: null argument");
@@ -8,6 +18,18 @@ extern "C" int pp_fit_phase_shift_batch(pp_ctx* c, const double* data, const dou
     HIP_TRY(hipSetDevice(c->device));
     const int M = nbin / 2;
     int rc;
+    {
+        const int cap = aux_chunk_cap(c, 2.0 * nbin * 8 + (2.0 * (M + 1) + M) * 16 + 64, nprof);
+        if (nprof > cap) {
+            for (int p0 = 0; p0 < nprof; p0 += cap) {
+                const int n = std::min(cap, nprof - p0);
+                if ((rc = pp_fit_phase_shift_batch(c, data + (size_t)p0 * nbin, model + (size_t)p0 * nbin,
+                                                   noise ? noise + p0 : nullptr, n, nbin, lo, hi, Ns, out7 + (size_t)p0 * 7)))
+                    return rc;
+            }
+            return PP_OK;
+        }
+    }
     // interleave rows: data_i, model_i
     const size_t rowb = (size_t)nbin * 8;
     if ((rc = c->data.reserve(2 * (size_t)nprof * rowb))) return rc;
@@ -89,6 +111,20 @@ extern "C" int pp_rotate_portraits(pp_ctx* c, const void* src, void* dst, int dt
     const size_t esz = dtype == PP_F64 ? 8 : 4;
     const size_t bytes = (size_t)nsub * nchan * nbin * esz;
     int rc;
+    if (!on_device) {
+        const size_t sub_b = (size_t)nchan * nbin * esz;
+        const int cap = aux_chunk_cap(c, (double)sub_b + 64.0 * nchan, nsub);
+        if (nsub > cap) {
+            for (int s0 = 0; s0 < nsub; s0 += cap) {
+                const int n = std::min(cap, nsub - s0);
+                if ((rc = pp_rotate_portraits(c, (const char*)src + s0 * sub_b, (char*)dst + s0 * sub_b, dtype, 0, n, nchan, nbin,
+                                              freqs + (freqs_stride ? (size_t)s0 * nchan : 0), freqs_stride, P + s0,
+                                              par3 + (size_t)s0 * 3, nu_DM, nu_GM)))
+                    return rc;
+            }
+            return PP_OK;
+        }
+    }
     const void* dsrc = src;
     void* ddst = dst;
     if (!on_device) {
@@ -134,6 +170,26 @@ extern "C" int pp_align_accumulate(pp_ctx* c, const void* src, int dtype, int on
     const size_t esz = dtype == PP_F64 ? 8 : 4;
     const size_t bytes = (size_t)nsub * nchan * nbin * esz;
     int rc;
+    if (!on_device) {
+        const size_t sub_b = (size_t)nchan * nbin * esz;
+        const int cap = aux_chunk_cap(c, (double)sub_b + 64.0 * nchan, nsub);
+        if (nsub > cap) {
+            // the sums of the runs are added on the host
+            std::vector<double> part((size_t)nchan * nbin), wpart((size_t)nchan);
+            std::fill(aligned, aligned + (size_t)nchan * nbin, 0.0);
+            std::fill(total_weights, total_weights + nchan, 0.0);
+            for (int s0 = 0; s0 < nsub; s0 += cap) {
+                const int n = std::min(cap, nsub - s0);
+                if ((rc = pp_align_accumulate(c, (const char*)src + s0 * sub_b, dtype, 0, n, nchan, nbin,
+                                              freqs + (freqs_stride ? (size_t)s0 * nchan : 0), freqs_stride, P + s0,
+                                              par3 + (size_t)s0 * 3, weights + (size_t)s0 * nchan, part.data(), wpart.data())))
+                    return rc;
+                for (size_t j = 0; j < part.size(); ++j) aligned[j] += part[j];
+                for (int j = 0; j < nchan; ++j) total_weights[j] += wpart[j];
+            }
+            return PP_OK;
+        }
+    }
     const void* dsrc = src;
     if (!on_device) {
         if ((rc = c->data.reserve(bytes))) return rc;
@@ -188,6 +244,22 @@ extern "C" int pp_channel_red_chi2(pp_ctx* c, const void* src, int dtype, int on
     const size_t bytes = (size_t)nsub * nchan * nbin * esz;
     const size_t nc = (size_t)nsub * nchan;
     int rc;
+    if (!on_device) {
+        const size_t sub_b = (size_t)nchan * nbin * esz;
+        const int cap = aux_chunk_cap(c, (double)sub_b + 64.0 * nchan, nsub);
+        if (nsub > cap) {
+            for (int s0 = 0; s0 < nsub; s0 += cap) {
+                const int n = std::min(cap, nsub - s0);
+                const size_t o = (size_t)s0 * nchan;
+                if ((rc = pp_channel_red_chi2(c, (const char*)src + s0 * sub_b, dtype, 0, n, nchan, nbin,
+                                              model_slot ? model_slot + s0 : nullptr, freqs + (freqs_stride ? o : 0),
+                                              freqs_stride, P + s0, params5 + (size_t)s0 * 5, nu_refs3 + (size_t)s0 * 3,
+                                              scales + o, errs + o, red_chi2 + o)))
+                    return rc;
+            }
+            return PP_OK;
+        }
+    }
     const void* dsrc = src;
     if (!on_device) {
         if ((rc = c->data.reserve(bytes))) return rc;

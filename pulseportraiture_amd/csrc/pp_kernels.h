@@ -1594,16 +1594,17 @@ __device__ inline bool step_propose(const FitArgs& a, SubState& s, const int* id
 }
 
 // One decision of the trust-region loop for one subint, given the objective, gradient
-// and Hessian just evaluated at s.xe: the ratio test on the pending proposal (or the
-// bookkeeping of an initial / closing evaluation), then the next proposal into s.xe.
+// and Hessian at s.xe (just evaluated: counted; or the cached values of that point):
+// the ratio test on the pending proposal (or the bookkeeping of an initial / closing
+// evaluation), then the next proposal into s.xe.
 // Returns true when the subint is finished (s.status set).  One thread.
-__device__ inline bool step_logic(const FitArgs& a, SubState& s, double f, const double* g, const double* H) {
+__device__ inline bool step_decide(const FitArgs& a, SubState& s, double f, const double* g, const double* H, bool counted) {
     bool finite = isfinite(f);
     for (int j = 0; j < 5; ++j) finite = finite && isfinite(g[j]);
     for (int j = 0; j < 25; ++j) finite = finite && isfinite(H[j]);
     const bool first = (s.fresh == 1), closing = (s.fresh == 2);
     s.fresh = 0;
-    s.nfev += 1;
+    if (counted) s.nfev += 1;
     bool done = false;
     if (closing) {
         // evaluation at the point of the final Newton step: the post-fit stage
@@ -1626,6 +1627,11 @@ __device__ inline bool step_logic(const FitArgs& a, SubState& s, double f, const
     } else {
         const double actual = s.f - f;
         const double rho = finite ? actual / s.pred_red : -1.0;
+#ifdef PP_STEP_TRACE
+        if (&s == &a.st[PP_STEP_TRACE])
+            printf("dev it %2d f %.17g f_new %.17g actual %.3e pred %.3e rho %.3f radius %.3e hits %d\n", s.iter, s.f, f,
+                   actual, s.pred_red, rho, s.radius, s.hits_boundary);
+#endif
         if (rho < 0.25) s.radius *= 0.25;
         else if (rho > 0.75 && s.hits_boundary) s.radius = fmin(2.0 * s.radius, 1000.0);
         if (rho > 0.15) {
@@ -1642,6 +1648,28 @@ __device__ inline bool step_logic(const FitArgs& a, SubState& s, double f, const
         int idx[5], n = 0;
         for (int j = 0; j < 5; ++j) if (a.flags[j]) idx[n++] = j;
         PP_FOR_N(n, done = step_propose<N_>(a, s, idx));
+    }
+    return done;
+}
+
+// The evaluation at s.xe has arrived: decide, propose -- and keep deciding while the
+// next proposal is the very point evaluated last.  SciPy's ScalarFunction hands back
+// its cached values for that point without calling the objective (the reference's
+// nfeval does not count it either).  It matters in the iteration's tail: once the
+// optimum is reached to the last bit of f, a step whose actual reduction rounds to
+// <= 0 is rejected, the radius shrinks by 4, and the SAME step is proposed again --
+// ~15 times, until the radius is smaller than the step -- without a single new
+// evaluation.
+__device__ inline bool step_logic(const FitArgs& a, SubState& s, double f, const double* g, const double* H) {
+    for (int j = 0; j < 5; ++j) { s.xl[j] = s.xe[j]; s.gl[j] = g[j]; }
+    for (int j = 0; j < 25; ++j) s.Hl[j] = H[j];
+    s.fl = f;
+    bool done = step_decide(a, s, f, g, H, true);
+    while (!done && s.fresh == 0) {
+        bool same = true;
+        for (int j = 0; j < 5; ++j) same = same && (s.xe[j] == s.xl[j]);
+        if (!same) break;
+        done = step_decide(a, s, s.fl, s.gl, s.Hl, false);
     }
     return done;
 }

@@ -157,6 +157,15 @@ def test_raw_parity_table():
     assert max(row["trust_ncg"]["dDM"] for row in rows.values()) < DM_BAR
     # Newton: never farther from the reference than the reference is from its optimum
     assert max(row["newton"]["dphi"] for row in rows.values()) < 5e-9
+    # scattering fits walk SciPy's iteration evaluation by evaluation: the reference's
+    # nfeval is one more (SciPy evaluates the last proposal before it tests the
+    # predicted reduction; the device tests first).  Fits without scattering make ONE
+    # pass over the data (the iteration runs on the Taylor model).
+    for name, row in rows.items():
+        if row["fit_flags"][3] or row["fit_flags"][4]:
+            assert row["trust_ncg"]["nfeval"] == row["ref_nfeval"] - 1, (name, row)
+        else:
+            assert row["trust_ncg"]["nfeval"] == 1, (name, row)
 
 
 @pytest.mark.parametrize("name", ["fpf_64x256_phiDMGM", "fpf_64x256_scat",
@@ -1686,32 +1695,27 @@ def test_scattering_model_of_the_closing_iterations_walks_the_same_iteration(l10
     assert passes[0] == 0 and passes[1] > 0
     assert evals[1] < evals[0], (evals, "the model never took over")
     assert (b["return_code"] == 2).all()
-    # Identical iterates wherever the evaluation counts agree.  They need not: SciPy's
-    # exit -- predicted reduction <= 0 in floating point -- hangs on the last bit of f
-    # once the optimum is reached, so ANY change of rounding (the reference's own on
-    # another BLAS included) can add a final no-op evaluation, or send the iteration
-    # into / spare it the tail of rejected steps with shrinking radius; both ends sit at
-    # the optimum to ~1e-9 rot.
-    same = a["nfeval"] == b["nfeval"]
-    assert same.mean() >= 0.75, (a["nfeval"], b["nfeval"])
+    # Identical iterates -- except in the last step or two of some subints: once the
+    # optimum is reached to the last bit of f, SciPy's ratio test compares an actual
+    # reduction of 0 or +-1 ulp(f) with a predicted one of 1 ulp, so ANY change of
+    # rounding (the reference's own NumPy on another BLAS included) decides whether the
+    # last ~1e-10 rot step is accepted, rejected, or followed by one more of the kind;
+    # both ends sit at the optimum.
+    dphi = _dphi_arr(a["params"][:, 0], b["params"][:, 0])
+    t = 1.0 if l10 else 1e3       # (linear tau: badly scaled, flips inside the run as well)
+    same = dphi < 2e-12 * t
+    assert same.mean() >= 0.75, dphi
     if flags == [1, 1, 0, 1, 1] or flags == [1, 1, 0, 1, 0] and l10:
-        assert same.all(), (a["nfeval"], b["nfeval"])      # (no marginal exits in these draws)
-    ne = ~same
-    assert _dphi_arr(a["params"][ne, 0], b["params"][ne, 0]).max(initial=0.0) < 5e-8
-    np.testing.assert_allclose(a["chi2"][ne], b["chi2"][ne], rtol=1e-11)
-    one = np.abs(a["nfeval"] - b["nfeval"]) == 1           # a final evaluation that moved nothing
-    assert _dphi_arr(a["params"][one, 0], b["params"][one, 0]).max(initial=0.0) < 2e-12
+        assert same.all() and (a["nfeval"] == b["nfeval"]).all()      # (no marginal exits in these draws)
+    assert np.abs(a["nfeval"] - b["nfeval"]).max() <= 4
+    assert dphi.max() < 2e-9
+    np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-11)
     a = {k: v[same] for k, v in a.items() if isinstance(v, np.ndarray) and len(v) == len(same)}
     b = {k: v[same] for k, v in b.items() if isinstance(v, np.ndarray) and len(v) == len(same)}
-    # (linear tau: the badly scaled parameter set also flips accept/reject decisions
-    # inside runs of equal length; those end within 1e-9 rot of each other)
-    t = 1.0 if l10 else 1e3
-    assert np.abs(_dphi_arr(a["params"][:, 0], b["params"][:, 0])).max() < 2e-12 * t
     assert np.abs(a["params"][:, 1] - b["params"][:, 1]).max() < 1e-11 * t
     np.testing.assert_allclose(a["params"][:, 3:], b["params"][:, 3:], rtol=1e-10 * t, atol=1e-12)
     ii = np.where(flags)[0]
     np.testing.assert_allclose(a["param_errs"][:, ii], b["param_errs"][:, ii], rtol=1e-9 * t)
-    np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-12)
     np.testing.assert_allclose(a["scales"], b["scales"], rtol=1e-9 * t, atol=1e-12)
     np.testing.assert_allclose(a["snr"], b["snr"], rtol=1e-10)
 
@@ -1749,3 +1753,72 @@ def test_scattering_model_evaluations_that_fail_their_certificate_are_made_over_
     np.testing.assert_array_equal(refn["nfeval"], rn["nfeval"])
     assert np.abs(_dphi_arr(refn["params"][:, 0], rn["params"][:, 0])).max() < 2e-12
     np.testing.assert_allclose(refn["params"][:, 3:], rn["params"][:, 3:], rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_auxiliary_entry_points_split_host_inputs_that_exceed_the_work_budget(eng):
+    """fit_phase_shift_batch, rotate_portraits, align_accumulate and channel_red_chi2
+    take host arrays of any size: beyond `max_work_bytes` they pass through the device
+    in runs of whole subints, with the same results."""
+    from tests.synth_host import model_portrait
+    rng = np.random.default_rng(4242)
+    nsub, C, B = 11, 24, 256
+    freqs, model = model_portrait(C, B)
+    eng.set_model(model)
+    ports = model[None] * rng.uniform(0.5, 2.0, (nsub, C, 1)) + 0.02 * rng.standard_normal((nsub, C, B))
+    P = np.full(nsub, 0.004)
+    phi, DM = rng.uniform(-0.3, 0.3, nsub), rng.normal(0, 1e-3, nsub)
+    w = rng.uniform(0.5, 1.5, (nsub, C))
+    prof, mprof = ports.reshape(-1, B)[:40], np.tile(model, (nsub, 1))[:40]
+    params = np.zeros((nsub, 5)); params[:, 0] = phi; params[:, 1] = DM
+    nus = np.full((nsub, 3), freqs.mean())
+    scales = rng.uniform(0.5, 2.0, (nsub, C)); errs = np.full((nsub, C), 0.02)
+
+    def run():
+        return (eng.fit_phase_shift_batch(prof, mprof, noise=np.full(40, 0.02)),
+                eng.rotate_portraits(ports.copy(), freqs, P, phi=phi, DM=DM, nu_DM=freqs.mean()),
+                eng.align_accumulate(ports, freqs, P, phi, DM, freqs.mean(), w),
+                eng.channel_red_chi2(ports, freqs, P, params, nus, scales, errs))
+    whole = run()
+    eng.set_option("max_work_bytes", 3.4 * C * B * 8)      # three subints (or ~50 profiles) at a time
+    try:
+        split = run()
+    finally:
+        eng.set_option("max_work_bytes", 96e9)
+    np.testing.assert_array_equal(whole[0][:, :6], split[0][:, :6])     # (column 6 is the duration)
+    np.testing.assert_array_equal(whole[1], split[1])
+    np.testing.assert_allclose(whole[2][0], split[2][0], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(whole[2][1], split[2][1], rtol=1e-14)
+    np.testing.assert_array_equal(whole[3], split[3])
+
+
+@pytest.mark.gpu
+def test_evaluation_counts_follow_scipys_cache_of_the_last_point():
+    """Where the reference's iteration ends in its tail -- a step rejected for an actual
+    reduction of <= 0 ulp, re-proposed ~15 times while the radius shrinks to its length
+    -- SciPy's ScalarFunction answers every re-proposal from its cache and `nfeval`
+    counts one evaluation.  The device does the same (no pass over the data for a point
+    it has just evaluated): evaluations that are passes over the cross-spectrum =
+    the reference's nfeval - 1 (SciPy evaluates a proposal before it tests the predicted
+    reduction; the device tests first)."""
+    from oracle import pptoas_oracle as orc
+    flags, l10, nsub = [1, 0, 0, 1, 1], True, 24
+    e, data, freqs, model, P, x0, errs, nu_fit, kw = _full_shape_case(256, 1024, flags, l10, nsub=nsub,
+                                                                      tau_us=30.0, seed=9)
+    e.set_option("scat_model", 0)
+    r = e.fit_batch(data, freqs, P, x0, nu_outs=np.full((nsub, 3), nu_fit), **kw)
+    e.set_option("scat_model", 1)
+    host = data.cpu().numpy()
+    on, dphi = [], []
+    for i in range(nsub):
+        o = orc.fit_portrait_full(host[i], model, x0[i], P[i], freqs, [nu_fit] * 3, [nu_fit] * 3, errs[i],
+                                  flags, log10_tau=l10)
+        on.append(o.nfeval)
+        dphi.append(_dphi(r["params"][i, 0], o.phi))
+    on, dphi = np.array(on), np.array(dphi)
+    assert r["nfeval"].max() <= 16                       # (the tails of 27 iterations cost no passes)
+    assert (r["nfeval"] == on - 1).mean() >= 0.9, (r["nfeval"], on)
+    assert np.abs(r["nfeval"] - (on - 1)).max() <= 2
+    # the marginal last step (1 ulp of f predicted) may be taken by one and not the other
+    assert np.median(dphi) < 1e-13 and dphi.max() < 2e-9
+    assert (dphi < PHI_BAR).mean() >= 0.9

@@ -83,7 +83,7 @@ if f4:
         n4 = b4["config"]["nsub_per_gpu_per_step"]
         alg = b4["roofline"]["algorithmic_bytes_per_fit"]
         rows = {}
-        for kn in ("k_eval", "k_xspec", "k_step", "k_finalize"):
+        for kn in ("k_eval", "k_xspec", "k_scat_model(", "k_scat_model_solve", "k_step", "k_finalize"):
             fb = sum(v["sum_KiB"] for k, v in f4.items() if kn in k) * 2048
             wb = sum(v["sum_KiB"] for k, v in w4.items() if kn in k) * 1024
             nd = sum(v["dispatches"] for k, v in f4.items() if kn in k)
