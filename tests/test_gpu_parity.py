@@ -1822,3 +1822,53 @@ def test_evaluation_counts_follow_scipys_cache_of_the_last_point():
     # the marginal last step (1 ulp of f predicted) may be taken by one and not the other
     assert np.median(dphi) < 1e-13 and dphi.max() < 2e-9
     assert (dphi < PHI_BAR).mean() >= 0.9
+
+
+@pytest.mark.gpu
+def test_scattering_fits_in_sub_batches_with_model_slots_and_the_model_path(eng):
+    """Scattering fits whose subints reference two template slots, processed in
+    sub-batches of ~2 subints: identical to the whole batch and to single fits, with the
+    closing iterations on the per-channel model in every sub-batch."""
+    from tests.synth_host import make_inputs, caller_guess, model_portrait
+    C, B, N = 32, 512, 7
+    freqs, model = model_portrait(C, B)
+    model2 = np.roll(model, 5, axis=-1) * 1.3
+    eng.set_model(model, slot=0)
+    eng.set_model(model2, slot=2)
+    slots = np.array([0, 2, 0, 2, 2, 0, 0], dtype=np.int32)
+    data, x0, nuf = [], [], []
+    for i in range(N):
+        tmpl = model if slots[i] == 0 else model2
+        inp = make_inputs(C, B, 900 + i, model=tmpl, tau_us=25.0, sigma=0.03)
+        gss = caller_guess(inp, fit_scat=True, log10_tau=True, tau_guess_rot=1.3 * 25e-6 / inp["P"])
+        data.append(inp["data"]); x0.append(gss["init_params"]); nuf.append([gss["nu_fit"]] * 3)
+    data = np.array(data); P = np.full(N, inp["P"]); x0 = np.array(x0)
+    kw = dict(errs=np.full((N, C), 0.03), nu_fits=nuf, fit_flags=[1, 1, 0, 1, 1], log10_tau=True,
+              model_slot=slots)
+    eng.set_option("profile", 1)
+    eng.kernel_times(reset=True)
+    whole = eng.fit_batch(data, freqs, P, x0, **kw)
+    assert eng.kernel_times(reset=True).get("scat_model", (0, 0))[1] > 0
+    eng.set_option("profile", 0)
+    eng.set_option("max_work_bytes", 2.5 * C * B * 16)
+    try:
+        parts = eng.fit_batch(data, freqs, P, x0, **kw)
+    finally:
+        eng.set_option("max_work_bytes", 96e9)
+    for k in ("params", "param_errs", "nu_refs", "chi2", "snr", "scales", "nfeval"):
+        np.testing.assert_array_equal(whole[k], parts[k])
+    assert (whole["return_code"] == 2).all() and (whole["nfeval"] > 5).all()
+    for i in (1, 5):
+        single = eng.fit_batch(data[i:i + 1], freqs, P[i:i + 1], x0[i:i + 1], errs=kw["errs"][i:i + 1],
+                               nu_fits=nuf[i:i + 1], fit_flags=kw["fit_flags"], log10_tau=True,
+                               model_slot=slots[i:i + 1])
+        np.testing.assert_array_equal(single["params"][0], whole["params"][i])
+    # against the ordinary path
+    eng.set_option("scat_model", 0)
+    try:
+        plain = eng.fit_batch(data, freqs, P, x0, **kw)
+    finally:
+        eng.set_option("scat_model", 1)
+    d = _dphi_arr(plain["params"][:, 0], whole["params"][:, 0])
+    assert np.median(d) < 2e-12 and d.max() < 2e-9
+    np.testing.assert_allclose(plain["chi2"], whole["chi2"], rtol=1e-11)
