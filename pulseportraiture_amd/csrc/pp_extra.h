@@ -571,6 +571,7 @@ struct FpsArgs {
     double* out7;          // [nprof][7]
     double lo, hi;
     int Ns, M, nprof;
+    int finish;            // 0: Newton polish to rounding; 1: SciPy brute's own finish (Nelder-Mead simplex)
 };
 
 // sum_k X_k e^{2 pi i k phi} weighted by (1, k, k^2): returns Re-sum, k*Im-sum,
@@ -638,19 +639,71 @@ __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
     const int Ns = a.Ns;
     double bestv = INFINITY;
     int bestj = 0x7fffffff;
+    // (grid point j = j * step + lo, the arithmetic of numpy's mgrid)
+    const double h = (Ns > 1) ? (a.hi - a.lo) / (double)(Ns - 1) : 0.5;
     for (int j = tid; j < Ns; j += 256) {
-        const double phi = (Ns > 1) ? a.lo + (a.hi - a.lo) * (double)j / (double)(Ns - 1) : a.lo;
+        const double phi = (Ns > 1) ? __dadd_rn(__dmul_rn((double)j, h), a.lo) : a.lo;
         double s0, s1, s2;
         fps_sums(X, M, phi, 0, 1, s0, s1, s2);
         const double v = -s0 / err2;
         if (v < bestv) { bestv = v; bestj = j; }
     }
     const int best = min(block_argmin256(bestv, bestj, shv, shj), Ns - 1);
-    // polish: safeguarded Newton on f(phi) = -Re sum X e / err2 inside +-1 grid step
-    const double h = (Ns > 1) ? (a.hi - a.lo) / (double)(Ns - 1) : 0.5;
-    double phi = (Ns > 1) ? a.lo + (a.hi - a.lo) * (double)best / (double)(Ns - 1) : a.lo;
-    double lo = phi - h, hi = phi + h;
+    double phi = (Ns > 1) ? __dadd_rn(__dmul_rn((double)best, h), a.lo) : a.lo;
     double f = 0.0, f2 = 0.0;
+    // objective at one phase, the same in every thread
+    auto feval = [&](double x) -> double {
+        double s[3];
+        fps_sums(X, M, x, tid, 256, s[0], s[1], s[2]);
+        block_sum<3>(s, scratch);
+        __syncthreads();
+        return -s[0] / err2;
+    };
+    if (a.finish == 1) {
+        // What scipy.optimize.brute does after its grid (the reference calls it with
+        // the default finish = fmin, pplib.py:2085): Nelder-Mead from the best grid
+        // point, xtol = ftol = 1e-4, at most 200 iterations / evaluations --
+        // operation by operation for one dimension (scipy/optimize/_optimize.py
+        // _minimize_neldermead: rho 1, chi 2, psi 1/2, sigma 1/2; second vertex
+        // 1.05 x0, or 0.00025 when x0 = 0).  The reference's phase IS this simplex's
+        // best vertex, ~1e-5 rot from the maximum of the correlation.
+        double sim0 = phi, sim1 = (phi != 0.0) ? __dmul_rn(1.05, phi) : 0.00025;
+        double f0 = feval(sim0), f1 = feval(sim1);
+        int fcalls = 2, iterations = 1;
+        auto order = [&]() {           // argsort of two values, stable
+            if (f1 < f0) { const double t = sim0; sim0 = sim1; sim1 = t; const double u = f0; f0 = f1; f1 = u; }
+        };
+        order();
+        while (fcalls < 200 && iterations < 200) {
+            if (fabs(sim1 - sim0) <= 1e-4 && fabs(f0 - f1) <= 1e-4) break;
+            const double xbar = sim0;
+            const double xr = __dsub_rn(__dmul_rn(2.0, xbar), sim1);
+            const double fxr = feval(xr); ++fcalls;
+            bool shrink = false;
+            if (fxr < f0) {
+                const double xe = __dsub_rn(__dmul_rn(3.0, xbar), __dmul_rn(2.0, sim1));
+                const double fxe = feval(xe); ++fcalls;
+                if (fxe < fxr) { sim1 = xe; f1 = fxe; } else { sim1 = xr; f1 = fxr; }
+            } else if (fxr < f1) {      // (f0 <= fxr: outside contraction)
+                const double xc = __dsub_rn(__dmul_rn(1.5, xbar), __dmul_rn(0.5, sim1));
+                const double fxc = feval(xc); ++fcalls;
+                if (fxc <= fxr) { sim1 = xc; f1 = fxc; } else shrink = true;
+            } else {                    // inside contraction
+                const double xcc = __dadd_rn(__dmul_rn(0.5, xbar), __dmul_rn(0.5, sim1));
+                const double fxcc = feval(xcc); ++fcalls;
+                if (fxcc < f1) { sim1 = xcc; f1 = fxcc; } else shrink = true;
+            }
+            if (shrink) {
+                sim1 = __dadd_rn(sim0, __dmul_rn(0.5, __dsub_rn(sim1, sim0)));
+                f1 = feval(sim1); ++fcalls;
+            }
+            ++iterations;
+            order();
+        }
+        phi = sim0;
+    } else {
+    // polish: safeguarded Newton on f(phi) = -Re sum X e / err2 inside +-1 grid step
+    double lo = phi - h, hi = phi + h;
     for (int it = 0; it < 60; ++it) {
         double s[3];
         fps_sums(X, M, phi, tid, 256, s[0], s[1], s[2]);
@@ -665,6 +718,7 @@ __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
         const double step = fabs(nxt - phi);
         phi = nxt;
         if (step < 1e-15) break;
+    }
     }
     // value and curvature at the final phase
     double s[3];

@@ -54,7 +54,7 @@ extern "C" int pp_fit_phase_shift_batch(pp_ctx* c, const double* data, const dou
             if ((rc = upload(c, c->errs, noise, (size_t)nprof * 8))) return rc;
             dnoise = c->errs.as<double>();
         }
-        FpsArgs fa{spec, dnoise, c->o_params.as<double>(), lo, hi, Ns, M, nprof};
+        FpsArgs fa{spec, dnoise, c->o_params.as<double>(), lo, hi, Ns, M, nprof, c->fps_finish};
         hipLaunchKernelGGL(k_fps, dim3(nprof), dim3(256), 0, c->stream, fa, xwork);
     }
     HIP_TRY(hipGetLastError());

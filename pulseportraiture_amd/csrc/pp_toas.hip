@@ -97,6 +97,7 @@ struct pp_ctx {
     int moments_in_xspec = 1;   // fold the Taylor moments into k_xspec (mode 2) when it applies
     int scat_model = 1;         // scattering fits: closing iterations on the per-channel model (pp_scatmodel.h)
     double scat_model_tol = 1e-10;
+    int fps_finish = 0;         // pp_fit_phase_shift_batch: 0 = Newton polish, 1 = SciPy brute's simplex finish
     int paired_split = 1;       // 2048-bin rows: last FFT stage + split in registers (k_xspec_p1024)
     int seed_chan_stride = 16;  // device phase seed: pilot pass over every n-th channel (1 = all channels)
     double seed_min_snr = 8.0;  // pilot seeds below this peak significance are redone from all channels
@@ -223,6 +224,7 @@ extern "C" int pp_set_option(pp_ctx* c, const char* name, double value) {
     else if (n == "paired_split") c->paired_split = (int)value;
     else if (n == "scat_model") c->scat_model = (int)value;
     else if (n == "scat_model_tol") c->scat_model_tol = value;
+    else if (n == "fps_finish") c->fps_finish = (int)value;
     else if (n == "seed_chan_stride") c->seed_chan_stride = std::max(1, (int)value);
     else if (n == "seed_min_snr") c->seed_min_snr = value;
     else if (n == "seed_ndm") c->seed_ndm = std::max(1, (int)value);

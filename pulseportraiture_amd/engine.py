@@ -286,7 +286,14 @@ class Engine(object):
         return out
 
     def fit_phase_shift_batch(self, data, model, noise=None, bounds=(-0.5, 0.5),
-                              Ns=100):
+                              Ns=100, finish='newton'):
+        """1-D FFTFIT of nprof profile pairs: Ns-point brute grid over `bounds` (both
+        ends included), then finish = 'newton': the exact local optimum; 'simplex':
+        what scipy.optimize.brute does by default and the reference returns
+        (pplib.py:2085) -- Nelder-Mead to xtol = ftol = 1e-4, step for step.
+        Returns [nprof, 7]: phase, phase_err, scale, scale_err, snr, red_chi2, duration."""
+        if finish not in ('newton', 'simplex'):
+            raise ValueError("finish must be 'newton' or 'simplex'")
         d = _f64(np.atleast_2d(data))
         nprof, nbin = d.shape
         m = _f64(np.atleast_2d(model), (nprof, nbin))
@@ -298,9 +305,13 @@ class Engine(object):
             nz = _f64([np.nan if v is None else v for v in
                        np.broadcast_to(np.asarray(noise, dtype=object), (nprof,))])
         out = np.empty((nprof, 7))
-        _check(self._lib.pp_fit_phase_shift_batch(
-            self._ctx, _dp(d), _dp(m), _dp(nz), nprof, nbin, float(bounds[0]),
-            float(bounds[1]), int(Ns), _dp(out)), "pp_fit_phase_shift_batch")
+        self.set_option("fps_finish", 1 if finish == 'simplex' else 0)
+        try:
+            _check(self._lib.pp_fit_phase_shift_batch(
+                self._ctx, _dp(d), _dp(m), _dp(nz), nprof, nbin, float(bounds[0]),
+                float(bounds[1]), int(Ns), _dp(out)), "pp_fit_phase_shift_batch")
+        finally:
+            self.set_option("fps_finish", 0)
         return out
 
     def rotate_portraits(self, ports, freqs, P, phi=0.0, DM=0.0, GM=0.0, nu_DM=np.inf,

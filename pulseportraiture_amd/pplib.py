@@ -192,15 +192,18 @@ def get_noise(data, method=default_noise_method, frac=4, chans=False):
     return noise if chans else noise[0]
 
 
-def fit_phase_shift(data, model, noise=None, bounds=[-0.5, 0.5], Ns=100):
-    """Fit a phase shift between a data and a model profile on the GPU:
-    Ns-point brute grid over `bounds` (both ends included), refined to the
-    local optimum (the reference polishes with a simplex to ~1e-4)."""
+def fit_phase_shift(data, model, noise=None, bounds=[-0.5, 0.5], Ns=100, finish='simplex'):
+    """Fit a phase shift between a data and a model profile on the GPU (pplib.py:2054):
+    Ns-point brute grid over `bounds` (both ends included), then -- like the
+    reference, whose scipy.optimize.brute finishes with fmin -- the Nelder-Mead
+    simplex to xtol = ftol = 1e-4, retraced step for step, so the returned phase is the
+    reference's (~1e-5 rot from the optimum of the correlation).  finish='newton'
+    returns the exact local optimum instead."""
     eng = default_engine()
     out = eng.fit_phase_shift_batch(np.asarray(data, dtype=np.float64)[None],
                                     np.asarray(model, dtype=np.float64)[None],
                                     noise=None if noise is None else [noise],
-                                    bounds=bounds, Ns=Ns)[0]
+                                    bounds=bounds, Ns=Ns, finish=finish)[0]
     return DataBunch(phase=out[0], phase_err=out[1], scale=out[2],
                      scale_err=out[3], snr=out[4], red_chi2=out[5],
                      duration=out[6])

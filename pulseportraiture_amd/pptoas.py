@@ -312,26 +312,90 @@ class GetTOAs(object):
             mdl["params"][1] = 0.0
         eng.set_model_gaussian(mdl, freqs_row, nbin, P, slot=slot)
 
+    def _reference_phase_seeds(self, eng, port, d, ok_isubs, mask, nu_fit_DM, DM_guess, tau_lin,
+                               nu_fit_tau, fit_scat, use_ird):
+        """phi_guess of every good subint exactly as the reference forms it
+        (pptoas.py:421-457): rot_prof = weighted mean over the good channels of the
+        portrait dedispersed at DM_guess to their mean frequency (device: rotation +
+        mean), fitted against the mean of the template's good channels (scattered by
+        the guessed tau when fitting scattering) with fit_phase_shift(Ns=100) -- brute
+        grid + SciPy's simplex finish retraced on the device --, then moved from
+        nu_mean to nu_fit_DM."""
+        import torch
+        from .pplib import Dconst, phase_transform
+        isubs = np.asarray(ok_isubs, dtype=int)
+        nok, nchan, nbin = port.shape
+        freqs, P = d.freqs[isubs], np.asarray(d.Ps, dtype=np.float64)[isubs]
+        w = np.asarray(d.weights, dtype=np.float64)[isubs] * mask
+        nu_mean = np.array([freqs[j, mask[j] > 0].mean() for j in range(nok)])
+        dev = "cuda:%d" % eng.device
+        wt = torch.as_tensor(w, device=dev)
+        profs = np.empty((nok, nbin))
+        step = max(1, int(4e9 // (nchan * nbin * 8)))
+        for s0 in range(0, nok, step):
+            s1 = min(nok, s0 + step)
+            chunk = port[s0:s1]
+            chunk = (chunk.to(torch.float64).clone() if torch.is_tensor(chunk) else
+                     torch.as_tensor(np.ascontiguousarray(chunk, dtype=np.float64), device=dev))
+            # rotate_data(portx, 0.0, DM_guess, P, freqsx, nu_mean): the nu_mean term is
+            # the same for every channel and rides on the phase argument
+            eng.rotate_portraits(chunk, freqs[s0:s1], P[s0:s1],
+                                 phi=-Dconst * DM_guess / P[s0:s1] * nu_mean[s0:s1] ** -2.0,
+                                 DM=np.full(s1 - s0, DM_guess), nu_DM=np.inf)
+            ws = wt[s0:s1]
+            profs[s0:s1] = ((chunk * ws[:, :, None]).sum(dim=1) / ws.sum(dim=1)[:, None]).cpu().numpy()
+            del chunk
+        mprofs, cache = np.empty((nok, nbin)), {}
+        for j, isub in enumerate(isubs):
+            key = (d.freqs[isub].tobytes(), float(d.Ps[isub]), mask[j].tobytes(),
+                   float(tau_lin[j]), float(nu_fit_tau[j]))
+            if key not in cache:
+                ich = np.where(mask[j] > 0)[0]
+                modelx = self._model_for(d.freqs[isub], nbin, d.Ps[isub], unscattered=fit_scat)[ich]
+                if use_ird:
+                    from .pptoaslib import instrumental_response_port_FT
+                    irf = instrumental_response_port_FT(nbin, d.freqs[isub, ich], self.ird['DM'], d.Ps[isub],
+                                                        self.ird['wids'], self.ird['irf_types'])
+                    modelx = np.fft.irfft(irf * np.fft.rfft(modelx, axis=-1), axis=-1)
+                mprof = modelx.mean(axis=0)
+                if fit_scat:
+                    k = np.arange(nbin // 2 + 1)
+                    mprof = np.fft.irfft(np.fft.rfft(mprof) / (1.0 + 2.0j * np.pi * k * tau_lin[j]))
+                cache[key] = mprof
+            mprofs[j] = cache[key]
+        out = eng.fit_phase_shift_batch(profs, mprofs, Ns=100, finish='simplex')
+        return np.array([phase_transform(out[j, 0], DM_guess, nu_mean[j], nu_fit_DM[j], P[j], mod=True)
+                         for j in range(nok)])
+
     def get_TOAs(self, datafile=None, tscrunch=False, nu_refs=None, DM0=None,
                  bary=True, fit_DM=True, fit_GM=False, fit_scat=False,
                  log10_tau=True, scat_guess=None, fix_alpha=False,
                  print_phase=False, print_flux=False, print_parangle=False,
                  add_instrumental_response=False, addtnl_toa_flags={},
                  method='trust-ncg', bounds=None, nu_fits=None, show_plot=False,
-                 quiet=None):
-        """Same arguments as the reference (pptoas.py:150-156).  Not supported
-        here: tscrunch and show_plot (they raise) -- they live in PSRCHIVE / the
-        plotting code.  Every `method` runs the device's Newton solver to the
-        rounding of the objective: the phase seed is formed on the device (the exact
-        maximum of the channel-summed cross-correlation, where the reference polishes
-        a 100-point grid with a simplex to 1e-4), so SciPy's iterates from the
-        reference's own starting point cannot be retraced here, and the optimum is
-        the point closest to wherever they stop (fit_portrait_full, given the same
-        init_params as the reference, does retrace them)."""
+                 quiet=None, seed='device'):
+        """Same arguments as the reference (pptoas.py:150-156), plus `seed`.  Not
+        supported here: tscrunch and show_plot (they raise) -- they live in PSRCHIVE /
+        the plotting code.
+
+        seed='device' (default, the fast path): the phase seed is formed inside the fit
+        (the exact maximum of the channel-summed cross-correlation on a pilot subset of
+        the channels) and every `method` runs the Newton solver to the rounding of the
+        objective -- the optimum itself, within ~1e-9 rot of wherever SciPy's iteration
+        stops from the reference's own starting point.
+
+        seed='reference': the reference's initial guesses, formed the way it forms them
+        (pptoas.py:421-457: dedisperse to the mean frequency, weighted mean over the
+        good channels, fit_phase_shift with SciPy's simplex finish retraced step for
+        step, phase_transform to nu_fit) at the price of one more pass over the data;
+        method='trust-ncg' then retraces SciPy's iteration from that very point and
+        returns the reference's own numbers, GM and scattering fits included."""
         if quiet is None:
             quiet = self.quiet
         if tscrunch or show_plot:
             raise NotImplementedError("tscrunch / plots are outside the accelerated path")
+        if seed not in ('device', 'reference'):
+            raise ValueError("seed must be 'device' or 'reference'")
         use_ird = bool(add_instrumental_response and
                        (self.ird['DM'] or len(self.ird['wids'])))
         if method not in ('trust-ncg', 'Newton-CG', 'TNC'):
@@ -423,6 +487,8 @@ class GetTOAs(object):
                 # initial guesses (pptoas.py:421-460); the phase comes from the
                 # device seed
                 tau_guess, alpha_guess = 0.0, 0.0
+                if j == 0:
+                    tau_lin = np.zeros(nok)      # tau_guess [rot] before any log10 (seed='reference')
                 if fit_scat:
                     P = d.Ps[isub]
                     if self.scat_guess is not None:
@@ -435,6 +501,7 @@ class GetTOAs(object):
                                 (nu_fit_arr[j, 2] / self.model_nu_ref) ** alpha_guess
                         else:
                             tau_guess = 0.0
+                    tau_lin[j] = tau_guess
                     if log10_tau:
                         if tau_guess == 0.0:
                             tau_guess = nbin ** -1
@@ -449,6 +516,10 @@ class GetTOAs(object):
                     fl = list(self.fit_flags)
                 flags_per.append(tuple(fl))
             port = _dededisperse(eng, _take_subints(d.subints, ok_isubs), d, ok_isubs)
+            if seed == 'reference':
+                x0[:, 0] = self._reference_phase_seeds(eng, port, d, ok_isubs, mask, nu_fit_arr[:, 0],
+                                                       DM_stored, tau_lin, nu_fit_arr[:, 2], fit_scat,
+                                                       use_ird)
             # ---- one device call per distinct flag set (normally one) ----
             res = None
             for fl in sorted(set(flags_per)):
@@ -460,7 +531,9 @@ class GetTOAs(object):
                                   nu_fits=nu_fit_arr[sel], nu_outs=nu_ref_arr[sel],
                                   fit_flags=fl, log10_tau=log10_tau, option=0,
                                   is_toa=True, model_slot=slot_of[sel],
-                                  chan_mask=mask[sel], seed_ns=100, method='newton')
+                                  chan_mask=mask[sel],
+                                  seed_ns=100 if seed == 'device' else 0,
+                                  method='newton' if seed == 'device' else method)
                 if res is None:
                     res = {k: (np.zeros((nok,) + v.shape[1:], dtype=v.dtype)
                                if isinstance(v, np.ndarray) else v) for k, v in r.items()}
@@ -726,7 +799,7 @@ class GetTOAs(object):
             t0 = time.time()
             out = eng.fit_phase_shift_batch(np.concatenate(profs), np.concatenate(mprofs),
                                             np.concatenate(noises).astype(np.float64),
-                                            bounds=(-0.5, 0.5), Ns=100)
+                                            bounds=(-0.5, 0.5), Ns=100, finish='simplex')
             fit_duration = time.time() - t0
             # ---- TOA bookkeeping (pptoas.py:994-1088) ----
             for (isub, ichan), r in zip(where, out):

@@ -330,8 +330,10 @@ def test_float32_portraits(eng):
 
 
 def test_fit_phase_shift_matches_reference_rows():
-    """1-D FFTFIT seed stage: grid + polish.  The reference polishes with a
-    simplex to xtol=1e-4, so phases agree to that level."""
+    """1-D FFTFIT seed stage (pplib.py:2054-2099): brute grid + SciPy's own finish, the
+    Nelder-Mead simplex to xtol = ftol = 1e-4, retraced step for step -- the phase the
+    reference returns (its simplex's best vertex, ~1e-5 rot from the optimum), not
+    merely a phase within its tolerance.  finish='newton' lands on the optimum."""
     from oracle import pptoas_oracle as orc
     from pulseportraiture_amd.pplib import fit_phase_shift
     g = _load("fit_phase_shift_256")
@@ -339,15 +341,18 @@ def test_fit_phase_shift_matches_reference_rows():
         shift, noise = row[0], (None if np.isnan(row[1]) else row[1])
         d = orc.rotate_data(g["prof"], -shift)
         r = fit_phase_shift(d, g["model_prof"], noise=noise, Ns=100)
-        assert _dphi(r.phase, row[2]) < 1e-4   # grid ends -0.5 and 0.5 tie
+        assert _dphi(r.phase, row[2]) < 1e-12       # (grid ends -0.5 and 0.5 tie: mod 1)
         np.testing.assert_allclose([r.phase_err, r.scale, r.scale_err, r.snr,
-                                    r.red_chi2], row[3:], rtol=2e-4)
-        # and it is the exact local optimum of the oracle's objective
+                                    r.red_chi2], row[3:], rtol=1e-9)
+        rn = fit_phase_shift(d, g["model_prof"], noise=noise, Ns=100, finish='newton')
+        assert 1e-9 < _dphi(rn.phase, row[2]) < 1e-4
+        # ... which is the exact local optimum of the oracle's objective
         dF = np.fft.rfft(d); dF[0] = 0
         mF = np.fft.rfft(g["model_prof"]); mF[0] = 0
-        f0 = orc.fit_phase_shift_function(r.phase, mF, dF, 1.0)
-        for eps in (-1e-7, 1e-7):
-            assert orc.fit_phase_shift_function(r.phase + eps, mF, dF, 1.0) >= f0
+        k = np.arange(len(dF))
+        f1 = -np.real((2j * np.pi * k * dF * np.conj(mF) * np.exp(2j * np.pi * k * rn.phase)).sum())
+        f2 = -np.real((-4 * np.pi ** 2 * k ** 2 * dF * np.conj(mF) * np.exp(2j * np.pi * k * rn.phase)).sum())
+        assert abs(f1 / f2) < 1e-13
 
 
 def test_legacy_fit_portrait_matches_reference():
@@ -533,6 +538,63 @@ def test_get_TOAs_matches_reference_caller(name):
         assert set(gt.zap_channels[0][j]) - set(edge) == zap_want
     if name == "gettoas_zap":
         assert all(len(z) >= 1 for z in gt.zap_channels[0])
+
+
+def _gettoas_from_golden(g):
+    from pulseportraiture_amd.pptoas import GetTOAs, MJD, data_from_arrays
+    epochs = [MJD(int(d), float(f)) for d, f in zip(g["epoch_days"], g["epoch_fracs"])]
+    data = data_from_arrays(
+        g["subints"], g["freqs"], g["Ps"], epochs, weights=g["weights"],
+        noise_stds=g["noise_stds"], SNRs=g["SNRs"], DM=float(g["scal_DM"]),
+        doppler_factors=g["doppler_factors"],
+        backend_delay=float(g["scal_backend_delay"]), telescope=str(g["scal_telescope"]),
+        telescope_code=str(g["scal_telescope_code"]), backend=str(g["scal_backend"]),
+        frontend=str(g["scal_frontend"]), bw=float(g["scal_bw"]), nu0=float(g["scal_nu0"]),
+        subtimes=g["subtimes"], source=str(g["scal_source"]), filename="fake.fits")
+    kw = {}
+    for k in g.files:
+        if k.startswith("kw_"):
+            v = g[k]
+            kw[k[3:]] = v.item() if v.ndim == 0 else tuple(v.tolist())
+    gt = GetTOAs(data, os.path.join(GOLDEN, "example.gmodel"), quiet=True)
+    if "out_ird_DM" in g.files:     # instrumental response: smearing + rect + gauss
+        gt.instrumental_response_dict = gt.ird = {
+            'DM': float(g["out_ird_DM"]), 'wids': [float(v) for v in g["out_ird_wids"]],
+            'irf_types': [str(v) for v in g["out_ird_types"]]}
+    return gt, kw
+
+
+@pytest.mark.parametrize("name", ["gettoas_phiDM", "gettoas_phiDM_nurefs", "gettoas_GM",
+                                  "gettoas_scat", "gettoas_zap", "gettoas_ird"])
+def test_get_TOAs_with_the_references_seed_returns_the_references_numbers(name):
+    """Caller level, RAW: with seed='reference' the initial guesses are formed the way
+    the reference forms them (dedisperse to nu_mean, weighted channel mean,
+    fit_phase_shift with SciPy's simplex finish retraced, phase_transform) and
+    'trust-ncg' retraces SciPy's iteration from that very point -- so get_TOAs returns
+    what the reference's own get_TOAs returned for the same arrays, GM and scattering
+    fits included, with no polishing of the reference's answer and no relaxed bar."""
+    g = _load(name)
+    gt, kw = _gettoas_from_golden(g)
+    gt.get_TOAs(quiet=True, seed='reference', **kw)
+    ok = g["out_ok_isubs"]
+    np.testing.assert_array_equal(gt.ok_isubs[0], ok)
+    assert _dphi_arr(np.asarray(gt.phis[0])[ok], g["out_phis"][ok]).max() < PHI_BAR
+    assert np.abs(np.asarray(gt.DMs[0])[ok] - g["out_DMs"][ok]).max() < DM_BAR
+    np.testing.assert_allclose(np.asarray(gt.GMs[0])[ok], g["out_GMs"][ok], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(np.asarray(gt.taus[0])[ok], g["out_taus"][ok], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(np.asarray(gt.alphas[0])[ok], g["out_alphas"][ok], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(np.array(gt.nu_refs[0])[ok], g["out_nu_refs"][ok], rtol=1e-10)
+    for isub in ok:
+        t = gt.TOAs[0][isub]
+        dt_days = (t.intday() - g["out_TOA_days"][isub]) + (t.fracday() - g["out_TOA_fracs"][isub])
+        assert abs(dt_days) * 86400.0 < 1e-10 * g["Ps"][isub] + 1e-15
+    for fld, rt in (("phi_errs", 1e-7), ("DM_errs", 1e-7), ("snrs", 1e-9), ("red_chi2s", 1e-9),
+                    ("TOA_errs", 1e-7), ("GM_errs", 1e-7), ("tau_errs", 1e-7), ("alpha_errs", 1e-7)):
+        if "out_" + fld in g.files:
+            np.testing.assert_allclose(np.asarray(getattr(gt, fld)[0], dtype=float)[ok],
+                                       g["out_" + fld][ok], rtol=rt)
+    np.testing.assert_allclose(gt.scales[0][ok], g["out_scales"][ok], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(gt.DeltaDM_means[0], g["out_DeltaDM_mean"], rtol=0, atol=1e-10)
 
 
 @pytest.mark.parametrize("nbin", [32, 64, 128])
@@ -1212,20 +1274,24 @@ def test_narrowband_TOAs_match_reference_caller():
     used = g["weights"] > 0
     used[[i for i in range(len(used)) if i not in set(g["out_ok_isubs"])]] = False
     dph = np.abs((gt.phis[0] - g["out_phis"] + 0.5) % 1.0 - 0.5)
-    assert dph[used].max() < 1e-4 and not gt.phis[0][~used].any()
+    # (SciPy's simplex finish of every channel's fit is retraced: the reference's own
+    # phases, not merely phases within its 1e-4 tolerance)
+    assert dph[used].max() < 1e-11 and not gt.phis[0][~used].any()
     for fld in ("phi_errs", "scales", "scale_errs", "channel_snrs", "TOA_errs"):
         np.testing.assert_allclose(np.asarray(getattr(gt, fld)[0], dtype=float)[used],
-                                   g["out_" + fld][used], rtol=3e-4)
+                                   g["out_" + fld][used], rtol=1e-8)
     np.testing.assert_allclose(gt.channel_red_chi2s[0][g["out_ok_isubs"]],
-                               g["out_channel_red_chi2s"][g["out_ok_isubs"]], rtol=3e-4)
+                               g["out_channel_red_chi2s"][g["out_ok_isubs"]], rtol=1e-8)
     for isub, ichan in zip(*np.where(used)):
         t = gt.TOAs[0][isub, ichan]
         dt = (t.intday() - g["out_TOA_days"][isub, ichan]) + \
             (t.fracday() - g["out_TOA_fracs"][isub, ichan])
-        # (a phase at the +-0.5 edge of the search interval may come out one turn
-        # away from the reference's: the same pulse, numbered differently)
+        # (a phase at the +-0.5 edge of the search interval -- the two grid ends tie --
+        # may come out one turn away from the reference's: the same pulse, numbered
+        # differently, its simplex started from the other end)
         turns = dt * 86400.0 / g["Ps"][isub]
-        assert abs(turns - round(turns)) < 1e-4 + 1e-9 and abs(round(turns)) <= 1
+        assert abs(round(turns)) <= 1
+        assert abs(turns - round(turns)) < (1e-10 if round(turns) == 0 else 1e-7)
     t0 = gt.TOA_list[0]
     assert sorted(t0.flags.keys()) == list(g["out_toa0_flag_names"])
     assert t0.frequency == float(g["out_toa0_frequency"]) and t0.DM is None
@@ -1401,9 +1467,13 @@ def test_fit_phase_shift_grid_of_nbin_points():
     prof = np.exp(-0.5 * ((ph - 0.3) / 0.01) ** 2)
     rng = np.random.default_rng(9)
     d = orc.rotate_data(prof, -0.3217) + rng.normal(0, 0.01, B)
-    a = fit_phase_shift(d, prof, Ns=100)
-    b = fit_phase_shift(d, prof, Ns=B)
+    a = fit_phase_shift(d, prof, Ns=100, finish='newton')
+    b = fit_phase_shift(d, prof, Ns=B, finish='newton')
     assert abs(a.phase - b.phase) < 1e-12 and abs(a.phase - 0.3217) < 5 * a.phase_err
+    # the reference's simplex finish stops within its xtol of that optimum, from either grid
+    for Ns in (100, B):
+        s = fit_phase_shift(d, prof, Ns=Ns)
+        assert 0 < abs(s.phase - a.phase) < 1e-4
     np.testing.assert_allclose([a.scale, a.snr, a.red_chi2], [b.scale, b.snr, b.red_chi2], rtol=1e-12)
 
 
