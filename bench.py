@@ -266,7 +266,7 @@ def main():
                 self.guess = "device seed inside the timed fit (seed_ns=%d)" % self.seed_ns
             else:
                 x0[:, 0] = self.pptoas_phase_guess()
-                self.guess = "pptoas preamble (rotate to nu_mean, mean profile, fit_phase_shift Ns=100)"
+                self.guess = "pptoas preamble (rotate to nu_mean, mean profile, fit_phase_shift Ns=100 with SciPy's simplex finish retraced)"
             if flags[3]:
                 t0 = 1.5 * self.tau_rot * (self.nu_fit / 1500.0) ** -4.0
                 x0[:, 3] = np.log10(t0) if self.log10_tau else t0
@@ -276,7 +276,8 @@ def main():
         def pptoas_phase_guess(self):
             """pptoas.py:421-457 on the device: dedisperse every subint at the header
             DM to the mean frequency, average over channels, 1-D FFTFIT against the
-            template's mean profile (Ns = 100), move the phase to nu_fit."""
+            template's mean profile (Ns = 100 grid + SciPy's simplex finish, retraced:
+            the guess the reference itself would start from), move the phase to nu_fit."""
             nu_mean = float(self.freqs.mean())
             profs = np.empty((self.nsub, self.B))
             step = max(1, min(self.nsub, int(8e9 // (self.C * self.B * 8))))
@@ -287,7 +288,7 @@ def main():
                                      nu_DM=nu_mean)
                 profs[s0:s0 + n] = chunk.mean(dim=1).cpu().numpy()
                 del chunk
-            out = eng.fit_phase_shift_batch(profs, self.seed_prof, Ns=100)
+            out = eng.fit_phase_shift_batch(profs, self.seed_prof, Ns=100, finish='simplex')
             phi = out[:, 0] + DCONST * args.dm0 / self.P * (self.nu_fit ** -2 - nu_mean ** -2)
             return (phi + 0.5) % 1.0 - 0.5
 

@@ -108,6 +108,10 @@ void* pp_stream(pp_ctx* ctx);
  *                  repay the pass); 0 = every evaluation is a pass over the cross-spectrum
  *   "scat_model_tol"  predicted relative truncation below which that pass is asked
  *                  for (default 1e-10; the certificate guards the result either way)
+ *   "fps_finish"   pp_fit_phase_shift_batch after its brute grid: 0 (default) = Newton to
+ *                  the exact local optimum; 1 = what scipy.optimize.brute does by default
+ *                  and the reference therefore returns (pplib.py:2085): the Nelder-Mead
+ *                  simplex to xtol = ftol = 1e-4, operation by operation
  *   "moments_in_xspec"  1 (default) = the Taylor moments are accumulated inside
  *                  the transform kernel and no cross-spectrum is stored; 0 = store
  *                  the cross-spectrum and take the moments in a second pass
