@@ -1436,7 +1436,12 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
                 for (int j = 0; j < 9; ++j) H[j] = H2[j];
             }
             ++it;
-            if (it >= a.max_iter || !(radius > 1e-300)) { ok = false; break; }
+            if (it >= a.max_iter || !(radius > 1e-300)) {
+#ifdef PP_TAYLOR_TRACE
+                if (tid == 0) printf("taylor %d: iteration limit it %d radius %.3e\n", i, it, radius);
+#endif
+                ok = false; break;
+            }
         }
     } else if (ok) {
         double fprev = INFINITY;
@@ -1497,10 +1502,23 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
         for (int j = 0; j < 3; ++j)
             if (fl[j]) {
                 const double hjj = fabs(H[j * 3 + j]);
-                if (!(ev[j] <= tol[j] * hjj)) ok = false;
+#if defined(PP_TAYLOR_TRACE) && PP_TAYLOR_TRACE >= 2
+                if (tid == 0 && j == 0) printf("tmargin %d %.4e %.4e\n", i, ev[j] / (tol[j] * hjj), dpath);
+#endif
+                if (!(ev[j] <= tol[j] * hjj)) {
+#ifdef PP_TAYLOR_TRACE
+                    if (tid == 0) printf("taylor %d: certificate %d: err %.3e > tol %.3e (dpath %.3e, it %d) x0 %.9f %.9f dx %.3e %.3e f %.10e\n", i, j, ev[j], tol[j] * hjj, dpath, it, st.xe[0], st.xe[1], dx[0], dx[1], f);
+#endif
+                    ok = false;
+                }
             }
         // every point the iteration visited must lie inside the model's range
-        if (!(dpath < 0.02)) ok = false;
+        if (!(dpath < 0.02)) {
+#ifdef PP_TAYLOR_TRACE
+            if (tid == 0) printf("taylor %d: path %.3e left the model's range (it %d)\n", i, dpath, it);
+#endif
+            ok = false;
+        }
         if (ok && tid == 0) {
             for (int j = 0; j < 3; ++j) st.x[j] = st.xe[j] + dx[j];
             st.x[3] = st.xe[3]; st.x[4] = st.xe[4];

@@ -97,6 +97,7 @@ struct pp_ctx {
     int moments_in_xspec = 1;   // fold the Taylor moments into k_xspec (mode 2) when it applies
     int scat_model = 1;         // scattering fits: closing iterations on the per-channel model (pp_scatmodel.h)
     double scat_model_tol = 1e-10;
+    int debug_poison = 0;       // fill the work buffers with NaN bit patterns before every batch (finds unwritten reads)
     int fps_finish = 0;         // pp_fit_phase_shift_batch: 0 = Newton polish, 1 = SciPy brute's simplex finish
     int paired_split = 1;       // 2048-bin rows: last FFT stage + split in registers (k_xspec_p1024)
     int seed_chan_stride = 16;  // device phase seed: pilot pass over every n-th channel (1 = all channels)
@@ -225,6 +226,7 @@ extern "C" int pp_set_option(pp_ctx* c, const char* name, double value) {
     else if (n == "scat_model") c->scat_model = (int)value;
     else if (n == "scat_model_tol") c->scat_model_tol = value;
     else if (n == "fps_finish") c->fps_finish = (int)value;
+    else if (n == "debug_poison") c->debug_poison = (int)value;
     else if (n == "seed_chan_stride") c->seed_chan_stride = std::max(1, (int)value);
     else if (n == "seed_min_snr") c->seed_min_snr = value;
     else if (n == "seed_ndm") c->seed_ndm = std::max(1, (int)value);
@@ -583,6 +585,20 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         if (out->channel_snrs) if ((rc = c->o_csnr.reserve(nc * 8))) return rc;
     }
 
+    if (c->debug_poison) {
+        // every buffer a kernel of this batch reads must have been written by one: stale
+        // contents become NaNs that surface as failed certificates / non-finite results
+        // (bit mask: 1 tay, 2 sdraw, 4 noise, 8 wts, 16 csum, 32 ph0, 64 X, 128 mdl)
+        const int pz = c->debug_poison;
+        if ((pz & 1) && taylor) HIP_TRY(hipMemsetAsync(c->tay.p, 0xFF, nc * PP_TSTRIDE * 8, c->stream));
+        if (pz & 2) HIP_TRY(hipMemsetAsync(c->sdraw.p, 0xFF, nc * 8, c->stream));
+        if (pz & 4) HIP_TRY(hipMemsetAsync(c->noise.p, 0xFF, nc * 8, c->stream));
+        if (pz & 8) HIP_TRY(hipMemsetAsync(c->wts.p, 0xFF, nc * 8, c->stream));
+        if (pz & 16) HIP_TRY(hipMemsetAsync(c->csum.p, 0xFF, 2 * nc * ncs * 8, c->stream));
+        if ((pz & 32) && xmode != 0) HIP_TRY(hipMemsetAsync(c->ph0.p, 0xFF, nc * 8, c->stream));
+        if ((pz & 64) && xstore) HIP_TRY(hipMemsetAsync(c->X.p, 0xFF, nc * Kt * sizeof(cplx), c->stream));
+        if ((pz & 128) && smodel) HIP_TRY(hipMemsetAsync(c->mdl.p, 0xFF, nc * PP_MROW * 8, c->stream));
+    }
     // ---- argument blocks ----
     const bool tail = (in->errs == nullptr);
     XspecArgs xa;

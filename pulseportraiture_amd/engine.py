@@ -27,7 +27,24 @@ def _check(rc, what):
 
 
 def _is_device_array(x):
-    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda") and bool(x.is_cuda)
+    """A device-resident array (torch tensor).  The engine launches on its OWN HIP
+    stream, the array's contents were produced on the caller's (torch's current
+    stream, asynchronously): wait for the producer before the engine may touch it --
+    otherwise a kernel of ours can read a tensor whose `clone()` / `to()` / fill has
+    not finished (seen as rare, run-dependent garbage in a few rows).  The engine's
+    calls end with a synchronise of its own stream, so the other direction is safe."""
+    if hasattr(x, "data_ptr") and hasattr(x, "is_cuda") and bool(x.is_cuda):
+        _wait_for_producer(x)
+        return True
+    return False
+
+
+def _wait_for_producer(x):
+    try:
+        import torch
+        torch.cuda.current_stream(x.device).synchronize()
+    except ImportError:      # (another array library: its arrays must be complete when handed over)
+        pass
 
 
 def _dp(a):

@@ -1942,3 +1942,25 @@ def test_scattering_fits_in_sub_batches_with_model_slots_and_the_model_path(eng)
     d = _dphi_arr(plain["params"][:, 0], whole["params"][:, 0])
     assert np.median(d) < 2e-12 and d.max() < 2e-9
     np.testing.assert_allclose(plain["chi2"], whole["chi2"], rtol=1e-11)
+
+
+@pytest.mark.gpu
+def test_engine_waits_for_the_callers_stream(eng):
+    """Device tensors handed to the engine are produced on torch's stream, the engine
+    launches on its own: it must wait for the producer.  A 2 GB convert + clone (the
+    copy runs on a DMA engine, beside compute kernels) is handed over right away; without
+    the wait the rotation reads rows that have not arrived yet (max error ~20 instead
+    of rounding -- how the bench's phase guesses once went wrong in 1 subint of 1000)."""
+    import torch
+    from tests.synth_host import model_portrait
+    C, B, N = 512, 2048, 256
+    freqs, model = model_portrait(C, B)
+    b32 = torch.as_tensor(np.tile(model, (N, 1, 1)), device="cuda:0").to(torch.float32)
+    want = b32.to(torch.float64)
+    torch.cuda.synchronize()
+    for rep in range(4):
+        chunk = b32.to(torch.float64).clone()
+        eng.rotate_portraits(chunk, freqs, np.full(N, 0.005), phi=0.0, DM=0.0)   # identity (FFT round trip)
+        err = (chunk - want).abs().max().item()
+        assert err < 1e-12, (rep, err)
+        del chunk
