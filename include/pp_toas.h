@@ -64,6 +64,14 @@ extern "C" {
 
 typedef struct pp_ctx pp_ctx;
 
+/* Streams.  A context launches everything on its own non-blocking HIP stream
+ * (pp_stream) and every entry point returns after synchronising it, so outputs --
+ * host or device -- are complete on return.  Device pointers passed IN (portraits,
+ * errs, masks, output tensors) must be complete as well: if they were produced on
+ * another stream (e.g. an asynchronous copy or kernel of the caller's framework),
+ * synchronise that stream, or make pp_stream wait on an event of it, before the
+ * call.  The Python binding does the former for torch tensors. */
+
 /* ---- context ---------------------------------------------------------- */
 int pp_abi_version(void);
 const char* pp_last_error(void);
