@@ -264,6 +264,21 @@ int pp_fit_phase_shift_batch(pp_ctx* ctx, const double* data,
                              int nprof, int nbin, double lo, double hi, int Ns,
                              double* out7);
 
+/* The reference's initial phase guess of nsub subints (pptoas.py:421-457), data side
+ * fused into one read of the portraits:
+ *   rot_prof_i = np.average(rotate_data(port_i, phi_i, DM_i, P_i, freqs_i, nu_DM),
+ *                           axis=0, weights=weights_i)      (par3 = phi, DM, GM per subint)
+ *   out7[i]    = fit_phase_shift(rot_prof_i, model_profs_i, Ns=Ns, bounds=(lo, hi))
+ * with the finish selected by option "fps_finish".  Channels of zero weight are not
+ * read.  weights [nsub][nchan] and model_profs [nsub][nbin] are host arrays; `src` is
+ * a host or device pointer (`on_device`), dtype PP_F64 / PP_F32. */
+int pp_reference_phase_seed(pp_ctx* ctx, const void* src, int dtype, int on_device,
+                            int nsub, int nchan, int nbin, const double* freqs,
+                            int64_t freqs_stride, const double* P, const double* par3,
+                            double nu_DM, double nu_GM, const double* weights,
+                            const double* model_profs, double lo, double hi, int Ns,
+                            double* out7);
+
 /* Fourier rotation / (de)dispersion of portraits: dst[i][n] = irfft(rfft(src[i][n])
  * e^{2 pi i k phi_in}), phi_in = par[i][0] + Dconst par[i][1] (nu_n^-2 - nu_DM^-2)/P_i
  * + Dconst^2 par[i][2] (nu_n^-4 - nu_GM^-4)/P_i.  rotate_data (pplib.py:2338-2426),

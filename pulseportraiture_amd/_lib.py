@@ -67,6 +67,10 @@ SYMBOLS = {
                                            c_double_p, C.c_int, C.c_int,
                                            C.c_double, C.c_double, C.c_int,
                                            c_double_p]),
+    "pp_reference_phase_seed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, c_double_p, C.c_int64, c_double_p, c_double_p,
+                                          C.c_double, C.c_double, c_double_p, c_double_p, C.c_double,
+                                          C.c_double, C.c_int, c_double_p]),
     "pp_rotate_portraits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, c_double_p,
                                       C.c_int64, c_double_p, c_double_p, C.c_double,

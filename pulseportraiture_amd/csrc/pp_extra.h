@@ -167,6 +167,93 @@ __global__ __launch_bounds__(FftPlan<M>::T) void k_rotate(RotateArgs a) {
 }
 
 // --------------------------------------------------------------------------
+// The data side of the reference's initial guess (pptoas.py:421-423) in one read of
+// the portraits:  rot_prof = np.average(rotate_data(portx, 0, DM_guess, P, freqsx,
+// nu_mean), axis=0, weights=weightsx).  Rotation and the channel mean are linear, so
+// the mean is taken in the Fourier domain: every workgroup transforms a run of
+// channels of one subint and accumulates  w_n d_nk e^{2 pi i k phi_n}  in registers
+// (k = tid, tid + T, ...), channels of zero weight are not even read; a second
+// kernel adds the runs and divides by the summed weights.  The Nyquist harmonic
+// keeps its real part only, as rotate_data's irfft does.
+// --------------------------------------------------------------------------
+struct RotMeanArgs {
+    const void* src;       // [nsub][nchan][B]
+    const double* freqs; long long freqs_stride;
+    const double* P;       // [nsub]
+    const double* par;     // [nsub][3] phi, DM, GM
+    const double* w;       // [nsub][nchan]
+    const cplx* twB;
+    double inv_nuDM2, inv_nuGM4;
+    cplx* part;            // [nsub][nrun][M + 1]
+    double* wpart;         // [nsub][nrun]
+    int nsub, nchan, nrun, cpr;   // channels per run
+};
+
+template <int M, typename Tio>
+__global__ __launch_bounds__(FftPlan<M>::T) void k_rot_mean(RotMeanArgs a) {
+    constexpr int T = FftPlan<M>::T;
+    constexpr int KPT = M / T + 1;            // harmonics 0..M over T lanes
+    __shared__ cplx lds[FftPlan<M>::LDS_ELEMS];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x / a.nrun, run = blockIdx.x % a.nrun;
+    const double P = a.P[i];
+    cplx acc[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) acc[j] = make_double2(0.0, 0.0);
+    double wsum = 0.0;
+    const int n0 = run * a.cpr, n1 = min(a.nchan, n0 + a.cpr);
+    for (int n = n0; n < n1; ++n) {
+        const double w = a.w[(size_t)i * a.nchan + n];
+        if (w == 0.0) continue;
+        wsum += w;
+        const double nu = a.freqs[(size_t)i * a.freqs_stride + n];
+        const double a2 = 1.0 / (nu * nu);
+        const double phin = a.par[i * 3] + PP_DCONST * a.par[i * 3 + 1] * (a2 - a.inv_nuDM2) / P +
+                            PP_DCONST * PP_DCONST * a.par[i * 3 + 2] * (a2 * a2 - a.inv_nuGM4) / P;
+        fft_row<M, Tio>(lds, reinterpret_cast<const Tio*>(a.src) + ((size_t)i * a.nchan + n) * (2 * M), a.twB, tid);
+        const cplx z0 = lds[0];
+        cplx e = unit_phasor((double)tid, phin);
+        const cplx wT = unit_phasor((double)T, phin);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int k = tid + j * T;
+            if (k <= M) {
+                cplx y;
+                if (k == 0) y = make_double2(z0.x + z0.y, 0.0);
+                else if (k == M) y = make_double2((z0.x - z0.y) * e.x, 0.0);
+                else y = cmul(rfft_harmonic<M>(lds, a.twB, k), e);
+                acc[j].x = fma(w, y.x, acc[j].x);
+                acc[j].y = fma(w, y.y, acc[j].y);
+            }
+            e = cmul(e, wT);
+        }
+        __syncthreads();        // the image is rewritten by the next row
+    }
+    cplx* out = a.part + ((size_t)i * a.nrun + run) * (M + 1);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int k = tid + j * T;
+        if (k <= M) out[k] = acc[j];
+    }
+    if (tid == 0) a.wpart[(size_t)i * a.nrun + run] = wsum;
+}
+
+// mean spectrum of every subint: sum of its runs / summed weights -> spec[i][0..M]
+__global__ void k_rot_mean_finish(const cplx* part, const double* wpart, int nsub, int nrun, int M, cplx* spec) {
+    const int i = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > M) return;
+    double wt = 0.0;
+    cplx s = make_double2(0.0, 0.0);
+    for (int r = 0; r < nrun; ++r) {
+        wt += wpart[(size_t)i * nrun + r];
+        const cplx v = part[((size_t)i * nrun + r) * (M + 1) + k];
+        s.x += v.x; s.y += v.y;
+    }
+    const double inv = (wt > 0.0) ? 1.0 / wt : 0.0;
+    spec[(size_t)i * (M + 1) + k] = make_double2(s.x * inv, s.y * inv);
+}
+
+// --------------------------------------------------------------------------
 // Gaussian-component template portraits on the device:
 // gen_gaussian_portrait + gaussian_profile + evolve_parameter (pplib.py:853-930,
 // 770-825, 996-1046), optionally scattered in the Fourier domain
@@ -572,6 +659,7 @@ struct FpsArgs {
     double lo, hi;
     int Ns, M, nprof;
     int finish;            // 0: Newton polish to rounding; 1: SciPy brute's own finish (Nelder-Mead simplex)
+    const cplx* specm;     // nullptr: rows of `spec` alternate data_i, model_i; else spec = data rows, specm = model rows
 };
 
 // sum_k X_k e^{2 pi i k phi} weighted by (1, k, k^2): returns Re-sum, k*Im-sum,
@@ -616,8 +704,8 @@ __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
     __shared__ double scratch[4 * 4];
     __shared__ double shv[4];
     __shared__ int shj[4];
-    const cplx* d = a.spec + (size_t)(2 * i) * (M + 1);
-    const cplx* m = a.spec + (size_t)(2 * i + 1) * (M + 1);
+    const cplx* d = a.specm ? a.spec + (size_t)i * (M + 1) : a.spec + (size_t)(2 * i) * (M + 1);
+    const cplx* m = a.specm ? a.specm + (size_t)i * (M + 1) : a.spec + (size_t)(2 * i + 1) * (M + 1);
     cplx* X = xwork + (size_t)i * M;
     const int H = M + 1, kc = (int)(0.75 * H);
     double v[3] = {0.0, 0.0, 0.0};   // sum |d|^2, sum |m|^2, tail of |d|^2

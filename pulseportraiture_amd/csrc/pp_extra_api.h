@@ -54,7 +54,7 @@ extern "C" int pp_fit_phase_shift_batch(pp_ctx* c, const double* data, const dou
             if ((rc = upload(c, c->errs, noise, (size_t)nprof * 8))) return rc;
             dnoise = c->errs.as<double>();
         }
-        FpsArgs fa{spec, dnoise, c->o_params.as<double>(), lo, hi, Ns, M, nprof, c->fps_finish};
+        FpsArgs fa{spec, dnoise, c->o_params.as<double>(), lo, hi, Ns, M, nprof, c->fps_finish, nullptr};
         hipLaunchKernelGGL(k_fps, dim3(nprof), dim3(256), 0, c->stream, fa, xwork);
     }
     HIP_TRY(hipGetLastError());
@@ -64,6 +64,90 @@ extern "C" int pp_fit_phase_shift_batch(pp_ctx* c, const double* data, const dou
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     for (int i = 0; i < nprof; ++i) out7[(size_t)i * 7 + 6] = 1e-3 * ms / nprof;
+    return PP_OK;
+}
+
+// ---- the reference's initial phase guess, data side fused --------------------
+extern "C" int pp_reference_phase_seed(pp_ctx* c, const void* src, int dtype, int on_device, int nsub, int nchan,
+                                       int nbin, const double* freqs, int64_t freqs_stride, const double* P,
+                                       const double* par3, double nu_DM, double nu_GM, const double* weights,
+                                       const double* model_profs, double lo, double hi, int Ns, double* out7) {
+    if (!c || !src || !freqs || !P || !par3 || !weights || !model_profs || !out7)
+        return fail(PP_EINVAL, "pp_reference_phase_seed: null argument");
+    if (!nbin_ok(nbin) || nsub < 1 || nchan < 1 || Ns < 1) return fail(PP_EINVAL, "pp_reference_phase_seed: bad shape");
+    if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_reference_phase_seed: dtype %d", dtype);
+    if (freqs_stride != 0 && freqs_stride != nchan) return fail(PP_EINVAL, "freqs_stride must be 0 or nchan");
+    HIP_TRY(hipSetDevice(c->device));
+    const int M = nbin / 2;
+    const size_t esz = dtype == PP_F64 ? 8 : 4;
+    const size_t sub_b = (size_t)nchan * nbin * esz;
+    int rc;
+    if (!on_device) {
+        const int cap = aux_chunk_cap(c, (double)sub_b + 64.0 * nchan + 64.0 * nbin, nsub);
+        if (nsub > cap) {
+            for (int s0 = 0; s0 < nsub; s0 += cap) {
+                const int n = std::min(cap, nsub - s0);
+                if ((rc = pp_reference_phase_seed(c, (const char*)src + s0 * sub_b, dtype, 0, n, nchan, nbin,
+                                                  freqs + (freqs_stride ? (size_t)s0 * nchan : 0), freqs_stride, P + s0,
+                                                  par3 + (size_t)s0 * 3, nu_DM, nu_GM, weights + (size_t)s0 * nchan,
+                                                  model_profs + (size_t)s0 * nbin, lo, hi, Ns, out7 + (size_t)s0 * 7)))
+                    return rc;
+            }
+            return PP_OK;
+        }
+    }
+    const void* dsrc = src;
+    if (!on_device) {
+        if ((rc = c->data.reserve((size_t)nsub * sub_b))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->data.p, src, (size_t)nsub * sub_b, hipMemcpyHostToDevice, c->stream));
+        dsrc = c->data.p;
+    }
+    if ((rc = upload(c, c->freqs, freqs, (size_t)(freqs_stride ? (size_t)nsub * nchan : nchan) * 8))) return rc;
+    if ((rc = upload(c, c->P, P, (size_t)nsub * 8))) return rc;
+    if ((rc = upload(c, c->x0, par3, (size_t)nsub * 24))) return rc;
+    if ((rc = upload(c, c->wts, weights, (size_t)nsub * nchan * 8))) return rc;
+    if ((rc = upload(c, c->errs, model_profs, (size_t)nsub * nbin * 8))) return rc;
+    // runs of channels per subint: enough workgroups to fill the device
+    int nrun = std::max(1, std::min(nchan / 16 > 0 ? nchan / 16 : 1, (4096 + nsub - 1) / nsub));
+    const int cpr = (nchan + nrun - 1) / nrun;
+    nrun = (nchan + cpr - 1) / cpr;
+    const size_t H = (size_t)M + 1;
+    // X: [nsub][nrun][H] partial spectra | [nsub][H] data spectra | [nsub][H] model spectra | [nsub][M] k_fps work
+    if ((rc = c->X.reserve(((size_t)nsub * nrun * H + 2 * (size_t)nsub * H + (size_t)nsub * M) * sizeof(cplx)))) return rc;
+    if ((rc = c->sdraw.reserve((size_t)nsub * nrun * 8))) return rc;
+    if ((rc = c->o_params.reserve((size_t)nsub * 56))) return rc;
+    const cplx* tw = nullptr;
+    if ((rc = get_twiddles(c, nbin, &tw))) return rc;
+    cplx* part = c->X.as<cplx>();
+    cplx* dspec = part + (size_t)nsub * nrun * H;
+    cplx* mspec = dspec + (size_t)nsub * H;
+    cplx* xwork = mspec + (size_t)nsub * H;
+    RotMeanArgs ra{dsrc, c->freqs.as<double>(), (long long)freqs_stride, c->P.as<double>(), c->x0.as<double>(),
+                   c->wts.as<double>(), tw, std::isinf(nu_DM) ? 0.0 : 1.0 / (nu_DM * nu_DM),
+                   std::isinf(nu_GM) ? 0.0 : 1.0 / (nu_GM * nu_GM * nu_GM * nu_GM), part, c->sdraw.as<double>(),
+                   nsub, nchan, nrun, cpr};
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    {
+        Prof pr(c, KF_FPS);
+        PP_DISPATCH_M(M, {
+            const int T = FftPlan<MM>::T;
+            if (dtype == PP_F64) hipLaunchKernelGGL((k_rot_mean<MM, double>), dim3(nsub * nrun), dim3(T), 0, c->stream, ra);
+            else hipLaunchKernelGGL((k_rot_mean<MM, float>), dim3(nsub * nrun), dim3(T), 0, c->stream, ra);
+            hipLaunchKernelGGL(k_rot_mean_finish, dim3((M + 1 + 255) / 256, nsub), dim3(256), 0, c->stream,
+                               (const cplx*)part, (const double*)c->sdraw.as<double>(), nsub, nrun, M, dspec);
+            hipLaunchKernelGGL((k_rfft_rows<MM, double>), dim3(fft_grid(T, nsub)), dim3(T), 0, c->stream,
+                               (const void*)c->errs.p, mspec, tw, nsub);
+        });
+        FpsArgs fa{dspec, nullptr, c->o_params.as<double>(), lo, hi, Ns, M, nsub, c->fps_finish, mspec};
+        hipLaunchKernelGGL(k_fps, dim3(nsub), dim3(256), 0, c->stream, fa, xwork);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipMemcpyAsync(out7, c->o_params.p, (size_t)nsub * 56, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    for (int i = 0; i < nsub; ++i) out7[(size_t)i * 7 + 6] = 1e-3 * ms / nsub;
     return PP_OK;
 }
 

@@ -331,6 +331,31 @@ class Engine(object):
             self.set_option("fps_finish", 0)
         return out
 
+    def reference_phase_seed(self, ports, freqs, P, weights, model_profs, phi=0.0, DM=0.0, GM=0.0,
+                             nu_DM=np.inf, nu_GM=np.inf, bounds=(-0.5, 0.5), Ns=100, finish='simplex'):
+        """fit_phase_shift(np.average(rotate_data(port_i, phi_i, DM_i, P_i, freqs_i, nu_DM),
+        axis=0, weights=weights_i), model_profs_i, Ns) for every subint, the rotation
+        and the channel mean fused into one read of the portraits (pptoas.py:421-457).
+        Returns [nsub, 7] like fit_phase_shift_batch."""
+        src, dtype, on_dev, (nsub, nchan, nbin), keep = self._ports_arg(ports)
+        freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+        fstride = 0 if freqs.ndim == 1 else nchan
+        P = _f64(np.broadcast_to(np.asarray(P, dtype=np.float64), (nsub,)))
+        par = np.ascontiguousarray(np.stack([
+            np.broadcast_to(np.asarray(v, dtype=np.float64), (nsub,)) for v in (phi, DM, GM)], axis=1))
+        w = _f64(weights, (nsub, nchan))
+        mp = _f64(np.broadcast_to(np.asarray(model_profs, dtype=np.float64), (nsub, nbin)))
+        out = np.empty((nsub, 7))
+        self.set_option("fps_finish", 1 if finish == 'simplex' else 0)
+        try:
+            _check(self._lib.pp_reference_phase_seed(
+                self._ctx, src, dtype, on_dev, nsub, nchan, nbin, _dp(freqs), fstride, _dp(P), _dp(par),
+                float(nu_DM), float(nu_GM), _dp(w), _dp(mp), float(bounds[0]), float(bounds[1]), int(Ns),
+                _dp(out)), "pp_reference_phase_seed")
+        finally:
+            self.set_option("fps_finish", 0)
+        return out
+
     def rotate_portraits(self, ports, freqs, P, phi=0.0, DM=0.0, GM=0.0, nu_DM=np.inf,
                          nu_GM=np.inf):
         """Fourier-rotate ports[nsub,nchan,nbin] (numpy -> new numpy array; CUDA

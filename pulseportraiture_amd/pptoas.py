@@ -321,30 +321,12 @@ class GetTOAs(object):
         the guessed tau when fitting scattering) with fit_phase_shift(Ns=100) -- brute
         grid + SciPy's simplex finish retraced on the device --, then moved from
         nu_mean to nu_fit_DM."""
-        import torch
         from .pplib import Dconst, phase_transform
         isubs = np.asarray(ok_isubs, dtype=int)
         nok, nchan, nbin = port.shape
         freqs, P = d.freqs[isubs], np.asarray(d.Ps, dtype=np.float64)[isubs]
         w = np.asarray(d.weights, dtype=np.float64)[isubs] * mask
         nu_mean = np.array([freqs[j, mask[j] > 0].mean() for j in range(nok)])
-        dev = "cuda:%d" % eng.device
-        wt = torch.as_tensor(w, device=dev)
-        profs = np.empty((nok, nbin))
-        step = max(1, int(4e9 // (nchan * nbin * 8)))
-        for s0 in range(0, nok, step):
-            s1 = min(nok, s0 + step)
-            chunk = port[s0:s1]
-            chunk = (chunk.to(torch.float64).clone() if torch.is_tensor(chunk) else
-                     torch.as_tensor(np.ascontiguousarray(chunk, dtype=np.float64), device=dev))
-            # rotate_data(portx, 0.0, DM_guess, P, freqsx, nu_mean): the nu_mean term is
-            # the same for every channel and rides on the phase argument
-            eng.rotate_portraits(chunk, freqs[s0:s1], P[s0:s1],
-                                 phi=-Dconst * DM_guess / P[s0:s1] * nu_mean[s0:s1] ** -2.0,
-                                 DM=np.full(s1 - s0, DM_guess), nu_DM=np.inf)
-            ws = wt[s0:s1]
-            profs[s0:s1] = ((chunk * ws[:, :, None]).sum(dim=1) / ws.sum(dim=1)[:, None]).cpu().numpy()
-            del chunk
         mprofs, cache = np.empty((nok, nbin)), {}
         for j, isub in enumerate(isubs):
             key = (d.freqs[isub].tobytes(), float(d.Ps[isub]), mask[j].tobytes(),
@@ -363,7 +345,13 @@ class GetTOAs(object):
                     mprof = np.fft.irfft(np.fft.rfft(mprof) / (1.0 + 2.0j * np.pi * k * tau_lin[j]))
                 cache[key] = mprof
             mprofs[j] = cache[key]
-        out = eng.fit_phase_shift_batch(profs, mprofs, Ns=100, finish='simplex')
+        # rotate_data(portx, 0.0, DM_guess, P, freqsx, nu_mean): the nu_mean term is the
+        # same for every channel of a subint and rides on the phase argument; rotation,
+        # weighted channel mean (channels of zero weight are not read) and the fit run
+        # in one device call
+        out = eng.reference_phase_seed(port, freqs, P, w, mprofs,
+                                       phi=-Dconst * DM_guess / P * nu_mean ** -2.0,
+                                       DM=np.full(nok, DM_guess), nu_DM=np.inf, Ns=100, finish='simplex')
         return np.array([phase_transform(out[j, 0], DM_guess, nu_mean[j], nu_fit_DM[j], P[j], mod=True)
                          for j in range(nok)])
 

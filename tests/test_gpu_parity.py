@@ -1964,3 +1964,37 @@ def test_engine_waits_for_the_callers_stream(eng):
         err = (chunk - want).abs().max().item()
         assert err < 1e-12, (rep, err)
         del chunk
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,on_device", [(np.float64, False), (np.float32, False), (np.float64, True)])
+def test_fused_reference_seed_equals_rotation_mean_and_fit(eng, dtype, on_device):
+    """pp_reference_phase_seed = rotate_data + np.average over the channels +
+    fit_phase_shift in one read of the portraits (the Fourier-domain mean of the
+    rotated rows): against the same three steps made one after the other, and against
+    the host formula, with ragged masks and weights."""
+    import torch
+    from tests.synth_host import model_portrait
+    from oracle import pptoas_oracle as orc
+    rng = np.random.default_rng(808)
+    N, C, B = 9, 40, 512
+    freqs, model = model_portrait(C, B)
+    P = np.full(N, 0.0045)
+    DM = 12.5 + rng.normal(0, 2e-4, N)
+    shift = rng.uniform(-0.45, 0.45, N)
+    ports = np.array([orc.rotate_data(model * rng.uniform(0.5, 2.0, (C, 1)), -shift[i], -DM[i], P[i], freqs,
+                                      freqs.mean()) for i in range(N)])
+    ports = (ports + 0.02 * rng.standard_normal(ports.shape)).astype(dtype)
+    w = rng.uniform(0.5, 1.5, (N, C))
+    w[:, 7] = 0.0; w[2, 20:30] = 0.0
+    mprof = model.mean(axis=0)
+    nu_mean = np.array([freqs[w[i] > 0].mean() for i in range(N)])
+    arg = torch.as_tensor(ports, device="cuda:0") if on_device else ports
+    got = eng.reference_phase_seed(arg, freqs, P, w, mprof, phi=-orc.Dconst * 12.5 / P * nu_mean ** -2.0,
+                                   DM=np.full(N, 12.5), Ns=100, finish='simplex')
+    # the three steps on the host (the reference's own order of operations)
+    profs = np.array([np.average(orc.rotate_data(ports[i].astype(np.float64), 0.0, 12.5, P[i], freqs, nu_mean[i]),
+                                 axis=0, weights=w[i]) for i in range(N)])
+    want = eng.fit_phase_shift_batch(profs, np.tile(mprof, (N, 1)), Ns=100, finish='simplex')
+    assert _dphi_arr(got[:, 0], want[:, 0]).max() < 1e-11
+    np.testing.assert_allclose(got[:, 1:6], want[:, 1:6], rtol=1e-8)
