@@ -191,29 +191,53 @@ struct RotMeanArgs {
 
 template <int M, typename Tio>
 __global__ __launch_bounds__(FftPlan<M>::T) void k_rot_mean(RotMeanArgs a) {
-    constexpr int T = FftPlan<M>::T;
+    constexpr int T = FftPlan<M>::T, R1 = FftPlan<M>::R1, PER1 = FftPlan<M>::PER1;
     constexpr int KPT = M / T + 1;            // harmonics 0..M over T lanes
+    typedef typename RawOf<Tio>::type Raw;
     __shared__ cplx lds[FftPlan<M>::LDS_ELEMS];
     const int tid = threadIdx.x;
     const int i = blockIdx.x / a.nrun, run = blockIdx.x % a.nrun;
     const double P = a.P[i];
+    const double* wrow = a.w + (size_t)i * a.nchan;
+    const Tio* base = reinterpret_cast<const Tio*>(a.src) + (size_t)i * a.nchan * (2 * M);
     cplx acc[KPT];
 #pragma unroll
     for (int j = 0; j < KPT; ++j) acc[j] = make_double2(0.0, 0.0);
     double wsum = 0.0;
     const int n0 = run * a.cpr, n1 = min(a.nchan, n0 + a.cpr);
-    for (int n = n0; n < n1; ++n) {
-        const double w = a.w[(size_t)i * a.nchan + n];
-        if (w == 0.0) continue;
+    // next channel of non-zero weight at or after n (n1 if none)
+    auto next_good = [&](int n) { while (n < n1 && wrow[n] == 0.0) ++n; return n; };
+    RowTwiddles<M> tw;
+    load_row_twiddles<M>(tw, a.twB, tid);
+    // W_B^tid and W_B^T: split twiddles by recurrence
+    const cplx wb0 = a.twB[min(tid, M)], wbT = a.twB[min(T, M)];
+    Raw cur[PER1][R1];
+    int n = next_good(n0);
+    if (n < n1) stage_load_global<M, T, R1>(cur, base + (size_t)n * (2 * M), tid);
+    while (n < n1) {
+        const double w = wrow[n];
         wsum += w;
         const double nu = a.freqs[(size_t)i * a.freqs_stride + n];
         const double a2 = 1.0 / (nu * nu);
         const double phin = a.par[i * 3] + PP_DCONST * a.par[i * 3 + 1] * (a2 - a.inv_nuDM2) / P +
                             PP_DCONST * PP_DCONST * a.par[i * 3 + 2] * (a2 * a2 - a.inv_nuGM4) / P;
-        fft_row<M, Tio>(lds, reinterpret_cast<const Tio*>(a.src) + ((size_t)i * a.nchan + n) * (2 * M), a.twB, tid);
+        {
+            cplx v[PER1][R1];
+#pragma unroll
+            for (int ii = 0; ii < PER1; ++ii)
+#pragma unroll
+                for (int k = 0; k < R1; ++k) v[ii][k] = to_cplx(cur[ii][k]);
+            fft_first_stage<M>(lds, v, tw, tid);
+        }
+        // the first stage has consumed the row: its registers receive the next one,
+        // whose loads stay in flight under the rest of this row (as in k_xspec)
+        const int nn = next_good(n + 1);
+        stage_load_global<M, T, R1>(cur, base + (size_t)(nn < n1 ? nn : n) * (2 * M), tid);
+        fft_later_stages<M>(lds, tw, tid);
         const cplx z0 = lds[0];
         cplx e = unit_phasor((double)tid, phin);
         const cplx wT = unit_phasor((double)T, phin);
+        cplx wb = wb0;
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             const int k = tid + j * T;
@@ -221,13 +245,15 @@ __global__ __launch_bounds__(FftPlan<M>::T) void k_rot_mean(RotMeanArgs a) {
                 cplx y;
                 if (k == 0) y = make_double2(z0.x + z0.y, 0.0);
                 else if (k == M) y = make_double2((z0.x - z0.y) * e.x, 0.0);
-                else y = cmul(rfft_harmonic<M>(lds, a.twB, k), e);
+                else y = cmul(rfft_harmonic_w<M>(lds, wb, k), e);
                 acc[j].x = fma(w, y.x, acc[j].x);
                 acc[j].y = fma(w, y.y, acc[j].y);
             }
             e = cmul(e, wT);
+            wb = cmul(wb, wbT);
         }
-        __syncthreads();        // the image is rewritten by the next row
+        lds_sync<T>();          // the image is rewritten by the next row
+        n = nn;
     }
     cplx* out = a.part + ((size_t)i * a.nrun + run) * (M + 1);
 #pragma unroll
