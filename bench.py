@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--method", default="trust-ncg", choices=["trust-ncg", "newton"])
     ap.add_argument("--dm0", type=float, default=34.56789)
     ap.add_argument("--sigma", type=float, default=0.05)
+    ap.add_argument("--dm-offset", type=float, nargs=2, default=[3e-4, 2e-4], metavar=("MEAN", "SIGMA"),
+                    help="injected DM minus the guessed (header) DM: mean and scatter [pc cm^-3]")
     ap.add_argument("--seed", type=int, default=20260101)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true")
@@ -250,7 +252,7 @@ def main():
             rng = np.random.default_rng([args.seed, first_subint])
             inj = np.zeros((nsub, 3))
             inj[:, 0] = rng.uniform(-0.5, 0.5, nsub)
-            inj[:, 1] = args.dm0 + rng.normal(3e-4, 2e-4, nsub)
+            inj[:, 1] = args.dm0 + rng.normal(args.dm_offset[0], args.dm_offset[1], nsub)
             if flags[2]:
                 inj[:, 2] = rng.normal(0.25, 0.05, nsub)
             self.inj = inj
@@ -391,7 +393,7 @@ def main():
                 "config": {"workload": args.workload, "note": batch.note,
                            "nsub_per_gpu_per_step": nsub, "nchan": C, "nbin": B,
                            "fit_flags": batch.flags, "input_dtype": args.input_dtype,
-                           "bytes_per_sample_resident": batch.s_bytes, "dm0": args.dm0,
+                           "bytes_per_sample_resident": batch.s_bytes, "dm0": args.dm0, "dm_offset": list(args.dm_offset),
                            "sigma": args.sigma, "model_harmonics_kept": batch.nharm,
                            "method": args.method, "phase_guesses": batch.guess,
                            "device_phase_seed_ns": args.seed_ns,
