@@ -92,6 +92,10 @@ void* pp_stream(pp_ctx* ctx);
  *   "max_work_bytes"  cap on device scratch per call (larger batches are split)
  *   "taylor"       1 (default) = fits without scattering first try the
  *                  per-channel Taylor-model solve; 0 = always iterate
+ *   "taylor_recentre"  fits of phase / DM whose Taylor model fails its certificate (poor
+ *                  guesses) are expanded again about the tentative answer -- one more pass
+ *                  over those subints' data -- before falling back to evaluations over a
+ *                  stored cross-spectrum: how many times (default 1, 0 = never)
  *   "seed_chan_stride"  device phase seed (seed_ns > 0) of fits without scattering:
  *                  the seed is formed in a pilot pass over every n-th channel (default
  *                  16; 1 = from all channels, with the cross-spectrum stored), then the

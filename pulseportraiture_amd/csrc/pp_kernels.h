@@ -102,6 +102,10 @@ struct FitArgs {
     double* mdl;              // [nsub][PP_MROW][nchan]
     int use_model;
     double model_tol;         // predicted relative truncation below which the model pass is asked for
+    // one-pass flow: a subint whose certificate fails is expanded again about its tentative answer,
+    // up to `recentre` times
+    int recentre;
+    double* x0w;              // [nsub][5] the expansion points k_phase0 reads (writable view of x0)
 };
 
 __device__ __forceinline__ int sub_of(const int* act, int j) { return act ? act[j] : j; }
@@ -574,6 +578,7 @@ __global__ void k_init_state(FitArgs a) {
     s.hits_boundary = 0;
     s.iter = 0; s.nfev = 0; s.status = PP_RC_MAXITER; s.done = 0; s.cur = 1; s.fresh = 1;
     s.model = 0; s.geo[0] = s.geo[1] = s.geo[2] = s.geo[3] = 0.0;
+    s.recentred = 0;
     if (i == 0) *a.nactive = a.nsub;
 }
 
@@ -1312,6 +1317,7 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
     constexpr int NT = CPT ? 512 : 256, NWV = NT / 64;
     const int i = blockIdx.x, tid = threadIdx.x;
     SubState& st = a.st[i];
+    if (st.done) return;                 // (second launch, after a re-expansion of the others)
     __shared__ double scratch[NWV * 12];
     __shared__ double shx[8];
     const double P = a.P[i];
@@ -1407,7 +1413,7 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
     bool ok = true;
     int it = 0;
     double dpath = evalm(dx, f, g, H);   // (0 at the expansion point)
-    if (tid == 0) {
+    if (tid == 0 && st.recentred == 0) {     // (objective hooks: at init_params only)
         st.f0 = f;
         for (int j = 0; j < 5; ++j) st.g0[j] = j < 3 ? g[j] : 0.0;
         for (int r_ = 0; r_ < 5; ++r_)
@@ -1526,13 +1532,27 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
             for (int j = 0; j < 5; ++j) st.g[j] = j < 3 ? g[j] : 0.0;
             for (int r_ = 0; r_ < 5; ++r_)
                 for (int c_ = 0; c_ < 5; ++c_) st.H[r_ * 5 + c_] = (r_ < 3 && c_ < 3) ? H[r_ * 3 + c_] : 0.0;
-            st.cur = buf; st.nfev = 1; st.iter = it; st.status = PP_RC_STALL; st.done = 1; st.fresh = 0;
+            st.cur = buf; st.nfev = 1 + st.recentred; st.iter = it; st.status = PP_RC_STALL; st.done = 1; st.fresh = 0;
             atomicSub(a.nactive, 1);
         }
     }
-    // (not ok: fall back to evaluations over X, starting from the initial point;
-    // k_init_state left fresh = 1)
-    if (!ok && tid == 0) st.fresh = 1;
+    // Not ok.  The tentative answer x0 + dx is usually still far better than x0 (the
+    // harmonics that carry the power are within the model's reach long after the
+    // highest ones have left it): expand again about it -- one more pass over this
+    // subint's data, at most a.recentre times -- before falling back to evaluations over
+    // the cross-spectrum
+    // (which start from st.xe, fresh = 1 as k_init_state left it).  Phase / DM fits only:
+    // they end at the optimum whatever the path; a GM fit's exit point depends on it.
+    if (!ok && tid == 0) {
+        bool fin = isfinite(dpath) && dpath < 0.25;
+        for (int j = 0; j < 3; ++j) fin = fin && isfinite(dx[j]);
+        if (st.recentred < a.recentre && fin) {
+            for (int j = 0; j < 3; ++j) st.xe[j] += dx[j];
+            for (int j = 0; j < 5; ++j) { st.x[j] = st.xe[j]; a.x0w[i * 5 + j] = st.xe[j]; }
+            st.recentred += 1;
+        } else st.recentred = a.recentre + 1;                // (no further expansion)
+        st.fresh = 1;
+    }
 }
 
 // unpack the 21 accumulators into g[5], H[25] with the fit flags applied
@@ -1636,9 +1656,14 @@ __device__ inline bool step_decide(const FitArgs& a, SubState& s, double f, cons
         }
         s.status = PP_RC_STALL; done = true;
     } else if (first) {
-        s.f = f; s.f0 = f;
-        for (int j = 0; j < 5; ++j) { s.g[j] = g[j]; s.g0[j] = g[j]; }
-        for (int j = 0; j < 25; ++j) { s.H[j] = H[j]; s.H0[j] = H[j]; }
+        s.f = f;
+        for (int j = 0; j < 5; ++j) s.g[j] = g[j];
+        for (int j = 0; j < 25; ++j) s.H[j] = H[j];
+        if (s.recentred == 0) {          // (objective hooks: at init_params only)
+            s.f0 = f;
+            for (int j = 0; j < 5; ++j) s.g0[j] = g[j];
+            for (int j = 0; j < 25; ++j) s.H0[j] = H[j];
+        }
         s.cur = 1 - s.cur;
         if (!finite) { s.status = PP_RC_NAN; done = true; }
         if (a.max_iter <= 0) { s.status = PP_RC_MAXITER; done = true; }

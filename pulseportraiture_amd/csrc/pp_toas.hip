@@ -97,6 +97,8 @@ struct pp_ctx {
     int moments_in_xspec = 1;   // fold the Taylor moments into k_xspec (mode 2) when it applies
     int scat_model = 1;         // scattering fits: closing iterations on the per-channel model (pp_scatmodel.h)
     double scat_model_tol = 1e-10;
+    int taylor_recentre = 1;    // one-pass flow: re-expansions about the tentative answer when the certificate fails
+                                // (0 = none; a second one rarely rescues what the first did not)
     int debug_poison = 0;       // fill the work buffers with NaN bit patterns before every batch (finds unwritten reads)
     int fps_finish = 0;         // pp_fit_phase_shift_batch: 0 = Newton polish, 1 = SciPy brute's simplex finish
     int paired_split = 1;       // 2048-bin rows: last FFT stage + split in registers (k_xspec_p1024)
@@ -227,6 +229,7 @@ extern "C" int pp_set_option(pp_ctx* c, const char* name, double value) {
     else if (n == "scat_model_tol") c->scat_model_tol = value;
     else if (n == "fps_finish") c->fps_finish = (int)value;
     else if (n == "debug_poison") c->debug_poison = (int)value;
+    else if (n == "taylor_recentre") c->taylor_recentre = (int)value;
     else if (n == "seed_chan_stride") c->seed_chan_stride = std::max(1, (int)value);
     else if (n == "seed_min_snr") c->seed_min_snr = value;
     else if (n == "seed_ndm") c->seed_ndm = std::max(1, (int)value);
@@ -654,6 +657,8 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.o_rec = out->records_dev ? out->records_dev + (size_t)s0 * PP_RECORD_WIDTH : nullptr;
     fa.act = nullptr; fa.nact = ns; fa.nchan_x = C; fa.cstep = 1; fa.coff = 0;
     fa.mdl = c->mdl.as<double>(); fa.use_model = smodel ? 1 : 0; fa.model_tol = c->scat_model_tol;
+    fa.recentre = (taylor && xmom && !in->fit_flags[2]) ? std::max(0, c->taylor_recentre) : 0;
+    fa.x0w = c->x0.as<double>();
 
     auto run_xspec = [&](const XspecArgs& x, int mode) -> int {
         Prof pr(c, KF_XSPEC);
@@ -795,9 +800,32 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         HIP_TRY(hipMemcpyAsync(c->nactive_h, fa.nactive, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         all_done = (c->nactive_h[0] <= 0);
+        for (int rep = 0; rep < fa.recentre && !all_done; ++rep) {
+            // some subints failed the certificate (poor guesses): k_taylor_solve moved
+            // their expansion points to its tentative answers -- take the Taylor model of
+            // THOSE again (one more pass over their rows, nothing stored) and solve again
+            int nleft = 0;
+            if ((rc = list_active(nullptr, 0.0, &nleft))) return rc;
+            {
+                Prof pr(c, KF_PREP);
+                hipLaunchKernelGGL(k_phase0, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, ns, C,
+                                   xa.x0, xa.P, xa.nu_fit, xa.freqs, xa.freqs_stride, c->ph0.as<double>());
+            }
+            XspecArgs xl = xa;
+            xl.act = c->act.as<int>(); xl.nsub = nleft;
+            if ((rc = run_xspec(xl, xmode))) return rc;
+            {
+                Prof pr(c, KF_TAYLOR);
+                hipLaunchKernelGGL(k_taylor_solve<0>, dim3(ns), dim3(256), 0, c->stream, fa);
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(c->nactive_h, fa.nactive, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            all_done = (c->nactive_h[0] <= 0);
+        }
         if (!all_done && !xstore) {
-            // some subints failed the certificate (poor guesses): they need evaluations
-            // over the cross-spectrum, which was not stored -- transform THOSE again
+            // still not certified: they need evaluations over the cross-spectrum, which
+            // was not stored -- transform THOSE again, keeping it
             int nleft = 0;
             if ((rc = list_active(nullptr, 0.0, &nleft))) return rc;
             if ((rc = store_x_for_list(nleft))) return rc;

@@ -1998,3 +1998,42 @@ def test_fused_reference_seed_equals_rotation_mean_and_fit(eng, dtype, on_device
     want = eng.fit_phase_shift_batch(profs, np.tile(mprof, (N, 1)), Ns=100, finish='simplex')
     assert _dphi_arr(got[:, 0], want[:, 0]).max() < 1e-11
     np.testing.assert_allclose(got[:, 1:6], want[:, 1:6], rtol=1e-8)
+
+
+@pytest.mark.gpu
+def test_poor_dm_guesses_get_one_more_expansion_instead_of_evaluations(eng):
+    """Subints whose DM guess is a few 1e-3 pc cm^-3 off leave the Taylor model's
+    certified range; instead of a re-transform with the cross-spectrum stored plus ~6
+    evaluations over it, their model is taken once more about the first solve's
+    tentative answer (one more pass over their rows: nfeval 2) -- same answers as the
+    evaluation loop (taylor_recentre = 0), as fits from good guesses, and the objective
+    hooks still refer to init_params."""
+    nsub = 96
+    data, freqs, P, x0, kw = _medium_batch(eng, nsub)
+    good = eng.fit_batch(data, freqs, P, x0, **kw)
+    poor = np.arange(5, nsub, 9)
+    x1 = x0.copy()
+    x1[poor, 1] += np.where(np.arange(len(poor)) % 2, 5e-3, -4.5e-3)
+    # (the phase guess refers to nu_fit: a DM error tilts the channels about it)
+    eng.set_option("profile", 1)
+    eng.kernel_times(reset=True)
+    r = eng.fit_batch(data, freqs, P, x1, objective=True, **kw)
+    kt = eng.kernel_times(reset=True)
+    eng.set_option("profile", 0)
+    eng.set_option("taylor_recentre", 0)
+    try:
+        loop = eng.fit_batch(data, freqs, P, x1, objective=True, **kw)
+    finally:
+        eng.set_option("taylor_recentre", 1)
+    ok = np.setdiff1d(np.arange(nsub), poor)
+    assert (r["nfeval"][ok] == 1).all() and (r["nfeval"][poor] == 2).all(), r["nfeval"][poor]
+    assert (loop["nfeval"][poor] >= 3).all()
+    assert kt.get("eval", (0, 0))[1] == 0 and kt["xspec"][1] == 2       # no evaluation over a stored cross-spectrum
+    assert (r["return_code"] == 2).all()
+    for ref in (loop, good):
+        assert _dphi_common(r, ref, P) < PHI_BAR
+        assert np.abs(r["params"][:, 1] - ref["params"][:, 1]).max() < DM_BAR
+        np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-10)
+        np.testing.assert_allclose(r["param_errs"][:, :2], ref["param_errs"][:, :2], rtol=1e-6)
+    np.testing.assert_allclose(r["obj_f"], loop["obj_f"], rtol=1e-12)
+    np.testing.assert_allclose(r["obj_grad"], loop["obj_grad"], rtol=1e-7, atol=1e-3)
