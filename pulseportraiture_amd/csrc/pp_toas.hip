@@ -657,7 +657,10 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.o_rec = out->records_dev ? out->records_dev + (size_t)s0 * PP_RECORD_WIDTH : nullptr;
     fa.act = nullptr; fa.nact = ns; fa.nchan_x = C; fa.cstep = 1; fa.coff = 0;
     fa.mdl = c->mdl.as<double>(); fa.use_model = smodel ? 1 : 0; fa.model_tol = c->scat_model_tol;
-    fa.recentre = (taylor && xmom && !in->fit_flags[2]) ? std::max(0, c->taylor_recentre) : 0;
+    // (a GM fit walked the SciPy way ends where its path ends: it keeps the exact path; the
+    // Newton solver converges to the optimum from anywhere)
+    fa.recentre = (taylor && xmom && (!in->fit_flags[2] || in->method == PP_METHOD_NEWTON))
+                      ? std::max(0, c->taylor_recentre) : 0;
     fa.x0w = c->x0.as<double>();
 
     auto run_xspec = [&](const XspecArgs& x, int mode) -> int {
