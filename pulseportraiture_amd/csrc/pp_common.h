@@ -39,6 +39,15 @@ __device__ __forceinline__ const T* as_global(const T* p) {
     return (const T*)(gp_t)(uintptr_t)p;
 }
 
+// One rounding per operation, as NumPy does it: hipcc contracts a * b + c into an FMA
+// even through __dmul_rn / __dadd_rn, which moves a Nelder-Mead vertex by an ulp -- and
+// turns the grid point 18 * (1/36) - 0.5 = 0 into -2.8e-17, sending SciPy's simplex down
+// its "x0 != 0" branch.  The empty asm pins the intermediate result.
+__device__ __forceinline__ double rn_pin(double r) { asm volatile("" : "+v"(r)); return r; }
+__device__ __forceinline__ double mul_rn(double a, double b) { return rn_pin(a * b); }
+__device__ __forceinline__ double add_rn(double a, double b) { return rn_pin(a + b); }
+__device__ __forceinline__ double sub_rn(double a, double b) { return rn_pin(a - b); }
+
 // 1/x for x >= 1 (no zeros or denormals to honour; huge and infinite x give 0): the
 // hardware estimate refined by two Newton steps, ~1 ulp, instead of the dozen
 // instructions of the IEEE division sequence

@@ -303,8 +303,8 @@ struct GaussArgs {
 
 __device__ __forceinline__ double gauss_evolve(double nu, double nu_ref, double value, double evol, int code) {
     // power law in logs (pplib.py:1017-1030), else linear in frequency
-    if (code == 0) return exp(__dadd_rn(__dmul_rn(log(nu) - log(nu_ref), evol), log(value)));
-    return __dadd_rn(__dmul_rn(nu - nu_ref, evol), value);
+    if (code == 0) return exp(add_rn(mul_rn(log(nu) - log(nu_ref), evol), log(value)));
+    return add_rn(mul_rn(nu - nu_ref, evol), value);
 }
 
 // bin centre j of nbin (get_bin_centers -> numpy.linspace: j*step + start, last = stop)
@@ -312,7 +312,7 @@ __device__ __forceinline__ double gauss_bin_centre(int j, int nbin) {
     const double start = 1.0 / (double)(nbin * 2), stop = 1.0 - start;
     if (j == nbin - 1) return stop;
     const double step = (stop - start) / (double)(nbin - 1);
-    return __dadd_rn(__dmul_rn((double)j, step), start);
+    return add_rn(mul_rn((double)j, step), start);
 }
 
 struct GaussComp { double mean, sigma, norm, fact, amp; int on; };
@@ -323,7 +323,7 @@ __device__ __forceinline__ double gauss_wrap(double x, double mean) {
 }
 __device__ __forceinline__ double gauss_val(double x, const GaussComp& g) {
     const double z = (gauss_wrap(x, g.mean) - g.mean) / g.sigma;
-    return (fabs(z) < 20.0) ? exp(-0.5 * __dmul_rn(z, z)) / g.norm : 0.0;
+    return (fabs(z) < 20.0) ? exp(-0.5 * mul_rn(z, z)) / g.norm : 0.0;
 }
 
 template <int M>
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(FftPlan<M>::T) void k_gauss_portrait(GaussArgs a) {
                 if (v > vb || (v == vb && j < jb)) { vb = v; jb = j; }
             }
             const double zpk = (gauss_wrap(gauss_bin_centre(jb, B), g.mean) - loc) / g.sigma;
-            g.fact = (vb > 0.0) ? exp(-0.5 * __dmul_rn(zpk, zpk)) / vb : 0.0;
+            g.fact = (vb > 0.0) ? exp(-0.5 * mul_rn(zpk, zpk)) / vb : 0.0;
             gc[c] = g;
         }
         __syncthreads();
@@ -365,9 +365,9 @@ __global__ __launch_bounds__(FftPlan<M>::T) void k_gauss_portrait(GaussArgs a) {
             double sum = 0.0;
             for (int c = 0; c < a.ngauss; ++c) {
                 const GaussComp g = gc[c];
-                if (g.on) sum = __dadd_rn(sum, __dmul_rn(g.amp, __dmul_rn(g.fact, gauss_val(x, g))));
+                if (g.on) sum = add_rn(sum, mul_rn(g.amp, mul_rn(g.fact, gauss_val(x, g))));
             }
-            reinterpret_cast<double*>(zin)[j] = __dadd_rn(a.dc, sum);
+            reinterpret_cast<double*>(zin)[j] = add_rn(a.dc, sum);
         }
         __syncthreads();
         double* out = a.out + (size_t)n * B;
@@ -470,8 +470,8 @@ __global__ __launch_bounds__(256) void k_spline_portrait(SplineArgs a) {
         // numpy.dot(proj, eigvec.T) + mean_prof: the products summed in component order
         double s = 0.0;
         for (int cidx = 0; cidx < a.ncomp; ++cidx)
-            s = __dadd_rn(s, __dmul_rn(proj[cidx], a.basis[(size_t)(cidx + 1) * a.nbin + b]));
-        out[b] = __dadd_rn(s, a.basis[b]);
+            s = add_rn(s, mul_rn(proj[cidx], a.basis[(size_t)(cidx + 1) * a.nbin + b]));
+        out[b] = add_rn(s, a.basis[b]);
     }
 }
 
@@ -756,14 +756,14 @@ __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
     // (grid point j = j * step + lo, the arithmetic of numpy's mgrid)
     const double h = (Ns > 1) ? (a.hi - a.lo) / (double)(Ns - 1) : 0.5;
     for (int j = tid; j < Ns; j += 256) {
-        const double phi = (Ns > 1) ? __dadd_rn(__dmul_rn((double)j, h), a.lo) : a.lo;
+        const double phi = (Ns > 1) ? add_rn(mul_rn((double)j, h), a.lo) : a.lo;
         double s0, s1, s2;
         fps_sums(X, M, phi, 0, 1, s0, s1, s2);
         const double v = -s0 / err2;
         if (v < bestv) { bestv = v; bestj = j; }
     }
     const int best = min(block_argmin256(bestv, bestj, shv, shj), Ns - 1);
-    double phi = (Ns > 1) ? __dadd_rn(__dmul_rn((double)best, h), a.lo) : a.lo;
+    double phi = (Ns > 1) ? add_rn(mul_rn((double)best, h), a.lo) : a.lo;
     double f = 0.0, f2 = 0.0;
     // objective at one phase, the same in every thread
     auto feval = [&](double x) -> double {
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
         // _minimize_neldermead: rho 1, chi 2, psi 1/2, sigma 1/2; second vertex
         // 1.05 x0, or 0.00025 when x0 = 0).  The reference's phase IS this simplex's
         // best vertex, ~1e-5 rot from the maximum of the correlation.
-        double sim0 = phi, sim1 = (phi != 0.0) ? __dmul_rn(1.05, phi) : 0.00025;
+        double sim0 = phi, sim1 = (phi != 0.0) ? mul_rn(1.05, phi) : 0.00025;
         double f0 = feval(sim0), f1 = feval(sim1);
         int fcalls = 2, iterations = 1;
         auto order = [&]() {           // argsort of two values, stable
@@ -791,24 +791,24 @@ __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
         while (fcalls < 200 && iterations < 200) {
             if (fabs(sim1 - sim0) <= 1e-4 && fabs(f0 - f1) <= 1e-4) break;
             const double xbar = sim0;
-            const double xr = __dsub_rn(__dmul_rn(2.0, xbar), sim1);
+            const double xr = sub_rn(mul_rn(2.0, xbar), sim1);
             const double fxr = feval(xr); ++fcalls;
             bool shrink = false;
             if (fxr < f0) {
-                const double xe = __dsub_rn(__dmul_rn(3.0, xbar), __dmul_rn(2.0, sim1));
+                const double xe = sub_rn(mul_rn(3.0, xbar), mul_rn(2.0, sim1));
                 const double fxe = feval(xe); ++fcalls;
                 if (fxe < fxr) { sim1 = xe; f1 = fxe; } else { sim1 = xr; f1 = fxr; }
             } else if (fxr < f1) {      // (f0 <= fxr: outside contraction)
-                const double xc = __dsub_rn(__dmul_rn(1.5, xbar), __dmul_rn(0.5, sim1));
+                const double xc = sub_rn(mul_rn(1.5, xbar), mul_rn(0.5, sim1));
                 const double fxc = feval(xc); ++fcalls;
                 if (fxc <= fxr) { sim1 = xc; f1 = fxc; } else shrink = true;
             } else {                    // inside contraction
-                const double xcc = __dadd_rn(__dmul_rn(0.5, xbar), __dmul_rn(0.5, sim1));
+                const double xcc = add_rn(mul_rn(0.5, xbar), mul_rn(0.5, sim1));
                 const double fxcc = feval(xcc); ++fcalls;
                 if (fxcc < f1) { sim1 = xcc; f1 = fxcc; } else shrink = true;
             }
             if (shrink) {
-                sim1 = __dadd_rn(sim0, __dmul_rn(0.5, __dsub_rn(sim1, sim0)));
+                sim1 = add_rn(sim0, mul_rn(0.5, sub_rn(sim1, sim0)));
                 f1 = feval(sim1); ++fcalls;
             }
             ++iterations;
