@@ -213,8 +213,10 @@ struct SubState {
     double xl[5], fl, gl[5], Hl[25];   // the point evaluated last and its f, g, H (SciPy's cache of one point)
     int fresh;         // the next evaluation is 1: an initial one, 2: the closing one (no ratio test)
     int recentred;     // one-pass flow: 1 = the Taylor model was taken again about the first solve's answer
+    int nmodel;        // model passes of this subint whose iteration left the model's range
     int model;         // scattering model of the closing iterations: 0 not yet, 1 the next evaluation
                        // is the model pass, 3 not (again) for this subint
+    double xprev[5];   // the accepted point before the last accepted step (convergence-rate estimate)
     double geo[4];     // max |d phi_n/d DM|, |d phi_n/d GM|, |ln(nu_n/nu_tau)| over the channels; template keff
 };
 

@@ -578,7 +578,8 @@ __global__ void k_init_state(FitArgs a) {
     s.hits_boundary = 0;
     s.iter = 0; s.nfev = 0; s.status = PP_RC_MAXITER; s.done = 0; s.cur = 1; s.fresh = 1;
     s.model = 0; s.geo[0] = s.geo[1] = s.geo[2] = s.geo[3] = 0.0;
-    s.recentred = 0;
+    s.recentred = 0; s.nmodel = 0;
+    for (int j = 0; j < 5; ++j) s.xprev[j] = s.x[j];
     if (i == 0) *a.nactive = a.nsub;
 }
 
@@ -1678,7 +1679,7 @@ __device__ inline bool step_decide(const FitArgs& a, SubState& s, double f, cons
         if (rho < 0.25) s.radius *= 0.25;
         else if (rho > 0.75 && s.hits_boundary) s.radius = fmin(2.0 * s.radius, 1000.0);
         if (rho > 0.15) {
-            for (int j = 0; j < 5; ++j) { s.x[j] = s.xe[j]; s.g[j] = g[j]; }
+            for (int j = 0; j < 5; ++j) { s.xprev[j] = s.x[j]; s.x[j] = s.xe[j]; s.g[j] = g[j]; }
             for (int j = 0; j < 25; ++j) s.H[j] = H[j];
             s.f = f;
             s.cur = 1 - s.cur;

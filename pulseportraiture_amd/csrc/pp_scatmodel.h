@@ -128,14 +128,39 @@ __device__ inline void scat_model_request(const FitArgs& a, SubState& s) {
         for (int c = 0; c < n; ++c) Hs[r * n + c] = s.H[idx[r] * 5 + idx[c]];
     }
     if (!chol_solve(n, Hs, mg, pn)) return;
-    double D[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int r = 0; r < n; ++r) D[idx[r]] = fabs(pn[r]);
-    for (int j = 0; j < 5; ++j) D[j] += fabs(s.xe[j] - s.x[j]);
-    const double dphi = D[0] + D[1] * s.geo[0] + D[2] * s.geo[1];
-    const double rel = (a.log10_tau ? PP_LN10 * D[3] : D[3] / tau) + D[4] * s.geo[2];
-    const double x = 1.25 * s.geo[3] * dphi, rho = 2.0 * rel;
-    if (!(x < 0.5) || !(rho < 0.2) || !(PP_TWO_PI * (double)a.Kt * dphi < 1.0)) return;
-    if (series_tail(PP_MP, x, rho) * (PP_MP + 1) <= a.model_tol) s.model = 1;
+    double pnf[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int r = 0; r < n; ++r) pnf[idx[r]] = pn[r];
+    // per-channel size of a parameter displacement: phase [rot] and relative tau_n
+    auto dphi_of = [&](const double* v) { return fabs(v[0]) + fabs(v[1]) * s.geo[0] + fabs(v[2]) * s.geo[1]; };
+    auto rel_of = [&](const double* v) {
+        return (a.log10_tau ? PP_LN10 * fabs(v[3]) : fabs(v[3]) / tau) + fabs(v[4]) * s.geo[2];
+    };
+    auto inside = [&](double dphi, double rel) {
+        const double x = 1.25 * s.geo[3] * dphi, rho = 2.0 * rel;
+        if (!(x < 0.5) || !(rho < 0.2) || !(PP_TWO_PI * (double)a.Kt * dphi < 1.0)) return false;
+        return series_tail(PP_MP, x, rho) * (PP_MP + 1) <= a.model_tol;
+    };
+    double pr[5], D[5];
+    for (int j = 0; j < 5; ++j) { pr[j] = s.xe[j] - s.x[j]; D[j] = fabs(pnf[j]) + fabs(pr[j]); }
+    // (a) nothing between x, the proposal and the predicted optimum leaves the range
+    if (inside(dphi_of(D), rel_of(D))) { s.model = 1; return; }
+    // (b) one evaluation earlier, on a bet: the proposal is the full Newton step (the CG
+    // iteration converged, no boundary), so it lands about (relative step)^2 from the
+    // optimum in tau_n -- the scale of the objective's nonlinearity in ln tau is 1 -- and
+    // within a tenth of the step in phase, where the objective is far closer to quadratic
+    // (measured: 0.025).  Twice that must be inside the range, to
+    // a looser tolerance: the certificate of every model evaluation is what guards the
+    // result, and a lost bet costs the difference between the model pass and an ordinary
+    // one, once (a subint gets a second chance under (a) only).
+    if (s.hits_boundary || s.nmodel > 0) return;
+    double dn[5];
+    for (int j = 0; j < 5; ++j) dn[j] = pnf[j] - pr[j];
+    const double px = dphi_of(pr), prl = rel_of(pr), dx_ = dphi_of(dn), dr_ = rel_of(dn);
+    if (!(dx_ <= 0.1 * px + 1e-7) || !(dr_ <= 0.1 * prl + 1e-6)) return;
+    const double ex = 2.0 * (0.1 * px + dx_), er = 2.0 * (prl * prl + dr_);
+    const double x = 1.25 * s.geo[3] * ex, rho = 2.0 * er;
+    if (!(x < 0.5) || !(rho < 0.2) || !(PP_TWO_PI * (double)a.Kt * ex < 1.0)) return;
+    if (series_tail(PP_MP, x, rho) * (PP_MP + 1) <= 1e4 * a.model_tol) s.model = 1;
 }
 
 // --------------------------------------------------------------------------
@@ -402,7 +427,10 @@ __global__ __launch_bounds__(256) void k_scat_model_solve(FitArgs a) {
             for (int j = 0; j < 5; ++j)      // (static indices: acc stays in registers)
                 if (a.flags[j] && !(acc[PP_NACC + j] <= tol[j] * fabs(H[j * 5 + j]))) ok = false;
             if (!ok) {
-                ss.model = 3;                // the ordinary path evaluates this proposal over X
+                // the ordinary path evaluates this proposal over X; one more model pass may
+                // be asked for later (criterion (a) only)
+                ss.nmodel += 1;
+                ss.model = (ss.nmodel < 2) ? 0 : 3;
                 flag = 2;
             } else {
                 ss.model = 2;

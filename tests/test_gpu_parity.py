@@ -1817,7 +1817,8 @@ def test_scattering_model_evaluations_that_fail_their_certificate_are_made_over_
     e.set_option("profile", 0)
     e.set_option("scat_model_tol", 1e-10)
     np.testing.assert_array_equal(ref["nfeval"], r["nfeval"])
-    assert np.abs(_dphi_arr(ref["params"][:, 0], r["params"][:, 0])).max() < 2e-12
+    # (evaluations on the model and over the data alternate here: same iterates, rounding apart)
+    assert np.abs(_dphi_arr(ref["params"][:, 0], r["params"][:, 0])).max() < 1e-11
     np.testing.assert_allclose(ref["params"][:, 3:], r["params"][:, 3:], rtol=1e-10)
     np.testing.assert_allclose(ref["chi2"], r["chi2"], rtol=1e-12)
     # early model passes were abandoned: more passes over the data than evaluations the
