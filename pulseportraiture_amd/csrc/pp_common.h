@@ -215,7 +215,8 @@ struct SubState {
     int recentred;     // one-pass flow: 1 = the Taylor model was taken again about the first solve's answer
     int nmodel;        // model passes of this subint whose iteration left the model's range
     int model;         // scattering model of the closing iterations: 0 not yet, 1 the next evaluation
-                       // is the model pass, 3 not (again) for this subint
+                       // is the model pass, 3 not (again) for this subint, 4 / 5 a model pass was just
+                       // abandoned (k_step turns them into 0 / 3)
     double xprev[5];   // the accepted point before the last accepted step (convergence-rate estimate)
     double geo[4];     // max |d phi_n/d DM|, |d phi_n/d GM|, |ln(nu_n/nu_tau)| over the channels; template keff
 };

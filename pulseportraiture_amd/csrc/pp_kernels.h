@@ -102,6 +102,7 @@ struct FitArgs {
     double* mdl;              // [nsub][PP_MROW][nchan]
     int use_model;
     double model_tol;         // predicted relative truncation below which the model pass is asked for
+    int model_bet;            // criterion (b): ask one evaluation earlier when the proposal is the full Newton step
     // one-pass flow: a subint whose certificate fails is expanded again about its tentative answer,
     // up to `recentre` times
     int recentre;
@@ -1725,6 +1726,12 @@ __global__ __launch_bounds__(64) void k_step(FitArgs a) {
     const int i = sub_of(a.act, blockIdx.x), tid = threadIdx.x;
     SubState& s = a.st[i];
     if (s.done || s.model == 1) return;      // (model == 1: k_scat_model_solve owns this evaluation)
+    if (s.model >= 4) {
+        // the model pass of this iteration was abandoned: the evaluation it stood for is
+        // still to be made (next iteration, over the cross-spectrum)
+        if (tid == 0) s.model = (s.model == 4) ? 0 : 3;
+        return;
+    }
     __shared__ double acc[PP_NACC];
     if (tid < PP_NACC) {
         double v = 0.0;

@@ -152,7 +152,7 @@ __device__ inline void scat_model_request(const FitArgs& a, SubState& s) {
     // a looser tolerance: the certificate of every model evaluation is what guards the
     // result, and a lost bet costs the difference between the model pass and an ordinary
     // one, once (a subint gets a second chance under (a) only).
-    if (s.hits_boundary || s.nmodel > 0) return;
+    if (!a.model_bet || s.hits_boundary || s.nmodel > 0) return;
     double dn[5];
     for (int j = 0; j < 5; ++j) dn[j] = pnf[j] - pr[j];
     const double px = dphi_of(pr), prl = rel_of(pr), dx_ = dphi_of(dn), dr_ = rel_of(dn);
@@ -312,18 +312,21 @@ __device__ __forceinline__ void scat_model_sums(const double* row, size_t rs, do
 // The iterations on the model: one 256-thread block per subint whose model pass
 // just ran.  Every round evaluates f, g, H at the pending proposal s.xe from the
 // rows (the first round at the centre itself: exact), checks the certificate, and
-// lets thread 0 run the same step_logic as k_step.  An evaluation that fails the
-// certificate is left to the ordinary path (model = 3: no further model passes for
-// this subint).
+// lets thread 0 run the same step_logic as k_step.  All or nothing: either the whole
+// remaining iteration runs on the model (then the sums of the accepted point are
+// published for the post-fit stage), or -- an evaluation fails its certificate -- the
+// state the kernel was entered with is restored untouched and the ordinary path makes
+// this very evaluation over the cross-spectrum: a lost model pass changes nothing
+// but the time.
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_scat_model_solve(FitArgs a) {
     const int i = sub_of(a.act, blockIdx.x), tid = threadIdx.x;
     SubState& st = a.st[i];
     if (st.done || st.model != 1) return;
-    __shared__ SubState ss;
-    __shared__ double scratch[4 * (PP_NACC + 5)];
+    __shared__ SubState ss, ss_in;
+    __shared__ double scratch[4 * (PP_NACC + 6)];
     __shared__ int flag;
-    if (tid == 0) ss = st;
+    if (tid == 0) { ss = st; ss_in = st; }
     __syncthreads();
     const double P = a.P[i];
     const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1], nutau = a.nu_fit[i * 3 + 2];
@@ -340,17 +343,20 @@ __global__ __launch_bounds__(256) void k_scat_model_solve(FitArgs a) {
 #endif
     for (int round = 0;; ++round) {
         double xe[5];
-        for (int j = 0; j < 5; ++j) xe[j] = ss.xe[j];
-        const int trial = 1 - ss.cur;
+        // (after the iteration has ended: one more sweep at the accepted point, which
+        // only publishes its sums)
+        const bool publish = round > 0 && flag == 3;
+        for (int j = 0; j < 5; ++j) xe[j] = publish ? ss.x[j] : ss.xe[j];
+        const int outbuf = ss.cur;
         __syncthreads();
         const double tau_e = a.log10_tau ? pow(10.0, xe[3]) : xe[3];
         const double dlnt = a.log10_tau ? PP_LN10 * (xe[3] - xc[3]) : log(tau_e / tau_c);
         const double dal = xe[4] - xc[4];
         const double dph = xe[0] - xc[0], dDM = xe[1] - xc[1], dGM = xe[2] - xc[2];
-        double* csum = a.csum + ((size_t)trial * a.nsub + i) * a.nchan * a.ncs;
-        double acc[PP_NACC + 5];
+        double* csum = a.csum + ((size_t)outbuf * a.nsub + i) * a.nchan * a.ncs;
+        double acc[PP_NACC + 6];
 #pragma unroll
-        for (int j = 0; j < PP_NACC + 5; ++j) acc[j] = 0.0;
+        for (int j = 0; j < PP_NACC + 6; ++j) acc[j] = 0.0;
         bool inside = (tau_e > 0.0);
         for (int n = tid; n < a.nchan; n += 256) {
             const double w = wts[n];
@@ -377,9 +383,10 @@ __global__ __launch_bounds__(256) void k_scat_model_solve(FitArgs a) {
             const double d = dph + dDM * cg.p1 + dGM * cg.p2;
             double cs[PP_NCS];
             scat_model_sums(row, rs, d, eps, cs);
-            if (round > 0) {
+            if (publish) {
 #pragma unroll
                 for (int j = 0; j < PP_NCS; ++j) csum[(size_t)n * a.ncs + j] = cs[j];
+                continue;
             }
             if (w == 0.0) continue;
             const Local L = local_terms(cs, w);
@@ -406,12 +413,16 @@ __global__ __launch_bounds__(256) void k_scat_model_solve(FitArgs a) {
                 const double gp = 3.0 * w * r * e1 * kmax, gt = 3.0 * w * r * e1 * kb;
                 acc[PP_NACC] += gp; acc[PP_NACC + 1] += gp * fabs(cg.p1); acc[PP_NACC + 2] += gp * fabs(cg.p2);
                 acc[PP_NACC + 3] += gt * fabs(cg.q1); acc[PP_NACC + 4] += gt * fabs(cg.q2);
+                // ... and of f itself (no derivative: one order more, rho without its factor 2):
+                // SciPy's decisions hang on the last bits of f
+                acc[PP_NACC + 5] += 2.0 * w * r * W0 * series_tail(PP_MP + 1, x, 0.5 * rho) * fma(y, y, 1.0 + y);
             }
         }
 #ifdef PP_SOLVE_TIMING
         t1 = clock64(); tA += t1 - t0; t0 = t1;
 #endif
-        block_sum<PP_NACC + 5>(acc, scratch);
+        if (publish) break;
+        block_sum<PP_NACC + 6>(acc, scratch);
         if (tid == 0) flag = 0;
         __syncthreads();
         if (!inside) flag = 1;               // (any thread)
@@ -426,13 +437,25 @@ __global__ __launch_bounds__(256) void k_scat_model_solve(FitArgs a) {
 #pragma unroll
             for (int j = 0; j < 5; ++j)      // (static indices: acc stays in registers)
                 if (a.flags[j] && !(acc[PP_NACC + j] <= tol[j] * fabs(H[j * 5 + j]))) ok = false;
+            // f to a quarter of its last bit
+            if (!(acc[PP_NACC + 5] <= 0.25 * 2.220446049250313e-16 * fabs(f))) ok = false;
             if (!ok) {
-                // the ordinary path evaluates this proposal over X; one more model pass may
-                // be asked for later (criterion (a) only)
+                // back to the state of entry: the ordinary path evaluates the centre over X
+                // and goes on from there; one more model pass may be asked for later
+                // (criterion (a) only)
+                ss = ss_in;
                 ss.nmodel += 1;
-                ss.model = (ss.nmodel < 2) ? 0 : 3;
+                // (4 / 5: k_step of THIS iteration must leave the subint alone -- its
+                // evaluation has not been made, the partial sums are an older one's -- and
+                // turns the mark into 0 / 3)
+                ss.model = (ss.nmodel < 2) ? 4 : 5;
                 flag = 2;
             } else {
+#ifdef PP_STEP_TRACE
+                if (i == PP_STEP_TRACE)
+                    printf("mdl round %d it %2d f %.17g f_new %.17g actual %.3e pred %.3e radius %.3e  (f-bound %.2e ulp)\n", round,
+                           ss.iter, ss.f, f, ss.f - f, ss.pred_red, ss.radius, acc[PP_NACC + 5] / (2.220446049250313e-16 * fabs(f)));
+#endif
                 ss.model = 2;
                 const bool done = step_logic(a, ss, f, g, H);
                 ss.model = 1;
@@ -444,7 +467,8 @@ __global__ __launch_bounds__(256) void k_scat_model_solve(FitArgs a) {
         t1 = clock64(); tC += t1 - t0; t0 = t1;
         if (flag >= 2 && tid == 0 && i == 0) printf("solve i=0 rounds %d: loop %lld  sum %lld  logic %lld cycles\n", round + 1, tA, tB, tC);
 #endif
-        if (flag >= 2) break;
+        if (flag == 2) break;
+        // (flag == 3: the loop comes round once more to publish)
     }
     if (tid == 0) {
         if (ss.done) { ss.model = 3; atomicSub(a.nactive, 1); }

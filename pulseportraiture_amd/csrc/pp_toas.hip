@@ -97,6 +97,7 @@ struct pp_ctx {
     int moments_in_xspec = 1;   // fold the Taylor moments into k_xspec (mode 2) when it applies
     int scat_model = 1;         // scattering fits: closing iterations on the per-channel model (pp_scatmodel.h)
     double scat_model_tol = 1e-10;
+    int scat_model_bet = 1;
     int taylor_recentre = 1;    // one-pass flow: re-expansions about the tentative answer when the certificate fails
                                 // (0 = none; a second one rarely rescues what the first did not)
     int debug_poison = 0;       // fill the work buffers with NaN bit patterns before every batch (finds unwritten reads)
@@ -227,6 +228,7 @@ extern "C" int pp_set_option(pp_ctx* c, const char* name, double value) {
     else if (n == "paired_split") c->paired_split = (int)value;
     else if (n == "scat_model") c->scat_model = (int)value;
     else if (n == "scat_model_tol") c->scat_model_tol = value;
+    else if (n == "scat_model_bet") c->scat_model_bet = (int)value;
     else if (n == "fps_finish") c->fps_finish = (int)value;
     else if (n == "debug_poison") c->debug_poison = (int)value;
     else if (n == "taylor_recentre") c->taylor_recentre = (int)value;
@@ -656,7 +658,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.o_f0 = c->o_f0.as<double>(); fa.o_g0 = c->o_g0.as<double>(); fa.o_H0 = c->o_H0.as<double>();
     fa.o_rec = out->records_dev ? out->records_dev + (size_t)s0 * PP_RECORD_WIDTH : nullptr;
     fa.act = nullptr; fa.nact = ns; fa.nchan_x = C; fa.cstep = 1; fa.coff = 0;
-    fa.mdl = c->mdl.as<double>(); fa.use_model = smodel ? 1 : 0; fa.model_tol = c->scat_model_tol;
+    fa.mdl = c->mdl.as<double>(); fa.use_model = smodel ? 1 : 0; fa.model_tol = c->scat_model_tol; fa.model_bet = c->scat_model_bet;
     // (a GM fit walked the SciPy way ends where its path ends: it keeps the exact path; the
     // Newton solver converges to the optimum from anywhere)
     fa.recentre = (taylor && xmom && (!in->fit_flags[2] || in->method == PP_METHOD_NEWTON))

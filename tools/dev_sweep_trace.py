@@ -12,7 +12,7 @@ from pulseportraiture_amd.engine import Engine
 c = make_case(int(sys.argv[1]))
 print("case", c["k"], c["flags"], "log10", c["l10"], "C", c["C"], "nbin", c["nbin"], "option", c["option"])
 eng = Engine(0)
-eng.set_option("scat_model", 0)
+eng.set_option("scat_model", int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 eng.set_model(c["model"])
 kw = dict(errs=c["errs"][None], chan_mask=c["mask"][None], nu_fits=[[c["nu_fit"]] * 3],
           nu_outs=[[c["nu_fit"]] * 3], fit_flags=c["flags"], log10_tau=c["l10"], option=c["option"])
