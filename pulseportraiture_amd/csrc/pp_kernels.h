@@ -1546,7 +1546,9 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
     // (which start from st.xe, fresh = 1 as k_init_state left it).  Phase / DM fits only:
     // they end at the optimum whatever the path; a GM fit's exit point depends on it.
     if (!ok && tid == 0) {
-        bool fin = isfinite(dpath) && dpath < 0.25;
+        // (only from inside the model's nominal range: farther out the tentative answer may
+        // belong to another maximum of the correlation altogether)
+        bool fin = isfinite(dpath) && dpath < 0.02;
         for (int j = 0; j < 3; ++j) fin = fin && isfinite(dx[j]);
         if (st.recentred < a.recentre && fin) {
             for (int j = 0; j < 3; ++j) st.xe[j] += dx[j];
