@@ -48,6 +48,15 @@ for b in range(nb):
             kw = dict(errs=errs, chan_mask=masks, nu_fits=nuf, nu_outs=nuf, fit_flags=flags, log10_tau=l10,
                       method=method, seed_ns=seed_ns)
             whole = eng.fit_batch(data, freqs, Ps, x0, **kw)
+            # the same batch through the device in sub-batches of two or three subints
+            eng.set_option("max_work_bytes", 2.7 * C * nbin * 24)
+            try:
+                parts = eng.fit_batch(data, freqs, Ps, x0, **kw)
+            finally:
+                eng.set_option("max_work_bytes", 96e9)
+            dsub = np.abs(whole["params"] - parts["params"]).max()
+            wsub = worst.setdefault(("sub-batches", method, seed_ns), [0.0, 0, 0])
+            wsub[0] = max(wsub[0], dsub); wsub[1] += int((whole["nfeval"] != parts["nfeval"]).sum()); wsub[2] += N
             for i in range(N):
                 one = eng.fit_batch(data[i:i + 1], freqs, Ps[i:i + 1], x0[i:i + 1], errs=errs[i:i + 1],
                                     chan_mask=masks[i:i + 1], nu_fits=nuf[i:i + 1], nu_outs=nuf[i:i + 1],
