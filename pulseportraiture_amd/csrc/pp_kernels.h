@@ -580,6 +580,8 @@ __global__ void k_init_state(FitArgs a) {
     s.iter = 0; s.nfev = 0; s.status = PP_RC_MAXITER; s.done = 0; s.cur = 1; s.fresh = 1;
     s.model = 0; s.geo[0] = s.geo[1] = s.geo[2] = s.geo[3] = 0.0;
     s.recentred = 0; s.nmodel = 0;
+    for (int j = 0; j < 5; ++j) s.xl[j] = NAN;          // (no point evaluated yet)
+    s.fl = NAN;
     for (int j = 0; j < 5; ++j) s.xprev[j] = s.x[j];
     if (i == 0) *a.nactive = a.nsub;
 }

@@ -19,7 +19,8 @@ def make_case(k):
     rng = np.random.default_rng(90000 + k)
     flags, scat = FLAGS[k % len(FLAGS)]
     C = int(rng.integers(6, 48))
-    nbin = int(2 ** rng.integers(6, 11))
+    lo, hi = (int(v) for v in os.environ.get("PP_SWEEP_LOG2NBIN", "6,11").split(","))   # e.g. "11,14": 2048..8192
+    nbin = int(2 ** rng.integers(lo, hi))
     l10 = bool(rng.random() < 0.6) if scat else False
     tau_us = float(rng.uniform(15.0, 45.0)) if scat else None
     freqs, model = model_portrait(C, nbin)
