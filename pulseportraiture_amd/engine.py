@@ -5,6 +5,7 @@ reference-shaped single-subint functions in pptoaslib.py / pplib.py marshal
 into it.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -81,6 +82,11 @@ class Engine(object):
         _check(self._lib.pp_create(int(device), C.byref(ctx)), "pp_create")
         self._ctx = ctx
         self.device = int(device)
+        if os.environ.get("PP_DEBUG_POISON"):
+            # work buffers start every batch filled with NaN bit patterns: a kernel that reads
+            # what no kernel of the batch wrote shows up in the results (a poor man's
+            # sanitizer; run the GPU tests once with PP_DEBUG_POISON=255)
+            self.set_option("debug_poison", int(os.environ["PP_DEBUG_POISON"]))
         self._digests = {}      # slot -> content digest of the resident template
 
     def close(self):
