@@ -83,6 +83,7 @@ __device__ inline void scat_model_geometry(const FitArgs& a, int i, SubState& s)
     const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
     const double* wts = a.wts + (size_t)i * a.nchan;
     double m1 = 0.0, m2 = 0.0, m3 = 0.0;
+#pragma unroll 4
     for (int n = threadIdx.x; n < a.nchan; n += 64) {
         if (wts[n] == 0.0) continue;
         double p1, p2;
@@ -94,19 +95,27 @@ __device__ inline void scat_model_geometry(const FitArgs& a, int i, SubState& s)
     const int slot = a.slot ? a.slot[i] : 0;
     const double* msq = as_global(a.msq[slot]);
     const int* ktv = a.ktab ? as_global(a.ktab[slot]) : nullptr;
+    // 16 channels across the band at once: 4 lanes per channel, eight loads in flight per lane
     double keff = 0.0;
-    for (int n = 0; n < a.nchan; n += max(1, a.nchan / 16)) {
-        if (wts[n] == 0.0) continue;
-        const int ktn = ktv ? ktv[n] : a.Kt;
+    {
+        const int lane = threadIdx.x, cq = lane >> 2, q = lane & 3;
+        const int stride = max(1, a.nchan / 16), n = cq * stride;
         double w0 = 0.0, wp = 0.0;
-        for (int k = threadIdx.x; k < ktn; k += 64) {
-            const double m = sqrt(msq[(size_t)n * a.M + k]), kap = PP_TWO_PI * (double)(k + 1);
-            double kp = kap;
-            for (int q = 0; q < PP_MP; ++q) kp *= kap;
-            w0 += m; wp = fma(m, kp, wp);
+        if (n < a.nchan && wts[n] != 0.0) {
+            const int ktn = ktv ? ktv[n] : a.Kt;
+            const double* mrow = msq + (size_t)n * a.M;
+#pragma unroll 8
+            for (int k = q; k < ktn; k += 4) {
+                const double m = sqrt(mrow[k]), kap = PP_TWO_PI * (double)(k + 1);
+                double kp = kap;
+#pragma unroll
+                for (int qq = 0; qq < PP_MP; ++qq) kp *= kap;
+                w0 += m; wp = fma(m, kp, wp);
+            }
         }
-        w0 = group_sum<64>(w0); wp = group_sum<64>(wp);
-        if (w0 > 0.0) keff = fmax(keff, exp(log(wp / w0) / (double)(PP_MP + 1)));
+        w0 = group_sum<4>(w0); wp = group_sum<4>(wp);
+        if (w0 > 0.0) keff = exp(log(wp / w0) / (double)(PP_MP + 1));
+        keff = group_max<64>(keff);
     }
     if (threadIdx.x == 0) { s.geo[0] = m1; s.geo[1] = m2; s.geo[2] = m3; s.geo[3] = keff; }
 }
