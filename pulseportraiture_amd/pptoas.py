@@ -204,6 +204,25 @@ def _dededisperse(eng, port, d, ok_isubs):
                                 nu_DM=float(d.nu0))
 
 
+def _to_device_once(eng, port):
+    """Host portraits as a device tensor when they fit comfortably in free HBM (so that
+    two engine calls do not both pay the H->D copy); unchanged otherwise."""
+    try:
+        import torch
+    except ImportError:
+        return port
+    if torch.is_tensor(port) or not torch.cuda.is_available():
+        return port
+    a = np.asarray(port)
+    try:
+        free_b, _ = torch.cuda.mem_get_info(eng.device)
+        if a.nbytes * 2.5 > free_b:
+            return port
+        return torch.as_tensor(np.ascontiguousarray(a), device="cuda:%d" % eng.device)
+    except RuntimeError:
+        return port
+
+
 def _noise_rows(d, isubs):
     """noise_stds[isubs, 0] of a DataBunch, measured from the power spectrum
     (pplib.get_noise, what load_data stores: pplib.py:2727-2731) when the bunch was
@@ -505,6 +524,8 @@ class GetTOAs(object):
                 flags_per.append(tuple(fl))
             port = _dededisperse(eng, _take_subints(d.subints, ok_isubs), d, ok_isubs)
             if seed == 'reference':
+                # the portraits are read twice (seed, fit): hand them to the device once
+                port = _to_device_once(eng, port)
                 x0[:, 0] = self._reference_phase_seeds(eng, port, d, ok_isubs, mask, nu_fit_arr[:, 0],
                                                        DM_stored, tau_lin, nu_fit_arr[:, 2], fit_scat,
                                                        use_ird)
@@ -513,7 +534,13 @@ class GetTOAs(object):
             for fl in sorted(set(flags_per)):
                 sel = np.array([k for k, f in enumerate(flags_per) if f == fl])
                 # (all subints in one call is the normal case: no gather copy then)
-                psel = port if len(sel) == nok else np.ascontiguousarray(port[sel])
+                if len(sel) == nok:
+                    psel = port
+                elif hasattr(port, "is_cuda"):       # (device tensor: gather on the device)
+                    import torch
+                    psel = port[torch.as_tensor(sel, device=port.device)].contiguous()
+                else:
+                    psel = np.ascontiguousarray(port[sel])
                 r = eng.fit_batch(psel, d.freqs[ok_isubs][sel], d.Ps[ok_isubs][sel],
                                   x0[sel], errs=None if errs is None else errs[sel],
                                   nu_fits=nu_fit_arr[sel], nu_outs=nu_ref_arr[sel],
