@@ -476,7 +476,7 @@ def test_get_TOAs_matches_reference_caller(name):
         gt.instrumental_response_dict = gt.ird = {
             'DM': float(g["out_ird_DM"]), 'wids': [float(v) for v in g["out_ird_wids"]],
             'irf_types': [str(v) for v in g["out_ird_types"]]}
-    gt.get_TOAs(quiet=True, **kw)
+    gt.get_TOAs(quiet=True, seed='device', **kw)     # (the fast path: seed inside the fit, Newton solver)
     ok = g["out_ok_isubs"]
     np.testing.assert_array_equal(gt.ok_isubs[0], ok)
     hard = name in ("gettoas_GM", "gettoas_scat")
@@ -836,7 +836,7 @@ def test_get_TOAs_with_spline_model():
     data = data_from_arrays(sub, freqs, [P, P], [56000.0, 56000.1],
                             noise_stds=np.full((2, 1, C), sig), DM=DM0)
     gt = GetTOAs(data, path, quiet=True)
-    gt.get_TOAs(bary=False, quiet=True)
+    gt.get_TOAs(bary=False, quiet=True, seed='device')
     nu_fit = guess_fit_freq(freqs, np.ones(C))
     for i in range(2):
         # start the oracle at the device answer, referred to its fit frequency
@@ -1504,7 +1504,7 @@ def test_get_TOAs_of_a_dedispersed_bunch(eng):
     from pulseportraiture_amd.pptoas import GetTOAs
     g = _load("gettoas_phiDM")
     plain = GetTOAs(_gettoas_bunch(g), os.path.join(GOLDEN, "example.gmodel"), quiet=True)
-    plain.get_TOAs(quiet=True)
+    plain.get_TOAs(quiet=True, seed='device')
     # what PSRCHIVE's dedisperse() would have stored: every channel advanced by the
     # stored DM's delay relative to the centre frequency
     nsub = g["subints"].shape[0]
@@ -1512,7 +1512,7 @@ def test_get_TOAs_of_a_dedispersed_bunch(eng):
                                DM=np.full(nsub, float(g["scal_DM"])), nu_DM=float(g["scal_nu0"]))
     dd = GetTOAs(_gettoas_bunch(g, subints=ded[:, None], dmc=1),
                  os.path.join(GOLDEN, "example.gmodel"), quiet=True)
-    dd.get_TOAs(quiet=True)
+    dd.get_TOAs(quiet=True, seed='device')
     ok = plain.ok_isubs[0]
     # (a rotation keeps only the real part of the Nyquist harmonic, so the round trip
     # changes the data by one harmonic's worth of noise: agreement to a small
@@ -1536,7 +1536,7 @@ def test_callers_measure_the_noise_when_the_bunch_has_none():
     a = GetTOAs(_gettoas_bunch(g), os.path.join(GOLDEN, "example.gmodel"), quiet=True)
     b = GetTOAs(_gettoas_bunch(g, noise_stds=None), os.path.join(GOLDEN, "example.gmodel"), quiet=True)
     for gt in (a, b):
-        gt.get_TOAs(quiet=True)
+        gt.get_TOAs(quiet=True, seed='device')
         gt.get_channels_to_zap(SNR_threshold=8.0, rchi2_threshold=1.3, iterate=True)
     ok = a.ok_isubs[0]
     np.testing.assert_allclose(np.asarray(b.phi_errs[0])[ok], np.asarray(a.phi_errs[0])[ok], rtol=0.05)
@@ -2044,3 +2044,32 @@ def test_poor_dm_guesses_get_one_more_expansion_instead_of_evaluations(eng):
         np.testing.assert_allclose(r["param_errs"][:, :2], ref["param_errs"][:, :2], rtol=1e-6)
     np.testing.assert_allclose(r["obj_f"], loop["obj_f"], rtol=1e-12)
     np.testing.assert_allclose(r["obj_grad"], loop["obj_grad"], rtol=1e-7, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_get_TOAs_default_seed_on_the_other_caller_scenarios(eng):
+    """The default (seed='reference': the reference's own guesses + its trust-ncg) on a
+    dedispersed bunch, a bunch without noise_stds and a spline template: same TOAs as the
+    fast path (seed='device', Newton) to within SciPy's exit distance."""
+    from pulseportraiture_amd.pptoas import GetTOAs
+    g = _load("gettoas_phiDM")
+    nsub = g["subints"].shape[0]
+    ded = eng.rotate_portraits(np.ascontiguousarray(g["subints"][:, 0]), g["freqs"], g["Ps"],
+                               DM=np.full(nsub, float(g["scal_DM"])), nu_DM=float(g["scal_nu0"]))
+    bunches = {"dispersed": _gettoas_bunch(g), "dmc": _gettoas_bunch(g, subints=ded[:, None], dmc=1),
+               "no noise_stds": _gettoas_bunch(g, noise_stds=None)}
+    for name, bunch in bunches.items():
+        out = {}
+        for seed in ("reference", "device"):
+            gt = GetTOAs(bunch, os.path.join(GOLDEN, "example.gmodel"), quiet=True)
+            if seed == "reference":
+                gt.get_TOAs(quiet=True)                   # (the default)
+            else:
+                gt.get_TOAs(quiet=True, seed='device')
+            out[seed] = gt
+        ok = out["device"].ok_isubs[0]
+        np.testing.assert_array_equal(out["reference"].ok_isubs[0], ok)
+        for i in ok:
+            dt = (out["reference"].TOAs[0][i] - out["device"].TOAs[0][i]).in_days() * 86400.0
+            assert abs(dt) < 2e-9 * g["Ps"][i] + 1e-15, (name, i, dt)
+        assert np.abs(np.asarray(out["reference"].DMs[0])[ok] - np.asarray(out["device"].DMs[0])[ok]).max() < DM_BAR
