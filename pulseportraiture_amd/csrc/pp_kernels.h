@@ -61,6 +61,10 @@ struct XspecArgs {
     // (subint, channel) with row pitch nchan_full.
     const int* act;
     int cstep, coff, nchan_full;
+    // dynamic dealing of row chunks (RowWalk): a device counter that only grows, and
+    // its value when this launch started
+    unsigned* ticket;
+    unsigned ticket_base;
 };
 
 struct FitArgs {
@@ -181,6 +185,69 @@ __global__ void k_model_kcut(const cplx* mft, const double* mmax, int /*nchan*/,
 // TAIL: also measure the noise from the top quarter of the power spectrum
 // (errs == NULL).
 // --------------------------------------------------------------------------
+// Rows are dealt to the persistent grid in chunks of PP_ROW_CHUNK consecutive rows
+// (= subints of one channel): workgroup b starts with chunk b and draws every
+// further chunk from a device counter.  With equal shares per workgroup the two
+// waves of a SIMD do not finish together -- the SIMD issues its older wave first,
+// so that wave ran through its share in 13.9 ms and left the younger one alone for
+// the last 2.7 ms of 16.6 (tools/dev_xspec_stamps.py: ends bimodal, mean / max
+// 0.87-0.90), and the XCDs hold clocks 5 % apart.  Drawn on demand, every wave works
+// until the rows run out.  The ticket is drawn (lane 0, one returning atomic) at the
+// first row of a chunk and read where the last row of the chunk queues its prefetch:
+// everything older than that prefetch has landed by then, the atomic included.  The
+// counter is never reset: a launch consumes exactly one ticket per chunk, which the
+// host adds to the base it passes to the next launch (32 bits, wrapping: only the
+// difference is used).  The template row is re-read (L2) once per chunk.
+#ifndef PP_ROW_CHUNK
+#define PP_ROW_CHUNK 32
+#endif
+// DYN = false (workgroups of several waves: the ticket would have to cross waves):
+// chunk c goes to workgroup c mod G; the tickets are then not drawn at all.
+template <bool DYN>
+struct RowWalk {
+    long long row, row_nx, cstart, cend;
+    unsigned tick;     // lane 0: the ticket; kept per-lane (not uniform) so that it stays
+                       // in a VGPR and nothing waits for the atomic before next() reads it
+    bool more, more_nx;
+    __device__ __forceinline__ void start(long long nrows) {
+        cstart = (long long)blockIdx.x * PP_ROW_CHUNK;
+        cend = min(nrows, cstart + PP_ROW_CHUNK);
+        row = cstart;
+        more = row < nrows;
+        row_nx = row; more_nx = more;
+        tick = threadIdx.x;
+    }
+    // top of a row: draw the ticket of the chunk after this one
+    __device__ __forceinline__ void draw(unsigned* ticket) {
+        if (DYN && row == cstart && threadIdx.x == 0) tick = atomicAdd(ticket, 1u);
+    }
+    // (subint, channel) of the row after this one: the next of the chunk, or the
+    // first of the chunk the ticket names (one division per chunk, all scalar)
+    __device__ __forceinline__ void next(int i, int n, int& i_nx, int& n_nx, long long nrows, int nsub,
+                                         unsigned base) {
+        row_nx = row + 1;
+        i_nx = i + 1; n_nx = n;
+        if (i_nx == nsub) { i_nx = 0; ++n_nx; }
+        more_nx = true;
+        if (row_nx == cend) {
+            if (DYN) {
+                const unsigned t = __builtin_amdgcn_readfirstlane(tick) - base;
+                cstart = ((long long)gridDim.x + (long long)t) * PP_ROW_CHUNK;
+            } else {
+                cstart += (long long)gridDim.x * PP_ROW_CHUNK;
+            }
+            cend = min(nrows, cstart + PP_ROW_CHUNK);
+            row_nx = cstart;
+            more_nx = row_nx < nrows;
+            if (more_nx) {
+                n_nx = __builtin_amdgcn_readfirstlane((int)(row_nx / nsub));
+                i_nx = __builtin_amdgcn_readfirstlane((int)(row_nx % nsub));
+            }
+        }
+    }
+    __device__ __forceinline__ void advance() { row = row_nx; more = more_nx; }
+};
+
 #ifndef PP_SPLIT_U
 #define PP_SPLIT_U 4          // harmonics per thread processed together in the split loop
 #endif
@@ -207,8 +274,23 @@ __global__ void k_model_kcut(const cplx* mft, const double* mmax, int /*nchan*/,
 // MODE 2 requires 2 Kt < M (each thread then owns harmonics k only); MODE 3 is
 // the same for any Kt <= M: harmonic M-k is formed with k from the same two
 // transform outputs.
+#ifndef PP_XSPEC_STAMPS
+#define PP_XSPEC_STAMPS 0     // diagnostic builds: per-workgroup wall / shader clocks and placement
+#endif
+#if PP_XSPEC_STAMPS
+__device__ unsigned long long g_xspec_stamps[8192 * 6];
+#endif
 template <int M, typename Tin, bool TAIL, int MODE>
 __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void k_xspec(XspecArgs a) {
+#if PP_XSPEC_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        unsigned long long* st = g_xspec_stamps + 6 * blockIdx.x;
+        st[0] = __builtin_amdgcn_s_memrealtime();
+        st[2] = __builtin_amdgcn_s_memtime();
+        st[4] = __builtin_amdgcn_s_getreg((3 << 11) | 20);        // XCC_ID
+        st[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID
+    }
+#endif
     constexpr bool FUSE = (MODE != 0);
     constexpr bool M2 = (MODE == 2 || MODE == 3), PAIR = (MODE == 3);
     constexpr int T = FftPlan<M>::T, R1 = FftPlan<M>::R1, PER1 = FftPlan<M>::PER1;
@@ -233,11 +315,11 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
     // Each block takes a contiguous run of rows in (channel, subint) order: the
     // channel -- hence the template row -- changes once per nsub rows, and the
     // (subint, channel) indices advance without divisions.
-    const long long R = (nrows + gridDim.x - 1) / gridDim.x;
-    long long row = (long long)blockIdx.x * R;
-    const long long rend = min(nrows, row + R);
+    RowWalk<(NW == 1)> rw;
+    rw.start(nrows);
+    long long row = rw.row;
     int n = 0, i = 0;
-    if (row < rend) {
+    if (rw.more) {
         n = __builtin_amdgcn_readfirstlane((int)(row / a.nsub));
         i = __builtin_amdgcn_readfirstlane((int)(row % a.nsub));
         const size_t rc = (size_t)sub_of(a.act, i) * a.nchan_full + (a.coff + n * a.cstep);
@@ -253,9 +335,8 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
     cplx mc2[CRES ? KPT : 1];
     const cplx* mheld = nullptr;
     int i_nx = i, n_nx = n;
-    for (; row < rend; ++row, i = i_nx, n = n_nx) {
-        i_nx = i + 1; n_nx = n;
-        if (i_nx == a.nsub) { i_nx = 0; ++n_nx; }
+    for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
+        rw.draw(a.ticket);
         // Everything derived from the thread index and the twiddles is invariant
         // over this loop, and the compiler hoists all of it (LDS addresses of every
         // stage, twiddle powers: ~50 VGPRs held across the whole row).  Recomputing
@@ -278,13 +359,17 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const int k = tid + 1 + j * T;
-                // halved: the split below then forms 2 d_k without its factors 1/2
-                const cplx mk = (k <= ktn) ? mrow[k - 1] : make_double2(0.0, 0.0);
-                mv2[j] = make_double2(0.5 * mk.x, 0.5 * mk.y);
+                // halved: the split below then forms 2 d_k without its factors 1/2.
+                // (unconditional loads from a clamped index: loads under a branch are
+                // waited for one by one, and the row is re-read once per chunk of rows)
+                const cplx mk = mrow[min(k, M) - 1];
+                const double hk = (k <= ktn) ? 0.5 : 0.0;
+                mv2[j] = make_double2(hk * mk.x, hk * mk.y);
                 if (CRES) {
                     const int kp = M - k;
-                    const cplx mp = (kp <= ktn && kp != k && kp > 0) ? mrow[kp - 1] : make_double2(0.0, 0.0);
-                    mc2[j] = make_double2(0.5 * mp.x, 0.5 * mp.y);
+                    const cplx mp = mrow[max(kp, 1) - 1];
+                    const double hp = (kp <= ktn && kp != k && kp > 0) ? 0.5 : 0.0;
+                    mc2[j] = make_double2(hp * mp.x, hp * mp.y);
                 }
             }
             mheld = mrow;
@@ -320,7 +405,8 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         // every use of an earlier load, because on the path without it no younger
         // loads exist)
         {
-            const size_t rn = (row + 1 < rend)
+            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base);
+            const size_t rn = rw.more_nx
                 ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
             stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);
         }
@@ -529,6 +615,13 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         }
         lds_sync<T>();
     }
+#if PP_XSPEC_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        unsigned long long* st = g_xspec_stamps + 6 * blockIdx.x;
+        st[1] = __builtin_amdgcn_s_memrealtime();
+        st[3] = __builtin_amdgcn_s_memtime();
+    }
+#endif
 }
 
 }  // namespace pp

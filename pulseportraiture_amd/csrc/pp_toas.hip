@@ -82,6 +82,8 @@ struct pp_ctx {
     // work buffers
     DevBuf data, X, sdraw, noise, wts, freqs, errs, mask, P, x0, nufit, nuout, slot, state, csum, partial;
     std::map<const void*, int> occ_cache;   // resident workgroups per CU, by kernel
+    DevBuf ticket;                          // k_xspec's chunk counter (RowWalk); never reset,
+    unsigned ticket_base = 0;               // ... its value before the next launch (wraps)
     int ncu = 0;                            // compute units of the device
     DevBuf o_pack;   // per-subint scalar outputs, one allocation -> one D2H copy
     void* o_host = nullptr; size_t o_host_cap = 0;   // pinned staging of o_pack
@@ -158,6 +160,9 @@ static int ctx_init(pp_ctx* c) {
         if (rc) return rc;
         HIP_TRY(hipMemset(t->p, 0, sizeof(void*) * PP_MAX_SLOTS));
     }
+    int rc = c->ticket.reserve(64);
+    if (rc) return rc;
+    HIP_TRY(hipMemset(c->ticket.p, 0, 64));
     return PP_OK;
 }
 
@@ -193,7 +198,7 @@ extern "C" int pp_destroy(pp_ctx* c) {
     for (auto& kv : c->twiddles) kv.second.release();
     for (auto& s : c->slots) { s.mft.release(); s.msum.release(); s.mmax.release(); s.mdc.release(); s.kt.release(); s.msq.release(); }
     if (c->o_host) (void)hipHostFree(c->o_host);
-    DevBuf* bufs[] = {&c->o_pack, &c->mft_table, &c->msum_table, &c->kt_table, &c->mdc_table, &c->msq_table, &c->data, &c->X, &c->sdraw, &c->noise, &c->wts, &c->freqs,
+    DevBuf* bufs[] = {&c->ticket, &c->o_pack, &c->mft_table, &c->msum_table, &c->kt_table, &c->mdc_table, &c->msq_table, &c->data, &c->X, &c->sdraw, &c->noise, &c->wts, &c->freqs,
                       &c->errs, &c->mask, &c->P, &c->x0, &c->nufit, &c->nuout, &c->slot, &c->state, &c->csum,
                       &c->partial, &c->o_params, &c->o_errs, &c->o_nu, &c->o_cov, &c->o_chi2, &c->o_rchi2,
                       &c->o_snr, &c->o_nfev, &c->o_rc, &c->o_scales, &c->o_serrs, &c->o_csnr, &c->o_f0, &c->o_g0,
@@ -458,9 +463,14 @@ static int resident_grid(pp_ctx* c, K kernel, int T, long long nrows, int fallba
 }
 
 template <int MM, typename TIN>
-static void launch_xspec(pp_ctx* c, const XspecArgs& xa, bool tail, int mode) {
+static void launch_xspec(pp_ctx* c, const XspecArgs& xa_in, bool tail, int mode) {
     const int T = FftPlan<MM>::T;
-    const long long nrows = (long long)xa.nsub * xa.nchan;
+    const long long nrows = (long long)xa_in.nsub * xa_in.nchan;
+    // one ticket per chunk of rows is drawn by the launch (RowWalk)
+    XspecArgs xa = xa_in;
+    xa.ticket = c->ticket.as<unsigned>();
+    xa.ticket_base = c->ticket_base;
+    if (T == 64) c->ticket_base += (unsigned)((nrows + PP_ROW_CHUNK - 1) / PP_ROW_CHUNK);
     const dim3 blk(T);
     if constexpr (MM == 1024 && sizeof(TIN) == 4) {
         // 2048-bin rows whose template keeps fewer than 512 harmonics: last stage
@@ -989,3 +999,12 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
 }
 
 #include "pp_extra_api.h"
+
+#if PP_XSPEC_STAMPS
+// diagnostic builds only: the stamps of the last k_xspec launch (6 words per workgroup)
+extern "C" int pp_debug_xspec_stamps(unsigned long long* out, int nwg) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp::g_xspec_stamps), sizeof(unsigned long long) * 6 * (size_t)nwg)
+               == hipSuccess ? 0 : -1;
+}
+#endif

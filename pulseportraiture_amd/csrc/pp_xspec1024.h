@@ -65,11 +65,11 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
     int tid = threadIdx.x;
     const long long nrows = (long long)a.nsub * a.nchan;
     Raw cur[PER1][R1];
-    const long long R = (nrows + gridDim.x - 1) / gridDim.x;
-    long long row = (long long)blockIdx.x * R;
-    const long long rend = min(nrows, row + R);
+    RowWalk<true> rw;
+    rw.start(nrows);
+    long long row = rw.row;
     int n = 0, i = 0;
-    if (row < rend) {
+    if (rw.more) {
         n = __builtin_amdgcn_readfirstlane((int)(row / a.nsub));
         i = __builtin_amdgcn_readfirstlane((int)(row % a.nsub));
         const size_t rc = (size_t)i * a.nchan + n;
@@ -79,9 +79,8 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
     cplx mA[NS], mB[NS];
     const cplx* mheld = nullptr;
     int i_nx = i, n_nx = n;
-    for (; row < rend; ++row, i = i_nx, n = n_nx) {
-        i_nx = i + 1; n_nx = n;
-        if (i_nx == a.nsub) { i_nx = 0; ++n_nx; }
+    for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
+        rw.draw(a.ticket);
         if (PP_OPAQUE_ROW == 1 || (PP_OPAQUE_ROW == 2 && M2)) asm volatile("" : "+v"(tid));
         // stage twiddles are re-read every row (three L1-resident loads, issued before
         // the prefetch) instead of living in 12 registers through the harmonic phase,
@@ -101,10 +100,12 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
                 const int ka = tid + 128 * j, kb = tb + 128 * j;
-                const cplx ma = (ka >= 1 && ka <= ktn) ? mrow[ka - 1] : make_double2(0.0, 0.0);
-                const cplx mb = (kb <= ktn) ? mrow[kb - 1] : make_double2(0.0, 0.0);
-                mA[j] = make_double2(0.5 * ma.x, 0.5 * ma.y);
-                mB[j] = make_double2(0.5 * mb.x, 0.5 * mb.y);
+                // (unconditional loads from clamped indices: see k_xspec)
+                const cplx ma = mrow[max(ka, 1) - 1];
+                const cplx mb = mrow[min(kb, M) - 1];
+                const double ha = (ka >= 1 && ka <= ktn) ? 0.5 : 0.0, hb = (kb <= ktn) ? 0.5 : 0.0;
+                mA[j] = make_double2(ha * ma.x, ha * ma.y);
+                mB[j] = make_double2(hb * mb.x, hb * mb.y);
             }
             mheld = mrow;
         }
@@ -125,7 +126,8 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
         __builtin_amdgcn_sched_barrier(0);
 #endif
         {
-            const size_t rn = (row + 1 < rend) ? (size_t)i_nx * a.nchan + n_nx : rc;
+            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base);
+            const size_t rn = rw.more_nx ? (size_t)i_nx * a.nchan + n_nx : rc;
             stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);
         }
 #if PP_SB_PREFETCH
