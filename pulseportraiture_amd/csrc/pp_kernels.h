@@ -359,18 +359,14 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const int k = tid + 1 + j * T;
-                // halved: the split below then forms 2 d_k without its factors 1/2.
-                // (unconditional loads from a clamped index: loads under a branch are
-                // waited for one by one, and the row is re-read once per chunk of rows)
-                const cplx mk = mrow[min(k, M) - 1];
-                const double hk = (k <= ktn) ? 0.5 : 0.0;
-                mv2[j] = make_double2(hk * mk.x, hk * mk.y);
-                if (CRES) {
-                    const int kp = M - k;
-                    const cplx mp = mrow[max(kp, 1) - 1];
-                    const double hp = (kp <= ktn && kp != k && kp > 0) ? 0.5 : 0.0;
-                    mc2[j] = make_double2(hp * mp.x, hp * mp.y);
-                }
+                // Unconditional loads from a clamped index, and no arithmetic on them
+                // here: the row is re-read once per chunk of rows, loads under a branch
+                // are waited for one by one, and anything computed from them now would
+                // wait in front of the transform.  The split forms 2 d_k (its factors
+                // 1/2 are applied to the 12 sums at the end -- exact) and skips the
+                // harmonics beyond ktn itself.
+                mv2[j] = mrow[min(k, M) - 1];
+                if (CRES) mc2[j] = mrow[max(M - k, 1) - 1];
             }
             mheld = mrow;
         }
@@ -522,7 +518,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                         if (kp <= ktn && kp != k) {
                             cplx mp;
                             if (CRES) mp = mc2[j];
-                            else { const cplx t = mrow[kp - 1]; mp = make_double2(0.5 * t.x, 0.5 * t.y); }
+                            else mp = mrow[kp - 1];
                             const cplx xp = cmulc(make_double2(E.x - wo.y, -E.y - wo.x), mp);
                             taylor_sums(xp, cmul(xp, cmulc(eM, e)), PP_TWO_PI * (double)kp);
                         }
@@ -534,7 +530,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             if (PAIR && ktn == M && tid == 0) {
                 // Nyquist harmonic: d_M = Re Z_0 - Im Z_0
                 const cplx z0 = lds[0], mM = mrow[M - 1];
-                const double dM = z0.x - z0.y;
+                const double dM = 2.0 * (z0.x - z0.y);     // (the sums are halved at the end)
                 const cplx x = make_double2(dM * mM.x, -dM * mM.y);
                 taylor_sums(x, cmul(x, eM), PP_TWO_PI * (double)M);
             }
@@ -600,6 +596,8 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             const int q = wave_reduce16_index(tid);
             if (q < PP_TSTRIDE) {
                 // Re(i^q z): +Re, -Im, -Re, +Im, ...
+                // (x 1/2: the template values were used unhalved against 2 d_k)
+                tv *= 0.5;
                 a.tay[rc * PP_TSTRIDE + q] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
             }
         }
