@@ -298,7 +298,12 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
     constexpr int NW = T / 64;
     typedef typename RawOf<Tin>::type Raw;
     // the image doubles as scratch of the MODE 2 reduction (one region per wave)
-    constexpr int WRED = PP_WRED_DOUBLES(PP_TSTRIDE) / 2;   // in cplx
+    // one wave per row: S_d and the noise tail ride along with the 12 Taylor sums in
+    // the one reduction through LDS (no chain of 6 dependent lane exchanges each)
+    constexpr bool RIDE = M2 && NW == 1;
+    constexpr int NRED = RIDE ? PP_TSTRIDE + (TAIL ? 2 : 1) : PP_TSTRIDE;
+    static_assert(NRED <= 16, "wave_reduce_lds takes 16 values");
+    constexpr int WRED = PP_WRED_DOUBLES(NRED) / 2;   // in cplx
     constexpr int LDSN = (M2 && NW * WRED > FftPlan<M>::LDS_ELEMS) ? NW * WRED : FftPlan<M>::LDS_ELEMS;
     __shared__ cplx lds[LDSN];
     __shared__ double red[(M2 ? 16 : 5) * NW + 4];
@@ -497,14 +502,28 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                     for (int q = T; q < M; q <<= 1) eM = cmul(eM, eM);
                 }
             }
+            // The two transform outputs of slot j + 1 are read (unconditionally: the
+            // addresses stay inside the image) before slot j is worked on, so that the
+            // LDS round trip of every slot but the first hides under arithmetic.
+            // (Not with the noise tail or the paired harmonics: the 8 registers of the
+            // look-ahead spill there, and those slots are read in place.)
+            constexpr bool AHEAD = !TAIL && !PAIR;
+            // (rows shorter than two harmonics per lane: lanes beyond M/2 read slot 0 of lane 0)
+            constexpr bool INSIDE = (KPT * T <= M);
+            const cplx* pk0 = (INSIDE || tid + 1 <= M / 2) ? pk : lds + lds_pad<PL>(1);
+            const cplx* pc0 = (INSIDE || tid + 1 <= M / 2) ? pc : lds + lds_pad<PL>(M - 1);
+            cplx zk_nx = pk0[0], zc_nx = pc0[0];
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const int k = tid + 1 + j * T;
+                const cplx zk = (!AHEAD && j > 0) ? pk0[j * JS] : zk_nx;
+                cplx zc = (!AHEAD && j > 0) ? pc0[-j * JS] : zc_nx;
+                if (j + 1 < KPT) {
+                    if (AHEAD) { zk_nx = pk0[(j + 1) * JS]; zc_nx = pc0[-(j + 1) * JS]; }
+                }
                 // (pairs: k runs to M/2 only -- the upper half comes as partners;
                 // matters when M/2 is not a multiple of the block size)
                 if (k <= ktn && (!PAIR || 2 * k <= M)) {
-                    const cplx zk = pk[j * JS];
-                    cplx zc = pc[-j * JS];
                     zc.y = -zc.y;
                     const cplx E = make_double2(zk.x + zc.x, zk.y + zc.y);
                     const cplx O = make_double2(zk.x - zc.x, zk.y - zc.y);
@@ -561,11 +580,20 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                 if (MODE == 1) e = cmul(e, wst);
             }
         }
-        sd = group_sum<64>(sd);
-        if (TAIL) tail = group_sum<64>(tail);
+        if (!RIDE) {
+            sd = group_sum<64>(sd);
+            if (TAIL) tail = group_sum<64>(tail);
+        }
         if (MODE == 1) { s0 = group_sum<64>(s0); s1 = group_sum<64>(s1); s2 = group_sum<64>(s2); }
         double tv = 0.0;
-        if (M2) {
+        if (RIDE) {
+            double tr[NRED];
+#pragma unroll
+            for (int j = 0; j < PP_TSTRIDE; ++j) tr[j] = tm[j];
+            tr[PP_TSTRIDE] = sd;
+            if (TAIL) tr[NRED - 1] = tail;
+            tv = wave_reduce_lds(tr, tid, reinterpret_cast<double*>(lds));
+        } else if (M2) {
             if (NW > 1) lds_sync<T>();   // other waves may still read the transform
             tv = wave_reduce_lds(tm, tid & 63, reinterpret_cast<double*>(lds + (tid >> 6) * WRED));
         }
@@ -601,7 +629,11 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                 a.tay[rc * PP_TSTRIDE + q] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
             }
         }
-        if (tid == 0) {
+        if (RIDE) {
+            // lane quads 12 and 13 hold the totals of S_d and of the tail
+            if (tid == 4 * PP_TSTRIDE) a.sdraw[rc] = tv;
+            if (TAIL && tid == 4 * (PP_TSTRIDE + 1)) a.noise[rc] = sqrt(tv / (2.0 * M) / (double)(H - kc));
+        } else if (tid == 0) {
             a.sdraw[rc] = sd;
             if (TAIL) a.noise[rc] = sqrt(tail / (2.0 * M) / (double)(H - kc));
             if (MODE == 1) {
