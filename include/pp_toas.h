@@ -111,6 +111,11 @@ void* pp_stream(pp_ctx* ctx);
  *   "paired_split" 1 (default) = 2048-bin rows whose template keeps fewer than 512
  *                  harmonics take the transform kernel that does the last FFT stage
  *                  and the even/odd split in registers; 0 = the generic kernel
+ *   "one_exchange" 1 (default) = 2048-bin rows whose template keeps fewer than 512
+ *                  harmonics, fitted without scattering and with the noise given, take the
+ *                  transform kernel whose FFT crosses the LDS once (lane-swap first
+ *                  exchange) and whose split reads only the partner harmonics;
+ *                  0 = the kernels above
  *   "scat_model"   scattering fits: 1 (default) = once the trust-ncg iteration is
  *                  predicted to stay within its range, ONE more pass over the
  *                  cross-spectrum leaves a degree-8 polynomial model of every channel's

@@ -62,28 +62,38 @@ __device__ __forceinline__ double recip_ge1(double x) {
 // reduction, then Taylor polynomials on |y| <= 1/8 (truncation < 1e-19; a few
 // rounding errors of 2^-53).  A third of the instructions of the library
 // sincospi, whose own range reduction is redundant after ours.
+// A constant held in a scalar register pair: the compiler otherwise builds every
+// 64-bit literal in VGPRs (two v_mov_b32 per use, on the f64-bound VALU); the
+// scalar moves issue beside the vector instructions and a VOP3 takes one SGPR operand.
+template <bool SC>
+__device__ __forceinline__ double kconst(double v) {
+    if (SC) asm volatile("" : "+s"(v));
+    return v;
+}
+// SC: polynomial coefficients from scalar registers (k_xspec: -30 VALU per row)
+template <bool SC = false>
 __device__ __forceinline__ void sincos_turns(double t, double* sn, double* cs) {
     const double q = rint(4.0 * t);
     const double y = fma(-0.25, q, t);          // exact
     const double u = y * y;
-    double ps = 0x1.aaec32af93359p-4;
-    ps = fma(ps, u, -0x1.6fadb9f155744p-1);
-    ps = fma(ps, u, 0x1.e8f434d018d63p+1);
-    ps = fma(ps, u, -0x1.e3074fde8871fp+3);
-    ps = fma(ps, u, 0x1.50783487ee782p+5);
-    ps = fma(ps, u, -0x1.32d2cce62bd86p+6);
-    ps = fma(ps, u, 0x1.466bc6775aae2p+6);
-    ps = fma(ps, u, -0x1.4abbce625be53p+5);
-    ps = fma(ps, u, 0x1.921fb54442d18p+2);
+    double ps = kconst<SC>(0x1.aaec32af93359p-4);
+    ps = fma(ps, u, kconst<SC>(-0x1.6fadb9f155744p-1));
+    ps = fma(ps, u, kconst<SC>(0x1.e8f434d018d63p+1));
+    ps = fma(ps, u, kconst<SC>(-0x1.e3074fde8871fp+3));
+    ps = fma(ps, u, kconst<SC>(0x1.50783487ee782p+5));
+    ps = fma(ps, u, kconst<SC>(-0x1.32d2cce62bd86p+6));
+    ps = fma(ps, u, kconst<SC>(0x1.466bc6775aae2p+6));
+    ps = fma(ps, u, kconst<SC>(-0x1.4abbce625be53p+5));
+    ps = fma(ps, u, kconst<SC>(0x1.921fb54442d18p+2));
     const double s0 = ps * y;
-    double pc = 0x1.20c62c2f2d7f5p-2;
-    pc = fma(pc, u, -0x1.b6e24f44b128fp+0);
-    pc = fma(pc, u, 0x1.f9d38a3763cc3p+2);
-    pc = fma(pc, u, -0x1.a6d1f2a204a8cp+4);
-    pc = fma(pc, u, 0x1.e1f506891babbp+5);
-    pc = fma(pc, u, -0x1.55d3c7e3cbffap+6);
-    pc = fma(pc, u, 0x1.03c1f081b5ac4p+6);
-    pc = fma(pc, u, -0x1.3bd3cc9be45dep+4);
+    double pc = kconst<SC>(0x1.20c62c2f2d7f5p-2);
+    pc = fma(pc, u, kconst<SC>(-0x1.b6e24f44b128fp+0));
+    pc = fma(pc, u, kconst<SC>(0x1.f9d38a3763cc3p+2));
+    pc = fma(pc, u, kconst<SC>(-0x1.a6d1f2a204a8cp+4));
+    pc = fma(pc, u, kconst<SC>(0x1.e1f506891babbp+5));
+    pc = fma(pc, u, kconst<SC>(-0x1.55d3c7e3cbffap+6));
+    pc = fma(pc, u, kconst<SC>(0x1.03c1f081b5ac4p+6));
+    pc = fma(pc, u, kconst<SC>(-0x1.3bd3cc9be45dep+4));
     const double c0 = fma(pc, u, 1.0);
     const int qi = (int)q;
     const bool odd = qi & 1;
@@ -95,6 +105,7 @@ __device__ __forceinline__ void sincos_turns(double t, double* sn, double* cs) {
 // exp(2 pi i k phi) with the product reduced modulo 1 before the sincos:
 // k*phi is formed exactly (fma residual), so large non-dedispersed phase
 // shifts do not lose the fraction.
+template <bool SC = false>
 __device__ __forceinline__ cplx unit_phasor(double k, double phi) {
     double pfrac = phi - rint(phi);          // exact
     double prod = k * pfrac;
@@ -102,7 +113,7 @@ __device__ __forceinline__ cplx unit_phasor(double k, double phi) {
     double r = (prod - rint(prod)) + err;
     double s, c;
 #if PP_FAST_SINCOS
-    sincos_turns(r, &s, &c);
+    sincos_turns<SC>(r, &s, &c);
 #else
     sincospi(2.0 * r, &s, &c);
 #endif

@@ -62,13 +62,19 @@ __device__ __forceinline__ void dft_reg<8>(cplx (&v)[8]) {
     v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
 }
 
-template <>
-__device__ __forceinline__ void dft_reg<16>(cplx (&v)[16]) {
-    const double c1 = 0.92387953251128673848, s1 = 0.38268343236508978178;
-    const double h = 0.70710678118654752440;
+// The radix-16 butterfly in two halves.  After the first (the four column DFT4s) none
+// of the 16 inputs is live any more: a caller that streams rows can queue the next
+// row's loads into those registers there, a quarter of the way into the stage,
+// instead of after its twiddles and stores (k_xspec: the wave then has a row of HBM
+// loads in flight for all but ~60 instructions of every row).
+__device__ __forceinline__ void dft16_first(cplx (&v)[16]) {
     // F_q[j2] = DFT4 over m of v[4m + q]   (stored back in v[4*j2 + q])
 #pragma unroll
     for (int q = 0; q < 4; ++q) dft4(v[q], v[4 + q], v[8 + q], v[12 + q]);
+}
+__device__ __forceinline__ void dft16_second(cplx (&v)[16]) {
+    const double c1 = 0.92387953251128673848, s1 = 0.38268343236508978178;
+    const double h = 0.70710678118654752440;
     // twiddle v[4*j2 + q] *= W16^(q*j2)
     const cplx w1 = make_double2(c1, -s1), w2 = make_double2(h, -h), w3 = make_double2(s1, -c1);
     const cplx w6 = make_double2(-h, -h), w9 = make_double2(-c1, s1);
@@ -94,6 +100,16 @@ __device__ __forceinline__ void dft_reg<16>(cplx (&v)[16]) {
             v[4 * b + a] = t;
         }
 }
+template <>
+__device__ __forceinline__ void dft_reg<16>(cplx (&v)[16]) {
+    dft16_first(v);
+    dft16_second(v);
+}
+
+// "nothing to do in the middle of the stage"
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+template <typename F> struct IsNoMid { static constexpr bool value = false; };
+template <> struct IsNoMid<NoMid> { static constexpr bool value = true; };
 
 template <int PADLOG>
 __device__ __forceinline__ int lds_pad(int i) { return i + (i >> PADLOG); }
@@ -191,9 +207,11 @@ __device__ __forceinline__ void stage_load_lds(cplx (&v)[PER][R], const cplx* ld
 // butterflies + inter-stage twiddles + in-place write + LDS sync.
 // tw[i] = W_M^(t - t%S) of this thread's i-th butterfly (unused in the last
 // stage): loop-invariant per thread, so callers hoist it out of their row loop.
-template <int M, int T, int R, int S, int PADLOG, int PER, typename TW, bool TREE = false>
+// mid(): called once, as soon as the stage's input registers are dead (after the first
+// half of a single radix-16 butterfly, else after the last butterfly).
+template <int M, int T, int R, int S, int PADLOG, int PER, typename TW, bool TREE = false, typename Mid = NoMid>
 __device__ __forceinline__ void stage_finish(cplx (&v)[PER][R], cplx* lds, const TW& tw, int tid,
-                                             double* power = nullptr) {
+                                             double* power = nullptr, Mid mid = Mid()) {
     constexpr int NBF = StageGeom<M, T, R>::NBF;
     static_assert(PER == StageGeom<M, T, R>::PER, "register tile does not match the stage");
     constexpr bool LAST = (S * R == M);
@@ -201,7 +219,15 @@ __device__ __forceinline__ void stage_finish(cplx (&v)[PER][R], cplx* lds, const
     for (int i = 0; i < PER; ++i) {
         const int t = tid + T * i;
         if (NBF % T == 0 || t < NBF) {
-            dft_reg<R>(v[i]);
+            if constexpr (R == 16 && PER == 1 && !IsNoMid<Mid>::value) {
+                dft16_first(v[i]);
+                mid();
+                dft16_second(v[i]);
+            } else {
+                dft_reg<R>(v[i]);
+                // (only where every lane runs the butterfly: mid() is wave-uniform work)
+                if constexpr (!IsNoMid<Mid>::value && NBF % T == 0) { if (i == PER - 1) mid(); }
+            }
             const int q = t & (S - 1);
             const int ob = q + S * R * (t / S);
             if constexpr (!LAST) {
@@ -272,6 +298,7 @@ __device__ __forceinline__ void stage_finish(cplx (&v)[PER][R], cplx* lds, const
             }
         }
     }
+    if constexpr (!IsNoMid<Mid>::value && NBF % T != 0) mid();
     lds_sync<T>();
 }
 
@@ -360,12 +387,12 @@ __device__ __forceinline__ void opaque_twiddles(RowTwiddles<M>& tw) {
 
 // first stage from registers (TREE: twiddle powers by the product tree -- fewer
 // multiplications, a few more registers; for callers with registers to spare there)
-template <int M, bool TREE = false, int PER1_, int R1_>
+template <int M, bool TREE = false, int PER1_, int R1_, typename Mid = NoMid>
 __device__ __forceinline__ void fft_first_stage(cplx* lds, cplx (&v)[PER1_][R1_], const RowTwiddles<M>& tw,
-                                                int tid) {
+                                                int tid, Mid mid = Mid()) {
     typedef FftPlan<M> P;
     static_assert(PER1_ == P::PER1 && R1_ == P::R1, "first-stage tile mismatch");
-    stage_finish<M, P::T, P::R1, 1, P::PADLOG, PER1_, decltype(tw.t1), TREE>(v, lds, tw.t1, tid);
+    stage_finish<M, P::T, P::R1, 1, P::PADLOG, PER1_, decltype(tw.t1), TREE, Mid>(v, lds, tw.t1, tid, nullptr, mid);
 }
 
 // the remaining stages, LDS to LDS

@@ -264,6 +264,9 @@ struct RowWalk {
 #ifndef PP_SB_LATE
 #define PP_SB_LATE 1
 #endif
+#ifndef PP_PREFETCH_MID
+#define PP_PREFETCH_MID 1       // next row's loads queued inside the first stage (0: after it)
+#endif
 #ifndef PP_OPAQUE_ROW
 #define PP_OPAQUE_ROW 2         // 0 never, 1 always, 2 only in MODE 2 (register-bound)
 #endif
@@ -385,6 +388,26 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             for (int ii = 0; ii < PER1; ++ii)
 #pragma unroll
                 for (int k = 0; k < R1; ++k) v[ii][k] = to_cplx(cur[ii][k]);
+            // The next row's HBM loads are queued as soon as this row's registers are
+            // dead -- after the first quarter of the first stage, not after its twiddles
+            // and stores: a wave has one row in flight, and whatever part of a row's time
+            // it spends with nothing in flight the memory system idles for
+            // (unconditional -- the last row of the run fetches itself again: a prefetch
+            // under a branch makes the compiler drain the whole queue, vmcnt(0), before
+            // every use of an earlier load, because on the path without it no younger
+            // loads exist)
+            auto prefetch = [&]() {
+#if PP_SB_PREFETCH
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base);
+                const size_t rn = rw.more_nx
+                    ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
+                stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);
+#if PP_SB_PREFETCH
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            };
 #if PP_XSPEC_ABLATE == 1
             double keep = 0.0;
 #pragma unroll
@@ -392,28 +415,16 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
 #pragma unroll
                 for (int k = 0; k < R1; ++k) keep += v[ii][k].x * v[ii][k].y;
             if (keep == 1.2345e300) a.sdraw[0] = keep;
+            prefetch();
+#else
+#if PP_PREFETCH_MID
+            fft_first_stage<M, M2>(lds, v, tw, tid, prefetch);
 #else
             fft_first_stage<M, M2>(lds, v, tw, tid);
+            prefetch();
+#endif
 #endif
         }
-#if PP_SB_PREFETCH
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        // the first stage has consumed the row: its registers now receive the
-        // NEXT row, whose HBM loads stay in flight under the rest of this one
-        // (unconditional -- the last row of the run fetches itself again: a prefetch
-        // under a branch makes the compiler drain the whole queue, vmcnt(0), before
-        // every use of an earlier load, because on the path without it no younger
-        // loads exist)
-        {
-            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base);
-            const size_t rn = rw.more_nx
-                ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
-            stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);
-        }
-#if PP_SB_PREFETCH
-        __builtin_amdgcn_sched_barrier(0);
-#endif
 #if PP_XSPEC_ABLATE == 1 || PP_XSPEC_ABLATE == 2
         lds_sync<T>();
         continue;
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             // e^{2 pi i (tid+1) phi}: one sincos per lane (k = lane+1); lane 63
             // holds e^{2 pi i 64 phi}, whose powers give the wave offset and the
             // per-iteration step e^{2 pi i T phi}
-            const cplx el = unit_phasor((double)((tid & 63) + 1), phin);
+            const cplx el = unit_phasor<true>((double)((tid & 63) + 1), phin);
             const cplx w64 = make_double2(__shfl(el.x, 63, 64), __shfl(el.y, 63, 64));
             e = el;
             for (int q = 0; q < (tid >> 6); ++q) e = cmul(e, w64);
@@ -473,12 +484,39 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             const cplx* pk = lds + lds_pad<PL>(tid + 1);
             const cplx* pc = lds + lds_pad<PL>(M - 1 - tid);
             setup_phasors();
+            // One wave per row and a template cut that is a multiple of 64 (k_model_kcut):
+            // a slot of 64 harmonics is kept or dropped as a whole -- a scalar branch, no
+            // per-lane compare / exec mask --, slot 0 is always kept and starts the sums
+            // (no zeroing), and kappa_k = 2 pi (lane + 1) + 2 pi 64 j takes one addition
+            // of a scalar constant instead of a conversion and a product.
+            constexpr bool UNI = (T == 64) && (M >= 64) && !PAIR;
+            const int ktu = UNI ? __builtin_amdgcn_readfirstlane(ktn) : 0;
+            const double kap0 = PP_TWO_PI * (double)(tid + 1);
+            if (!UNI) {
 #pragma unroll
-            for (int j = 0; j < PP_TSTRIDE; ++j) tm[j] = 0.0;
+                for (int j = 0; j < PP_TSTRIDE; ++j) tm[j] = 0.0;
+            }
             // kappa^2, ^4 .. ^10 once per harmonic; every sum is then one FMA
-            auto taylor_sums = [&](const cplx& x, const cplx& z, double kap) {
+            // (first: the sums start from this harmonic)
+            auto taylor_sums = [&](const cplx& x, const cplx& z, double kap, bool first) {
                 const double p2 = kap * kap, p4 = p2 * p2, p6 = p4 * p2, p8 = p4 * p4, p10 = p8 * p2;
                 const double ui = z.y * kap;
+                const double ax = fabs(x.x) + fabs(x.y);
+                if (first) {
+                    tm[0] = z.x;
+                    tm[1] = ui;
+                    tm[2] = p2 * z.x;
+                    tm[3] = p2 * ui;
+                    tm[4] = p4 * z.x;
+                    tm[5] = p4 * ui;
+                    tm[6] = p6 * z.x;
+                    tm[7] = p6 * ui;
+                    tm[8] = p8 * z.x;
+                    tm[9] = p8 * ui;
+                    tm[10] = p10 * z.x;
+                    tm[11] = (p10 * kap) * ax;
+                    return;
+                }
                 tm[0] += z.x;
                 tm[1] += ui;
                 tm[2] = fma(p2, z.x, tm[2]);
@@ -490,7 +528,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                 tm[8] = fma(p8, z.x, tm[8]);
                 tm[9] = fma(p8, ui, tm[9]);
                 tm[10] = fma(p10, z.x, tm[10]);
-                tm[11] = fma(p10 * kap, fabs(x.x) + fabs(x.y), tm[11]);
+                tm[11] = fma(p10 * kap, ax, tm[11]);
             };
             cplx eM = wst;     // e^{2 pi i M phi}: the partner of e_k is eM conj(e_k)
             if (PAIR) {
@@ -523,14 +561,17 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                 }
                 // (pairs: k runs to M/2 only -- the upper half comes as partners;
                 // matters when M/2 is not a multiple of the block size)
-                if (k <= ktn && (!PAIR || 2 * k <= M)) {
+                const bool keep = UNI ? (j == 0 || j * T < ktu) : (k <= ktn && (!PAIR || 2 * k <= M));
+                if (keep) {
                     zc.y = -zc.y;
                     const cplx E = make_double2(zk.x + zc.x, zk.y + zc.y);
                     const cplx O = make_double2(zk.x - zc.x, zk.y - zc.y);
                     const cplx wo = cmul(wb, O);
                     // 2 d_k = E - i W^k O
                     const cplx x = cmulc(make_double2(E.x + wo.y, E.y - wo.x), mv2[j]);
-                    taylor_sums(x, cmul(x, e), PP_TWO_PI * (double)k);
+                    const double kap = !UNI ? PP_TWO_PI * (double)k
+                                            : (j == 0 ? kap0 : kap0 + kconst<true>(PP_TWO_PI * (double)(j * T)));
+                    taylor_sums(x, cmul(x, e), kap, UNI && j == 0);
                     if (PAIR) {
                         // 2 d_{M-k} = conj(E) - i conj(W^k O)   (W^{M-k} = -conj W^k)
                         const int kp = M - k;
@@ -539,7 +580,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                             if (CRES) mp = mc2[j];
                             else mp = mrow[kp - 1];
                             const cplx xp = cmulc(make_double2(E.x - wo.y, -E.y - wo.x), mp);
-                            taylor_sums(xp, cmul(xp, cmulc(eM, e)), PP_TWO_PI * (double)kp);
+                            taylor_sums(xp, cmul(xp, cmulc(eM, e)), PP_TWO_PI * (double)kp, false);
                         }
                     }
                 }
@@ -551,7 +592,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                 const cplx z0 = lds[0], mM = mrow[M - 1];
                 const double dM = 2.0 * (z0.x - z0.y);     // (the sums are halved at the end)
                 const cplx x = make_double2(dM * mM.x, -dM * mM.y);
-                taylor_sums(x, cmul(x, eM), PP_TWO_PI * (double)M);
+                taylor_sums(x, cmul(x, eM), PP_TWO_PI * (double)M, false);
             }
         }
         for (int kb = 1 + tid; !M2 && kb <= ktn; kb += PP_SPLIT_U * T) {
@@ -656,6 +697,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
 
 }  // namespace pp
 #include "pp_xspec1024.h"
+#include "pp_xspec1024q.h"
 namespace pp {
 
 // plain rFFT of rows (parity hook): out[row][0..M] complex

@@ -105,6 +105,7 @@ struct pp_ctx {
     int debug_poison = 0;       // fill the work buffers with NaN bit patterns before every batch (finds unwritten reads)
     int fps_finish = 0;         // pp_fit_phase_shift_batch: 0 = Newton polish, 1 = SciPy brute's simplex finish
     int paired_split = 1;       // 2048-bin rows: last FFT stage + split in registers (k_xspec_p1024)
+    int one_exchange = 1;       // 2048-bin rows, mode 2, noise given: one-exchange FFT (k_xspec_q1024)
     int seed_chan_stride = 16;  // device phase seed: pilot pass over every n-th channel (1 = all channels)
     double seed_min_snr = 8.0;  // pilot seeds below this peak significance are redone from all channels
     int seed_ndm = 1;           // DM trials of the coarse (phi, DM) seed grid (1 = phase only, at the guessed DM)
@@ -231,6 +232,7 @@ extern "C" int pp_set_option(pp_ctx* c, const char* name, double value) {
     else if (n == "taylor") c->use_taylor = (int)value;
     else if (n == "moments_in_xspec") c->moments_in_xspec = (int)value;
     else if (n == "paired_split") c->paired_split = (int)value;
+    else if (n == "one_exchange") c->one_exchange = (int)value;
     else if (n == "scat_model") c->scat_model = (int)value;
     else if (n == "scat_model_tol") c->scat_model_tol = value;
     else if (n == "scat_model_bet") c->scat_model_bet = (int)value;
@@ -472,6 +474,15 @@ static void launch_xspec(pp_ctx* c, const XspecArgs& xa_in, bool tail, int mode)
     xa.ticket_base = c->ticket_base;
     if (T == 64) c->ticket_base += (unsigned)((nrows + PP_ROW_CHUNK - 1) / PP_ROW_CHUNK);
     const dim3 blk(T);
+    if constexpr (MM == 1024) {
+        // 2048-bin rows, Taylor sums only, noise given: the one-exchange transform
+        // (pp_xspec1024q.h) -- a third of the LDS traffic of the general kernel
+        if (c->one_exchange && mode == 2 && !tail && 2 * xa.Kt < MM) {
+            const dim3 grid(resident_grid(c, k_xspec_q1024<TIN>, T, nrows, fft_grid(T, nrows)));
+            hipLaunchKernelGGL((k_xspec_q1024<TIN>), grid, blk, 0, c->stream, xa);
+            return;
+        }
+    }
     if constexpr (MM == 1024 && sizeof(TIN) == 4) {
         // 2048-bin rows whose template keeps fewer than 512 harmonics: last stage
         // and split in registers (pp_xspec1024.h)

@@ -1,0 +1,252 @@
+// k_xspec for 2048-bin rows whose template keeps fewer than 512 harmonics (MODE 2,
+// noise given): the benchmark shape, built on the one-exchange FFT of pp_fftq.h.
+//
+// Same contract as k_xspec<1024, Tin, false, 2> (pp_kernels.h).  What differs is the
+// path of the row through the LDS, which is the unit this kernel saturates (one LDS
+// per CU, eight resident rows; see pp_fftq.h):
+//
+//   k_xspec          stage-1 store, stage-2 load + store, stage-3 load + store,
+//                    split loads (k and M - k)                    110 ds_*_b128 per row
+//   this kernel      one 16 x 16 transpose (16 + 16), then the split reads only the
+//                    PARTNERS: lane t ends with Z[lam + 64 kd] in register kd and works
+//                    on harmonics k = lam + 64 j (j = 0..6) -- Z_k is already in its
+//                    registers; Z_{M-k} = Z[(64 - lam) + 64 (15 - j)] sits in register
+//                    15 - j of the lane that owns 64 - lam, so every lane publishes its
+//                    registers 9..15 and reads seven values back     46 per row
+//
+// The lane that owns lam = 0 has no harmonic 0 to work on (F0_fact = 0): it takes
+// k = 64 (j + 1) instead, from its registers 1..7, and is its own partner.  Both
+// exchanges are free of bank conflicts: the transpose writes with a pitch of 17
+// elements and reads contiguously; the partner map sends every aligned group of eight
+// lanes to eight lanes with distinct low three bits.
+#pragma once
+#include "pp_fftq.h"
+
+namespace pp {
+
+#ifndef PP_Q_ABLATE
+#define PP_Q_ABLATE 0      // timing experiments: 1 = no row loads, 2 = row loads only
+#endif
+#ifndef PP_Q_SPLIT_PREFETCH
+#define PP_Q_SPLIT_PREFETCH 1    // f64 rows: the next row is fetched in two halves
+#endif
+#ifndef PP_Q_TW_RELOAD
+#define PP_Q_TW_RELOAD 1       // f64 rows only
+#endif
+#ifndef PP_Q_PREFETCH_F64
+#define PP_Q_PREFETCH_F64 1     // where the next row's loads are queued (fftq1024's WHEN)
+#endif
+#ifndef PP_Q_PREFETCH_F32
+#define PP_Q_PREFETCH_F32 0
+#endif
+template <typename Tin>
+__global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
+    constexpr int M = 1024, T = 64, R1 = 16, PER1 = 1;
+    constexpr int NSL = 7;                     // slots: 2 Kt < M  ->  k <= 448 = 64 * 7
+    typedef typename RawOf<Tin>::type Raw;
+    constexpr int NRED = PP_TSTRIDE + 1;       // the 12 Taylor sums and S_d
+    static_assert(NRED <= 16, "wave_reduce_lds takes 16 values");
+    static_assert(PP_TJ == 10, "power ladder written for order 10");
+    constexpr int WRED = PP_WRED_DOUBLES(NRED) / 2;   // in cplx
+    constexpr int LDSN = WRED > FFTQ_LDS_ELEMS ? WRED : FFTQ_LDS_ELEMS;
+    __shared__ cplx lds[LDSN];
+    int tid = threadIdx.x;
+    const long long nrows = (long long)a.nsub * a.nchan;
+    Raw cur[PER1][R1];
+    // stage twiddles: W_1024^tid, W_64^(tid & 15)
+    // f64 rows re-read them every row (three L1-resident loads, older than the prefetch)
+    // instead of holding 12 registers through the whole row: with them held, three of the
+    // template values spill to scratch, and a scratch reload queues BEHIND the prefetched
+    // row (vector memory returns in order) -- the split then waits for the next row's HBM
+    // data (15.1 -> 14.1 ms per 1024 fits)
+    constexpr bool TWR = PP_Q_TW_RELOAD && sizeof(Tin) == 8;
+    cplx t1 = a.twB[2 * tid], t2 = a.twB[32 * (tid & 15)];
+    // this lane's harmonics k = kb + 64 j; split twiddle W_B^kb, stepped by W_B^64
+    const int lam0 = fftq_lambda(tid);
+    cplx wb0 = a.twB[lam0 ? lam0 : 64];
+    const cplx wbT = a.twB[64];
+    RowWalk<true> rw;
+    rw.start(nrows);
+    long long row = rw.row;
+    int n = 0, i = 0;
+    if (rw.more) {
+        n = __builtin_amdgcn_readfirstlane((int)(row / a.nsub));
+        i = __builtin_amdgcn_readfirstlane((int)(row % a.nsub));
+        const size_t rc = (size_t)sub_of(a.act, i) * a.nchan_full + (a.coff + n * a.cstep);
+        stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rc * (2 * M), tid);
+    }
+    // this lane's template values (unhalved: the sums are halved at the end), reloaded
+    // when the channel changes
+    cplx mv2[NSL];
+    const cplx* mheld = nullptr;
+    int i_nx = i, n_nx = n;
+    for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
+        rw.draw(a.ticket);
+        // (everything derived from the lane number is recomputed per row: held across
+        // the row it would cost the registers the prefetched row needs)
+        asm volatile("" : "+v"(tid));
+        const int lam = fftq_lambda(tid);
+        const bool l0 = (lam == 0);
+        const int kb = l0 ? 64 : lam;
+        if (TWR) {
+            t1 = as_global(a.twB)[2 * tid];
+            t2 = as_global(a.twB)[32 * (tid & 15)];
+            wb0 = as_global(a.twB)[kb];
+        } else {
+            asm volatile("" : "+v"(t1.x), "+v"(t1.y), "+v"(t2.x), "+v"(t2.y), "+v"(wb0.x), "+v"(wb0.y));
+        }
+        const int ia = sub_of(a.act, i), ne = a.coff + n * a.cstep;   // true subint, channel
+        const size_t rc = (size_t)ia * a.nchan_full + ne;
+        // loads whose results are needed late are issued before the prefetch (vector
+        // memory returns in order)
+        const cplx* mrow = as_global(a.slot ? a.mft[a.slot[ia]] : a.mft0) + (size_t)ne * M;
+        const int ktn = a.ktab ? as_global(a.slot ? a.ktab[a.slot[ia]] : a.kt0)[ne] : a.Kt;
+        if (mrow != mheld) {
+#pragma unroll
+            for (int j = 0; j < NSL; ++j) mv2[j] = mrow[kb + 64 * j - 1];   // k <= 448: inside the row
+            mheld = mrow;
+        }
+        const double phin = a.ph0[rc];
+        double sd = 0.0;
+        cplx v[R1];
+#pragma unroll
+        for (int k = 0; k < R1; ++k) v[k] = to_cplx(cur[0][k]);
+        // the next row's HBM loads are queued as soon as this row's registers are dead
+        // (unconditional: the last row of the run fetches itself again, see k_xspec)
+        // f64 rows: in two halves -- eight registers' worth inside the first stage, the
+        // rest once the second half of this row's outputs has been published: with the
+        // whole next row in flight from the start, 64 + 64 row registers on top of the
+        // template row and the sums do not fit the 256 of two waves per SIMD
+        constexpr bool HALVES = PP_Q_SPLIT_PREFETCH && sizeof(Tin) == 8;
+        const Tin* nxrow = nullptr;
+        auto load_some = [&](int k0, int k1) {
+            const char* gb = reinterpret_cast<const char*>(nxrow);
+            const unsigned boff = (unsigned)tid * (unsigned)sizeof(Raw);
+#pragma unroll
+            for (int k = 0; k < R1; ++k)
+                if (k >= k0 && k < k1)
+                    cur[0][k] = *reinterpret_cast<const Raw*>(gb + (size_t)(k * 64) * sizeof(Raw) + boff);
+        };
+        auto prefetch = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base);
+            const size_t rn = rw.more_nx
+                ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
+            nxrow = reinterpret_cast<const Tin*>(a.data) + rn * (2 * M);
+#if PP_Q_ABLATE == 1
+            // timing experiment: no HBM traffic, the same row again (made opaque)
+#pragma unroll
+            for (int k = 0; k < R1; ++k) asm volatile("" : "+v"(cur[0][k].x), "+v"(cur[0][k].y));
+            if (rn == 0x7fffffffffffull) a.sdraw[0] = 0.0;
+#else
+            load_some(0, HALVES ? R1 / 2 : R1);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#if PP_Q_ABLATE == 2
+        // timing experiment: the loads and nothing else
+        {
+            double keep = 0.0;
+#pragma unroll
+            for (int k = 0; k < R1; ++k) keep += v[k].x * v[k].y;
+            if (keep == 1.2345e300) a.sdraw[0] = keep;
+            prefetch();
+            continue;
+        }
+#endif
+        fftq1024<(sizeof(Tin) == 8 ? PP_Q_PREFETCH_F64 : PP_Q_PREFETCH_F32)>(v, lds, t1, t2, tid, &sd, prefetch);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- partners through LDS: registers 9..15 out, seven values back ----
+        {
+            cplx* pub = lds + tid;
+#pragma unroll
+            for (int s = 0; s < NSL; ++s) pub[64 * s] = v[9 + s];
+            lds_sync<T>();
+        }
+#if PP_Q_ABLATE != 1
+        if (HALVES) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_some(R1 / 2, R1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+        const cplx* pc = lds + fftq_lane_of((64 - lam) & 63);   // slot j: register 15 - j -> pc[64 (6 - j)]
+        // ---- phasors: e^{2 pi i kb phi}; lane 0 (kb = 64) holds the step ----
+        const cplx el = unit_phasor<true>((double)kb, phin);
+        const cplx wst = make_double2(bcast_lane0(el.x), bcast_lane0(el.y));
+        cplx e = el, wb = wb0;
+        const int ktu = __builtin_amdgcn_readfirstlane(ktn);
+        const double kap0 = PP_TWO_PI * (double)kb;
+        double tm[PP_TSTRIDE];
+        cplx zc_nx = pc[64 * 6];
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            cplx zc = zc_nx;
+            if (j + 1 < NSL) zc_nx = pc[64 * (5 - j)];
+            // the template cut is a multiple of 64: a slot is kept or dropped as a whole
+            if (j == 0 || 64 * j < ktu) {
+                const cplx zk = csel(l0, v[j + 1], v[j]);
+                zc.y = -zc.y;
+                const cplx E = make_double2(zk.x + zc.x, zk.y + zc.y);
+                const cplx O = make_double2(zk.x - zc.x, zk.y - zc.y);
+                const cplx wo = cmul(wb, O);
+                // 2 d_k = E - i W^k O
+                const cplx x = cmulc(make_double2(E.x + wo.y, E.y - wo.x), mv2[j]);
+                const cplx z = cmul(x, e);
+                const double kap = j == 0 ? kap0 : kap0 + kconst<true>(PP_TWO_PI * (double)(64 * j));
+                // kappa^2, ^4 .. ^10 once per harmonic; every sum is then one FMA
+                const double p2 = kap * kap, p4 = p2 * p2, p6 = p4 * p2, p8 = p4 * p4, p10 = p8 * p2;
+                const double ui = z.y * kap;
+                const double ax = fabs(x.x) + fabs(x.y);
+                if (j == 0) {
+                    tm[0] = z.x;
+                    tm[1] = ui;
+                    tm[2] = p2 * z.x;
+                    tm[3] = p2 * ui;
+                    tm[4] = p4 * z.x;
+                    tm[5] = p4 * ui;
+                    tm[6] = p6 * z.x;
+                    tm[7] = p6 * ui;
+                    tm[8] = p8 * z.x;
+                    tm[9] = p8 * ui;
+                    tm[10] = p10 * z.x;
+                    tm[11] = (p10 * kap) * ax;
+                } else {
+                    tm[0] += z.x;
+                    tm[1] += ui;
+                    tm[2] = fma(p2, z.x, tm[2]);
+                    tm[3] = fma(p2, ui, tm[3]);
+                    tm[4] = fma(p4, z.x, tm[4]);
+                    tm[5] = fma(p4, ui, tm[5]);
+                    tm[6] = fma(p6, z.x, tm[6]);
+                    tm[7] = fma(p6, ui, tm[7]);
+                    tm[8] = fma(p8, z.x, tm[8]);
+                    tm[9] = fma(p8, ui, tm[9]);
+                    tm[10] = fma(p10, z.x, tm[10]);
+                    tm[11] = fma(p10 * kap, ax, tm[11]);
+                }
+            }
+            wb = cmul(wb, wbT);
+            e = cmul(e, wst);
+        }
+        // ---- the 12 sums and S_d: one reduction through LDS ----
+        double tr[NRED];
+#pragma unroll
+        for (int j = 0; j < PP_TSTRIDE; ++j) tr[j] = tm[j];
+        tr[PP_TSTRIDE] = sd;
+        lds_sync<T>();      // (the partner reads are older than the reduction's writes)
+        double tv = wave_reduce_lds(tr, tid, reinterpret_cast<double*>(lds));
+        if ((tid & 3) == 0) {
+            const int q = wave_reduce16_index(tid);
+            if (q < PP_TSTRIDE) {
+                // Re(i^q z): +Re, -Im, -Re, +Im, ...   (x 1/2: unhalved template against 2 d_k)
+                tv *= 0.5;
+                a.tay[rc * PP_TSTRIDE + q] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
+            }
+        }
+        if (tid == 4 * PP_TSTRIDE) a.sdraw[rc] = tv;
+        lds_sync<T>();
+    }
+}
+
+}  // namespace pp

@@ -2073,3 +2073,51 @@ def test_get_TOAs_default_seed_on_the_other_caller_scenarios(eng):
             dt = (out["reference"].TOAs[0][i] - out["device"].TOAs[0][i]).in_days() * 86400.0
             assert abs(dt) < 2e-9 * g["Ps"][i] + 1e-15, (name, i, dt)
         assert np.abs(np.asarray(out["reference"].DMs[0])[ok] - np.asarray(out["device"].DMs[0])[ok]).max() < DM_BAR
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_one_exchange_transform_matches_general_kernel_and_oracle(dtype):
+    """2048-bin rows, (phi, DM), noise given: the one-exchange transform kernel
+    (k_xspec_q1024: lane-swap first exchange, split from the partners only) against
+    the general kernel (option one_exchange=0) on the same batch -- every output --
+    and against the CPU oracle on one subint.  512 channels keep the oracle quick; the
+    batch spans several row chunks and two template cuts' worth of slots."""
+    import torch
+    from oracle import pptoas_oracle as orc
+    from pulseportraiture_amd.engine import Engine
+    from pulseportraiture_amd import gmodel
+    from pulseportraiture_amd.pplib import guess_fit_freq, Dconst
+    C, B, nsub = 512, 2048, 40
+    e = Engine(0)
+    freqs, model, P0 = gmodel.example_model(C, B)
+    e.set_model(model)
+    rng = np.random.default_rng(2048)
+    P = np.full(nsub, P0)
+    inj = np.zeros((nsub, 3))
+    inj[:, 0] = rng.uniform(-0.5, 0.5, nsub)
+    inj[:, 1] = 34.56789 + rng.normal(3e-4, 2e-4, nsub)
+    data = torch.empty((nsub, C, B), dtype=torch.float64 if dtype == "f64" else torch.float32, device="cuda:0")
+    e.synth_portraits(data, freqs, P, inj, 0.05, 20260102, 0)
+    nu_fit = float(guess_fit_freq(freqs))
+    x0 = np.zeros((nsub, 5))
+    x0[:, 0] = (inj[:, 0] + Dconst * inj[:, 1] / P / nu_fit ** 2 + 1e-4 * rng.standard_normal(nsub) + 0.5) % 1.0 - 0.5
+    x0[:, 1] = 34.56789
+    errs = np.full((nsub, C), 0.05)
+    kw = dict(errs=errs, nu_fits=np.full((nsub, 3), nu_fit), fit_flags=[1, 1, 0, 0, 0])
+    e.set_option("profile", 1)
+    e.set_option("one_exchange", 0)
+    a = e.fit_batch(data, freqs, P, x0, **kw)
+    e.set_option("one_exchange", 1)
+    b = e.fit_batch(data, freqs, P, x0, **kw)
+    assert (b["return_code"] == 2).all() and (b["nfeval"] == 1).all()
+    assert np.max(np.abs((a["params"][:, 0] - b["params"][:, 0] + 0.5) % 1.0 - 0.5)) < PHI_BAR
+    assert np.max(np.abs(a["params"][:, 1] - b["params"][:, 1])) < DM_BAR
+    np.testing.assert_allclose(b["param_errs"][:, :2], a["param_errs"][:, :2], rtol=1e-9)
+    np.testing.assert_allclose(b["chi2"], a["chi2"], rtol=1e-11)
+    np.testing.assert_allclose(b["snr"], a["snr"], rtol=1e-11)
+    np.testing.assert_allclose(b["scales"], a["scales"], rtol=1e-7, atol=1e-9)
+    o = orc.fit_portrait_full(data[3].double().cpu().numpy(), model, x0[3], P[3], freqs, [nu_fit] * 3,
+                              [None] * 3, errs[3], [1, 1, 0, 0, 0], log10_tau=False)
+    assert _dphi(b["params"][3, 0], o.phi) < PHI_BAR and abs(b["params"][3, 1] - o.DM) < DM_BAR
+    np.testing.assert_allclose(b["chi2"][3], o.chi2, rtol=1e-10)
+    np.testing.assert_allclose(b["scales"][3], o.scales, rtol=1e-7, atol=1e-9)
