@@ -264,6 +264,104 @@ __global__ __launch_bounds__(FftPlan<M>::T) void k_rot_mean(RotMeanArgs a) {
     if (tid == 0) a.wpart[(size_t)i * a.nrun + run] = wsum;
 }
 
+// k_rot_mean for 2048-bin rows on the one-exchange FFT (pp_fftq.h): lane t ends with
+// Z[lam + 64 kd] in register kd and accumulates harmonics k = lam + 64 kd (kd = 0..15;
+// the lane that owns lam = 0 also takes the Nyquist harmonic).  The even/odd split needs
+// Z_{M-k} = Z[(64 - lam) + 64 (15 - kd)]: every lane publishes its 16 registers and reads
+// 16 values of its partner lane -- 64 LDS instructions per row where the Stockham plan
+// takes 130.
+template <typename Tio>
+__global__ __launch_bounds__(64, 2) void k_rot_mean_q1024(RotMeanArgs a) {
+    constexpr int M = 1024, T = 64, R1 = 16;
+    typedef typename RawOf<Tio>::type Raw;
+    __shared__ cplx lds[FFTQ_LDS_ELEMS];
+    int tid = threadIdx.x;
+    const int i = blockIdx.x / a.nrun, run = blockIdx.x % a.nrun;
+    const double P = a.P[i];
+    const double* wrow = a.w + (size_t)i * a.nchan;
+    const Tio* base = reinterpret_cast<const Tio*>(a.src) + (size_t)i * a.nchan * (2 * M);
+    cplx acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = make_double2(0.0, 0.0);
+    double accN = 0.0, wsum = 0.0;
+    const int n0 = run * a.cpr, n1 = min(a.nchan, n0 + a.cpr);
+    // next channel of non-zero weight at or after n (n1 if none)
+    auto next_good = [&](int n) { while (n < n1 && wrow[n] == 0.0) ++n; return n; };
+    const cplx wbT = a.twB[64];
+    Raw cur[1][R1];
+    int n = next_good(n0);
+    if (n < n1) stage_load_global<M, T, R1>(cur, base + (size_t)n * (2 * M), tid);
+    while (n < n1) {
+        asm volatile("" : "+v"(tid));
+        const int lam = fftq_lambda(tid);
+        const bool l0 = (lam == 0);
+        // twiddles re-read per row (L1-resident, older than the prefetch)
+        const cplx t1 = as_global(a.twB)[2 * tid], t2 = as_global(a.twB)[32 * (tid & 15)];
+        const cplx wb0 = as_global(a.twB)[lam];
+        const double w = wrow[n];
+        wsum += w;
+        const double nu = a.freqs[(size_t)i * a.freqs_stride + n];
+        const double a2 = 1.0 / (nu * nu);
+        const double phin = a.par[i * 3] + PP_DCONST * a.par[i * 3 + 1] * (a2 - a.inv_nuDM2) / P +
+                            PP_DCONST * PP_DCONST * a.par[i * 3 + 2] * (a2 * a2 - a.inv_nuGM4) / P;
+        cplx v[R1];
+#pragma unroll
+        for (int k = 0; k < R1; ++k) v[k] = to_cplx(cur[0][k]);
+        const int nn = next_good(n + 1);
+        auto prefetch = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            stage_load_global<M, T, R1>(cur, base + (size_t)(nn < n1 ? nn : n) * (2 * M), tid);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        fftq1024<1>(v, lds, t1, t2, tid, nullptr, prefetch);
+        // ---- partners through LDS ----
+        {
+            cplx* pub = lds + tid;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) pub[64 * s] = v[s];
+            lds_sync<T>();
+        }
+        // slot kd reads register 15 - kd of the partner lane; the lane that owns lam = 0 is
+        // its own partner and reads its register 16 - kd (kd >= 1)
+        const cplx* pc = lds + fftq_lane_of((64 - lam) & 63) + (l0 ? 64 : 0);
+        // e^{2 pi i lam phi}; lane 0 computes the step e^{2 pi i 64 phi} instead and starts from 1
+        const cplx el = unit_phasor<true>(l0 ? 64.0 : (double)lam, phin);
+        const cplx wst = make_double2(bcast_lane0(el.x), bcast_lane0(el.y));
+        cplx e = l0 ? make_double2(1.0, 0.0) : el;
+        cplx wb = wb0;
+        const cplx z0 = v[0];      // (lane 0: Z_0)
+#pragma unroll
+        for (int kd = 0; kd < 16; ++kd) {
+            const cplx zk = v[kd];
+            cplx zc = pc[64 * (15 - kd)];
+            zc.y = -zc.y;
+            const cplx E = make_double2(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
+            const cplx O = make_double2(0.5 * (zk.x - zc.x), 0.5 * (zk.y - zc.y));
+            const cplx wo = cmul(wb, O);
+            cplx y = cmul(make_double2(E.x + wo.y, E.y - wo.x), e);
+            if (kd == 0) {
+                // harmonic 0 of lane 0: d_0 = Re Z_0 + Im Z_0
+                y.x = l0 ? z0.x + z0.y : y.x;
+                y.y = l0 ? 0.0 : y.y;
+            }
+            acc[kd].x = fma(w, y.x, acc[kd].x);
+            acc[kd].y = fma(w, y.y, acc[kd].y);
+            wb = cmul(wb, wbT);
+            e = cmul(e, wst);
+        }
+        // Nyquist (lane 0; e is now e^{2 pi i 1024 phi} there): real part only, as irfft keeps it
+        accN = fma(w, (z0.x - z0.y) * e.x, accN);
+        lds_sync<T>();          // the image is rewritten by the next row
+        n = nn;
+    }
+    cplx* out = a.part + ((size_t)i * a.nrun + run) * (M + 1);
+    const int lam = fftq_lambda(tid);
+#pragma unroll
+    for (int kd = 0; kd < 16; ++kd) out[lam + 64 * kd] = acc[kd];
+    if (lam == 0) out[M] = make_double2(accN, 0.0);
+    if (tid == 0) a.wpart[(size_t)i * a.nrun + run] = wsum;
+}
+
 // mean spectrum of every subint: sum of its runs / summed weights -> spec[i][0..M]
 __global__ void k_rot_mean_finish(const cplx* part, const double* wpart, int nsub, int nrun, int M, cplx* spec) {
     const int i = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -131,7 +131,11 @@ extern "C" int pp_reference_phase_seed(pp_ctx* c, const void* src, int dtype, in
         Prof pr(c, KF_FPS);
         PP_DISPATCH_M(M, {
             const int T = FftPlan<MM>::T;
-            if (dtype == PP_F64) hipLaunchKernelGGL((k_rot_mean<MM, double>), dim3(nsub * nrun), dim3(T), 0, c->stream, ra);
+            if (MM == 1024 && c->one_exchange) {
+                // 2048-bin rows: the one-exchange transform (k_rot_mean_q1024)
+                if (dtype == PP_F64) hipLaunchKernelGGL((k_rot_mean_q1024<double>), dim3(nsub * nrun), dim3(64), 0, c->stream, ra);
+                else hipLaunchKernelGGL((k_rot_mean_q1024<float>), dim3(nsub * nrun), dim3(64), 0, c->stream, ra);
+            } else if (dtype == PP_F64) hipLaunchKernelGGL((k_rot_mean<MM, double>), dim3(nsub * nrun), dim3(T), 0, c->stream, ra);
             else hipLaunchKernelGGL((k_rot_mean<MM, float>), dim3(nsub * nrun), dim3(T), 0, c->stream, ra);
             hipLaunchKernelGGL(k_rot_mean_finish, dim3((M + 1 + 255) / 256, nsub), dim3(256), 0, c->stream,
                                (const cplx*)part, (const double*)c->sdraw.as<double>(), nsub, nrun, M, dspec);

@@ -2121,3 +2121,42 @@ def test_one_exchange_transform_matches_general_kernel_and_oracle(dtype):
     assert _dphi(b["params"][3, 0], o.phi) < PHI_BAR and abs(b["params"][3, 1] - o.DM) < DM_BAR
     np.testing.assert_allclose(b["chi2"][3], o.chi2, rtol=1e-10)
     np.testing.assert_allclose(b["scales"][3], o.scales, rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fused_reference_seed_2048_bins_one_exchange_kernel(eng, dtype):
+    """2048-bin portraits take k_rot_mean_q1024 (one-exchange FFT, split from the partner
+    lanes): the fused seed against rotation + channel mean + fit_phase_shift made one
+    after the other on the host, and against the general kernel (one_exchange = 0);
+    ragged weights, runs of different lengths, every harmonic up to Nyquist compared
+    through the fitted scale / errors / chi^2."""
+    from tests.synth_host import model_portrait
+    from oracle import pptoas_oracle as orc
+    rng = np.random.default_rng(2048)
+    N, C, B = 5, 48, 2048
+    freqs, model = model_portrait(C, B)
+    P = np.full(N, 0.0045)
+    DM = 12.5 + rng.normal(0, 2e-4, N)
+    shift = rng.uniform(-0.45, 0.45, N)
+    ports = np.array([orc.rotate_data(model * rng.uniform(0.5, 2.0, (C, 1)), -shift[i], -DM[i], P[i], freqs,
+                                      freqs.mean()) for i in range(N)])
+    ports = (ports + 0.02 * rng.standard_normal(ports.shape)).astype(dtype)
+    w = rng.uniform(0.5, 1.5, (N, C))
+    w[:, 7] = 0.0; w[2, 20:30] = 0.0
+    mprof = model.mean(axis=0)
+    nu_mean = np.array([freqs[w[i] > 0].mean() for i in range(N)])
+    kw = dict(phi=-orc.Dconst * 12.5 / P * nu_mean ** -2.0, DM=np.full(N, 12.5), Ns=100, finish='simplex')
+    got = eng.reference_phase_seed(ports, freqs, P, w, mprof, **kw)
+    eng.set_option("one_exchange", 0)
+    try:
+        old = eng.reference_phase_seed(ports, freqs, P, w, mprof, **kw)
+    finally:
+        eng.set_option("one_exchange", 1)
+    profs = np.array([np.average(orc.rotate_data(ports[i].astype(np.float64), 0.0, 12.5, P[i], freqs, nu_mean[i]),
+                                 axis=0, weights=w[i]) for i in range(N)])
+    want = eng.fit_phase_shift_batch(profs, np.tile(mprof, (N, 1)), Ns=100, finish='simplex')
+    assert _dphi_arr(got[:, 0], want[:, 0]).max() < 1e-11
+    np.testing.assert_allclose(got[:, 1:6], want[:, 1:6], rtol=1e-8)
+    assert _dphi_arr(got[:, 0], old[:, 0]).max() < 1e-11
+    np.testing.assert_allclose(got[:, 1:6], old[:, 1:6], rtol=1e-8)
