@@ -144,7 +144,8 @@ def main():
                     help="subints the 1-core CPU leg fits (0 = as many as fit in ~10 s)")
     ap.add_argument("--seed-ns", type=int, default=0,
                     help="> 0: ignore the phase guesses and seed the phase on the device "
-                         "with an N-point grid (the whole pptoas preamble + fit)")
+                         "with an N-point grid (the whole pptoas preamble + fit); "
+                         "< 0: the reference's own preamble inside every timed step")
     ap.add_argument("--truth-guesses", action="store_true",
                     help="phase guesses = injected phase + 1e-4 rot of noise instead of the "
                          "fit_phase_shift seed (experiments)")
@@ -350,7 +351,7 @@ def main():
         return
 
     batch = Batch(args.workload, args.nsub, args.input_dtype, rank * (args.nsub or WORKLOADS[args.workload][4]),
-                  seed_ns=args.seed_ns)
+                  seed_ns=max(args.seed_ns, 0), reseed=(args.seed_ns < 0))
     res, gathered, elapsed, ktimes = timed(batch, args.steps, args.warmup)
 
     line = None
@@ -368,9 +369,11 @@ def main():
                     and tp["kernel"] == fam):
                 traffic = tp["hbm_bytes_per_fit"] * nsub
                 if "valu_issue_frac_per_wave" in tp:
-                    co_limit = {"resource": "f64 VALU issue",
+                    co_limit = {"resource": "power cap (shader clock under this kernel against 2.4 GHz) "
+                                            "with the f64 VALU issuing busy_frac of the time",
                                 "busy_frac": round(tp["valu_issue_frac_per_wave"] *
                                                    tp.get("waves_per_simd", 1), 3),
+                                "shader_clock_ghz": tp.get("shader_clock_ghz"),
                                 "source": tp.get("counters_source")}
         except (OSError, KeyError, ValueError):
             pass

@@ -107,8 +107,11 @@ extern "C" int pp_reference_phase_seed(pp_ctx* c, const void* src, int dtype, in
     if ((rc = upload(c, c->x0, par3, (size_t)nsub * 24))) return rc;
     if ((rc = upload(c, c->wts, weights, (size_t)nsub * nchan * 8))) return rc;
     if ((rc = upload(c, c->errs, model_profs, (size_t)nsub * nbin * 8))) return rc;
+#ifndef PP_ROTMEAN_WGS
+#define PP_ROTMEAN_WGS 8192
+#endif
     // runs of channels per subint: enough workgroups to fill the device
-    int nrun = std::max(1, std::min(nchan / 16 > 0 ? nchan / 16 : 1, (4096 + nsub - 1) / nsub));
+    int nrun = std::max(1, std::min(nchan / 16 > 0 ? nchan / 16 : 1, (PP_ROTMEAN_WGS + nsub - 1) / nsub));
     const int cpr = (nchan + nrun - 1) / nrun;
     nrun = (nchan + cpr - 1) / cpr;
     const size_t H = (size_t)M + 1;

@@ -67,6 +67,15 @@ if fb > 0:
                   counters_source=f"profiles/{R}_sq_counters.txt (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)")
     except Exception as ex:
         print("no SQ counters for the co-limit:", ex)
+    try:
+        # GRBM_GUI_ACTIVE / 8 XCDs / duration of the same counter pass
+        g = cval("GRBM_GUI_ACTIVE")
+        durs = [float(x) for x in re.findall(r"xspec duration ms ([0-9.]+)", txt)]
+        if durs:
+            tl["shader_clock_ghz"] = round(g / 8 / (durs[-1] * 1e6), 3)
+            tl["counters_source"] += "; GRBM_GUI_ACTIVE / 8 / duration"
+    except Exception as ex:
+        print("no clock:", ex)
     json.dump(tl, open(f"{O}/traffic_latest.json", "w"), indent=1)
 # configs[3]: per-launch traffic of the evaluator and of the transform
 def first(pat):
@@ -99,3 +108,6 @@ if f4:
         print("cfg4 traffic summary failed:", ex)
 PY
 ls -la $O
+# shader clock under the transform kernels (power cap) and the one-exchange kernel against the general one
+./tools/run_clock_probe.sh "--opt one_exchange=0" "--opt one_exchange=1" "--input-dtype f32 --opt one_exchange=0" "--input-dtype f32 --opt one_exchange=1" > $O/${R}_clock_probe.txt 2>&1
+./tools/run_ab_option.sh one_exchange > $O/${R}_one_exchange_ab.txt 2>&1
