@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64, 2) void k_rot_mean_q1024(RotMeanArgs a) {
         // twiddles re-read per row (L1-resident, older than the prefetch)
         const cplx t1 = as_global(a.twB)[2 * tid], t2 = as_global(a.twB)[32 * (tid & 15)];
         const cplx wb0 = as_global(a.twB)[lam];
-        const double w = wrow[n];
+        const double w = wrow[n], hw = 0.5 * w;
         wsum += w;
         const double nu = a.freqs[(size_t)i * a.freqs_stride + n];
         const double a2 = 1.0 / (nu * nu);
@@ -335,17 +335,18 @@ __global__ __launch_bounds__(64, 2) void k_rot_mean_q1024(RotMeanArgs a) {
             const cplx zk = v[kd];
             cplx zc = pc[64 * (15 - kd)];
             zc.y = -zc.y;
-            const cplx E = make_double2(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
-            const cplx O = make_double2(0.5 * (zk.x - zc.x), 0.5 * (zk.y - zc.y));
+            // 2 d_k = E - i W^k O with E, O unhalved; the half goes into the weight (exact)
+            const cplx E = make_double2(zk.x + zc.x, zk.y + zc.y);
+            const cplx O = make_double2(zk.x - zc.x, zk.y - zc.y);
             const cplx wo = cmul(wb, O);
             cplx y = cmul(make_double2(E.x + wo.y, E.y - wo.x), e);
             if (kd == 0) {
                 // harmonic 0 of lane 0: d_0 = Re Z_0 + Im Z_0
-                y.x = l0 ? z0.x + z0.y : y.x;
+                y.x = l0 ? 2.0 * (z0.x + z0.y) : y.x;
                 y.y = l0 ? 0.0 : y.y;
             }
-            acc[kd].x = fma(w, y.x, acc[kd].x);
-            acc[kd].y = fma(w, y.y, acc[kd].y);
+            acc[kd].x = fma(hw, y.x, acc[kd].x);
+            acc[kd].y = fma(hw, y.y, acc[kd].y);
             wb = cmul(wb, wbT);
             e = cmul(e, wst);
         }
