@@ -5,6 +5,8 @@ the two must agree to rounding.  Exercises the lists, the compaction, the re-exp
 the fallbacks and the scattering model together.  (GPU box)   python tools/sweep_batch.py [nbatch]"""
 import sys
 import numpy as np
+import os
+LOG2NBIN = tuple(int(v) for v in os.environ.get("PP_SWEEP_LOG2NBIN", "7,11").split(","))   # e.g. "11,12": 2048 only
 sys.path.insert(0, ".")
 from tests.synth_host import make_inputs, caller_guess, model_portrait
 from pulseportraiture_amd.engine import Engine
@@ -18,7 +20,7 @@ worst = {}
 nfit = 0
 for b in range(nb):
     flags, scat = FLAGS[b % len(FLAGS)]
-    C = int(rng.integers(8, 40)); nbin = int(2 ** rng.integers(7, 11)); N = int(rng.integers(5, 14))
+    C = int(rng.integers(8, 40)); nbin = int(2 ** rng.integers(*LOG2NBIN)); N = int(rng.integers(5, 14))
     l10 = bool(rng.random() < 0.6) if scat else False
     freqs, model = model_portrait(C, nbin)
     eng.set_model(model)
