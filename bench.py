@@ -151,6 +151,9 @@ def main():
                          "fit_phase_shift seed (experiments)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="engine option (pp_set_option), e.g. scat_model=0; repeatable")
+    ap.add_argument("--measured-noise", action="store_true",
+                    help="errs=None: the noise of every channel is measured from the top quarter of its "
+                         "power spectrum inside the transform (get_noise_PS) instead of being given")
     ap.add_argument("--harm-eps", type=float, default=None,
                     help="override the harmonic-truncation threshold (experiments)")
     args = ap.parse_args()
@@ -295,7 +298,8 @@ def main():
                 # the reference's own preamble inside the timed step: one more read of the
                 # portraits (rotation + channel mean + fit_phase_shift), then the fit
                 self.x0[:, 0] = self.pptoas_phase_guess()
-            return eng.fit_batch(self.data[:n], self.freqs, self.P[:n], self.x0[:n], errs=self.errs_dev[:n],
+            return eng.fit_batch(self.data[:n], self.freqs, self.P[:n], self.x0[:n],
+                                 errs=None if args.measured_noise else self.errs_dev[:n],
                                  nu_fits=np.full((n, 3), self.nu_fit), fit_flags=self.flags,
                                  log10_tau=self.log10_tau, per_channel="device",
                                  seed_ns=self.seed_ns, method=method or args.method, records=records)

@@ -475,11 +475,16 @@ static void launch_xspec(pp_ctx* c, const XspecArgs& xa_in, bool tail, int mode)
     if (T == 64) c->ticket_base += (unsigned)((nrows + PP_ROW_CHUNK - 1) / PP_ROW_CHUNK);
     const dim3 blk(T);
     if constexpr (MM == 1024) {
-        // 2048-bin rows, Taylor sums only, noise given: the one-exchange transform
+        // 2048-bin rows, Taylor sums only (noise given or measured): the one-exchange transform
         // (pp_xspec1024q.h) -- a third of the LDS traffic of the general kernel
-        if (c->one_exchange && mode == 2 && !tail && 2 * xa.Kt < MM) {
-            const dim3 grid(resident_grid(c, k_xspec_q1024<TIN>, T, nrows, fft_grid(T, nrows)));
-            hipLaunchKernelGGL((k_xspec_q1024<TIN>), grid, blk, 0, c->stream, xa);
+        if (c->one_exchange && mode == 2 && 2 * xa.Kt < MM) {
+            if (tail) {
+                const dim3 grid(resident_grid(c, k_xspec_q1024<TIN, true>, T, nrows, fft_grid(T, nrows)));
+                hipLaunchKernelGGL((k_xspec_q1024<TIN, true>), grid, blk, 0, c->stream, xa);
+            } else {
+                const dim3 grid(resident_grid(c, k_xspec_q1024<TIN, false>, T, nrows, fft_grid(T, nrows)));
+                hipLaunchKernelGGL((k_xspec_q1024<TIN, false>), grid, blk, 0, c->stream, xa);
+            }
             return;
         }
     }

@@ -39,12 +39,16 @@ namespace pp {
 #ifndef PP_Q_PREFETCH_F32
 #define PP_Q_PREFETCH_F32 0
 #endif
-template <typename Tin>
+// TAIL: also measure the noise from the top quarter of the power spectrum (errs == NULL,
+// get_noise_PS): harmonics 768..1023 are this lane's registers 12..15 against the
+// partner's registers 3..0 (five more registers published, four more read back), the
+// Nyquist harmonic is Re Z_0 - Im Z_0.
+template <typename Tin, bool TAIL>
 __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
     constexpr int M = 1024, T = 64, R1 = 16, PER1 = 1;
     constexpr int NSL = 7;                     // slots: 2 Kt < M  ->  k <= 448 = 64 * 7
     typedef typename RawOf<Tin>::type Raw;
-    constexpr int NRED = PP_TSTRIDE + 1;       // the 12 Taylor sums and S_d
+    constexpr int NRED = PP_TSTRIDE + (TAIL ? 2 : 1);       // the 12 Taylor sums, S_d (and the noise tail)
     static_assert(NRED <= 16, "wave_reduce_lds takes 16 values");
     static_assert(PP_TJ == 10, "power ladder written for order 10");
     constexpr int WRED = PP_WRED_DOUBLES(NRED) / 2;   // in cplx
@@ -161,7 +165,35 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
             cplx* pub = lds + tid;
 #pragma unroll
             for (int s = 0; s < NSL; ++s) pub[64 * s] = v[9 + s];
+            if (TAIL) {
+#pragma unroll
+                for (int r = 0; r < 5; ++r) pub[64 * (NSL + r)] = v[r];
+            }
             lds_sync<T>();
+        }
+        double tail = 0.0;
+        if (TAIL) {
+            // |2 d_k|^2 for k = lam + 64 kd, kd = 12..15; W_B^k = W_B^kb0 W_B^(64 kd) with
+            // kb0 = lam (the lane that owns lam = 0: kb = 64, one step ahead) and
+            // W_B^768 = exp(-3 pi i / 4).  Partner: register 15 - kd of the partner lane
+            // (own register 16 - kd for lam = 0).
+            const double h = 0.70710678118654752440;
+            const cplx* pt = lds + fftq_lane_of((64 - lam) & 63) + (l0 ? 64 : 0);
+            // lam != 0: W^lam W^768;  lam = 0: wb0 = W^64, wanted W^768 = W^64 W^704 -> use W^768 directly
+            cplx wt = l0 ? make_double2(-h, -h) : cmul(wb0, make_double2(-h, -h));
+#pragma unroll
+            for (int kd = 12; kd < 16; ++kd) {
+                const cplx zk = v[kd];
+                cplx zc = pt[64 * (NSL + 15 - kd)];
+                zc.y = -zc.y;
+                const cplx E = make_double2(zk.x + zc.x, zk.y + zc.y);
+                const cplx O = make_double2(zk.x - zc.x, zk.y - zc.y);
+                const cplx wo = cmul(wt, O);
+                tail += cnorm(make_double2(E.x + wo.y, E.y - wo.x));
+                wt = cmul(wt, wbT);
+            }
+            tail *= 0.25;
+            if (tid == 0) { const double dM = v[0].x - v[0].y; tail += dM * dM; }
         }
 #if PP_Q_ABLATE != 1
         if (HALVES) {
@@ -234,6 +266,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
 #pragma unroll
         for (int j = 0; j < PP_TSTRIDE; ++j) tr[j] = tm[j];
         tr[PP_TSTRIDE] = sd;
+        if (TAIL) tr[NRED - 1] = tail;
         lds_sync<T>();      // (the partner reads are older than the reduction's writes)
         double tv = wave_reduce_lds(tr, tid, reinterpret_cast<double*>(lds));
         if ((tid & 3) == 0) {
@@ -245,6 +278,10 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
             }
         }
         if (tid == 4 * PP_TSTRIDE) a.sdraw[rc] = tv;
+        if (TAIL && tid == 4 * (PP_TSTRIDE + 1)) {
+            constexpr int H = M + 1, kc = (int)(0.75 * H);   // get_noise_PS: int((1 - 1/4) * len(pows))
+            a.noise[rc] = sqrt(tv / (2.0 * M) / (double)(H - kc));
+        }
         lds_sync<T>();
     }
 }

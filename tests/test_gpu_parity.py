@@ -2121,6 +2121,21 @@ def test_one_exchange_transform_matches_general_kernel_and_oracle(dtype):
     assert _dphi(b["params"][3, 0], o.phi) < PHI_BAR and abs(b["params"][3, 1] - o.DM) < DM_BAR
     np.testing.assert_allclose(b["chi2"][3], o.chi2, rtol=1e-10)
     np.testing.assert_allclose(b["scales"][3], o.scales, rtol=1e-7, atol=1e-9)
+    # noise measured from the top quarter of the power spectrum (errs=None): the same kernel
+    # with the tail harmonics taken from registers 12..15 and the partner's 3..0
+    kn = dict(kw, errs=None)
+    e.set_option("one_exchange", 0)
+    an = e.fit_batch(data, freqs, P, x0, **kn)
+    e.set_option("one_exchange", 1)
+    bn = e.fit_batch(data, freqs, P, x0, **kn)
+    assert np.max(np.abs((an["params"][:, 0] - bn["params"][:, 0] + 0.5) % 1.0 - 0.5)) < PHI_BAR
+    assert np.max(np.abs(an["params"][:, 1] - bn["params"][:, 1])) < DM_BAR
+    np.testing.assert_allclose(bn["chi2"], an["chi2"], rtol=1e-10)
+    np.testing.assert_allclose(bn["param_errs"][:, :2], an["param_errs"][:, :2], rtol=1e-9)
+    on = orc.fit_portrait_full(data[5].double().cpu().numpy(), model, x0[5], P[5], freqs, [nu_fit] * 3,
+                               [None] * 3, None, [1, 1, 0, 0, 0], log10_tau=False)
+    assert _dphi(bn["params"][5, 0], on.phi) < PHI_BAR and abs(bn["params"][5, 1] - on.DM) < DM_BAR
+    np.testing.assert_allclose(bn["chi2"][5], on.chi2, rtol=(1e-10 if dtype == "f64" else 1e-6))
 
 
 @pytest.mark.gpu
