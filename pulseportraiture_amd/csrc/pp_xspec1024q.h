@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
 #pragma unroll
             for (int k = 0; k < R1; ++k)
                 if (k >= k0 && k < k1)
-                    cur[0][k] = *reinterpret_cast<const Raw*>(gb + (size_t)(k * 64) * sizeof(Raw) + boff);
+                    cur[0][k] = load_row_once<Raw>(gb + (size_t)(k * 64) * sizeof(Raw) + boff);
         };
         auto prefetch = [&]() {
             __builtin_amdgcn_sched_barrier(0);
