@@ -112,7 +112,7 @@ void* pp_stream(pp_ctx* ctx);
  *                  harmonics take the transform kernel that does the last FFT stage
  *                  and the even/odd split in registers; 0 = the generic kernel
  *   "one_exchange" 1 (default) = 2048-bin rows whose template keeps fewer than 512
- *                  harmonics, fitted without scattering and with the noise given, take the
+ *                  harmonics, fitted without scattering (noise given or measured), take the
  *                  transform kernel whose FFT crosses the LDS once (lane-swap first
  *                  exchange) and whose split reads only the partner harmonics;
  *                  0 = the kernels above

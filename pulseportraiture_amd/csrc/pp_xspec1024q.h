@@ -1,7 +1,7 @@
 // k_xspec for 2048-bin rows whose template keeps fewer than 512 harmonics (MODE 2,
-// noise given): the benchmark shape, built on the one-exchange FFT of pp_fftq.h.
+// noise given or measured): the benchmark shape, built on the one-exchange FFT of pp_fftq.h.
 //
-// Same contract as k_xspec<1024, Tin, false, 2> (pp_kernels.h).  What differs is the
+// Same contract as k_xspec<1024, Tin, TAIL, 2> (pp_kernels.h).  What differs is the
 // path of the row through the LDS, which is the unit this kernel saturates (one LDS
 // per CU, eight resident rows; see pp_fftq.h):
 //
