@@ -862,6 +862,12 @@ __device__ __forceinline__ void accumulate_channel(const Local& L, const ChanGeo
 #ifndef PP_EVAL_UNROLL
 #define PP_EVAL_UNROLL 2      // independent 16-byte loads in flight per lane
 #endif
+// The stored cross-spectrum is streamed once per evaluation pass: non-temporal, so that it does
+// not displace the template power rows the co-resident workgroups share (k_eval 6.87 -> 6.73 ms
+// per 6 passes of configs[3], 8.21 -> 7.93 with the Newton solver)
+#ifndef PP_NT_X_LOADS
+#define PP_NT_X_LOADS 1
+#endif
 template <bool SCAT>
 __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
     constexpr int LPC = 16;
@@ -903,7 +909,11 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
         if (w != 0.0) {
 #pragma unroll PP_EVAL_UNROLL
             for (int j = l; j < ktn; j += LPC) {
+#if PP_NT_X_LOADS
+                const cplx x = load_row_once<cplx>(reinterpret_cast<const char*>(xrow + j));
+#else
                 const cplx x = xrow[j];
+#endif
                 const cplx z = cmul(x, e);
                 if (!SCAT) {
                     s0 += z.x;

@@ -215,13 +215,16 @@ __global__ __launch_bounds__(256) void k_scat_model(FitArgs a) {
         if (w != 0.0 && l < ktn) {
             // the next harmonic's loads are issued before this one's arithmetic
             const double* mrow = msq + (size_t)n * a.M;
-            cplx xn = xrow[l];
+            cplx xn = PP_NT_X_LOADS ? load_row_once<cplx>(reinterpret_cast<const char*>(xrow + l)) : xrow[l];
             double Mn = mrow[l];
 #pragma unroll 1
             for (int j = l; j < ktn; j += LPC) {
                 const cplx x = xn;
                 const double Mk = Mn;
-                if (j + LPC < ktn) { xn = xrow[j + LPC]; Mn = mrow[j + LPC]; }
+                if (j + LPC < ktn) {
+                    xn = PP_NT_X_LOADS ? load_row_once<cplx>(reinterpret_cast<const char*>(xrow + j + LPC)) : xrow[j + LPC];
+                    Mn = mrow[j + LPC];
+                }
                 const cplx z = cmul(x, e);
                 const double kap = PP_TWO_PI * k, u = kap * cg.taun;
                 const double D = recip_ge1(fma(u, u, 1.0));
