@@ -53,7 +53,7 @@ constexpr int FFTQ_LDS_ELEMS = 4 * 272;      // four rows of 16 lanes x (16 x 17
 
 // t1 = W_1024^tid, t2 = W_64^(tid & 15).  mid() is called once, after the 16 inputs are
 // dead: WHEN = 0 a quarter into stage 1, 1 after the stage-1 twiddles (their powers no
-// longer live), 2 after the lane swaps.  power (optional) += this lane's share of
+// longer live), 2 after the lane swaps, 3 after the transpose (before the last stage).  power (optional) += this lane's share of
 // sum_{k=1}^{M-1} |Z_k|^2 + (Re Z_0 - Im Z_0)^2.
 template <int WHEN = 0, typename Mid>
 __device__ __forceinline__ void fftq1024(cplx (&v)[16], cplx* lds, const cplx t1, const cplx t2, int tid,
@@ -113,6 +113,7 @@ __device__ __forceinline__ void fftq1024(cplx (&v)[16], cplx* lds, const cplx t1
         for (int j = 0; j < 16; ++j) v[j] = rbase[17 * j];
         lds_sync<64>();
     }
+    if (WHEN == 3) mid();
     // ---- stage 3 ----
     dft_reg<16>(v);
     if (power) {

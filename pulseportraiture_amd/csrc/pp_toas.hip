@@ -488,6 +488,14 @@ static void launch_xspec(pp_ctx* c, const XspecArgs& xa_in, bool tail, int mode)
             return;
         }
     }
+    if constexpr (MM == 1024) {
+        // ... and with a template that keeps 512 harmonics or more (mode 3), noise given
+        if (c->one_exchange && mode == 3 && !tail) {
+            const dim3 grid(resident_grid(c, k_xspec_qf1024<TIN>, T, nrows, fft_grid(T, nrows)));
+            hipLaunchKernelGGL((k_xspec_qf1024<TIN>), grid, blk, 0, c->stream, xa);
+            return;
+        }
+    }
     if constexpr (MM == 1024 && sizeof(TIN) == 4) {
         // 2048-bin rows whose template keeps fewer than 512 harmonics: last stage
         // and split in registers (pp_xspec1024.h)

@@ -286,4 +286,173 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
     }
 }
 
+
+// --------------------------------------------------------------------------
+// The same for templates that keep 512 harmonics or more (k_xspec's MODE 3; data-derived
+// spline / PCA templates keep all 1024): every lane works on all 16 of its harmonics
+// k = kb + 64 j, publishes all 16 registers and reads 16 partner values.  The lane that
+// owns lam = 0 takes k = 64 (j + 1) from register (j + 1) & 15 -- its slot 15 is the Nyquist
+// harmonic, for which the general split formula with Z_k = Z_{M-k} = Z_0 and W_B^M = -1
+// gives 2 (Re Z_0 - Im Z_0) --, so one wave-uniform test keeps or drops a slot for every lane.
+// The 16 template values of a lane (64 registers) cannot live beside two rows: they are
+// read every row (L2 hits) between the transpose and the last stage, and the next row's
+// loads are queued only after them, at the start of the split, in two halves (vector memory
+// returns in order: template reads issued after the prefetch would wait for HBM).
+// --------------------------------------------------------------------------
+template <typename Tin>
+__global__ __launch_bounds__(64, 2) void k_xspec_qf1024(XspecArgs a) {
+    constexpr int M = 1024, T = 64, R1 = 16, PER1 = 1;
+    constexpr int NSL = 16;
+    typedef typename RawOf<Tin>::type Raw;
+    constexpr int NRED = PP_TSTRIDE + 1;       // the 12 Taylor sums and S_d
+    constexpr int WRED = PP_WRED_DOUBLES(NRED) / 2;   // in cplx
+    constexpr int LDSN = WRED > FFTQ_LDS_ELEMS ? WRED : FFTQ_LDS_ELEMS;
+    __shared__ cplx lds[LDSN];
+    int tid = threadIdx.x;
+    const long long nrows = (long long)a.nsub * a.nchan;
+    Raw cur[PER1][R1];
+    const cplx wbT = a.twB[64];
+    RowWalk<true> rw;
+    rw.start(nrows);
+    long long row = rw.row;
+    int n = 0, i = 0;
+    if (rw.more) {
+        n = __builtin_amdgcn_readfirstlane((int)(row / a.nsub));
+        i = __builtin_amdgcn_readfirstlane((int)(row % a.nsub));
+        const size_t rc = (size_t)sub_of(a.act, i) * a.nchan_full + (a.coff + n * a.cstep);
+        stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rc * (2 * M), tid);
+    }
+    int i_nx = i, n_nx = n;
+    for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
+        rw.draw(a.ticket);
+        asm volatile("" : "+v"(tid));
+        const int lam = fftq_lambda(tid);
+        const bool l0 = (lam == 0);
+        const int kb = l0 ? 64 : lam;
+        const cplx t1 = as_global(a.twB)[2 * tid], t2 = as_global(a.twB)[32 * (tid & 15)];
+        const cplx wb0 = as_global(a.twB)[kb];
+        const int ia = sub_of(a.act, i), ne = a.coff + n * a.cstep;   // true subint, channel
+        const size_t rc = (size_t)ia * a.nchan_full + ne;
+        const cplx* mrow = as_global(a.slot ? a.mft[a.slot[ia]] : a.mft0) + (size_t)ne * M;
+        const int ktn = a.ktab ? as_global(a.slot ? a.ktab[a.slot[ia]] : a.kt0)[ne] : a.Kt;
+        const double phin = a.ph0[rc];
+        double sd = 0.0;
+        cplx v[R1];
+#pragma unroll
+        for (int k = 0; k < R1; ++k) v[k] = to_cplx(cur[0][k]);
+        // this lane's 16 template values, read between the transpose and the last stage
+        cplx mv[NSL];
+        auto template_loads = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NSL; ++j) mv[j] = mrow[kb + 64 * j - 1];   // k <= 1024: inside the row
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        fftq1024<3>(v, lds, t1, t2, tid, &sd, template_loads);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- partners through LDS: all 16 registers out, 16 values back ----
+        {
+            cplx* pub = lds + tid;
+#pragma unroll
+            for (int s = 0; s < NSL; ++s) pub[64 * s] = v[s];
+            lds_sync<T>();
+        }
+        // ---- the next row: first half now (behind the template reads), second half after slot 7 ----
+        const Tin* nxrow;
+        auto load_some = [&](int k0, int k1) {
+            const char* gb = reinterpret_cast<const char*>(nxrow);
+            const unsigned boff = (unsigned)tid * (unsigned)sizeof(Raw);
+#pragma unroll
+            for (int k = 0; k < R1; ++k)
+                if (k >= k0 && k < k1) cur[0][k] = load_row_once<Raw>(gb + (size_t)(k * 64) * sizeof(Raw) + boff);
+        };
+        {
+            __builtin_amdgcn_sched_barrier(0);
+            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base);
+            const size_t rn = rw.more_nx
+                ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
+            nxrow = reinterpret_cast<const Tin*>(a.data) + rn * (2 * M);
+            load_some(0, R1 / 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const cplx* pc = lds + fftq_lane_of((64 - lam) & 63);   // slot j: register 15 - j of the partner
+        const cplx el = unit_phasor<true>((double)kb, phin);
+        const cplx wst = make_double2(bcast_lane0(el.x), bcast_lane0(el.y));
+        cplx e = el, wb = wb0;
+        const int ktu = __builtin_amdgcn_readfirstlane(ktn);
+        const double kap0 = PP_TWO_PI * (double)kb;
+        double tm[PP_TSTRIDE];
+        cplx zc_nx = pc[64 * 15];
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            cplx zc = zc_nx;
+            if (j + 1 < NSL) zc_nx = pc[64 * (14 - j)];
+            if (j == NSL / 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_some(R1 / 2, R1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the template cut is a multiple of 64: a slot is kept or dropped as a whole
+            if (j == 0 || 64 * j < ktu) {
+                const cplx zk = csel(l0, v[(j + 1) & 15], v[j]);
+                zc.y = -zc.y;
+                const cplx E = make_double2(zk.x + zc.x, zk.y + zc.y);
+                const cplx O = make_double2(zk.x - zc.x, zk.y - zc.y);
+                const cplx wo = cmul(wb, O);
+                // 2 d_k = E - i W^k O
+                const cplx x = cmulc(make_double2(E.x + wo.y, E.y - wo.x), mv[j]);
+                const cplx z = cmul(x, e);
+                const double kap = j == 0 ? kap0 : kap0 + kconst<true>(PP_TWO_PI * (double)(64 * j));
+                const double p2 = kap * kap, p4 = p2 * p2, p6 = p4 * p2, p8 = p4 * p4, p10 = p8 * p2;
+                const double ui = z.y * kap;
+                const double ax = fabs(x.x) + fabs(x.y);
+                if (j == 0) {
+                    tm[0] = z.x;
+                    tm[1] = ui;
+                    tm[2] = p2 * z.x;
+                    tm[3] = p2 * ui;
+                    tm[4] = p4 * z.x;
+                    tm[5] = p4 * ui;
+                    tm[6] = p6 * z.x;
+                    tm[7] = p6 * ui;
+                    tm[8] = p8 * z.x;
+                    tm[9] = p8 * ui;
+                    tm[10] = p10 * z.x;
+                    tm[11] = (p10 * kap) * ax;
+                } else {
+                    tm[0] += z.x;
+                    tm[1] += ui;
+                    tm[2] = fma(p2, z.x, tm[2]);
+                    tm[3] = fma(p2, ui, tm[3]);
+                    tm[4] = fma(p4, z.x, tm[4]);
+                    tm[5] = fma(p4, ui, tm[5]);
+                    tm[6] = fma(p6, z.x, tm[6]);
+                    tm[7] = fma(p6, ui, tm[7]);
+                    tm[8] = fma(p8, z.x, tm[8]);
+                    tm[9] = fma(p8, ui, tm[9]);
+                    tm[10] = fma(p10, z.x, tm[10]);
+                    tm[11] = fma(p10 * kap, ax, tm[11]);
+                }
+            }
+            wb = cmul(wb, wbT);
+            e = cmul(e, wst);
+        }
+        double tr[NRED];
+#pragma unroll
+        for (int j = 0; j < PP_TSTRIDE; ++j) tr[j] = tm[j];
+        tr[PP_TSTRIDE] = sd;
+        lds_sync<T>();      // (the partner reads are older than the reduction's writes)
+        double tv = wave_reduce_lds(tr, tid, reinterpret_cast<double*>(lds));
+        if ((tid & 3) == 0) {
+            const int q = wave_reduce16_index(tid);
+            if (q < PP_TSTRIDE) {
+                tv *= 0.5;
+                a.tay[rc * PP_TSTRIDE + q] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
+            }
+        }
+        if (tid == 4 * PP_TSTRIDE) a.sdraw[rc] = tv;
+        lds_sync<T>();
+    }
+}
+
 }  // namespace pp

@@ -2175,3 +2175,53 @@ def test_fused_reference_seed_2048_bins_one_exchange_kernel(eng, dtype):
     np.testing.assert_allclose(got[:, 1:6], want[:, 1:6], rtol=1e-8)
     assert _dphi_arr(got[:, 0], old[:, 0]).max() < 1e-11
     np.testing.assert_allclose(got[:, 1:6], old[:, 1:6], rtol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_one_exchange_transform_full_spectrum_template(dtype):
+    """A template that keeps every harmonic (harm_eps = 0: k_xspec's paired mode 3 /
+    k_xspec_qf1024, all 16 harmonics of every lane, the Nyquist harmonic as slot 15 of the
+    lane that owns lambda = 0) and one cut at 512..960 harmonics: the one-exchange kernel
+    against the general kernel on the same batch and against the CPU oracle."""
+    import torch
+    from oracle import pptoas_oracle as orc
+    from pulseportraiture_amd.engine import Engine
+    from pulseportraiture_amd import gmodel
+    from pulseportraiture_amd.pplib import guess_fit_freq, Dconst
+    C, B, nsub = 96, 2048, 36
+    for eps in (0.0, 1e-9):
+        e = Engine(0)
+        e.set_option("harm_eps", eps)
+        freqs, model, P0 = gmodel.example_model(C, B)
+        if eps:
+            # white "template noise": the cut then falls between 512 and 1024 harmonics
+            model = model + 2e-6 * np.random.default_rng(5).standard_normal(model.shape)
+        e.set_model(model)
+        rng = np.random.default_rng(77)
+        P = np.full(nsub, P0)
+        inj = np.zeros((nsub, 3))
+        inj[:, 0] = rng.uniform(-0.5, 0.5, nsub)
+        inj[:, 1] = 34.56789 + rng.normal(3e-4, 2e-4, nsub)
+        data = torch.empty((nsub, C, B), dtype=torch.float64 if dtype == "f64" else torch.float32, device="cuda:0")
+        e.synth_portraits(data, freqs, P, inj, 0.05, 20260103, 0)
+        nu_fit = float(guess_fit_freq(freqs))
+        x0 = np.zeros((nsub, 5))
+        x0[:, 0] = (inj[:, 0] + Dconst * inj[:, 1] / P / nu_fit ** 2 + 1e-4 * rng.standard_normal(nsub) + 0.5) % 1.0 - 0.5
+        x0[:, 1] = 34.56789
+        errs = np.full((nsub, C), 0.05)
+        kw = dict(errs=errs, nu_fits=np.full((nsub, 3), nu_fit), fit_flags=[1, 1, 0, 0, 0])
+        e.set_option("one_exchange", 0)
+        a = e.fit_batch(data, freqs, P, x0, **kw)
+        e.set_option("one_exchange", 1)
+        b = e.fit_batch(data, freqs, P, x0, **kw)
+        assert (b["return_code"] == 2).all() and (b["nfeval"] == a["nfeval"]).all()
+        assert np.max(np.abs((a["params"][:, 0] - b["params"][:, 0] + 0.5) % 1.0 - 0.5)) < PHI_BAR
+        assert np.max(np.abs(a["params"][:, 1] - b["params"][:, 1])) < DM_BAR
+        np.testing.assert_allclose(b["chi2"], a["chi2"], rtol=1e-11)
+        np.testing.assert_allclose(b["snr"], a["snr"], rtol=1e-11)
+        np.testing.assert_allclose(b["param_errs"][:, :2], a["param_errs"][:, :2], rtol=1e-9)
+        o = orc.fit_portrait_full(data[2].double().cpu().numpy(), model, x0[2], P[2], freqs, [nu_fit] * 3,
+                                  [None] * 3, errs[2], [1, 1, 0, 0, 0], log10_tau=False)
+        assert _dphi(b["params"][2, 0], o.phi) < PHI_BAR and abs(b["params"][2, 1] - o.DM) < DM_BAR
+        np.testing.assert_allclose(b["chi2"][2], o.chi2, rtol=1e-9)
