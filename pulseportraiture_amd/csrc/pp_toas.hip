@@ -489,10 +489,15 @@ static void launch_xspec(pp_ctx* c, const XspecArgs& xa_in, bool tail, int mode)
         }
     }
     if constexpr (MM == 1024) {
-        // ... and with a template that keeps 512 harmonics or more (mode 3), noise given
-        if (c->one_exchange && mode == 3 && !tail) {
-            const dim3 grid(resident_grid(c, k_xspec_qf1024<TIN>, T, nrows, fft_grid(T, nrows)));
-            hipLaunchKernelGGL((k_xspec_qf1024<TIN>), grid, blk, 0, c->stream, xa);
+        // ... and with a template that keeps 512 harmonics or more (mode 3)
+        if (c->one_exchange && mode == 3) {
+            if (tail) {
+                const dim3 grid(resident_grid(c, k_xspec_qf1024<TIN, true>, T, nrows, fft_grid(T, nrows)));
+                hipLaunchKernelGGL((k_xspec_qf1024<TIN, true>), grid, blk, 0, c->stream, xa);
+            } else {
+                const dim3 grid(resident_grid(c, k_xspec_qf1024<TIN, false>, T, nrows, fft_grid(T, nrows)));
+                hipLaunchKernelGGL((k_xspec_qf1024<TIN, false>), grid, blk, 0, c->stream, xa);
+            }
             return;
         }
     }

@@ -299,12 +299,15 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
 // loads are queued only after them, at the start of the split, in two halves (vector memory
 // returns in order: template reads issued after the prefetch would wait for HBM).
 // --------------------------------------------------------------------------
-template <typename Tin>
+// TAIL (errs == NULL): harmonics 768..1024 are slots 12..15 (11..15 for the lane that owns
+// lam = 0, whose slot 15 is the Nyquist harmonic); their split is formed whether or not the
+// template keeps them.
+template <typename Tin, bool TAIL>
 __global__ __launch_bounds__(64, 2) void k_xspec_qf1024(XspecArgs a) {
     constexpr int M = 1024, T = 64, R1 = 16, PER1 = 1;
     constexpr int NSL = 16;
     typedef typename RawOf<Tin>::type Raw;
-    constexpr int NRED = PP_TSTRIDE + 1;       // the 12 Taylor sums and S_d
+    constexpr int NRED = PP_TSTRIDE + (TAIL ? 2 : 1);       // the 12 Taylor sums, S_d (and the noise tail)
     constexpr int WRED = PP_WRED_DOUBLES(NRED) / 2;   // in cplx
     constexpr int LDSN = WRED > FFTQ_LDS_ELEMS ? WRED : FFTQ_LDS_ELEMS;
     __shared__ cplx lds[LDSN];
@@ -382,6 +385,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qf1024(XspecArgs a) {
         const int ktu = __builtin_amdgcn_readfirstlane(ktn);
         const double kap0 = PP_TWO_PI * (double)kb;
         double tm[PP_TSTRIDE];
+        double tail = 0.0;
         cplx zc_nx = pc[64 * 15];
 #pragma unroll
         for (int j = 0; j < NSL; ++j) {
@@ -393,14 +397,21 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qf1024(XspecArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             // the template cut is a multiple of 64: a slot is kept or dropped as a whole
-            if (j == 0 || 64 * j < ktu) {
+            const bool keep = (j == 0 || 64 * j < ktu);
+            if (keep || (TAIL && j >= 11)) {
                 const cplx zk = csel(l0, v[(j + 1) & 15], v[j]);
                 zc.y = -zc.y;
                 const cplx E = make_double2(zk.x + zc.x, zk.y + zc.y);
                 const cplx O = make_double2(zk.x - zc.x, zk.y - zc.y);
                 const cplx wo = cmul(wb, O);
                 // 2 d_k = E - i W^k O
-                const cplx x = cmulc(make_double2(E.x + wo.y, E.y - wo.x), mv[j]);
+                const cplx dd = make_double2(E.x + wo.y, E.y - wo.x);
+                if (TAIL && j >= 11) {
+                    const double pw = cnorm(dd);
+                    tail += (j >= 12 || l0) ? pw : 0.0;
+                }
+              if (keep) {
+                const cplx x = cmulc(dd, mv[j]);
                 const cplx z = cmul(x, e);
                 const double kap = j == 0 ? kap0 : kap0 + kconst<true>(PP_TWO_PI * (double)(64 * j));
                 const double p2 = kap * kap, p4 = p2 * p2, p6 = p4 * p2, p8 = p4 * p4, p10 = p8 * p2;
@@ -433,6 +444,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qf1024(XspecArgs a) {
                     tm[10] = fma(p10, z.x, tm[10]);
                     tm[11] = fma(p10 * kap, ax, tm[11]);
                 }
+              }
             }
             wb = cmul(wb, wbT);
             e = cmul(e, wst);
@@ -441,6 +453,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qf1024(XspecArgs a) {
 #pragma unroll
         for (int j = 0; j < PP_TSTRIDE; ++j) tr[j] = tm[j];
         tr[PP_TSTRIDE] = sd;
+        if (TAIL) tr[NRED - 1] = 0.25 * tail;
         lds_sync<T>();      // (the partner reads are older than the reduction's writes)
         double tv = wave_reduce_lds(tr, tid, reinterpret_cast<double*>(lds));
         if ((tid & 3) == 0) {
@@ -451,6 +464,10 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qf1024(XspecArgs a) {
             }
         }
         if (tid == 4 * PP_TSTRIDE) a.sdraw[rc] = tv;
+        if (TAIL && tid == 4 * (PP_TSTRIDE + 1)) {
+            constexpr int H = M + 1, kc = (int)(0.75 * H);   // get_noise_PS: int((1 - 1/4) * len(pows))
+            a.noise[rc] = sqrt(tv / (2.0 * M) / (double)(H - kc));
+        }
         lds_sync<T>();
     }
 }

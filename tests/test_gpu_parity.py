@@ -2225,3 +2225,18 @@ def test_one_exchange_transform_full_spectrum_template(dtype):
                                   [None] * 3, errs[2], [1, 1, 0, 0, 0], log10_tau=False)
         assert _dphi(b["params"][2, 0], o.phi) < PHI_BAR and abs(b["params"][2, 1] - o.DM) < DM_BAR
         np.testing.assert_allclose(b["chi2"][2], o.chi2, rtol=1e-9)
+        # noise measured from the power-spectrum tail (errs=None): slots 11 / 12..15, the
+        # Nyquist harmonic included, whether or not the template keeps them
+        kn = dict(kw, errs=None)
+        e.set_option("one_exchange", 0)
+        an = e.fit_batch(data, freqs, P, x0, **kn)
+        e.set_option("one_exchange", 1)
+        bn = e.fit_batch(data, freqs, P, x0, **kn)
+        assert np.max(np.abs((an["params"][:, 0] - bn["params"][:, 0] + 0.5) % 1.0 - 0.5)) < PHI_BAR
+        assert np.max(np.abs(an["params"][:, 1] - bn["params"][:, 1])) < DM_BAR
+        np.testing.assert_allclose(bn["chi2"], an["chi2"], rtol=1e-10)
+        np.testing.assert_allclose(bn["param_errs"][:, :2], an["param_errs"][:, :2], rtol=1e-9)
+        on = orc.fit_portrait_full(data[4].double().cpu().numpy(), model, x0[4], P[4], freqs, [nu_fit] * 3,
+                                   [None] * 3, None, [1, 1, 0, 0, 0], log10_tau=False)
+        assert _dphi(bn["params"][4, 0], on.phi) < PHI_BAR and abs(bn["params"][4, 1] - on.DM) < DM_BAR
+        np.testing.assert_allclose(bn["chi2"][4], on.chi2, rtol=(1e-9 if dtype == "f64" else 1e-6))
