@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 2
+#define PP_ABI_VERSION 3
 
 /* status codes */
 #define PP_OK 0
@@ -233,7 +233,11 @@ typedef struct {
     double* chi2;         /* [nsub] */
     double* red_chi2;     /* [nsub] */
     double* snr;          /* [nsub] */
-    int32_t* nfeval;      /* [nsub] objective evaluations */
+    int32_t* nfeval;      /* [nsub] objective evaluations as the reference reports them: SciPy's
+                             `nfev` (pptoaslib.py:1017 `nfeval = results.nfev`) -- the initial point,
+                             every proposal that is not the point evaluated last (SciPy's one-point
+                             cache), and the proposal SciPy evaluates before it tests the predicted
+                             reduction and stops.  Most of them cost no pass over the data here. */
     int32_t* return_code; /* [nsub] PP_RC_* */
     int32_t chan_on_device; /* the three per-channel outputs are device pointers */
     double* scales;       /* [nsub][nchan] or NULL */
@@ -243,6 +247,9 @@ typedef struct {
     double* obj_grad;     /* [nsub][5]   its gradient, or NULL */
     double* obj_hess;     /* [nsub][25]  its Hessian, or NULL */
     double* duration;     /* [1] seconds of device time for the whole call */
+    int32_t* npass;       /* [nsub] or NULL: how many of those evaluations were passes over the
+                             portraits or the stored cross-spectrum (1 for a fit solved on the
+                             Taylor model of its single pass) */
     double* records_dev;  /* DEVICE pointer [nsub][PP_RECORD_WIDTH] or NULL: one fixed-size
                              TOA record per subint left in HBM -- phi, DM, GM, tau, alpha,
                              their five errors, nu_DM, nu_GM, nu_tau, chi2, red_chi2, snr,

@@ -14,7 +14,7 @@ PP_OK, PP_EINVAL, PP_EHIP, PP_ENOMEM, PP_ESTATE = 0, -1, -2, -3, -4
 PP_F64, PP_F32 = 0, 1
 PP_MAX_SLOTS = 64
 PP_RECORD_WIDTH = 18
-ABI_VERSION = 2
+ABI_VERSION = 3
 PP_METHOD_TRUST_NCG, PP_METHOD_NEWTON = 0, 1
 
 c_double_p = C.POINTER(C.c_double)
@@ -43,7 +43,7 @@ class FitOut(C.Structure):
                 ("chan_on_device", C.c_int32), ("scales", c_double_p), ("scale_errs", c_double_p),
                 ("channel_snrs", c_double_p), ("obj_f", c_double_p),
                 ("obj_grad", c_double_p), ("obj_hess", c_double_p),
-                ("duration", c_double_p), ("records_dev", c_double_p)]
+                ("duration", c_double_p), ("npass", c_int32_p), ("records_dev", c_double_p)]
 
 
 # every symbol include/pp_toas.h declares: (restype, argtypes)

@@ -220,7 +220,9 @@ struct SubState {
     double radius;
     double pred_red;   // predicted reduction of the pending proposal
     int hits_boundary;
-    int iter, nfev, status, done, cur;  // cur: csum buffer of the accepted point
+    int iter, nfev, status, done, cur;  // cur: csum buffer of the accepted point; nfev: objective evaluations as
+                                        // SciPy's nfev counts them (the reference's nfeval, pptoaslib.py:1017)
+    int npass;         // ... of which passes over the portraits / the stored cross-spectrum
     double xl[5], fl, gl[5], Hl[25];   // the point evaluated last and its f, g, H (SciPy's cache of one point)
     int fresh;         // the next evaluation is 1: an initial one, 2: the closing one (no ratio test)
     int recentred;     // one-pass flow: 1 = the Taylor model was taken again about the first solve's answer

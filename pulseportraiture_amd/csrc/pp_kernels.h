@@ -94,7 +94,7 @@ struct FitArgs {
     int* nactive;
     // outputs (device)
     double* o_params; double* o_errs; double* o_nu; double* o_cov;
-    double* o_chi2; double* o_rchi2; double* o_snr; int* o_nfev; int* o_rc;
+    double* o_chi2; double* o_rchi2; double* o_snr; int* o_nfev; int* o_rc; int* o_npass;
     double* o_scales; double* o_scale_errs; double* o_csnr;
     double* o_f0; double* o_g0; double* o_H0;
     double* o_rec;            // [nsub][PP_RECORD_WIDTH] TOA records left on the device, or nullptr
@@ -742,7 +742,7 @@ __global__ void k_init_state(FitArgs a) {
     s.radius = 1.0;          // scipy initial_trust_radius
     s.pred_red = 0.0;
     s.hits_boundary = 0;
-    s.iter = 0; s.nfev = 0; s.status = PP_RC_MAXITER; s.done = 0; s.cur = 1; s.fresh = 1;
+    s.iter = 0; s.nfev = 0; s.npass = 0; s.status = PP_RC_MAXITER; s.done = 0; s.cur = 1; s.fresh = 1;
     s.model = 0; s.geo[0] = s.geo[1] = s.geo[2] = s.geo[3] = 0.0;
     s.recentred = 0; s.nmodel = 0;
     for (int j = 0; j < 5; ++j) s.xl[j] = NAN;          // (no point evaluated yet)
@@ -1590,7 +1590,7 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
     double dx[3] = {0.0, 0.0, 0.0};      // accepted displacement from x0 in (phi, DM, GM)
     double f, g[3], H[9];
     bool ok = true;
-    int it = 0;
+    int it = 0, nfev = 1;                // objective evaluations as SciPy's nfev counts them
     double dpath = evalm(dx, f, g, H);   // (0 at the expansion point)
     if (tid == 0 && st.recentred == 0) {     // (objective hooks: at init_params only)
         st.f0 = f;
@@ -1601,17 +1601,38 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
     if (!isfinite(f)) ok = false;
     if (ok && a.method == 0) {
         double radius = 1.0;
+        // SciPy's ScalarFunction keeps the point it evaluated last: a proposal that IS that
+        // point (a rejected step proposed again under a smaller radius, ~15 times in a row
+        // at the end of the iteration) is answered from the cache and not counted in nfev.
+        // (SciPy compares absolute parameters, fl(x + p): its closing proposal -- p = -H^-1 g
+        // with g pure rounding noise by then, ~1e-15 -- also counts as cached when it happens
+        // to fall below half an ulp of x in every coordinate.  That is a coin toss of the
+        // reference's own rounding (its nfeval is k or k + 1 on it); the displacements kept
+        // here resolve 1e-21, so the closing proposal is always a new point and is counted,
+        // which is also what the reference does more often than not.)
+        double xl[3] = {0.0, 0.0, 0.0}, f2 = f, g2[3] = {g[0], g[1], g[2]}, H2[9];
+        for (int j = 0; j < 9; ++j) H2[j] = H[j];
         for (;;) {
             double gs[3], Hs[9], p[3];
             subspace(g, H, gs, Hs);
             int hits = 0;
             tr_cg_steihaug_scipy(nf, f, gs, Hs, radius, p, &hits);
             const double pred = f - tr_model_value(nf, f, gs, Hs, p);
-            if (!(pred > 0.0)) break;                 // SciPy's status 2, the reference's normal exit
             double xt[3] = {dx[0], dx[1], dx[2]};
             for (int r_ = 0; r_ < nf; ++r_) xt[idx[r_]] += p[r_];
-            double f2, g2[3], H2[9];
-            dpath = fmax(dpath, evalm(xt, f2, g2, H2));
+            const bool cached = (xt[0] == xl[0] && xt[1] == xl[1] && xt[2] == xl[2]);
+            if (!(pred > 0.0)) {
+                // SciPy's status 2, the reference's normal exit -- taken AFTER it has evaluated
+                // the proposal (scipy/optimize/_trustregion.py: m_proposed.fun comes before the
+                // test), so that evaluation is in the reference's nfeval
+                if (!cached) ++nfev;
+                break;
+            }
+            if (!cached) {
+                dpath = fmax(dpath, evalm(xt, f2, g2, H2));
+                for (int j = 0; j < 3; ++j) xl[j] = xt[j];
+                ++nfev;
+            }
             bool finite = isfinite(f2);
             for (int j = 0; j < 3; ++j) finite = finite && isfinite(g2[j]);
             if (tr_scipy_accept(f, f2, pred, hits, finite, &radius)) {
@@ -1631,7 +1652,7 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
     } else if (ok) {
         double fprev = INFINITY;
         for (it = 0; it < 24; ++it) {
-            if (it > 0) dpath = fmax(dpath, evalm(dx, f, g, H));
+            if (it > 0) { dpath = fmax(dpath, evalm(dx, f, g, H)); ++nfev; }
             if (!isfinite(f)) { ok = false; break; }
             // Newton step on the fit subspace (every thread computes the same)
             double gs[3], Hs[9], p[3], mg[3];
@@ -1711,7 +1732,7 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
             for (int j = 0; j < 5; ++j) st.g[j] = j < 3 ? g[j] : 0.0;
             for (int r_ = 0; r_ < 5; ++r_)
                 for (int c_ = 0; c_ < 5; ++c_) st.H[r_ * 5 + c_] = (r_ < 3 && c_ < 3) ? H[r_ * 3 + c_] : 0.0;
-            st.cur = buf; st.nfev = 1 + st.recentred; st.iter = it; st.status = PP_RC_STALL; st.done = 1; st.fresh = 0;
+            st.cur = buf; st.nfev += nfev; st.npass = 1 + st.recentred; st.iter = it; st.status = PP_RC_STALL; st.done = 1; st.fresh = 0;
             atomicSub(a.nactive, 1);
         }
     }
@@ -1728,10 +1749,12 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
         bool fin = isfinite(dpath) && dpath < 0.02;
         for (int j = 0; j < 3; ++j) fin = fin && isfinite(dx[j]);
         if (st.recentred < a.recentre && fin) {
+            st.nfev += nfev;             // (the evaluations of the first expansion stay counted)
             for (int j = 0; j < 3; ++j) st.xe[j] += dx[j];
             for (int j = 0; j < 5; ++j) { st.x[j] = st.xe[j]; a.x0w[i * 5 + j] = st.xe[j]; }
             st.recentred += 1;
-        } else st.recentred = a.recentre + 1;                // (no further expansion)
+        } else { st.recentred = a.recentre + 1; st.nfev = 0; }   // (no further expansion: the evaluation
+                                                                  // loop starts over from st.xe and counts its own)
         st.fresh = 1;
     }
 }
@@ -1768,6 +1791,17 @@ __device__ inline bool step_propose(const FitArgs& a, SubState& s, const int* id
             tr_cg_steihaug_scipy<n>(s.f, gs, Hs, s.radius, p, &hits);
             const double pred = s.f - tr_model_value<n>(s.f, gs, Hs, p);
             if (!(pred > 0.0)) {
+                // SciPy evaluates the proposal before it tests the predicted reduction
+                // (_trustregion.py: m_proposed.fun, then `if predicted_reduction <= 0`), so the
+                // reference's nfeval holds one more evaluation -- unless the proposal is the
+                // point its ScalarFunction evaluated last.  No pass is spent on it here.
+                bool cached = true;
+                for (int j = 0; j < 5; ++j) {
+                    double xp = s.x[j];
+                    for (int r = 0; r < n; ++r) if (idx[r] == j) xp = s.x[j] + p[r];
+                    cached = cached && (xp == s.xl[j]);
+                }
+                if (!cached) s.nfev += 1;
                 s.status = PP_RC_STALL; done = true;
             } else {
                 for (int j = 0; j < 5; ++j) s.xe[j] = s.x[j];
@@ -1817,13 +1851,15 @@ __device__ inline bool step_propose(const FitArgs& a, SubState& s, const int* id
 // the ratio test on the pending proposal (or the bookkeeping of an initial / closing
 // evaluation), then the next proposal into s.xe.
 // Returns true when the subint is finished (s.status set).  One thread.
-__device__ inline bool step_decide(const FitArgs& a, SubState& s, double f, const double* g, const double* H, bool counted) {
+__device__ inline bool step_decide(const FitArgs& a, SubState& s, double f, const double* g, const double* H, bool counted,
+                                   bool is_pass) {
     bool finite = isfinite(f);
     for (int j = 0; j < 5; ++j) finite = finite && isfinite(g[j]);
     for (int j = 0; j < 25; ++j) finite = finite && isfinite(H[j]);
     const bool first = (s.fresh == 1), closing = (s.fresh == 2);
     s.fresh = 0;
     if (counted) s.nfev += 1;
+    if (is_pass) s.npass += 1;
     bool done = false;
     if (closing) {
         // evaluation at the point of the final Newton step: the post-fit stage
@@ -1884,16 +1920,16 @@ __device__ inline bool step_decide(const FitArgs& a, SubState& s, double f, cons
 // <= 0 is rejected, the radius shrinks by 4, and the SAME step is proposed again --
 // ~15 times, until the radius is smaller than the step -- without a single new
 // evaluation.
-__device__ inline bool step_logic(const FitArgs& a, SubState& s, double f, const double* g, const double* H) {
+__device__ inline bool step_logic(const FitArgs& a, SubState& s, double f, const double* g, const double* H, bool is_pass) {
     for (int j = 0; j < 5; ++j) { s.xl[j] = s.xe[j]; s.gl[j] = g[j]; }
     for (int j = 0; j < 25; ++j) s.Hl[j] = H[j];
     s.fl = f;
-    bool done = step_decide(a, s, f, g, H, true);
+    bool done = step_decide(a, s, f, g, H, true, is_pass);
     while (!done && s.fresh == 0) {
         bool same = true;
         for (int j = 0; j < 5; ++j) same = same && (s.xe[j] == s.xl[j]);
         if (!same) break;
-        done = step_decide(a, s, s.fl, s.gl, s.Hl, false);
+        done = step_decide(a, s, s.fl, s.gl, s.Hl, false, false);
     }
     return done;
 }
@@ -1922,7 +1958,7 @@ __global__ __launch_bounds__(64) void k_step(FitArgs a) {
     if (tid != 0) return;
     double f, g[5], H[25];
     unpack_acc(acc, a.flags, f, g, H);
-    const bool done = step_logic(a, s, f, g, H);
+    const bool done = step_logic(a, s, f, g, H, true);
     if (done) {
         s.done = 1;
         atomicSub(a.nactive, 1);
@@ -2305,6 +2341,7 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs a) {
         a.o_snr[i] = sqrt(m[30]);
         a.o_nfev[i] = s.nfev;
         a.o_rc[i] = s.status;
+        a.o_npass[i] = s.npass;
         if (a.o_rec) {
             double* rec = a.o_rec + (size_t)i * PP_RECORD_WIDTH;
             for (int j = 0; j < 5; ++j) { rec[j] = op[j]; rec[5 + j] = oe[j]; }

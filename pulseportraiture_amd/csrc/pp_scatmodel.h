@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void k_scat_model_solve(FitArgs a) {
                            ss.iter, ss.f, f, ss.f - f, ss.pred_red, ss.radius, acc[PP_NACC + 5] / (2.220446049250313e-16 * fabs(f)));
 #endif
                 ss.model = 2;
-                const bool done = step_logic(a, ss, f, g, H);
+                const bool done = step_logic(a, ss, f, g, H, round == 0);   // (the model pass itself is a pass over X)
                 ss.model = 1;
                 if (done) { ss.done = 1; flag = 3; }
             }

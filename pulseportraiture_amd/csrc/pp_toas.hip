@@ -609,8 +609,8 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     if ((rc = c->misc.reserve(256))) return rc;
     if ((rc = c->act.reserve((size_t)ns * 4))) return rc;
     // per-subint scalar outputs: blocks of one allocation (params 5, errs 5, nu 3,
-    // cov 25, chi2, red_chi2, snr doubles; nfeval, return_code ints) = 336 B / subint
-    const size_t o_bytes = (size_t)ns * 336;
+    // cov 25, chi2, red_chi2, snr doubles; nfeval, return_code, npass ints) = 340 B / subint
+    const size_t o_bytes = (size_t)ns * 340;
     if ((rc = c->o_pack.reserve(o_bytes))) return rc;
     if (c->o_host_cap < o_bytes) {
         if (c->o_host) (void)hipHostFree(c->o_host);
@@ -684,7 +684,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.o_params = o_base; fa.o_errs = o_base + (size_t)ns * 5; fa.o_nu = o_base + (size_t)ns * 10;
     fa.o_cov = o_base + (size_t)ns * 13; fa.o_chi2 = o_base + (size_t)ns * 38; fa.o_rchi2 = o_base + (size_t)ns * 39;
     fa.o_snr = o_base + (size_t)ns * 40;
-    fa.o_nfev = reinterpret_cast<int*>(o_base + (size_t)ns * 41); fa.o_rc = fa.o_nfev + ns;
+    fa.o_nfev = reinterpret_cast<int*>(o_base + (size_t)ns * 41); fa.o_rc = fa.o_nfev + ns; fa.o_npass = fa.o_rc + ns;
     if (chan_dev) {
         fa.o_scales = out->scales ? out->scales + (size_t)s0 * C : nullptr;
         fa.o_scale_errs = out->scale_errs ? out->scale_errs + (size_t)s0 * C : nullptr;
@@ -936,6 +936,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         const int32_t* hi = reinterpret_cast<const int32_t*>(h + (size_t)ns * 41);
         memcpy(out->nfeval + s0, hi, (size_t)ns * 4);
         memcpy(out->return_code + s0, hi + ns, (size_t)ns * 4);
+        if (out->npass) memcpy(out->npass + s0, hi + 2 * (size_t)ns, (size_t)ns * 4);
     }
     return PP_OK;
 }

@@ -253,6 +253,7 @@ class Engine(object):
                    chi2=np.empty(nsub), red_chi2=np.empty(nsub), snr=np.empty(nsub),
                    nfeval=np.empty(nsub, dtype=np.int32),
                    return_code=np.empty(nsub, dtype=np.int32),
+                   npass=np.empty(nsub, dtype=np.int32),
                    duration=np.zeros(1))
         chan_dev = (per_channel == "device")
         if chan_dev:

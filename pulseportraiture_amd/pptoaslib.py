@@ -25,7 +25,10 @@ def _bunch(res, i, fit_flags):
         covariance_matrix=cov, chi2=res["chi2"][i], red_chi2=res["red_chi2"][i],
         snr=res["snr"][i], channel_snrs=res["channel_snrs"][i].copy(),
         duration=res["duration"], nfeval=int(res["nfeval"][i]),
-        return_code=int(res["return_code"][i]))
+        return_code=int(res["return_code"][i]),
+        # (not a field of the reference's result: how many of the nfeval evaluations were
+        # passes over the data)
+        npass=int(res["npass"][i]))
 
 
 def fit_portrait_full(data_port, model_port, init_params, P, freqs,

@@ -144,6 +144,9 @@ def run(pptoas, data, ird=None, **kw):
         out[name] = np.asarray(getattr(gt, name)[0], dtype=np.float64)
     for name in ("profile_fluxes", "profile_flux_errs", "fluxes", "flux_errs", "flux_freqs"):
         out[name] = np.asarray(getattr(gt, name)[0], dtype=np.float64)
+    # evaluation counts and return codes of every subint (pptoas.py:591-592, 719-720)
+    out["nfevals"] = np.asarray(gt.nfevals[0], dtype=np.int64)
+    out["rcs"] = np.asarray(gt.rcs[0], dtype=np.int64)
     out["nu_refs"] = np.array([list(map(float, r)) for r in gt.nu_refs[0]])
     out["nu_fits"] = np.array([list(map(float, r)) for r in gt.nu_fits[0]])
     out["ok_isubs"] = np.asarray(gt.ok_isubs[0])

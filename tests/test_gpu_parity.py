@@ -125,7 +125,7 @@ def test_fit_matches_reference_golden(name):
 def test_raw_parity_table():
     """Raw |dphi|, |dDM| (and the other fitted parameters in units of their
     errors) of both device solvers against the reference's own output for every
-    fit_portrait_full golden; written to gpurun_out/parity_r02.json (the copy
+    fit_portrait_full golden; written to gpurun_out/parity_r03.json (the copy
     under profiles/ is the committed record).  'trust-ncg' must meet the bars on
     every row; 'newton' converges past the reference's exit and may sit up to its
     stall distance (~1.5e-9 rot) away."""
@@ -140,7 +140,7 @@ def test_raw_parity_table():
             row[key] = {"dphi": _dphi(r.phi, float(g["out_phi"])),
                         "dDM": abs(r.DM - float(g["out_DM"])),
                         "dparams_over_sigma": (np.abs(np.asarray(r.params) - g["out_params"]) / e).tolist(),
-                        "nfeval": int(r.nfeval), "return_code": int(r.return_code)}
+                        "nfeval": int(r.nfeval), "npass": int(r.npass), "return_code": int(r.return_code)}
         rows[name] = row
     print("%-32s %-12s %10s %10s   %10s %10s" % ("golden", "flags", "ncg dphi", "ncg dDM",
                                                  "newton dphi", "newton dDM"))
@@ -150,22 +150,26 @@ def test_raw_parity_table():
             row["trust_ncg"]["dDM"], row["newton"]["dphi"], row["newton"]["dDM"]))
     out = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "parity_r02.json"), "w") as fh:
+    with open(os.path.join(out, "parity_r03.json"), "w") as fh:
         json.dump({"bars": {"dphi": PHI_BAR, "dDM": DM_BAR}, "rows": rows}, fh, indent=1)
     worst = max(row["trust_ncg"]["dphi"] for row in rows.values())
     assert worst < PHI_BAR, worst
     assert max(row["trust_ncg"]["dDM"] for row in rows.values()) < DM_BAR
     # Newton: never farther from the reference than the reference is from its optimum
     assert max(row["newton"]["dphi"] for row in rows.values()) < 5e-9
-    # scattering fits walk SciPy's iteration evaluation by evaluation: the reference's
-    # nfeval is one more (SciPy evaluates the last proposal before it tests the
-    # predicted reduction; the device tests first).  Fits without scattering make ONE
-    # pass over the data (the iteration runs on the Taylor model).
+    # nfeval is the reference's own (pptoaslib.py:1017, SciPy's nfev), bit for bit: the
+    # device walks SciPy's iteration evaluation by evaluation -- on the Taylor / scattering
+    # model or over the data -- and counts what SciPy counts: not the re-proposals its
+    # one-point cache answers, but the proposal it evaluates before testing the predicted
+    # reduction.  Passes over the data are reported apart: ONE for fits without scattering
+    # (the iteration runs on the Taylor model), the reference's count - 1 at most otherwise
+    # (the closing proposal costs no pass: the device tests first).
     for name, row in rows.items():
+        assert row["trust_ncg"]["nfeval"] == row["ref_nfeval"], (name, row)
         if row["fit_flags"][3] or row["fit_flags"][4]:
-            assert row["trust_ncg"]["nfeval"] == row["ref_nfeval"] - 1, (name, row)
+            assert row["trust_ncg"]["npass"] <= row["ref_nfeval"] - 1, (name, row)
         else:
-            assert row["trust_ncg"]["nfeval"] == 1, (name, row)
+            assert row["trust_ncg"]["npass"] == 1, (name, row)
 
 
 @pytest.mark.parametrize("name", ["fpf_64x256_phiDMGM", "fpf_64x256_scat",
@@ -601,6 +605,18 @@ def test_get_TOAs_with_the_references_seed_returns_the_references_numbers(name):
                                        g["out_" + fld][ok], rtol=rt)
     np.testing.assert_allclose(gt.scales[0][ok], g["out_scales"][ok], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(gt.DeltaDM_means[0], g["out_DeltaDM_mean"], rtol=0, atol=max(1e-10, marginal))
+    # the evaluation counts and return codes the reference's own run recorded
+    # (pptoas.py:591-592: nfevals[isub] = results.nfeval = SciPy's nfev; 0 for a zapped subint)
+    np.testing.assert_array_equal(np.asarray(gt.rcs[0]), g["out_rcs"])
+    # The counting RULE is SciPy's (test_raw_parity_table: every fit_portrait_full golden to
+    # the count).  The count itself hangs on the iteration's tail: whether the model still
+    # "predicts a reduction" once g'H^-1 g has fallen to half an ulp of f (~1e-16 of it) is
+    # decided by the rounding noise of g, so two correct evaluations of the same objective --
+    # the reference's own with its channels in another order, tools/ref_self_scatter.py -- can
+    # stop one evaluation apart at the same answer.
+    nf = np.asarray(gt.nfevals[0])
+    assert np.abs(nf - g["out_nfevals"]).max() <= 1 and (nf == g["out_nfevals"]).mean() >= 0.4, (nf, g["out_nfevals"])
+    assert (nf[2] == 0) and (np.asarray(gt.nfevals[0])[ok] >= 3).all()      # (0 for the zapped subint)
 
 
 @pytest.mark.parametrize("nbin", [32, 64, 128])
@@ -643,7 +659,7 @@ def test_poor_guess_falls_back_to_evaluations(eng):
                               g["init_params"], **kw)
     finally:
         eng.set_option("taylor", 1)
-    assert good["nfeval"][0] == 1 and bad["nfeval"][0] >= 3 and plain["nfeval"][0] >= 3
+    assert good["npass"][0] == 1 and bad["npass"][0] >= 3 and plain["npass"][0] >= 3
     for r in (good, bad, plain):
         assert _dphi(r["params"][0, 0], float(g["out_phi"])) < PHI_BAR
         assert abs(r["params"][0, 1] - float(g["out_DM"])) < DM_BAR
@@ -709,7 +725,7 @@ def test_moments_in_xspec_match_two_pass_flow(nbin, wbins, flags):
     twopass = e.fit_batch(data, freqs, P, x0, **kw)
     e.set_option("taylor", 0)
     loop = e.fit_batch(data, freqs, P, x0, **kw)
-    assert (fused["nfeval"] == 1).all() and (twopass["nfeval"] == 1).all() and (loop["nfeval"] >= 2).all()
+    assert (fused["npass"] == 1).all() and (twopass["npass"] == 1).all() and (loop["npass"] >= 2).all()
     nfit = sum(flags)
     # the three-parameter problem is nearly degenerate (phi, DM, GM covary): its
     # optimum is defined less sharply, still far inside the 1e-9 / 1e-6 bars
@@ -747,7 +763,7 @@ def test_sub_batching_and_model_slots(eng):
         parts = eng.fit_batch(data, freqs, P, np.array(x0), **kw)
     finally:
         eng.set_option("max_work_bytes", 96e9)
-    for k in ("params", "param_errs", "nu_refs", "chi2", "snr", "scales", "nfeval"):
+    for k in ("params", "param_errs", "nu_refs", "chi2", "snr", "scales", "nfeval", "npass"):
         np.testing.assert_array_equal(whole[k], parts[k])
     # the scaled template changes the amplitudes, not the timing
     sc = whole["scales"]
@@ -1080,7 +1096,7 @@ def test_full_size_properties_4096x2048():
     errs = np.full((nsub, C), 0.05)
     kw = dict(errs=errs, nu_fits=np.full((nsub, 3), nu_fit), fit_flags=[1, 1, 0, 0, 0])
     r = e.fit_batch(data, freqs, P, x0, **kw)
-    assert (r["return_code"] == 2).all() and (r["nfeval"] == 1).all()
+    assert (r["return_code"] == 2).all() and (r["npass"] == 1).all()
     # injected values, referred to the output frequency of each fit
     nu_out = r["nu_refs"][:, 0]
     phi_true = inj[:, 0] + Dconst * inj[:, 1] / P / nu_out ** 2
@@ -1386,32 +1402,74 @@ def test_full_shapes_of_cfg3_and_cfg4_match_oracle(case):
     e, data, freqs, model, P, x0, errs, nu_fit, kw = _full_shape_case(C, B, flags, l10, tau_us=tau_us, gm=gm)
     rn = e.fit_batch(data, freqs, P, x0, **kw)
     rw = e.fit_batch(data, freqs, P, x0, method='newton', **kw)
-    host = data[0].cpu().numpy()
-    o = orc.fit_portrait_full(host, model, x0[0], P[0], freqs, [nu_fit] * 3, [None] * 3, errs[0],
-                              flags, log10_tau=l10)
     ii = np.where(flags)[0]
-    # SciPy's iteration step for step: the oracle's raw answer
-    assert _dphi(rn["params"][0, 0], o.phi) < PHI_BAR
-    assert abs(rn["params"][0, 1] - o.DM) < DM_BAR
-    tol = np.maximum(1e-6 * np.asarray(o.param_errs), 1e-9)
-    assert np.all(np.abs(rn["params"][0] - np.asarray(o.params))[2:] <= tol[2:])
-    np.testing.assert_allclose(rn["param_errs"][0][ii], np.asarray(o.param_errs)[ii], rtol=1e-5)
-    np.testing.assert_allclose(rn["nu_refs"][0], [o.nu_DM, o.nu_GM, o.nu_tau], rtol=1e-7)
-    np.testing.assert_allclose(rn["chi2"][0], o.chi2, rtol=1e-10)
-    np.testing.assert_allclose(rn["scales"][0], o.scales, rtol=1e-6, atol=1e-9)
-    np.testing.assert_allclose(rn["scale_errs"][0], o.scale_errs, rtol=1e-6)
-    np.testing.assert_allclose(rn["snr"][0], o.snr, rtol=1e-8)
-    # Newton: at the optimum of the oracle's objective
-    dFT = np.fft.rfft(host, axis=-1); dFT[:, 0] = 0
     mFT = np.fft.rfft(model, axis=-1); mFT[:, 0] = 0
-    args = (dFT, mFT, errs[0] * np.sqrt(B / 2.0), P[0], freqs, rw["nu_refs"][0, 0],
-            rw["nu_refs"][0, 1], rw["nu_refs"][0, 2], flags, l10)
-    step = _oracle_newton_step(args, rw["params"][0], flags)
-    assert abs(step[0]) < PHI_BAR and abs(step[1]) < DM_BAR, step
-    assert _dphi(rw["params"][0, 0], o.phi) < 5e-9
-    np.testing.assert_allclose(rw["chi2"][0], o.chi2, rtol=1e-10)
+    for i in range(data.shape[0]):             # every subint of the batch
+        host = data[i].cpu().numpy()
+        o = orc.fit_portrait_full(host, model, x0[i], P[i], freqs, [nu_fit] * 3, [None] * 3, errs[i],
+                                  flags, log10_tau=l10)
+        # SciPy's iteration step for step: the oracle's raw answer, and its evaluation count
+        assert _dphi(rn["params"][i, 0], o.phi) < PHI_BAR
+        assert abs(rn["params"][i, 1] - o.DM) < DM_BAR
+        tol = np.maximum(1e-6 * np.asarray(o.param_errs), 1e-9)
+        assert np.all(np.abs(rn["params"][i] - np.asarray(o.params))[2:] <= tol[2:])
+        np.testing.assert_allclose(rn["param_errs"][i][ii], np.asarray(o.param_errs)[ii], rtol=1e-5)
+        np.testing.assert_allclose(rn["nu_refs"][i], [o.nu_DM, o.nu_GM, o.nu_tau], rtol=1e-7)
+        np.testing.assert_allclose(rn["chi2"][i], o.chi2, rtol=1e-10)
+        np.testing.assert_allclose(rn["scales"][i], o.scales, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(rn["scale_errs"][i], o.scale_errs, rtol=1e-6)
+        np.testing.assert_allclose(rn["snr"][i], o.snr, rtol=1e-8)
+        assert abs(rn["nfeval"][i] - o.nfeval) <= 1, (i, rn["nfeval"], o.nfeval)      # (tail: +-1, see above)
+        # Newton: at the optimum of the oracle's objective
+        dFT = np.fft.rfft(host, axis=-1); dFT[:, 0] = 0
+        args = (dFT, mFT, errs[i] * np.sqrt(B / 2.0), P[i], freqs, rw["nu_refs"][i, 0],
+                rw["nu_refs"][i, 1], rw["nu_refs"][i, 2], flags, l10)
+        step = _oracle_newton_step(args, rw["params"][i], flags)
+        assert abs(step[0]) < PHI_BAR and abs(step[1]) < DM_BAR, step
+        assert _dphi(rw["params"][i, 0], o.phi) < 5e-9
+        np.testing.assert_allclose(rw["chi2"][i], o.chi2, rtol=1e-10)
     # every subint converged and recovered the injected DM within its error bar
     assert (rn["return_code"] == 2).all() and (rw["return_code"] == 2).all()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_headline_shape_matches_oracle_raw(dtype):
+    """BASELINE's target shape -- 4096 x 2048, phase + DM, the transform the bench line
+    times (k_xspec_q1024: one-exchange FFT, Taylor sums, nothing stored) -- against the
+    CPU oracle, RAW, on every one of 5 device-generated subints: f64-resident portraits and
+    f32-resident ones (the oracle is handed the same f32 values widened to f64; NumPy 2's
+    rfft of float32 input would be single precision)."""
+    import torch
+    from oracle import pptoas_oracle as orc
+    C, B, flags, nsub = 4096, 2048, [1, 1, 0, 0, 0], 5
+    e, data, freqs, model, P, x0, errs, nu_fit, kw = _full_shape_case(C, B, flags, False, nsub=nsub, seed=17)
+    assert 2 * e.model_nharm(0) < B // 2          # (the truncated-template plan: k_xspec_q1024)
+    if dtype == "f32":
+        data = data.to(torch.float32)
+    e.set_option("profile", 1)
+    e.kernel_times(reset=True)
+    r = e.fit_batch(data, freqs, P, x0, **kw)
+    kt = e.kernel_times(reset=True)
+    e.set_option("profile", 0)
+    assert kt["xspec"][1] == 1 and kt.get("eval", (0, 0))[1] == 0      # one pass, nothing stored
+    assert (r["return_code"] == 2).all() and (r["npass"] == 1).all()
+    worst = [0.0, 0.0]
+    for i in range(nsub):
+        host = data[i].cpu().numpy().astype(np.float64)
+        o = orc.fit_portrait_full(host, model, x0[i], P[i], freqs, [nu_fit] * 3, [None] * 3, errs[i],
+                                  flags, log10_tau=False)
+        worst = [max(worst[0], _dphi(r["params"][i, 0], o.phi)), max(worst[1], abs(r["params"][i, 1] - o.DM))]
+        assert _dphi(r["params"][i, 0], o.phi) < PHI_BAR, (i, worst)
+        assert abs(r["params"][i, 1] - o.DM) < DM_BAR, (i, worst)
+        np.testing.assert_allclose(r["param_errs"][i, :2], np.asarray(o.param_errs)[:2], rtol=1e-6)
+        np.testing.assert_allclose(r["nu_refs"][i, 0], o.nu_DM, rtol=1e-7)
+        np.testing.assert_allclose(r["chi2"][i], o.chi2, rtol=1e-10)
+        np.testing.assert_allclose(r["red_chi2"][i], o.red_chi2, rtol=1e-10)
+        np.testing.assert_allclose(r["snr"][i], o.snr, rtol=1e-8)
+        np.testing.assert_allclose(r["scales"][i], o.scales, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(r["scale_errs"][i], o.scale_errs, rtol=1e-6)
+        assert abs(r["nfeval"][i] - o.nfeval) <= 1, (i, r["nfeval"], o.nfeval)
+    print("headline shape %s: worst raw |dphi| %.2e |dDM| %.2e over %d subints" % (dtype, worst[0], worst[1], nsub))
 
 
 def test_device_mask_with_default_reference_frequencies(eng):
@@ -1596,7 +1654,7 @@ def test_mixed_batch_re_transforms_only_the_poor_guesses(eng):
     mixed = eng.fit_batch(data, freqs, P, x1, **kw)
     t_mixed = min(eng.fit_batch(data, freqs, P, x1, **kw)["duration"] for _ in range(3))
     ok = np.setdiff1d(np.arange(nsub), bad)
-    assert (mixed["nfeval"][ok] == 1).all() and (mixed["nfeval"][bad] >= 3).all()
+    assert (mixed["npass"][ok] == 1).all() and (mixed["npass"][bad] >= 3).all()
     for k in ("params", "param_errs", "chi2", "nu_refs"):
         np.testing.assert_array_equal(mixed[k][ok], good[k][ok])
     assert np.max(np.abs((mixed["params"][bad, 0] - good["params"][bad, 0] + 0.5) % 1 - 0.5)) < PHI_BAR
@@ -1635,7 +1693,7 @@ def test_pilot_seed_matches_full_seed(eng):
                 assert dphi < tol, (method, name, dphi)
                 assert np.max(np.abs(r["params"][:, 1] - full["params"][:, 1])) < 1e3 * tol
                 np.testing.assert_allclose(r["chi2"], full["chi2"], rtol=1e-11)
-                assert (r["return_code"] == 2).all() and (r["nfeval"] == 1).all()
+                assert (r["return_code"] == 2).all() and (r["npass"] == 1).all()
         # a third of the channels masked, measured noise: same agreement
         kw2 = dict(kw, errs=None, chan_mask=mask)
         eng.set_option("seed_chan_stride", 1)
@@ -1730,7 +1788,7 @@ def test_coarse_phase_dm_grid_recovers_a_poor_dm_guess(eng):
     finally:
         eng.set_option("seed_ndm", 1)
         eng.set_option("seed_dm_step", 0.0)
-    assert (one["nfeval"] > 1).all() and (grid["nfeval"] == 1).all()
+    assert (one["npass"] > 1).all() and (grid["npass"] == 1).all()
     assert (one["return_code"] == 2).all() and (grid["return_code"] == 2).all()
     assert _dphi_common(grid, one, P) < 1e-11
     assert np.max(np.abs(grid["params"][:, 1] - one["params"][:, 1])) < 1e-9
@@ -1875,9 +1933,9 @@ def test_evaluation_counts_follow_scipys_cache_of_the_last_point():
     reduction of <= 0 ulp, re-proposed ~15 times while the radius shrinks to its length
     -- SciPy's ScalarFunction answers every re-proposal from its cache and `nfeval`
     counts one evaluation.  The device does the same (no pass over the data for a point
-    it has just evaluated): evaluations that are passes over the cross-spectrum =
-    the reference's nfeval - 1 (SciPy evaluates a proposal before it tests the predicted
-    reduction; the device tests first)."""
+    it has just evaluated) and reports the reference's count as `nfeval`; the passes over
+    the cross-spectrum (`npass`) are one fewer (SciPy evaluates a proposal before it tests
+    the predicted reduction; the device tests first)."""
     from oracle import pptoas_oracle as orc
     flags, l10, nsub = [1, 0, 0, 1, 1], True, 24
     e, data, freqs, model, P, x0, errs, nu_fit, kw = _full_shape_case(256, 1024, flags, l10, nsub=nsub,
@@ -1893,9 +1951,12 @@ def test_evaluation_counts_follow_scipys_cache_of_the_last_point():
         on.append(o.nfeval)
         dphi.append(_dphi(r["params"][i, 0], o.phi))
     on, dphi = np.array(on), np.array(dphi)
-    assert r["nfeval"].max() <= 16                       # (the tails of 27 iterations cost no passes)
-    assert (r["nfeval"] == on - 1).mean() >= 0.9, (r["nfeval"], on)
-    assert np.abs(r["nfeval"] - (on - 1)).max() <= 2
+    assert r["npass"].max() <= 16                        # (the tails of 27 iterations cost no passes)
+    # (where the two part it is by a marginal exit -- an actual reduction of +-1 ulp of f read
+    # differently -- not by the counting rule)
+    assert (r["nfeval"] == on).mean() >= 0.9, (r["nfeval"], on)
+    assert np.abs(r["nfeval"] - on).max() <= 2
+    assert (r["npass"] <= r["nfeval"]).all() and (r["nfeval"] - r["npass"] <= 1).all()
     # the marginal last step (1 ulp of f predicted) may be taken by one and not the other
     assert np.median(dphi) < 1e-13 and dphi.max() < 2e-9
     assert (dphi < PHI_BAR).mean() >= 0.9
@@ -1932,7 +1993,7 @@ def test_scattering_fits_in_sub_batches_with_model_slots_and_the_model_path(eng)
         parts = eng.fit_batch(data, freqs, P, x0, **kw)
     finally:
         eng.set_option("max_work_bytes", 96e9)
-    for k in ("params", "param_errs", "nu_refs", "chi2", "snr", "scales", "nfeval"):
+    for k in ("params", "param_errs", "nu_refs", "chi2", "snr", "scales", "nfeval", "npass"):
         np.testing.assert_array_equal(whole[k], parts[k])
     assert (whole["return_code"] == 2).all() and (whole["nfeval"] > 5).all()
     for i in (1, 5):
@@ -2033,8 +2094,8 @@ def test_poor_dm_guesses_get_one_more_expansion_instead_of_evaluations(eng):
     finally:
         eng.set_option("taylor_recentre", 1)
     ok = np.setdiff1d(np.arange(nsub), poor)
-    assert (r["nfeval"][ok] == 1).all() and (r["nfeval"][poor] == 2).all(), r["nfeval"][poor]
-    assert (loop["nfeval"][poor] >= 3).all()
+    assert (r["npass"][ok] == 1).all() and (r["npass"][poor] == 2).all(), r["npass"][poor]
+    assert (loop["npass"][poor] >= 3).all()
     assert kt.get("eval", (0, 0))[1] == 0 and kt["xspec"][1] == 2       # no evaluation over a stored cross-spectrum
     assert (r["return_code"] == 2).all()
     for ref in (loop, good):
@@ -2109,7 +2170,7 @@ def test_one_exchange_transform_matches_general_kernel_and_oracle(dtype):
     a = e.fit_batch(data, freqs, P, x0, **kw)
     e.set_option("one_exchange", 1)
     b = e.fit_batch(data, freqs, P, x0, **kw)
-    assert (b["return_code"] == 2).all() and (b["nfeval"] == 1).all()
+    assert (b["return_code"] == 2).all() and (b["npass"] == 1).all()
     assert np.max(np.abs((a["params"][:, 0] - b["params"][:, 0] + 0.5) % 1.0 - 0.5)) < PHI_BAR
     assert np.max(np.abs(a["params"][:, 1] - b["params"][:, 1])) < DM_BAR
     np.testing.assert_allclose(b["param_errs"][:, :2], a["param_errs"][:, :2], rtol=1e-9)
@@ -2215,7 +2276,7 @@ def test_one_exchange_transform_full_spectrum_template(dtype):
         a = e.fit_batch(data, freqs, P, x0, **kw)
         e.set_option("one_exchange", 1)
         b = e.fit_batch(data, freqs, P, x0, **kw)
-        assert (b["return_code"] == 2).all() and (b["nfeval"] == a["nfeval"]).all()
+        assert (b["return_code"] == 2).all() and np.abs(b["nfeval"] - a["nfeval"]).max() <= 1 and (b["npass"] == a["npass"]).all()
         assert np.max(np.abs((a["params"][:, 0] - b["params"][:, 0] + 0.5) % 1.0 - 0.5)) < PHI_BAR
         assert np.max(np.abs(a["params"][:, 1] - b["params"][:, 1])) < DM_BAR
         np.testing.assert_allclose(b["chi2"], a["chi2"], rtol=1e-11)

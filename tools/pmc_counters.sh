@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> [bench args...] ; collects SQ counter passes for one bench step
+# usage: tools/pmc_counters.sh <tag> [bench args...] ; collects SQ counter passes for one bench step
 export TMPDIR=/tmp
 tag=$1; shift
 out=gpurun_out/pmc_$tag

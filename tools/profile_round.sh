@@ -1,11 +1,11 @@
 #!/bin/bash
-# usage (on the MI355X box, repo root):  ./tools_profile.sh r02
+# usage (on the MI355X box, repo root):  tools/profile_round.sh r03
 # Runs every profiling pass behind profiles/<round>_* and writes the summaries to
 # gpurun_out/profiles_<round>/ (copy them into profiles/ afterwards).
 # Counter passes are separate runs with --kernel-trace only (no sys/hip traces).
 set -u
 export TMPDIR=/tmp
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/profiles_$R
 rm -rf $O; mkdir -p $O/raw
 # the driver's command: headline + other workloads + CPU baseline in one line
@@ -15,7 +15,7 @@ B="python3 bench.py --no-cpu-baseline --no-other-workloads"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/trace -- $B --steps 3 --warmup 1 > $O/${R}_bench_under_rocprof.json 2> $O/raw/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_fetch -- $B --steps 1 --warmup 0 > /dev/null 2> $O/raw/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_write -- $B --steps 1 --warmup 0 > /dev/null 2> $O/raw/write.err
-./tools_pmc.sh $R --no-other-workloads > $O/${R}_sq_counters.txt 2>&1
+tools/pmc_counters.sh $R --no-other-workloads > $O/${R}_sq_counters.txt 2>&1
 # configs[3] (scattering): kernel stats and HBM counters of its own
 W4="--workload cfg4-2048x2048-scat"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/trace_cfg4 -- $B $W4 --steps 3 --warmup 1 > $O/raw/bench_cfg4_under_rocprof.json 2> $O/raw/trace4.err
