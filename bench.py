@@ -52,6 +52,29 @@ HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s copy)
 DCONST = 0.000241 ** -1
 
 
+def injected_params(seed, first, n, flags, dm0, dm_offset, block=1024):
+    """Injected (phi, DM, GM) of subints [first, first + n) of a job, and a unit-normal
+    draw per subint for experiments: a function of the GLOBAL subint index only (blocks
+    of `block` indices share one generator keyed on (seed, block number)), so shards,
+    sub-batches and ranks can cut the job anywhere and still make the same subints."""
+    inj = np.zeros((n, 3))
+    extra = np.zeros(n)
+    b0, b1 = first // block, (first + n - 1) // block
+    for b in range(b0, b1 + 1):
+        rng = np.random.default_rng([seed, b])
+        phi = rng.uniform(-0.5, 0.5, block)
+        ddm = rng.normal(dm_offset[0], dm_offset[1], block)
+        gm = rng.normal(0.25, 0.05, block)
+        ex = rng.standard_normal(block)
+        lo, hi = max(first, b * block), min(first + n, (b + 1) * block)
+        src, dst = slice(lo - b * block, hi - b * block), slice(lo - first, hi - first)
+        inj[dst, 0], inj[dst, 1] = phi[src], dm0 + ddm[src]
+        if flags[2]:
+            inj[dst, 2] = gm[src]
+        extra[dst] = ex[src]
+    return inj, extra
+
+
 def algorithmic_bytes_per_fit(C, B, s, n_share):
     """data + shared model + freqs/errs in, per-channel out."""
     return C * B * s + C * B * s / n_share + 40 * C + 512
@@ -120,6 +143,107 @@ def start_cpu_pool():
 
 
 # --------------------------------------------------------------------------
+class Batch(object):
+    """One workload's template, device-resident synthetic subints and guesses.
+    eng: the Engine; args: the run's settings (seed, dm0, dm_offset, sigma, truth_guesses,
+    measured_noise, method -- bench's argparse namespace or a stand-in); device: the
+    torch device of the resident portraits."""
+
+    def __init__(self, eng, args, device, workload, nsub, input_dtype, first_subint, seed_ns=0, reseed=False):
+        import torch
+        from pulseportraiture_amd import gmodel
+        from pulseportraiture_amd.pplib import guess_fit_freq
+        self.eng, self.args, self.device = eng, args, device
+        self.reseed = reseed
+        self.workload = workload
+        C, B, flags, log10_tau, nsub_def, note = WORKLOADS[workload]
+        self.C, self.B, self.flags, self.log10_tau, self.note = C, B, flags, log10_tau, note
+        self.nsub = nsub or nsub_def
+        self.input_dtype, self.seed_ns = input_dtype, seed_ns
+        self.s_bytes = 8 if input_dtype == "f64" else 4
+        self.freqs, self.model, self.P0 = gmodel.example_model(C, B)
+        self.nharm = self.eng.set_model(self.model)
+        self.gen_slot, self.tau_rot = 0, 0.0
+        if flags[3]:
+            # scattered template: tau = 20 us at 1500 MHz, alpha = -4 (SURVEY 8d)
+            self.tau_rot = 20e-6 / self.P0
+            taus = self.tau_rot * (self.freqs / 1500.0) ** -4.0
+            k = np.arange(B // 2 + 1)
+            smodel = np.fft.irfft(np.fft.rfft(self.model, axis=-1) /
+                                  (1.0 + 2j * np.pi * np.outer(taus, k)), axis=-1)
+            self.eng.set_model(smodel, slot=1)
+            self.gen_slot = 1
+        self.nu_fit = float(guess_fit_freq(self.freqs))
+        # template profile of the 1-D seed fit: the mean profile, scattered with the
+        # GUESSED tau at nu_fit when scattering is fitted (pptoas.py:430-452)
+        self.seed_prof = self.model.mean(axis=0)
+        if flags[3]:
+            tg = 1.5 * self.tau_rot * (self.nu_fit / 1500.0) ** -4.0
+            k = np.arange(B // 2 + 1)
+            self.seed_prof = np.fft.irfft(np.fft.rfft(self.seed_prof) / (1.0 + 2j * np.pi * k * tg))
+        self.data = torch.empty((self.nsub, C, B), device=self.device,
+                                dtype=torch.float64 if input_dtype == "f64" else torch.float32)
+        self.errs_dev = torch.full((self.nsub, C), self.args.sigma, dtype=torch.float64, device=self.device)
+        self.P = np.full(self.nsub, self.P0)
+        self.generate(first_subint)
+
+    def generate(self, first_subint):
+        """Fill the device buffer with subints [first, first + nsub) of the job
+        (RNG keyed on the global subint index) and form their guesses."""
+        nsub, flags = self.nsub, self.flags
+        inj, unit = injected_params(self.args.seed, first_subint, nsub, flags, self.args.dm0, self.args.dm_offset)
+        self.inj = inj
+        self.eng.synth_portraits(self.data, self.freqs, self.P, inj, self.args.sigma, self.args.seed,
+                                 first_subint, slot=self.gen_slot)
+        x0 = np.zeros((nsub, 5))
+        x0[:, 1] = self.args.dm0
+        if self.args.truth_guesses:
+            phi_true = inj[:, 0] + DCONST * inj[:, 1] / self.P / self.nu_fit ** 2 + \
+                DCONST ** 2 * inj[:, 2] / self.P / self.nu_fit ** 4
+            x0[:, 0] = (phi_true + 1e-4 * unit + 0.5) % 1.0 - 0.5
+            self.guess = "injected phase + 1e-4 rot noise"
+        elif self.seed_ns > 0:
+            self.guess = "device seed inside the timed fit (seed_ns=%d)" % self.seed_ns
+        else:
+            x0[:, 0] = self.pptoas_phase_guess()
+            self.guess = "pptoas preamble (rotate to nu_mean, mean profile, fit_phase_shift Ns=100 with SciPy's simplex finish retraced)"
+        if flags[3]:
+            t0 = 1.5 * self.tau_rot * (self.nu_fit / 1500.0) ** -4.0
+            x0[:, 3] = np.log10(t0) if self.log10_tau else t0
+            x0[:, 4] = -4.0
+        self.x0 = x0
+
+    def pptoas_phase_guess(self):
+        """pptoas.py:421-457 on the device: dedisperse every subint at the header
+        DM to the mean frequency, average over channels, 1-D FFTFIT against the
+        template's mean profile (Ns = 100 grid + SciPy's simplex finish, retraced:
+        the guess the reference itself would start from), move the phase to nu_fit."""
+        nu_mean = float(self.freqs.mean())
+        out = self.eng.reference_phase_seed(self.data, self.freqs, self.P, np.ones((self.nsub, self.C)),
+                                            self.seed_prof, DM=np.full(self.nsub, self.args.dm0), nu_DM=nu_mean,
+                                            Ns=100, finish='simplex')
+        phi = out[:, 0] + DCONST * self.args.dm0 / self.P * (self.nu_fit ** -2 - nu_mean ** -2)
+        return (phi + 0.5) % 1.0 - 0.5
+
+    def fit(self, records=None, method=None, n=None):
+        n = self.nsub if n is None else n         # (a ragged last sub-batch fits its first n)
+        if self.reseed:
+            # the reference's own preamble inside the timed step: one more read of the
+            # portraits (rotation + channel mean + fit_phase_shift), then the fit
+            self.x0[:, 0] = self.pptoas_phase_guess()
+        return self.eng.fit_batch(self.data[:n], self.freqs, self.P[:n], self.x0[:n],
+                                  errs=None if self.args.measured_noise else self.errs_dev[:n],
+                                  nu_fits=np.full((n, 3), self.nu_fit), fit_flags=self.flags,
+                                  log10_tau=self.log10_tau, per_channel="device",
+                                  seed_ns=self.seed_ns, method=method or self.args.method, records=records)
+
+    def free(self):
+        import torch
+        del self.data, self.errs_dev
+        torch.cuda.empty_cache()
+
+
+# --------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +278,8 @@ def main():
     ap.add_argument("--measured-noise", action="store_true",
                     help="errs=None: the noise of every channel is measured from the top quarter of its "
                          "power spectrum inside the transform (get_noise_PS) instead of being given")
+    ap.add_argument("--dump-records", default=None, metavar="PATH",
+                    help="--total-nsub: rank 0 saves the gathered [total, 18] records there (.npy)")
     ap.add_argument("--harm-eps", type=float, default=None,
                     help="override the harmonic-truncation threshold (experiments)")
     args = ap.parse_args()
@@ -211,103 +337,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ----------------------------------------------------------------------
-    class Batch(object):
-        """One workload's template, device-resident synthetic subints and guesses."""
-
-        def __init__(self, workload, nsub, input_dtype, first_subint, seed_ns=0, reseed=False):
-            self.reseed = reseed
-            self.workload = workload
-            C, B, flags, log10_tau, nsub_def, note = WORKLOADS[workload]
-            self.C, self.B, self.flags, self.log10_tau, self.note = C, B, flags, log10_tau, note
-            self.nsub = nsub or nsub_def
-            self.input_dtype, self.seed_ns = input_dtype, seed_ns
-            self.s_bytes = 8 if input_dtype == "f64" else 4
-            self.freqs, self.model, self.P0 = gmodel.example_model(C, B)
-            self.nharm = eng.set_model(self.model)
-            self.gen_slot, self.tau_rot = 0, 0.0
-            if flags[3]:
-                # scattered template: tau = 20 us at 1500 MHz, alpha = -4 (SURVEY 8d)
-                self.tau_rot = 20e-6 / self.P0
-                taus = self.tau_rot * (self.freqs / 1500.0) ** -4.0
-                k = np.arange(B // 2 + 1)
-                smodel = np.fft.irfft(np.fft.rfft(self.model, axis=-1) /
-                                      (1.0 + 2j * np.pi * np.outer(taus, k)), axis=-1)
-                eng.set_model(smodel, slot=1)
-                self.gen_slot = 1
-            self.nu_fit = float(guess_fit_freq(self.freqs))
-            # template profile of the 1-D seed fit: the mean profile, scattered with the
-            # GUESSED tau at nu_fit when scattering is fitted (pptoas.py:430-452)
-            self.seed_prof = self.model.mean(axis=0)
-            if flags[3]:
-                tg = 1.5 * self.tau_rot * (self.nu_fit / 1500.0) ** -4.0
-                k = np.arange(B // 2 + 1)
-                self.seed_prof = np.fft.irfft(np.fft.rfft(self.seed_prof) / (1.0 + 2j * np.pi * k * tg))
-            self.data = torch.empty((self.nsub, C, B), device=device,
-                                    dtype=torch.float64 if input_dtype == "f64" else torch.float32)
-            self.errs_dev = torch.full((self.nsub, C), args.sigma, dtype=torch.float64, device=device)
-            self.P = np.full(self.nsub, self.P0)
-            self.generate(first_subint)
-
-        def generate(self, first_subint):
-            """Fill the device buffer with subints [first, first + nsub) of the job
-            (RNG keyed on the global subint index) and form their guesses."""
-            nsub, flags = self.nsub, self.flags
-            rng = np.random.default_rng([args.seed, first_subint])
-            inj = np.zeros((nsub, 3))
-            inj[:, 0] = rng.uniform(-0.5, 0.5, nsub)
-            inj[:, 1] = args.dm0 + rng.normal(args.dm_offset[0], args.dm_offset[1], nsub)
-            if flags[2]:
-                inj[:, 2] = rng.normal(0.25, 0.05, nsub)
-            self.inj = inj
-            eng.synth_portraits(self.data, self.freqs, self.P, inj, args.sigma, args.seed,
-                                first_subint, slot=self.gen_slot)
-            x0 = np.zeros((nsub, 5))
-            x0[:, 1] = args.dm0
-            if args.truth_guesses:
-                phi_true = inj[:, 0] + DCONST * inj[:, 1] / self.P / self.nu_fit ** 2 + \
-                    DCONST ** 2 * inj[:, 2] / self.P / self.nu_fit ** 4
-                x0[:, 0] = (phi_true + 1e-4 * rng.standard_normal(nsub) + 0.5) % 1.0 - 0.5
-                self.guess = "injected phase + 1e-4 rot noise"
-            elif self.seed_ns > 0:
-                self.guess = "device seed inside the timed fit (seed_ns=%d)" % self.seed_ns
-            else:
-                x0[:, 0] = self.pptoas_phase_guess()
-                self.guess = "pptoas preamble (rotate to nu_mean, mean profile, fit_phase_shift Ns=100 with SciPy's simplex finish retraced)"
-            if flags[3]:
-                t0 = 1.5 * self.tau_rot * (self.nu_fit / 1500.0) ** -4.0
-                x0[:, 3] = np.log10(t0) if self.log10_tau else t0
-                x0[:, 4] = -4.0
-            self.x0 = x0
-
-        def pptoas_phase_guess(self):
-            """pptoas.py:421-457 on the device: dedisperse every subint at the header
-            DM to the mean frequency, average over channels, 1-D FFTFIT against the
-            template's mean profile (Ns = 100 grid + SciPy's simplex finish, retraced:
-            the guess the reference itself would start from), move the phase to nu_fit."""
-            nu_mean = float(self.freqs.mean())
-            out = eng.reference_phase_seed(self.data, self.freqs, self.P, np.ones((self.nsub, self.C)),
-                                           self.seed_prof, DM=np.full(self.nsub, args.dm0), nu_DM=nu_mean,
-                                           Ns=100, finish='simplex')
-            phi = out[:, 0] + DCONST * args.dm0 / self.P * (self.nu_fit ** -2 - nu_mean ** -2)
-            return (phi + 0.5) % 1.0 - 0.5
-
-        def fit(self, records=None, method=None, n=None):
-            n = self.nsub if n is None else n         # (a ragged last sub-batch fits its first n)
-            if self.reseed:
-                # the reference's own preamble inside the timed step: one more read of the
-                # portraits (rotation + channel mean + fit_phase_shift), then the fit
-                self.x0[:, 0] = self.pptoas_phase_guess()
-            return eng.fit_batch(self.data[:n], self.freqs, self.P[:n], self.x0[:n],
-                                 errs=None if args.measured_noise else self.errs_dev[:n],
-                                 nu_fits=np.full((n, 3), self.nu_fit), fit_flags=self.flags,
-                                 log10_tau=self.log10_tau, per_channel="device",
-                                 seed_ns=self.seed_ns, method=method or args.method, records=records)
-
-        def free(self):
-            del self.data, self.errs_dev
-            torch.cuda.empty_cache()
-
     def timed(batch, steps, warmup, method=None):
         """`steps` passes over the resident batch; records of all steps stay on the
         device and are gathered once before the clock stops."""
@@ -343,18 +372,29 @@ def main():
             "hbm_frac_of_8TBps": round(achieved / HBM_PEAK_GBPS, 4),
             "kernels_ms_per_step": {k: round(1e3 * v[0] / steps, 4) for k, v in ktimes.items() if v[1] > 0},
             "nfeval_mean": float(np.mean(res["nfeval"])), "nfeval_max": int(np.max(res["nfeval"])),
+            "npass_mean": float(np.mean(res["npass"])), "npass_max": int(np.max(res["npass"])),
             "return_codes": {str(k): int(v) for k, v in zip(*np.unique(res["return_code"],
                                                                       return_counts=True))}}
 
     # ======================================================================
+    def sync():
+        eng.synchronize()
+        torch.cuda.synchronize()
+
+    def make_batch(workload, nsub, first):
+        return Batch(eng, args, device, workload, nsub, args.input_dtype, first, seed_ns=args.seed_ns)
+
     if args.total_nsub > 0:
-        strong_scaling(args, eng, Batch, fence, ppdist, dist, torch, device, rank, world, use_dist)
+        sline = strong_scaling(args, make_batch, sync, fence, device, rank, world, use_dist)
+        if rank == 0:
+            print(json.dumps(sline))
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    batch = Batch(args.workload, args.nsub, args.input_dtype, rank * (args.nsub or WORKLOADS[args.workload][4]),
+    batch = Batch(eng, args, device, args.workload, args.nsub, args.input_dtype,
+                  rank * (args.nsub or WORKLOADS[args.workload][4]),
                   seed_ns=max(args.seed_ns, 0), reseed=(args.seed_ns < 0))
     res, gathered, elapsed, ktimes = timed(batch, args.steps, args.warmup)
 
@@ -408,6 +448,9 @@ def main():
                                           "1 gather at the end" % world},
                 "roofline": roofline,
                 "convergence": {"nfeval_mean": summ["nfeval_mean"], "nfeval_max": summ["nfeval_max"],
+                                "npass_mean": summ["npass_mean"], "npass_max": summ["npass_max"],
+                                "note": "nfeval: objective evaluations as the reference counts them (SciPy's "
+                                        "nfev); npass: how many of them were passes over the data",
                                 "return_codes": summ["return_codes"]},
                 "gathered_records": {"rows": int(rec.shape[0]),
                                      "checksum": ppdist.records_checksum(rec)["column_sums"][:3]}}
@@ -430,7 +473,7 @@ def main():
             if wl == args.workload and dt == args.input_dtype and sns == args.seed_ns and meth is None:
                 continue
             try:
-                b = Batch(wl, 0, dt, 0, seed_ns=max(sns, 0), reseed=(sns < 0))
+                b = Batch(eng, args, device, wl, 0, dt, 0, seed_ns=max(sns, 0), reseed=(sns < 0))
                 if sns < 0:
                     b.guess = "the reference's preamble INSIDE the timed step (fused rotation + channel mean + " \
                               "fit_phase_shift with the simplex finish), then trust-ncg from that guess"
@@ -445,6 +488,20 @@ def main():
                 b.free()
             except Exception as exc:      # a secondary workload must not lose the headline
                 others[key] = {"error": repr(exc)}
+        # configs[4]'s flow (contiguous shard, device-generated sub-batches, ragged last one, one
+        # gather) at a size one GPU finishes in seconds
+        try:
+            import copy
+            sargs = copy.copy(args)
+            sargs.total_nsub, sargs.nsub, sargs.dump_records = 3000, 1024, None
+            sl = strong_scaling(sargs, make_batch, sync, fence, device, rank, world, use_dist)
+            others["strong_3000"] = {"fits_per_s": sl["value"], "ms_total": sl["ms_per_step"],
+                                     "gather_ms": sl["gather_ms"], "rows": sl["gathered_records"]["rows"],
+                                     "sub_batches": sl["config"]["sub_batches_rank0"],
+                                     "max_abs_dDM_over_err": sl["max_abs_dDM_over_err"],
+                                     "workload": args.workload, "scaling": "strong"}
+        except Exception as exc:
+            others["strong_3000"] = {"error": repr(exc)}
         line["other_workloads"] = others
         if pool is not None:
             line["cpu_baseline"] = cpu_baseline(pool, keep["data"], main_model, main_freqs, main_P, main_x0,
@@ -464,32 +521,39 @@ def main():
         dist.destroy_process_group()
 
 
-def strong_scaling(args, eng, Batch, fence, ppdist, dist, torch, device, rank, world, use_dist):
+def strong_scaling(args, make_batch, sync, fence, device, rank, world, use_dist):
     """configs[4] as written: --total-nsub subints in all, rank r owns the contiguous
     shard shard_range(total, r, world) and fits it in device-generated sub-batches
     of --nsub (a sub-batch is generated, the clock runs only while it is fitted:
     inputs are resident when their timed region starts); every record stays in HBM
-    and ONE gather at the end brings them to rank 0."""
+    and ONE gather at the end brings them to rank 0.  Returns the JSON line's dict on
+    rank 0 (None elsewhere).  `make_batch(workload, nsub, first)` builds the resident
+    batch (bench's Batch; a stub in the CPU tests), `sync()` drains the device."""
+    import torch
+    import torch.distributed as dist
+    from pulseportraiture_amd import dist as ppdist
     C, B, flags, log10_tau, nsub_def, note = WORKLOADS[args.workload]
     nsub = args.nsub or nsub_def
     lo, hi = ppdist.shard_range(args.total_nsub, rank, world)
     counts = [b - a for a, b in (ppdist.shard_range(args.total_nsub, r, world) for r in range(world))]
     recs = torch.zeros((hi - lo, ppdist.RECORD_WIDTH), dtype=torch.float64, device=device)
-    batch = Batch(args.workload, nsub, args.input_dtype, lo, seed_ns=args.seed_ns)
+    batch = make_batch(args.workload, nsub, lo)
     batch.fit()                                  # warm-up (untimed)
     fit_s, done = 0.0, 0
     worst = 0.0
+    sub_batches = []
     while done < hi - lo:
         n = min(nsub, hi - lo - done)
         if done:
             batch.generate(lo + done)
-        eng.synchronize(); torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         res = batch.fit(records=recs[done:done + n], n=n)
-        eng.synchronize(); torch.cuda.synchronize()
+        sync()
         fit_s += time.perf_counter() - t0
         worst = max(worst, float(np.max(np.abs(res["params"][:n, 1] - batch.inj[:n, 1]) /
                                         res["param_errs"][:n, 1])))
+        sub_batches.append(n)
         done += n
     fence()
     t0 = time.perf_counter()
@@ -501,26 +565,34 @@ def strong_scaling(args, eng, Batch, fence, ppdist, dist, torch, device, rank, w
         t = torch.tensor([total_s, worst], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         total_s, worst = float(t[0].item()), float(t[1].item())
-    if rank == 0:
-        rec = gathered.cpu().numpy() if hasattr(gathered, "cpu") else np.asarray(gathered)
-        cs = ppdist.records_checksum(rec)
-        print(json.dumps({
-            "metric": "subint_fits_per_sec", "value": round(args.total_nsub / total_s, 2),
-            "unit": "fits/s", "n_gpus": world, "steps": 1, "warmup": 1,
-            "ms_per_step": round(1e3 * total_s, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": args.workload, "note": note, "total_nsub": args.total_nsub,
-                       "fits_per_rank": counts, "sub_batch": nsub, "nchan": C, "nbin": B,
-                       "fit_flags": flags, "input_dtype": args.input_dtype, "method": args.method,
-                       "phase_guesses": batch.guess,
-                       "timed": "fit of every sub-batch (inputs resident, generation excluded) + "
-                                "the one gather of all records",
-                       "parallelism": "contiguous subint shards over %d rank(s), records kept in "
-                                      "HBM, 1 gather at the end" % world},
-            "gather_ms": round(1e3 * gather_s, 3),
-            "gathered_records": {"rows": cs["rows"], "checksum": cs["column_sums"][:3],
-                                 "return_code_sum": cs["column_sums"][17]},
-            "max_abs_dDM_over_err": worst}))
+    guess = batch.guess
+    if hasattr(batch, "free"):
+        batch.free()
+    if rank != 0:
+        return None
+    rec = gathered.cpu().numpy() if hasattr(gathered, "cpu") else np.asarray(gathered)
+    if getattr(args, "dump_records", None):
+        np.save(args.dump_records, rec)
+    cs = ppdist.records_checksum(rec)
+    return {
+        "metric": "subint_fits_per_sec", "value": round(args.total_nsub / total_s, 2),
+        "unit": "fits/s", "n_gpus": world, "steps": 1, "warmup": 1,
+        "ms_per_step": round(1e3 * total_s, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": args.workload, "note": note, "total_nsub": args.total_nsub,
+                   "fits_per_rank": counts, "sub_batch": nsub, "sub_batches_rank0": sub_batches,
+                   "nchan": C, "nbin": B,
+                   "fit_flags": flags, "input_dtype": args.input_dtype, "method": args.method,
+                   "phase_guesses": guess,
+                   "timed": "fit of every sub-batch (inputs resident, generation excluded) + "
+                            "the one gather of all records",
+                   "parallelism": "contiguous subint shards over %d rank(s), records kept in "
+                                  "HBM, 1 gather at the end" % world},
+        "gather_ms": round(1e3 * gather_s, 3),
+        "gathered_records": {"rows": cs["rows"], "checksum": cs["column_sums"][:3],
+                             "column_sums": cs["column_sums"],
+                             "return_code_sum": cs["column_sums"][17]},
+        "max_abs_dDM_over_err": worst}
 
 
 def cpu_baseline(pool, data64, model, freqs, P, x0, sigma, nu_fit, flags, log10_tau, res, nsample):

@@ -265,6 +265,21 @@ typedef struct {
  * max_iter == 0 only evaluates the objective at init_params (obj_* outputs). */
 int pp_fit_portrait_batch(pp_ctx* ctx, const pp_fit_in* in, pp_fit_out* out);
 
+/* Asynchronous form.  pp_fit_submit copies the two argument blocks, starts
+ * the batch on a worker thread of the context and returns at once; pp_fit_wait blocks
+ * until it has finished and returns what pp_fit_portrait_batch would have returned (the
+ * message of a failure is then available from pp_last_error on the waiting thread);
+ * pp_fit_poll returns 1 once the batch is complete, 0 while it runs.  Every buffer the
+ * argument blocks point to must stay valid and untouched until pp_fit_wait returns; one
+ * batch per context may be in flight, and no other call may be made on that context
+ * meanwhile (PP_ESTATE on a second submit).  Batches submitted on two contexts of one
+ * GPU overlap: one context's host-to-device copies run beside the other's kernels.
+ * The reference has no counterpart: its loop over subints is serial
+ * (pptoas.py:344-489). */
+int pp_fit_submit(pp_ctx* ctx, const pp_fit_in* in, pp_fit_out* out);
+int pp_fit_poll(pp_ctx* ctx);
+int pp_fit_wait(pp_ctx* ctx);
+
 /* ---- building blocks exported for parity tests --------------------------- */
 /* rFFT of nrows real rows of length nbin (host pointers); out holds
  * nrows*(nbin/2+1) interleaved (re,im) doubles.  numpy.fft.rfft of

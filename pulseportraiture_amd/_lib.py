@@ -61,6 +61,9 @@ SYMBOLS = {
     "pp_model_dc": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     "pp_fit_portrait_batch": (C.c_int, [C.c_void_p, C.POINTER(FitIn),
                                         C.POINTER(FitOut)]),
+    "pp_fit_submit": (C.c_int, [C.c_void_p, C.POINTER(FitIn), C.POINTER(FitOut)]),
+    "pp_fit_poll": (C.c_int, [C.c_void_p]),
+    "pp_fit_wait": (C.c_int, [C.c_void_p]),
     "pp_rfft_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                c_double_p]),
     "pp_fit_phase_shift_batch": (C.c_int, [C.c_void_p, c_double_p, c_double_p,

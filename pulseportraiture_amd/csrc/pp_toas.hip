@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pp_kernels.h"
@@ -117,6 +119,14 @@ struct pp_ctx {
     double fam_sec[KF_COUNT] = {0};
     long long fam_n[KF_COUNT] = {0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // pp_fit_submit / pp_fit_wait: one fit in flight on a worker thread of the context
+    std::thread job;
+    bool job_active = false;
+    std::atomic<int> job_done{0};
+    int job_rc = 0;
+    std::string job_err;
+    pp_fit_in job_in;
+    pp_fit_out job_out;
 };
 
 struct Prof {
@@ -193,6 +203,7 @@ extern "C" int pp_create(int device_id, pp_ctx** out) {
 
 extern "C" int pp_destroy(pp_ctx* c) {
     if (!c) return PP_OK;
+    if (c->job_active) { c->job.join(); c->job_active = false; }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     resolve_spans(c);
@@ -1026,6 +1037,42 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
     }
     if (c->profile) resolve_spans(c);
     return PP_OK;
+}
+
+// --------------------------------------------------------------------------
+// asynchronous form: the batch runs on a worker thread of the context (host-to-device
+// copies, kernels and the few host checks of the iteration included), the caller's
+// thread is free meanwhile -- to read the next archive, or to drive another context
+// whose copies and kernels then overlap with this one's
+// --------------------------------------------------------------------------
+extern "C" int pp_fit_submit(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out) {
+    if (!c || !in || !out) return fail(PP_EINVAL, "pp_fit_submit: null argument");
+    if (c->job_active) return fail(PP_ESTATE, "pp_fit_submit: a submitted fit is pending (pp_fit_wait first)");
+    c->job_in = *in;
+    c->job_out = *out;
+    c->job_done.store(0);
+    c->job_active = true;
+    c->job = std::thread([c]() {
+        c->job_rc = pp_fit_portrait_batch(c, &c->job_in, &c->job_out);
+        c->job_err = g_err;              // (the worker's thread-local message)
+        c->job_done.store(1);
+    });
+    return PP_OK;
+}
+
+extern "C" int pp_fit_poll(pp_ctx* c) {
+    if (!c) return fail(PP_EINVAL, "null context");
+    if (!c->job_active) return fail(PP_ESTATE, "pp_fit_poll: nothing submitted");
+    return c->job_done.load() ? 1 : 0;
+}
+
+extern "C" int pp_fit_wait(pp_ctx* c) {
+    if (!c) return fail(PP_EINVAL, "null context");
+    if (!c->job_active) return fail(PP_ESTATE, "pp_fit_wait: nothing submitted");
+    c->job.join();
+    c->job_active = false;
+    if (c->job_rc) g_err = c->job_err;
+    return c->job_rc;
 }
 
 #include "pp_extra_api.h"

@@ -155,7 +155,7 @@ class Engine(object):
                   nu_outs=None, fit_flags=(1, 1, 0, 0, 0), log10_tau=False,
                   option=0, is_toa=True, model_slot=None, chan_mask=None,
                   per_channel=True, objective=False, seed_ns=0, method='trust-ncg',
-                  records=None):
+                  records=None, _submit=False):
         """Fit nsub subints.  data: [nsub,nchan,nbin] numpy array (f64/f32) or
         CUDA tensor.  freqs: [nchan] or [nsub,nchan].  Returns a dict of arrays
         (see include/pp_toas.h pp_fit_out).  errs / chan_mask may be CUDA
@@ -286,12 +286,45 @@ class Engine(object):
                 setattr(fout, name, arr.ctypes.data_as(c_int32_p))
             else:
                 setattr(fout, name, arr.ctypes.data_as(c_double_p))
+        res["fit_flags"] = [1 if f else 0 for f in fit_flags]
+        if _submit:
+            if getattr(self, "_pending", None) is not None:
+                raise EngineError("a submitted batch is pending: wait() first")
+            _check(self._lib.pp_fit_submit(self._ctx, C.byref(fin), C.byref(fout)), "pp_fit_submit")
+            # every array the argument blocks point to stays alive until wait()
+            self._pending = (res, (keep, freqs, P, x0, errs, nu_fits, nu_outs, slot, mask, chan_mask,
+                                   records, fin, fout))
+            return None
         _check(self._lib.pp_fit_portrait_batch(self._ctx, C.byref(fin),
                                                C.byref(fout)),
                "pp_fit_portrait_batch")
         del keep
         res["duration"] = float(res["duration"][0])
-        res["fit_flags"] = [1 if f else 0 for f in fit_flags]
+        return res
+
+    def submit(self, *args, **kwargs):
+        """fit_batch started on a worker thread of the context (pp_fit_submit): returns at
+        once; wait() returns the result dict.  The caller's arrays must not be modified
+        until then.  Two engines on one GPU overlap their copies and kernels."""
+        kwargs["_submit"] = True
+        self.fit_batch(*args, **kwargs)
+
+    def poll(self):
+        """True once the submitted batch is complete."""
+        rc = self._lib.pp_fit_poll(self._ctx)
+        if rc < 0:
+            _check(rc, "pp_fit_poll")
+        return bool(rc)
+
+    def wait(self):
+        """Block until the submitted batch is complete; returns what fit_batch returns."""
+        if getattr(self, "_pending", None) is None:
+            raise EngineError("nothing submitted")
+        res, keep = self._pending
+        self._pending = None
+        _check(self._lib.pp_fit_wait(self._ctx), "pp_fit_wait")
+        del keep
+        res["duration"] = float(res["duration"][0])
         return res
 
     # -- parity hooks / measurement ---------------------------------------

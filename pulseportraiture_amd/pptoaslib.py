@@ -43,9 +43,11 @@ def fit_portrait_full(data_port, model_port, init_params, P, freqs,
     Same arguments and result fields as the reference.  method='trust-ncg' (the
     reference's default) walks SciPy's trust-ncg iteration on the device and stops
     where the reference stops; 'Newton-CG' and 'TNC' both run the device's Newton
-    solver to the rounding of the objective (`bounds` are not applied: the
-    reference drops them too unless TNC, pptoaslib.py:995-997); an unknown method
-    exits like the reference does (pptoaslib.py:1008-1010)."""
+    solver to the rounding of the objective.  `bounds` are honoured for 'TNC' only,
+    like the reference (pptoaslib.py:995-997 drops them for the other methods): the
+    box-constrained optimum is found by an active-set iteration over device fits
+    (_fit_with_bounds); an unknown method exits like the reference does
+    (pptoaslib.py:1008-1010)."""
     if method not in _METHODS:
         print("Method '%s' is not implemented." % method)
         sys.exit()
@@ -53,6 +55,12 @@ def fit_portrait_full(data_port, model_port, init_params, P, freqs,
     flags = [1 if f else 0 for f in fit_flags]
     eng.set_model_cached(model_port, slot=0)
     data = np.asarray(data_port)
+    if method == 'TNC' and bounds is not None and any(
+            b is not None and (b[0] is not None or b[1] is not None) for b in bounds):
+        res = _fit_with_bounds(eng, data[None] if data.ndim == 2 else data, freqs, P, init_params,
+                               errs, list(nu_fits), list(nu_outs), flags, bounds, log10_tau, option,
+                               is_toa)
+        return _bunch(res, 0, flags)
     res = eng.fit_batch(data[None] if data.ndim == 2 else data, freqs, P,
                         init_params, errs=errs, nu_fits=[list(nu_fits)],
                         nu_outs=[list(nu_outs)], fit_flags=flags,
@@ -69,6 +77,63 @@ def fit_portrait_full(data_port, model_port, init_params, P, freqs,
             sys.stderr.write("Fit 'failed' with return code %d -- %s" %
                              (r.return_code, rcs))
     return r
+
+
+def _fit_with_bounds(eng, data, freqs, P, init_params, errs, nu_fits, nu_outs, flags, bounds,
+                     log10_tau, option, is_toa):
+    """method='TNC' with finite bounds (pptoaslib.py:995-1007: the only method the
+    reference applies them for).  The box applies to the parameters AT the fit's
+    reference frequencies, as in the reference.  Active-set iteration, every step one
+    device fit (Newton solver): parameters found outside their bounds are fixed at the
+    bound and the rest refitted; a fixed parameter whose gradient points back into the
+    box is released.  The post-fit quantities (zero-covariance frequencies, errors,
+    covariance, scales) are then taken at that point with the caller's fit_flags, as
+    the reference takes them at whatever its minimiser returns."""
+    lo = np.array([-np.inf if (b is None or b[0] is None) else float(b[0]) for b in bounds])
+    hi = np.array([np.inf if (b is None or b[1] is None) else float(b[1]) for b in bounds])
+    if np.any(lo > hi):
+        raise ValueError("bounds: lower > upper")
+    x = np.clip(np.asarray(init_params, dtype=np.float64).copy(), lo, hi)   # (TNC starts inside the box)
+    common = dict(errs=errs, nu_fits=[nu_fits], log10_tau=log10_tau, option=option, is_toa=is_toa)
+    active = {}
+    for _ in range(12):
+        fl = [1 if (f and j not in active) else 0 for j, f in enumerate(flags)]
+        for j, v in active.items():
+            x[j] = v
+        if any(fl):
+            # raw parameters: output frequencies = the fit's own
+            r = eng.fit_batch(data, freqs, P, x, nu_outs=[nu_fits], fit_flags=fl, method='newton', **common)
+            xs = r["params"][0].copy()
+            xs[0] = x[0] + ((xs[0] - x[0] + 0.5) % 1.0 - 0.5)     # (the phase comes back wrapped)
+        else:
+            xs = x.copy()
+        out = [j for j in range(5) if fl[j] and not (lo[j] <= xs[j] <= hi[j])]
+        if out:
+            j = max(out, key=lambda q: max(lo[q] - xs[q], xs[q] - hi[q]) / (abs(xs[q]) + 1e-300))
+            active[j] = lo[j] if xs[j] < lo[j] else hi[j]
+            x = np.clip(xs, lo, hi)
+            continue
+        x = xs
+        # gradient of the full problem at x: may a fixed parameter move back inside?
+        eng.set_option("max_iter", 0)
+        try:
+            g = eng.fit_batch(data, freqs, P, x, nu_outs=[nu_fits], fit_flags=flags, objective=True,
+                              method='newton', **common)["obj_grad"][0]
+        finally:
+            eng.set_option("max_iter", 64)
+        free = [j for j, v in active.items() if (v == lo[j] and g[j] < 0.0) or (v == hi[j] and g[j] > 0.0)]
+        if not free:
+            break
+        for j in free:
+            del active[j]
+    # post-fit stage at x with the caller's flags and output frequencies
+    eng.set_option("max_iter", 0)
+    try:
+        res = eng.fit_batch(data, freqs, P, x, nu_outs=[nu_outs], fit_flags=flags, method='newton', **common)
+    finally:
+        eng.set_option("max_iter", 64)
+    res["return_code"][:] = 2 if not active else 0     # (TNC's table: XCONVERGED / LOCALMINIMUM at a bound)
+    return res
 
 
 def rotate_portrait_full(port, phi, DM, GM, freqs, nu_DM=np.inf, nu_GM=np.inf, P=None):

@@ -115,6 +115,92 @@ def test_gather_tensor_records_world2_gloo():
     np.testing.assert_allclose(cs["column_sums"], want.sum(axis=0))
 
 
+class _StubBatch(object):
+    """What bench.strong_scaling needs of a resident batch, without a GPU: the 'fit' of
+    subint g (global index) is a fixed function of g, written into the records tensor
+    the way pp_fit_out.records_dev is."""
+    guess = "stub"
+
+    def __init__(self, workload, nsub, first):
+        self.nsub, self.calls = nsub, []
+        self.generate(first)
+
+    def generate(self, first):
+        self.first = first
+        self.inj = np.zeros((self.nsub, 3))
+        self.inj[:, 1] = 30.0 + 1e-3 * (first + np.arange(self.nsub))
+
+    def fit(self, records=None, n=None):
+        import torch
+        n = self.nsub if n is None else n
+        res = _fake_result(self.first, self.first + n)
+        res["params"][:, 1] = self.inj[:n, 1] + 0.5 * res["param_errs"][:, 1]
+        if records is not None:
+            assert tuple(records.shape) == (n, ppdist.RECORD_WIDTH)
+            records.copy_(torch.from_numpy(ppdist.pack_records(res)))
+            self.calls.append((self.first, n))
+        return res
+
+
+def _worker_strong(rank, world, port, total, nsub, q):
+    import argparse
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        args = argparse.Namespace(workload="cfg2-512x1024-phiDM", nsub=nsub, total_nsub=total, input_dtype="f64",
+                                  method="trust-ncg", dump_records=None)
+        made = []
+
+        def make_batch(workload, n, first):
+            made.append(_StubBatch(workload, n, first))
+            return made[-1]
+        line = bench.strong_scaling(args, make_batch, lambda: None, dist.barrier, "cpu", rank, world, True)
+        lo, hi = ppdist.shard_range(total, rank, world)
+        # this rank fitted exactly its contiguous shard, in sub-batches of nsub, the last one ragged
+        want, g = [], lo
+        while g < hi:
+            want.append((g, min(nsub, hi - g)))
+            g += nsub
+        assert made[0].calls == want, (made[0].calls, want)
+        q.put((rank, line))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_strong_scaling_shards_and_gathers_world2_gloo():
+    """bench.strong_scaling (configs[4]'s flow: contiguous shards, sub-batches, ragged
+    tails, ONE gather, max-over-ranks timing) driven on CPU with a stub batch, world 2."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    total, nsub, world = 2501, 600, 2           # shards 1251 + 1250; sub-batches 600, 600, 51 / 600, 600, 50
+    procs = [ctx.Process(target=_worker_strong, args=(r, world, port, total, nsub, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1] is None
+    line = got[0]
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2
+    assert line["config"]["fits_per_rank"] == [1251, 1250]
+    assert line["config"]["sub_batches_rank0"] == [600, 600, 51]
+    assert line["gathered_records"]["rows"] == total
+    want = _fake_result(0, total)
+    want["params"][:, 1] = 30.0 + 1e-3 * np.arange(total) + 0.5 * want["param_errs"][:, 1]
+    np.testing.assert_allclose(line["gathered_records"]["column_sums"], ppdist.pack_records(want).sum(axis=0),
+                               rtol=1e-13)
+    assert abs(line["max_abs_dDM_over_err"] - 0.5) < 1e-9
+    assert line["value"] > 0 and line["ms_per_step"] > 0
+
+
 def test_record_layout_matches_the_c_abi():
     """RECORD_FIELDS is the layout k_finalize writes into pp_fit_out.records_dev
     (include/pp_toas.h PP_RECORD_WIDTH)."""

@@ -1743,30 +1743,112 @@ def test_device_spline_portrait_matches_reference(eng):
     np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-11)
 
 
-def test_device_instrumental_response_matches_host(eng):
+def test_device_instrumental_response_matches_oracle(eng):
     """apply_response (constant responses x per-channel dispersive smearing, multiplied
-    into the resident template's spectrum on the device) against the same template
-    multiplied on the host with instrumental_response_port_FT (pptoaslib.py:145-179)."""
-    from pulseportraiture_amd.pptoaslib import (instrumental_response_port_FT,
-                                                instrumental_response_device_args)
+    into the resident template's spectrum on the device) against the ORACLE: the same fit
+    made by the CPU restatement with the template multiplied by its own
+    instrumental_response_port_FT (pptoaslib.py:145-179; pinned to the true reference's
+    arrays in tests/test_oracle_golden.py), raw."""
+    from oracle import pptoas_oracle as orc
+    from pulseportraiture_amd.pptoaslib import instrumental_response_device_args
     g = _load("fpf_64x256_phiDM")
     C, B = g["model"].shape
     P = float(g["P"])
     wids, types, DM = [0.011, 0.004], ["rect", "gauss"], 30.0
-    resp = instrumental_response_port_FT(B, g["freqs"], DM, P, wids, types)
-    host = np.fft.irfft(resp * np.fft.rfft(g["model"], axis=-1), axis=-1)
-    kw = dict(errs=g["errs"], nu_fits=[list(g["nu_fits"])], fit_flags=[1, 1, 0, 0, 0], method="newton")
-    eng.set_model(host)
-    a = eng.fit_batch(g["data"][None], g["freqs"], P, g["init_params"], **kw)
+    resp = orc.instrumental_response_port_FT(B, g["freqs"], DM, P, wids, types)
+    smeared = np.fft.irfft(resp * np.fft.rfft(g["model"], axis=-1), axis=-1)
+    o = orc.fit_portrait_full(g["data"], smeared, g["init_params"], P, g["freqs"], list(g["nu_fits"]),
+                              [None] * 3, g["errs"], [1, 1, 0, 0, 0], log10_tau=False)
+    kw = dict(errs=g["errs"], nu_fits=[list(g["nu_fits"])], fit_flags=[1, 1, 0, 0, 0])
     eng.set_model(g["model"])
     rconst, smear = instrumental_response_device_args(B, g["freqs"], DM, P, wids, types)
     eng.apply_response(0, rconst, smear)
     b = eng.fit_batch(g["data"][None], g["freqs"], P, g["init_params"], **kw)
-    assert _dphi(a["params"][0, 0], b["params"][0, 0]) < 1e-12
-    assert abs(a["params"][0, 1] - b["params"][0, 1]) < 1e-10
-    np.testing.assert_allclose(a["scales"], b["scales"], rtol=1e-10)
+    assert _dphi(b["params"][0, 0], o.phi) < PHI_BAR
+    assert abs(b["params"][0, 1] - o.DM) < DM_BAR
+    np.testing.assert_allclose(b["scales"][0], o.scales, rtol=1e-8)
+    np.testing.assert_allclose(b["chi2"][0], o.chi2, rtol=1e-10)
+    np.testing.assert_allclose(b["param_errs"][0, :2], np.asarray(o.param_errs)[:2], rtol=1e-7)
+    np.testing.assert_allclose(b["nu_refs"][0, 0], o.nu_DM, rtol=1e-8)
+    # ... and against the product's own host path (template smeared on the host, then uploaded)
+    eng.set_model(smeared)
+    a = eng.fit_batch(g["data"][None], g["freqs"], P, g["init_params"], **kw)
+    assert _dphi(a["params"][0, 0], b["params"][0, 0]) < 1e-11
     np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-11)
-    np.testing.assert_allclose(a["param_errs"], b["param_errs"], rtol=1e-9)
+
+
+def test_submit_and_wait_overlap_two_contexts():
+    """pp_fit_submit / pp_fit_wait: a host-array batch started on one
+    context runs on that context's worker thread while the calling thread fits another
+    batch on a second context; both return exactly what the synchronous call returns.
+    A second submit on a busy context is refused (PP_ESTATE), wait() without a submit
+    too."""
+    from pulseportraiture_amd.engine import Engine, EngineError
+    g = _load("fpf_128x512_phiDM_scint")
+    nsub = 48
+    rng = np.random.default_rng(3)
+    data = np.repeat(g["data"][None], nsub, axis=0) + 0.01 * rng.standard_normal((nsub,) + g["data"].shape)
+    x0 = np.tile(g["init_params"], (nsub, 1))
+    kw = dict(errs=np.tile(g["errs"], (nsub, 1)), nu_fits=np.tile(g["nu_fits"], (nsub, 1)), fit_flags=[1, 1, 0, 0, 0])
+    ea, eb = Engine(0), Engine(0)
+    ea.set_model(g["model"]); eb.set_model(g["model"])
+    sync = ea.fit_batch(data, g["freqs"], float(g["P"]), x0, **kw)
+    with pytest.raises(EngineError):
+        ea.wait()
+    ea.submit(data, g["freqs"], float(g["P"]), x0, **kw)
+    with pytest.raises(EngineError):
+        ea.submit(data, g["freqs"], float(g["P"]), x0, **kw)
+    other = eb.fit_batch(data[::-1].copy(), g["freqs"], float(g["P"]), x0, **kw)     # meanwhile, on context B
+    res = ea.wait()
+    assert ea.poll.__self__ is ea
+    for k in ("params", "param_errs", "nu_refs", "chi2", "snr", "scales", "nfeval", "npass", "return_code"):
+        np.testing.assert_array_equal(res[k], sync[k])
+        np.testing.assert_array_equal(other[k], sync[k][::-1])
+    # a failing batch reports through wait(), with the worker's message
+    ea.submit(data, g["freqs"], float(g["P"]), x0, model_slot=np.full(nsub, 7), **kw)
+    with pytest.raises(EngineError, match="slot"):
+        ea.wait()
+    ea.close(); eb.close()
+
+
+def test_tnc_bounds_are_honoured():
+    """method='TNC' is the one method the reference applies `bounds` for
+    (pptoaslib.py:995-1007).  Inactive bounds: the unbounded optimum.  An active bound
+    (DM capped 3 sigma below its optimum; tau floored above its optimum): the parameter
+    sits ON the bound and the others at the constrained optimum -- against the oracle's
+    SciPy TNC with the same bounds, to TNC's own convergence, and against the oracle's
+    objective: no feasible point nearby is lower."""
+    from oracle import pptoas_oracle as orc
+    from pulseportraiture_amd.pptoaslib import fit_portrait_full
+    g = _load("fpf_64x256_phiDM")
+    nus = list(g["nu_fits"])
+    args = (g["data"], g["model"], g["init_params"], float(g["P"]), g["freqs"], nus, nus, g["errs"], [1, 1, 0, 0, 0])
+    free = fit_portrait_full(*args, log10_tau=False, method='Newton-CG')
+    wide = fit_portrait_full(*args, bounds=[(-1.0, 1.0), (0.0, 100.0), (None, None), (None, None), (None, None)],
+                             log10_tau=False, method='TNC')
+    assert _dphi(wide.phi, free.phi) < 1e-12 and abs(wide.DM - free.DM) < 1e-12
+    cap = free.DM - 3.0 * free.DM_err
+    bnds = [(None, None), (None, cap), (None, None), (None, None), (None, None)]
+    r = fit_portrait_full(*args, bounds=bnds, log10_tau=False, method='TNC')
+    o = orc.fit_portrait_full(*args, bounds=bnds, log10_tau=False, method='TNC')
+    assert r.DM == cap and abs(o.DM - cap) < 1e-12
+    assert _dphi(r.phi, o.phi) < 1e-7, (r.phi, o.phi)          # (TNC stops at xtol, far from rounding)
+    np.testing.assert_allclose(r.chi2, o.chi2, rtol=1e-9)
+    # the device's point is the better constrained optimum: the oracle's objective along phi
+    B = g["data"].shape[1]
+    dFT = np.fft.rfft(g["data"], axis=-1); dFT[:, 0] = 0
+    mFT = np.fft.rfft(g["model"], axis=-1); mFT[:, 0] = 0
+    oargs = (dFT, mFT, g["errs"] * np.sqrt(B / 2.0), float(g["P"]), g["freqs"], nus[0], nus[1], nus[2],
+             [True, True, False, False, False], False)
+    f_at = lambda phi: orc.fit_portrait_full_function(np.array([phi, cap, 0.0, 0.0, 0.0]), *oargs)
+    f0 = f_at(r.phi)
+    assert f0 <= f_at(o.phi) + 1e-9 * abs(f0)
+    assert f0 < f_at(r.phi + 1e-6) and f0 < f_at(r.phi - 1e-6)
+    # errors are reported for every flagged parameter at the returned point, as the reference does
+    np.testing.assert_allclose(r.param_errs[:2], np.asarray(o.param_errs)[:2], rtol=1e-4)
+    # other methods drop the bounds (pptoaslib.py:995-997)
+    same = fit_portrait_full(*args, bounds=bnds, log10_tau=False, method='Newton-CG')
+    assert same.DM == free.DM
 
 
 def test_coarse_phase_dm_grid_recovers_a_poor_dm_guess(eng):

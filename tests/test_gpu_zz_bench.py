@@ -1,0 +1,56 @@
+"""The multi-GPU bench path as far as one GPU allows: `bench.py --total-nsub 2500 --nsub
+1024` (configs[4]'s strong-scaling flow: contiguous shard, device-generated sub-batches,
+a ragged last one, records kept in HBM, one gather) run in a fresh child process --
+started by tests/conftest.py before this process touched the GPU -- and its records
+checked against fits made directly in this process.  (Named to run last: the child
+works beside the other GPU tests.)"""
+import argparse
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(900)
+def test_strong_scaling_bench_in_a_child_process():
+    import torch
+    from tests.conftest import BENCH_CHILD, BENCH_CHILD_ARGS
+    import bench
+    from pulseportraiture_amd import dist as ppdist
+    from pulseportraiture_amd.engine import Engine
+    assert BENCH_CHILD.get("proc") is not None, "conftest did not start the bench child (GPU visible?)"
+    rc = BENCH_CHILD["proc"].wait(timeout=800)
+    BENCH_CHILD["out"].close(); BENCH_CHILD["err"].close()
+    text = open(os.path.join(BENCH_CHILD["tmp"], "line.json")).read().strip()
+    assert rc == 0 and text, open(os.path.join(BENCH_CHILD["tmp"], "stderr.txt")).read()[-2000:]
+    line = json.loads(text.splitlines()[-1])
+    total, nsub = 2500, 1024
+    assert line["scaling"] == "strong" and line["n_gpus"] == 1 and line["metric"] == "subint_fits_per_sec"
+    cfg = line["config"]
+    assert cfg["total_nsub"] == total and cfg["fits_per_rank"] == [total] and cfg["sub_batch"] == nsub
+    assert cfg["sub_batches_rank0"] == [1024, 1024, 452]              # (the ragged last sub-batch)
+    assert line["gathered_records"]["rows"] == total
+    assert line["value"] > 1e4 and line["max_abs_dDM_over_err"] < 6.0
+    rec = np.load(BENCH_CHILD["records"])
+    assert rec.shape == (total, ppdist.RECORD_WIDTH)
+    np.testing.assert_allclose(rec.sum(axis=0), line["gathered_records"]["column_sums"], rtol=1e-12)
+    assert (rec[:, 17] == 2).all() and (rec[:, 16] >= 3).all()
+    # the same subints fitted directly here: the first 48 of the job and the ragged tail
+    # [2048, 2500), generated from their global indices (bench.Batch, the child's defaults)
+    ns = argparse.Namespace(seed=20260101, dm0=34.56789, dm_offset=[3e-4, 2e-4], sigma=0.05,
+                            truth_guesses=False, measured_noise=False, method="trust-ncg")
+    eng = Engine(0)
+    dev = torch.device("cuda", 0)
+    for first, n in ((0, 48), (2048, total - 2048)):
+        b = bench.Batch(eng, ns, dev, cfg["workload"], n, "f64", first)
+        out = torch.zeros((n, ppdist.RECORD_WIDTH), dtype=torch.float64, device=dev)
+        r = b.fit(records=out)
+        mine = out.cpu().numpy()
+        np.testing.assert_array_equal(mine[:, 16:], rec[first:first + n, 16:])         # nfeval, return_code
+        np.testing.assert_allclose(mine[:, :16], rec[first:first + n, :16], rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(r["params"], rec[first:first + n, :5], rtol=1e-13, atol=1e-15)
+        b.free()
+    eng.close()

@@ -160,3 +160,19 @@ def test_helper_restatements():
     np.testing.assert_allclose(
         orc.phase_transform(0.3, 34.5, 1500.0, 1200.0, P, mod=True),
         g["phase_tr"], rtol=1e-14)
+
+
+def test_oracle_instrumental_response_matches_reference():
+    """instrumental_response_port_FT / gaussian_profile_FT of the oracle against the
+    arrays the true reference produced for the gettoas_ird golden (pptoaslib.py:14-50,
+    145-179; tests/golden/make_golden_gettoas.py)."""
+    import os
+    from oracle import pptoas_oracle as orc
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gettoas_ird.npz"))
+    ok = np.where(g["weights"][0] > 0)[0]
+    resp = orc.instrumental_response_port_FT(
+        g["subints"].shape[-1], g["freqs"][0][ok], float(g["out_ird_DM"]), float(g["Ps"][0]),
+        [float(v) for v in g["out_ird_wids"]], [str(v) for v in g["out_ird_types"]])
+    np.testing.assert_allclose(resp, g["out_ird_resp"], rtol=1e-13, atol=1e-15)
+    gft = orc.gaussian_profile_FT(g["subints"].shape[-1], 0.3, 0.02, 1.7)
+    np.testing.assert_allclose(gft, g["out_ird_gauss_FT"], rtol=1e-13, atol=1e-13)
