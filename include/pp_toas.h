@@ -123,6 +123,10 @@ void* pp_stream(pp_ctx* ctx);
  *                  each with a truncation certificate (DESIGN.md "Scattering fits");
  *                  2 = also for method 'newton' (whose few closing iterations do not
  *                  repay the pass); 0 = every evaluation is a pass over the cross-spectrum
+ *   "x_f32"        1 = scattering fits keep their stored cross-spectrum X_nk = d_nk m_nk* as
+ *                  pairs of floats (half the bytes of every evaluation pass, all arithmetic f64;
+ *                  without the closing model).  Off by default: it buys 8 % on configs[3] and
+ *                  costs chi2 its 1e-10 agreement with the reference
  *   "scat_model_tol"  predicted relative truncation below which that pass is asked
  *                  for (default 1e-10; the certificate guards the result either way)
  *   "fps_finish"   pp_fit_phase_shift_batch after its brute grid: 0 (default) = Newton to

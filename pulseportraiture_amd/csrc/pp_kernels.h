@@ -65,7 +65,14 @@ struct XspecArgs {
     // its value when this launch started
     unsigned* ticket;
     unsigned ticket_base;
+    int x_f32;                // the cross-spectrum is stored as pairs of floats (8 B per harmonic)
 };
+
+// one harmonic of the stored cross-spectrum (row pitch Kt elements of 16 or 8 bytes)
+__device__ __forceinline__ void store_x(const XspecArgs& a, size_t row, int k, const cplx& x) {
+    if (a.x_f32) reinterpret_cast<float2*>(a.X)[row * a.Kt + (k - 1)] = make_float2((float)x.x, (float)x.y);
+    else a.X[row * a.Kt + (k - 1)] = x;
+}
 
 struct FitArgs {
     int nsub, nchan, nbin, M, Kt;
@@ -111,6 +118,7 @@ struct FitArgs {
     // up to `recentre` times
     int recentre;
     double* x0w;              // [nsub][5] the expansion points k_phase0 reads (writable view of x0)
+    int x_f32;                // the cross-spectrum is stored as pairs of floats (k_eval<true, true> only)
 };
 
 __device__ __forceinline__ int sub_of(const int* act, int j) { return act ? act[j] : j; }
@@ -456,7 +464,6 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         __builtin_amdgcn_sched_barrier(0);
 #endif
         // ---- cross-spectrum (and the first evaluation's sums) ----
-        cplx* xrow = a.X + rx * a.Kt;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         cplx e = make_double2(1.0, 0.0), wst = make_double2(1.0, 0.0);
         auto setup_phasors = [&]() {
@@ -608,7 +615,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                 if (k <= ktn) {
                     const cplx d = rfft_harmonic_w<M>(lds, wb, k);
                     const cplx x = cmulc(d, mv[j]);
-                    xrow[k - 1] = x;
+                    store_x(a, rx, k, x);
                     if (MODE == 1) {
                         const cplx z = cmul(x, e);
                         const double kk = (double)k;
@@ -732,9 +739,7 @@ __global__ void k_prep(int nsub, int nchan, int nbin, const double* errs, const 
     wts[idx] = (mask && !mask[idx]) ? 0.0 : w;
 }
 
-__global__ void k_init_state(FitArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.nsub) return;
+__device__ inline void init_state(const FitArgs& a, int i) {
     SubState& s = a.st[i];
     for (int j = 0; j < 5; ++j) { s.x[j] = a.x0[i * 5 + j]; s.xe[j] = s.x[j]; s.g[j] = 0.0; }
     for (int j = 0; j < 25; ++j) s.H[j] = 0.0;
@@ -749,6 +754,11 @@ __global__ void k_init_state(FitArgs a) {
     s.fl = NAN;
     for (int j = 0; j < 5; ++j) s.xprev[j] = s.x[j];
     if (i == 0) *a.nactive = a.nsub;
+}
+
+__global__ void k_init_state(FitArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.nsub) init_state(a, i);
 }
 
 // per-channel geometry shared by evaluator and finaliser
@@ -811,6 +821,28 @@ __global__ __launch_bounds__(256) void k_phase0(int nsub, int nchan, const doubl
     ph0[idx] = x0[i * 5] + x0[i * 5 + 1] * p1 + x0[i * 5 + 2] * p2;
 }
 
+// Everything a batch needs before its transform, in one launch: phi_n at the initial
+// parameters (ph0 != nullptr: k_phase0), the weights when the noise is given (errs != nullptr:
+// k_prep; measured noise only exists after the transform) and the solver state (do_init:
+// k_init_state).
+__global__ __launch_bounds__(256) void k_setup(FitArgs a, const double* errs, const unsigned char* mask,
+                                               double* wts, double* ph0, int do_init) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.nsub * a.nchan) return;
+    const int i = (int)(idx / a.nchan), n = (int)(idx % a.nchan);
+    if (ph0) {
+        double p1, p2;
+        phase_geom(a.freqs[(size_t)i * a.freqs_stride + n], a.P[i], a.nu_fit[i * 3], a.nu_fit[i * 3 + 1], p1, p2);
+        ph0[idx] = a.x0[i * 5] + a.x0[i * 5 + 1] * p1 + a.x0[i * 5 + 2] * p2;
+    }
+    if (errs) {
+        const double e = errs[idx];
+        const double w = 1.0 / (e * e * (0.5 * a.nbin));
+        wts[idx] = (mask && !mask[idx]) ? 0.0 : w;
+    }
+    if (do_init && idx < a.nsub) init_state(a, (int)idx);
+}
+
 // local (phi_n, tau_n) derivatives of F_n = -C^2/S from weighted sums
 struct Local {
     double F, Gp, Gt, Lpp, Lpt, Ltt;
@@ -868,7 +900,7 @@ __device__ __forceinline__ void accumulate_channel(const Local& L, const ChanGeo
 #ifndef PP_NT_X_LOADS
 #define PP_NT_X_LOADS 1
 #endif
-template <bool SCAT>
+template <bool SCAT, bool XF32 = false>
 __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
     constexpr int LPC = 16;
     const int jx = blockIdx.x, i = sub_of(a.act, jx), chunk = blockIdx.y;
@@ -900,7 +932,9 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
         cplx e = unit_phasor((double)(l + 1), phin);
         const int src = ((tid & 63) & ~(LPC - 1)) | (LPC - 1);
         const cplx wst = make_double2(__shfl(e.x, src, 64), __shfl(e.y, src, 64));
-        const cplx* xrow = a.X + ((size_t)jx * a.nchan_x + nn) * a.Kt;
+        const size_t xoff = ((size_t)jx * a.nchan_x + nn) * a.Kt;
+        const cplx* xrow = a.X + xoff;
+        const float2* xrow32 = reinterpret_cast<const float2*>(a.X) + xoff;
         double s0 = 0, s1 = 0, s2 = 0, t1 = 0, t2 = 0, a1t = 0, S0 = 0, S1 = 0, S2 = 0;
         double k = (double)(l + 1);
         // harmonics beyond the template's kept range carry |m_nk|^2 < 2^-100 of
@@ -909,11 +943,14 @@ __global__ __launch_bounds__(256) void k_eval(FitArgs a) {
         if (w != 0.0) {
 #pragma unroll PP_EVAL_UNROLL
             for (int j = l; j < ktn; j += LPC) {
-#if PP_NT_X_LOADS
-                const cplx x = load_row_once<cplx>(reinterpret_cast<const char*>(xrow + j));
-#else
-                const cplx x = xrow[j];
-#endif
+                cplx x;
+                if (XF32) {
+                    const float2 xf = PP_NT_X_LOADS ? load_row_once<float2>(reinterpret_cast<const char*>(xrow32 + j))
+                                                    : xrow32[j];
+                    x = make_double2((double)xf.x, (double)xf.y);
+                } else {
+                    x = PP_NT_X_LOADS ? load_row_once<cplx>(reinterpret_cast<const char*>(xrow + j)) : xrow[j];
+                }
                 const cplx z = cmul(x, e);
                 if (!SCAT) {
                     s0 += z.x;
@@ -2342,6 +2379,7 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs a) {
         a.o_nfev[i] = s.nfev;
         a.o_rc[i] = s.status;
         a.o_npass[i] = s.npass;
+        if (i == 0) a.o_npass[a.nsub] = *a.nactive;     // (subints still unfinished: read back with the outputs)
         if (a.o_rec) {
             double* rec = a.o_rec + (size_t)i * PP_RECORD_WIDTH;
             for (int j = 0; j < 5; ++j) { rec[j] = op[j]; rec[5 + j] = oe[j]; }

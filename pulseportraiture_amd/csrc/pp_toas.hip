@@ -87,6 +87,8 @@ struct pp_ctx {
     DevBuf ticket;                          // k_xspec's chunk counter (RowWalk); never reset,
     unsigned ticket_base = 0;               // ... its value before the next launch (wraps)
     int ncu = 0;                            // compute units of the device
+    DevBuf inpack;   // per-batch small inputs (freqs, P, x0, nu_fit, nu_out, slot): one H2D copy
+    void* in_host = nullptr; size_t in_host_cap = 0;   // pinned staging of inpack
     DevBuf o_pack;   // per-subint scalar outputs, one allocation -> one D2H copy
     void* o_host = nullptr; size_t o_host_cap = 0;   // pinned staging of o_pack
     DevBuf o_params, o_errs, o_nu, o_cov, o_chi2, o_rchi2, o_snr, o_nfev, o_rc, o_scales, o_serrs, o_csnr,
@@ -102,6 +104,7 @@ struct pp_ctx {
     int scat_model = 1;         // scattering fits: closing iterations on the per-channel model (pp_scatmodel.h)
     double scat_model_tol = 1e-10;
     int scat_model_bet = 1;
+    int x_f32 = 0;              // 1 = scattering fits store the cross-spectrum as float pairs (measured: not worth it)
     int taylor_recentre = 1;    // one-pass flow: re-expansions about the tentative answer when the certificate fails
                                 // (0 = none; a second one rarely rescues what the first did not)
     int debug_poison = 0;       // fill the work buffers with NaN bit patterns before every batch (finds unwritten reads)
@@ -210,6 +213,8 @@ extern "C" int pp_destroy(pp_ctx* c) {
     for (auto& kv : c->twiddles) kv.second.release();
     for (auto& s : c->slots) { s.mft.release(); s.msum.release(); s.mmax.release(); s.mdc.release(); s.kt.release(); s.msq.release(); }
     if (c->o_host) (void)hipHostFree(c->o_host);
+    if (c->in_host) (void)hipHostFree(c->in_host);
+    c->inpack.release();
     DevBuf* bufs[] = {&c->ticket, &c->o_pack, &c->mft_table, &c->msum_table, &c->kt_table, &c->mdc_table, &c->msq_table, &c->data, &c->X, &c->sdraw, &c->noise, &c->wts, &c->freqs,
                       &c->errs, &c->mask, &c->P, &c->x0, &c->nufit, &c->nuout, &c->slot, &c->state, &c->csum,
                       &c->partial, &c->o_params, &c->o_errs, &c->o_nu, &c->o_cov, &c->o_chi2, &c->o_rchi2,
@@ -247,6 +252,7 @@ extern "C" int pp_set_option(pp_ctx* c, const char* name, double value) {
     else if (n == "scat_model") c->scat_model = (int)value;
     else if (n == "scat_model_tol") c->scat_model_tol = value;
     else if (n == "scat_model_bet") c->scat_model_bet = (int)value;
+    else if (n == "x_f32") c->x_f32 = (int)value;
     else if (n == "fps_finish") c->fps_finish = (int)value;
     else if (n == "debug_poison") c->debug_poison = (int)value;
     else if (n == "taylor_recentre") c->taylor_recentre = (int)value;
@@ -559,8 +565,34 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         ddata = c->data.p;
     }
     const size_t nc = (size_t)ns * C;
-    if (in->freqs_stride) { if ((rc = upload(c, c->freqs, in->freqs + (size_t)s0 * C, nc * 8))) return rc; }
-    else { if ((rc = upload(c, c->freqs, in->freqs, (size_t)C * 8))) return rc; }
+    // the small inputs travel in ONE copy from a pinned staging block (seven separate pageable
+    // copies cost more than the solve of a 512 x 1024 batch): freqs | P | x0 | nu_fit | nu_out | slot
+    const size_t nfreq = in->freqs_stride ? nc : (size_t)C;
+    const size_t in_doubles = nfreq + (size_t)ns * (1 + 5 + 3 + 3);
+    const size_t in_bytes = in_doubles * 8 + (size_t)ns * 4;
+    if ((rc = c->inpack.reserve(in_bytes))) return rc;
+    if (c->in_host_cap < in_bytes) {
+        if (c->in_host) (void)hipHostFree(c->in_host);
+        c->in_host = nullptr; c->in_host_cap = 0;
+        HIP_TRY(hipHostMalloc(&c->in_host, in_bytes, hipHostMallocDefault));
+        c->in_host_cap = in_bytes;
+    }
+    double* const d_freqs = c->inpack.as<double>();
+    double* const d_P = d_freqs + nfreq;
+    double* const d_x0 = d_P + ns;
+    double* const d_nufit = d_x0 + (size_t)ns * 5;
+    double* const d_nuout = d_nufit + (size_t)ns * 3;
+    int* const d_slot = reinterpret_cast<int*>(d_nuout + (size_t)ns * 3);
+    {
+        double* h = reinterpret_cast<double*>(c->in_host);
+        memcpy(h, in->freqs + (in->freqs_stride ? (size_t)s0 * C : 0), nfreq * 8); h += nfreq;
+        memcpy(h, in->P + s0, (size_t)ns * 8); h += ns;
+        memcpy(h, in->init_params + (size_t)s0 * 5, (size_t)ns * 40); h += (size_t)ns * 5;
+        memcpy(h, nufit_h.data() + (size_t)s0 * 3, (size_t)ns * 24); h += (size_t)ns * 3;
+        memcpy(h, nuout_h.data() + (size_t)s0 * 3, (size_t)ns * 24); h += (size_t)ns * 3;
+        if (in->model_slot) memcpy(h, in->model_slot + s0, (size_t)ns * 4);
+        HIP_TRY(hipMemcpyAsync(c->inpack.p, c->in_host, in_bytes, hipMemcpyHostToDevice, c->stream));
+    }
     const double* d_errs = nullptr;
     const unsigned char* d_mask = nullptr;
     if (in->aux_on_device) {
@@ -570,11 +602,6 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         if (in->errs) { if ((rc = upload(c, c->errs, in->errs + (size_t)s0 * C, nc * 8))) return rc; d_errs = c->errs.as<double>(); }
         if (in->chan_mask) { if ((rc = upload(c, c->mask, in->chan_mask + (size_t)s0 * C, nc))) return rc; d_mask = c->mask.as<unsigned char>(); }
     }
-    if ((rc = upload(c, c->P, in->P + s0, (size_t)ns * 8))) return rc;
-    if ((rc = upload(c, c->x0, in->init_params + (size_t)s0 * 5, (size_t)ns * 40))) return rc;
-    if ((rc = upload(c, c->nufit, nufit_h.data() + (size_t)s0 * 3, (size_t)ns * 24))) return rc;
-    if ((rc = upload(c, c->nuout, nuout_h.data() + (size_t)s0 * 3, (size_t)ns * 24))) return rc;
-    if (in->model_slot) if ((rc = upload(c, c->slot, in->model_slot + s0, (size_t)ns * 4))) return rc;
     // ---- work ----
     // no scattering: one pass over the data that leaves a Taylor model of every
     // channel + a solve on it replace the evaluation loop (fallback: the loop below,
@@ -616,12 +643,19 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // the Newton iteration only 2-3 of 6, less than the model pass costs)
     const bool smodel = scat && c->max_iter > 0 && (c->scat_model >= 2 || (c->scat_model == 1 && in->method == PP_METHOD_TRUST_NCG));
     if (smodel) if ((rc = c->mdl.reserve(nc * PP_MROW * 8))) return rc;
+    // Option x_f32 (off by default): the stored cross-spectrum of a scattering fit kept as float
+    // pairs, half the bytes of every evaluation pass.  Measured on configs[3] with the Newton
+    // solver (profiles/README.md, round 3): the six passes go from 7.92 to 7.28 ms only -- at
+    // ~48 f64 instructions per harmonic k_eval<true> is as close to its VALU floor as to its HBM
+    // floor -- while chi2 loses its 1e-10 agreement with the reference (6e-8 of every |X_nk|
+    // moves f by ~1e-6 of itself; the optimum by ~1e-11 rot).  Kept for experiments.
+    const bool xf32 = scat && !seeded && !smodel && c->max_iter > 0 && c->x_f32 > 0;
     if (xmode != 0) if ((rc = c->ph0.reserve(nc * 8))) return rc;
     if ((rc = c->misc.reserve(256))) return rc;
     if ((rc = c->act.reserve((size_t)ns * 4))) return rc;
     // per-subint scalar outputs: blocks of one allocation (params 5, errs 5, nu 3,
     // cov 25, chi2, red_chi2, snr doubles; nfeval, return_code, npass ints) = 340 B / subint
-    const size_t o_bytes = (size_t)ns * 340;
+    const size_t o_bytes = (size_t)ns * 340 + 8;       // (+ the count of unfinished subints)
     if ((rc = c->o_pack.reserve(o_bytes))) return rc;
     if (c->o_host_cap < o_bytes) {
         if (c->o_host) (void)hipHostFree(c->o_host);
@@ -662,15 +696,16 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     xa.mft0 = c->slots[0].mft.as<cplx>();
     xa.ktab = (const int* const*)c->kt_table.p;
     xa.kt0 = c->slots[0].kt.as<int>();
-    xa.slot = in->model_slot ? c->slot.as<int>() : nullptr;
+    xa.slot = in->model_slot ? d_slot : nullptr;
     xa.X = c->X.as<cplx>(); xa.sdraw = c->sdraw.as<double>(); xa.noise = c->noise.as<double>();
     xa.twB = tw; xa.nsub = ns; xa.nchan = C; xa.Kt = Kt;
-    xa.x0 = c->x0.as<double>(); xa.P = c->P.as<double>(); xa.nu_fit = c->nufit.as<double>();
-    xa.freqs = c->freqs.as<double>(); xa.freqs_stride = in->freqs_stride ? C : 0;
+    xa.x0 = d_x0; xa.P = d_P; xa.nu_fit = d_nufit;
+    xa.freqs = d_freqs; xa.freqs_stride = in->freqs_stride ? C : 0;
     xa.csum0 = c->csum.as<double>();
     xa.tay = c->tay.as<double>();
     xa.ph0 = c->ph0.as<double>();
     xa.act = nullptr; xa.cstep = 1; xa.coff = 0; xa.nchan_full = C;
+    xa.x_f32 = xf32 ? 1 : 0;
     FitArgs fa;
     memset(&fa, 0, sizeof fa);
     fa.nsub = ns; fa.nchan = C; fa.nbin = B; fa.M = M; fa.Kt = Kt;
@@ -683,11 +718,11 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.msq = (const double* const*)c->msq_table.p;
     fa.msum = (const double* const*)c->msum_table.p;
     fa.ktab = (const int* const*)c->kt_table.p;
-    fa.slot = in->model_slot ? c->slot.as<int>() : nullptr;
-    fa.freqs = c->freqs.as<double>(); fa.freqs_stride = in->freqs_stride ? C : 0;
+    fa.slot = in->model_slot ? d_slot : nullptr;
+    fa.freqs = d_freqs; fa.freqs_stride = in->freqs_stride ? C : 0;
     fa.wts = c->wts.as<double>(); fa.sdraw = c->sdraw.as<double>();
-    fa.P = c->P.as<double>(); fa.nu_fit = c->nufit.as<double>(); fa.nu_out = c->nuout.as<double>();
-    fa.x0 = c->x0.as<double>(); fa.st = c->state.as<SubState>();
+    fa.P = d_P; fa.nu_fit = d_nufit; fa.nu_out = d_nuout;
+    fa.x0 = d_x0; fa.st = c->state.as<SubState>();
     fa.csum = c->csum.as<double>(); fa.ncs = ncs;
     fa.tay = c->tay.as<double>();
     fa.partial = c->partial.as<double>(); fa.nchunk = nchunk; fa.cpc = cpc;
@@ -713,7 +748,8 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // Newton solver converges to the optimum from anywhere)
     fa.recentre = (taylor && xmom && (!in->fit_flags[2] || in->method == PP_METHOD_NEWTON))
                       ? std::max(0, c->taylor_recentre) : 0;
-    fa.x0w = c->x0.as<double>();
+    fa.x0w = d_x0;
+    fa.x_f32 = xf32 ? 1 : 0;
 
     auto run_xspec = [&](const XspecArgs& x, int mode) -> int {
         Prof pr(c, KF_XSPEC);
@@ -746,7 +782,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         cplx* ypart = c->seedbuf.as<cplx>();
         cplx* ywork = ypart + (size_t)f.nact * f.nchunk * Ks;
         Prof pr(c, KF_SEED);
-        const double* xbase = c->x0.as<double>();
+        const double* xbase = d_x0;
         if (ndm > 1) {
             // trial DMs: peak heights only, then the refined DM of every subint, then
             // the seed proper at that DM
@@ -754,14 +790,14 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             double* xb = c->xbase.as<double>();          // [ns][5] guesses as given
             double* xr = xb + (size_t)ns * 5;            // [ns][5] with the chosen DM
             double* pk = xr + (size_t)ns * 5;            // [ns][ndm]
-            HIP_TRY(hipMemcpyAsync(xb, c->x0.p, (size_t)ns * 40, hipMemcpyDeviceToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(xr, c->x0.p, (size_t)ns * 40, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(xb, d_x0, (size_t)ns * 40, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(xr, d_x0, (size_t)ns * 40, hipMemcpyDeviceToDevice, c->stream));
             for (int t = 0; t < ndm; ++t) {
                 const double off = (t - (ndm - 1) / 2) * c->seed_dm_step;
                 hipLaunchKernelGGL(k_seed_accum, dim3(f.nact, f.nchunk), dim3(256), 0, c->stream, f, ypart, Ks,
                                    (const double*)xb, off);
                 hipLaunchKernelGGL(k_seed_fit, dim3(f.nact), dim3(256), 0, c->stream, f, (const cplx*)ypart, ywork,
-                                   c->x0.as<double>(), (int)in->seed_ns, Ks, (double*)nullptr, (const double*)xb, off,
+                                   d_x0, (int)in->seed_ns, Ks, (double*)nullptr, (const double*)xb, off,
                                    pk, t, ndm);
             }
             hipLaunchKernelGGL(k_seed_dm_pick, dim3((f.nact + 63) / 64), dim3(64), 0, c->stream, f.act, f.nact,
@@ -770,7 +806,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         }
         hipLaunchKernelGGL(k_seed_accum, dim3(f.nact, f.nchunk), dim3(256), 0, c->stream, f, ypart, Ks, xbase, 0.0);
         hipLaunchKernelGGL(k_seed_fit, dim3(f.nact), dim3(256), 0, c->stream, f, (const cplx*)ypart, ywork,
-                           c->x0.as<double>(), (int)in->seed_ns, Ks, seedq, xbase, 0.0, (double*)nullptr, 0, 1);
+                           d_x0, (int)in->seed_ns, Ks, seedq, xbase, 0.0, (double*)nullptr, 0, 1);
         HIP_TRY(hipGetLastError());
         return PP_OK;
     };
@@ -823,23 +859,68 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     }
 
     // ---- rFFT + cross-spectrum (or the Taylor model) of every row ----
-    if (xmode != 0) {
+    // one launch in front of it: phi_n at the initial parameters, the weights when the noise is
+    // given, the solver state (a full seed rewrites x0 after the transform: state set then)
+    const bool wts_early = (d_errs != nullptr);
+    {
         Prof pr(c, KF_PREP);
-        hipLaunchKernelGGL(k_phase0, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, ns, C,
-                           xa.x0, xa.P, xa.nu_fit, xa.freqs, xa.freqs_stride, c->ph0.as<double>());
+        hipLaunchKernelGGL(k_setup, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, fa,
+                           wts_early ? d_errs : (const double*)nullptr, d_mask, c->wts.as<double>(),
+                           xmode != 0 ? c->ph0.as<double>() : (double*)nullptr, seed_full ? 0 : 1);
     }
     if (seed_full) {
         // the seed needs the cross-spectrum at a phase not known yet: store it, seed,
         // then take the Taylor moments (or iterate) in a second pass over it
         if ((rc = run_xspec(xa, 0))) return rc;
-        if ((rc = run_prep())) return rc;
+        if (!wts_early) if ((rc = run_prep())) return rc;
         if ((rc = run_seed(fa, nullptr))) return rc;
+        hipLaunchKernelGGL(k_init_state, dim3((ns + 63) / 64), dim3(64), 0, c->stream, fa);
     } else {
         if ((rc = run_xspec(xa, xmode))) return rc;
-        if ((rc = run_prep())) return rc;
+        if (!wts_early) if ((rc = run_prep())) return rc;
     }
-    hipLaunchKernelGGL(k_init_state, dim3((ns + 63) / 64), dim3(64), 0, c->stream, fa);
     HIP_TRY(hipGetLastError());
+    // ---- post-fit stage + every output in one round trip ----
+    auto finalize_and_fetch = [&]() -> int {
+        FitArgs ff = fa;
+        ff.act = nullptr; ff.nact = ns;
+        {
+            Prof pr(c, KF_FINAL);
+            hipLaunchKernelGGL(k_finalize, dim3(ns), dim3(256), 0, c->stream, ff);
+        }
+        HIP_TRY(hipGetLastError());
+#define PP_D2H(dst, buf, off, bytes) \
+    if (dst) HIP_TRY(hipMemcpyAsync((char*)(dst) + (off), (buf).p, (bytes), hipMemcpyDeviceToHost, c->stream))
+        HIP_TRY(hipMemcpyAsync(c->o_host, c->o_pack.p, o_bytes, hipMemcpyDeviceToHost, c->stream));
+        if (!chan_dev) {
+            PP_D2H(out->scales, c->o_scales, (size_t)s0 * C * 8, nc * 8);
+            PP_D2H(out->scale_errs, c->o_serrs, (size_t)s0 * C * 8, nc * 8);
+            PP_D2H(out->channel_snrs, c->o_csnr, (size_t)s0 * C * 8, nc * 8);
+        }
+        PP_D2H(out->obj_f, c->o_f0, (size_t)s0 * 8, (size_t)ns * 8);
+        PP_D2H(out->obj_grad, c->o_g0, (size_t)s0 * 40, (size_t)ns * 40);
+        PP_D2H(out->obj_hess, c->o_H0, (size_t)s0 * 200, (size_t)ns * 200);
+#undef PP_D2H
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return PP_OK;
+    };
+    auto unpack_outputs = [&]() {
+        const double* h = reinterpret_cast<const double*>(c->o_host);
+        memcpy(out->params + (size_t)s0 * 5, h, (size_t)ns * 40);
+        memcpy(out->param_errs + (size_t)s0 * 5, h + (size_t)ns * 5, (size_t)ns * 40);
+        memcpy(out->nu_refs + (size_t)s0 * 3, h + (size_t)ns * 10, (size_t)ns * 24);
+        memcpy(out->cov + (size_t)s0 * 25, h + (size_t)ns * 13, (size_t)ns * 200);
+        memcpy(out->chi2 + s0, h + (size_t)ns * 38, (size_t)ns * 8);
+        memcpy(out->red_chi2 + s0, h + (size_t)ns * 39, (size_t)ns * 8);
+        memcpy(out->snr + s0, h + (size_t)ns * 40, (size_t)ns * 8);
+        const int32_t* hi = reinterpret_cast<const int32_t*>(h + (size_t)ns * 41);
+        memcpy(out->nfeval + s0, hi, (size_t)ns * 4);
+        memcpy(out->return_code + s0, hi + ns, (size_t)ns * 4);
+        if (out->npass) memcpy(out->npass + s0, hi + 2 * (size_t)ns, (size_t)ns * 4);
+    };
+    auto unfinished = [&]() -> int {     // (as k_finalize saw it)
+        return reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(c->o_host) + (size_t)ns * 41)[3 * (size_t)ns];
+    };
     bool all_done = false;
     if (taylor) {
         if (xstore) {
@@ -852,9 +933,13 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             hipLaunchKernelGGL(k_taylor_solve<0>, dim3(ns), dim3(256), 0, c->stream, fa);
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(c->nactive_h, fa.nactive, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        all_done = (c->nactive_h[0] <= 0);
+        // The solve certifies nearly every subint of nearly every batch: the post-fit stage is
+        // launched straight behind it and the count of unfinished subints comes back with the
+        // outputs -- one host round trip per batch instead of two.  (When some are left, what
+        // the post-fit stage wrote for them is overwritten below.)
+        if ((rc = finalize_and_fetch())) return rc;
+        all_done = (unfinished() <= 0);
+        if (all_done) { unpack_outputs(); return PP_OK; }
         for (int rep = 0; rep < fa.recentre && !all_done; ++rep) {
             // some subints failed the certificate (poor guesses): k_taylor_solve moved
             // their expansion points to its tentative answers -- take the Taylor model of
@@ -894,7 +979,8 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             hipLaunchKernelGGL(k_accum, dim3(fa.nact, fa.nchunk), dim3(256), 0, c->stream, fa);
         } else {
             Prof pr(c, KF_EVAL);
-            if (scat) hipLaunchKernelGGL(k_eval<true>, dim3(fa.nact, fa.nchunk), dim3(256), 0, c->stream, fa);
+            if (scat && fa.x_f32) hipLaunchKernelGGL((k_eval<true, true>), dim3(fa.nact, fa.nchunk), dim3(256), 0, c->stream, fa);
+            else if (scat) hipLaunchKernelGGL(k_eval<true>, dim3(fa.nact, fa.nchunk), dim3(256), 0, c->stream, fa);
             else hipLaunchKernelGGL(k_eval_fast, dim3(fa.nact, fa.nchunk), dim3(256), 0, c->stream, fa);
         }
         if (smodel && it >= 2) {
@@ -915,40 +1001,8 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             if (c->nactive_h[0] <= 0) break;
         }
     }
-    fa.act = nullptr; fa.nact = ns;
-    {
-        Prof pr(c, KF_FINAL);
-        hipLaunchKernelGGL(k_finalize, dim3(ns), dim3(256), 0, c->stream, fa);
-    }
-    HIP_TRY(hipGetLastError());
-    // ---- outputs ----
-#define PP_D2H(dst, buf, off, bytes) \
-    if (dst) HIP_TRY(hipMemcpyAsync((char*)(dst) + (off), (buf).p, (bytes), hipMemcpyDeviceToHost, c->stream))
-    HIP_TRY(hipMemcpyAsync(c->o_host, c->o_pack.p, o_bytes, hipMemcpyDeviceToHost, c->stream));
-    if (!chan_dev) {
-        PP_D2H(out->scales, c->o_scales, (size_t)s0 * C * 8, nc * 8);
-        PP_D2H(out->scale_errs, c->o_serrs, (size_t)s0 * C * 8, nc * 8);
-        PP_D2H(out->channel_snrs, c->o_csnr, (size_t)s0 * C * 8, nc * 8);
-    }
-    PP_D2H(out->obj_f, c->o_f0, (size_t)s0 * 8, (size_t)ns * 8);
-    PP_D2H(out->obj_grad, c->o_g0, (size_t)s0 * 40, (size_t)ns * 40);
-    PP_D2H(out->obj_hess, c->o_H0, (size_t)s0 * 200, (size_t)ns * 200);
-#undef PP_D2H
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    {
-        const double* h = reinterpret_cast<const double*>(c->o_host);
-        memcpy(out->params + (size_t)s0 * 5, h, (size_t)ns * 40);
-        memcpy(out->param_errs + (size_t)s0 * 5, h + (size_t)ns * 5, (size_t)ns * 40);
-        memcpy(out->nu_refs + (size_t)s0 * 3, h + (size_t)ns * 10, (size_t)ns * 24);
-        memcpy(out->cov + (size_t)s0 * 25, h + (size_t)ns * 13, (size_t)ns * 200);
-        memcpy(out->chi2 + s0, h + (size_t)ns * 38, (size_t)ns * 8);
-        memcpy(out->red_chi2 + s0, h + (size_t)ns * 39, (size_t)ns * 8);
-        memcpy(out->snr + s0, h + (size_t)ns * 40, (size_t)ns * 8);
-        const int32_t* hi = reinterpret_cast<const int32_t*>(h + (size_t)ns * 41);
-        memcpy(out->nfeval + s0, hi, (size_t)ns * 4);
-        memcpy(out->return_code + s0, hi + ns, (size_t)ns * 4);
-        if (out->npass) memcpy(out->npass + s0, hi + 2 * (size_t)ns, (size_t)ns * 4);
-    }
+    if ((rc = finalize_and_fetch())) return rc;
+    unpack_outputs();
     return PP_OK;
 }
 

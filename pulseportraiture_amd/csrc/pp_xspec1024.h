@@ -183,7 +183,6 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
             if (l0) { const double dM = va[0].x - va[0].y; tail += dM * dM; }
         }
         // ---- cross-spectrum of the kept harmonics ----
-        cplx* xrow = a.X + rc * a.Kt;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         double tm[PP_TSTRIDE];
         cplx eA = make_double2(1.0, 0.0), eB = eA, e128 = eA;
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
         auto consume = [&](const cplx& x, const cplx& e, int k) {
             if (M2) taylor_sums(x, cmul(x, e), PP_TWO_PI * (double)k);
             else {
-                if (k >= 1 && k <= ktn) xrow[k - 1] = x;
+                if (k >= 1 && k <= ktn) store_x(a, rc, k, x);
                 if (MODE == 1) {
                     const cplx z = cmul(x, e);
                     const double kk = (double)k;

@@ -1777,6 +1777,29 @@ def test_device_instrumental_response_matches_oracle(eng):
     np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-11)
 
 
+@pytest.mark.parametrize("name", ["fpf_64x256_scat", "fpf_64x256_all5", "fpf_64x256_phiDMtau", "fpf_64x256_scat_lin"])
+def test_float_cross_spectrum_option(name):
+    """Option x_f32 (off by default): scattering fits of the Newton solver with the stored
+    cross-spectrum kept as pairs of floats (half the bytes of every evaluation pass; all
+    arithmetic f64).  The optimum moves by ~1e-11 rot -- inside the bars by two decades --
+    but chi2 only agrees to ~1e-6, which is why it is not the default."""
+    from pulseportraiture_amd.engine import default_engine
+    g = _load(name)
+    b = _golden_fit(g, 'Newton-CG')
+    default_engine().set_option("x_f32", 1)
+    try:
+        a = _golden_fit(g, 'Newton-CG')
+    finally:
+        default_engine().set_option("x_f32", 0)
+    assert _dphi(a.phi, b.phi) < 1e-10 and abs(a.DM - b.DM) < 1e-8
+    assert (a.phi, a.DM) != (b.phi, b.DM)                # (the option did take effect)
+    np.testing.assert_allclose(np.asarray(a.params)[2:], np.asarray(b.params)[2:], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(a.param_errs, b.param_errs, rtol=1e-5)
+    np.testing.assert_allclose(a.chi2, b.chi2, rtol=1e-5)
+    assert _dphi(a.phi, float(g["out_phi"])) < 5e-9 and abs(a.DM - float(g["out_DM"])) < DM_BAR
+    assert a.npass == b.npass
+
+
 def test_submit_and_wait_overlap_two_contexts():
     """pp_fit_submit / pp_fit_wait: a host-array batch started on one
     context runs on that context's worker thread while the calling thread fits another
