@@ -143,6 +143,9 @@ def start_cpu_pool():
 
 
 # --------------------------------------------------------------------------
+from pulseportraiture_amd.engine import EngineNotSupported  # noqa: E402  (no GPU touched by the import)
+
+
 class Batch(object):
     """One workload's template, device-resident synthetic subints and guesses.
     eng: the Engine; args: the run's settings (seed, dm0, dm_offset, sigma, truth_guesses,
@@ -155,6 +158,7 @@ class Batch(object):
         from pulseportraiture_amd.pplib import guess_fit_freq
         self.eng, self.args, self.device = eng, args, device
         self.reseed = reseed
+        self.fused_unavailable = False
         self.workload = workload
         C, B, flags, log10_tau, nsub_def, note = WORKLOADS[workload]
         self.C, self.B, self.flags, self.log10_tau, self.note = C, B, flags, log10_tau, note
@@ -227,15 +231,29 @@ class Batch(object):
 
     def fit(self, records=None, method=None, n=None):
         n = self.nsub if n is None else n         # (a ragged last sub-batch fits its first n)
-        if self.reseed:
-            # the reference's own preamble inside the timed step: one more read of the
-            # portraits (rotation + channel mean + fit_phase_shift), then the fit
+        ref_seed = None
+        if self.reseed and not getattr(self.args, "two_pass_seed", False) and not self.fused_unavailable:
+            # the reference's own preamble inside the timed step, formed from the SAME pass over
+            # the portraits as the fit (pp_seed_ref); batches without that path fall through
+            ref_seed = dict(weights=None, model_profs=self.seed_prof, nu_mean=np.full(n, float(self.freqs.mean())),
+                            Ns=100, finish='simplex')
+        elif self.reseed:
+            # ... or with one more read of the portraits (rotation + channel mean +
+            # fit_phase_shift), then the fit
             self.x0[:, 0] = self.pptoas_phase_guess()
+        try:
+            return self._fit(n, records, method, ref_seed)
+        except EngineNotSupported:
+            self.fused_unavailable = True
+            return self.fit(records=records, method=method, n=n)
+
+    def _fit(self, n, records, method, ref_seed):
         return self.eng.fit_batch(self.data[:n], self.freqs, self.P[:n], self.x0[:n],
                                   errs=None if self.args.measured_noise else self.errs_dev[:n],
                                   nu_fits=np.full((n, 3), self.nu_fit), fit_flags=self.flags,
                                   log10_tau=self.log10_tau, per_channel="device",
-                                  seed_ns=self.seed_ns, method=method or self.args.method, records=records)
+                                  seed_ns=self.seed_ns, method=method or self.args.method, records=records,
+                                  ref_seed=ref_seed)
 
     def free(self):
         import torch
@@ -278,6 +296,9 @@ def main():
     ap.add_argument("--measured-noise", action="store_true",
                     help="errs=None: the noise of every channel is measured from the top quarter of its "
                          "power spectrum inside the transform (get_noise_PS) instead of being given")
+    ap.add_argument("--two-pass-seed", action="store_true",
+                    help="--seed-ns -1: form the reference's guess in a pass of its own (pp_reference_phase_seed) "
+                         "instead of inside the fit's single pass")
     ap.add_argument("--dump-records", default=None, metavar="PATH",
                     help="--total-nsub: rank 0 saves the gathered [total, 18] records there (.npy)")
     ap.add_argument("--harm-eps", type=float, default=None,
@@ -475,8 +496,9 @@ def main():
             try:
                 b = Batch(eng, args, device, wl, 0, dt, 0, seed_ns=max(sns, 0), reseed=(sns < 0))
                 if sns < 0:
-                    b.guess = "the reference's preamble INSIDE the timed step (fused rotation + channel mean + " \
-                              "fit_phase_shift with the simplex finish), then trust-ncg from that guess"
+                    b.guess = "the reference's preamble INSIDE the timed step (rotation + channel mean + fit_phase_shift " \
+                              "with the simplex finish, from the fit's own single pass over the portraits), then " \
+                              "trust-ncg from that guess"
                 r, _, el, kt = timed(b, 3, 1, method=meth)
                 _, _, _, _, sm = summary(b, r, el, kt, 3, b.nsub * 3)
                 sm.update(workload=wl, input_dtype=dt, seed_ns=max(sns, 0), nsub=b.nsub,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 3
+#define PP_ABI_VERSION 4
 
 /* status codes */
 #define PP_OK 0
@@ -39,6 +39,9 @@ extern "C" {
 #define PP_EHIP (-2)     /* HIP runtime error */
 #define PP_ENOMEM (-3)   /* device memory */
 #define PP_ESTATE (-4)   /* call order / missing model */
+#define PP_ENOTSUP (-5)  /* the request is valid but this shape / option set has no device path
+                            (pp_fit_in.ref_seed: the caller then forms the guess with
+                            pp_reference_phase_seed and fits in a second call) */
 
 /* sample types of portraits */
 #define PP_F64 0
@@ -200,6 +203,30 @@ int pp_model_apply_response(pp_ctx* ctx, int slot, const double* rconst,
                             const double* smear_wid);
 
 /* ---- the batched fit ----------------------------------------------------- */
+/* The reference's own initial phase guess formed INSIDE the fit, from the same single pass over
+ * the portraits (pp_fit_in.ref_seed; pptoas.py:421-457):
+ *   rot_prof_i = np.average(rotate_data(port_i, 0.0, DM_i, P_i, freqs_i, nu_mean_i), axis=0,
+ *                           weights=weights_i)                    (DM_i = init_params[i][1])
+ *   phi_i      = fit_phase_shift(rot_prof_i, model_prof_i, Ns=Ns, bounds=(lo, hi)).phase
+ *   init_params[i][0] <- phase_transform(phi_i, DM_i, nu_mean_i, nu_fits[i][0], P_i, mod=True)
+ * and the fit then starts from there (init_params[.][0] as given is ignored).  The transform
+ * kernel takes the per-channel Taylor model about a provisional phase (a pilot pass over every
+ * 16th channel) together with the rotated channel sums; the iteration starts off-centre, at the
+ * reference's guess.  Available for 2048-bin portraits fitted without scattering whose template
+ * keeps fewer than 512 harmonics, nchan a multiple of 32 and >= 256, errs given, GM guesses 0:
+ * otherwise pp_fit_portrait_batch returns PP_ENOTSUP and nothing has been done. */
+typedef struct {
+    const double* weights;       /* [nsub][nchan] weights of the channel mean (0 = channel not used);
+                                    host, or device when pp_fit_in.aux_on_device; NULL = all 1 */
+    const double* model_profs;   /* host: [nsub][nbin], or [nbin] when model_prof_stride == 0 */
+    int64_t model_prof_stride;   /* 0 or nbin */
+    const double* nu_mean;       /* host [nsub]: mean frequency of the channels used */
+    double lo, hi;               /* bounds of the brute grid (-0.5, 0.5) */
+    int32_t Ns;                  /* its size (100) */
+    int32_t finish;              /* 1 = SciPy brute's simplex finish (what the reference returns), 0 = Newton */
+    double* seed_phase;          /* host [nsub] out, or NULL: the phase guesses formed (at nu_fit) */
+} pp_seed_ref;
+
 typedef struct {
     int32_t nsub, nchan, nbin;
     const void* data;          /* [nsub][nchan][nbin] */
@@ -227,6 +254,7 @@ typedef struct {
                                   the channel-summed cross-correlation at the guessed
                                   DM/GM/tau, polished to its maximum (the role of
                                   pptoas.py:421-457, fit_phase_shift with Ns=100) */
+    const pp_seed_ref* ref_seed; /* NULL, or: form the reference's own phase guess in the pass (above) */
 } pp_fit_in;
 
 typedef struct {

@@ -10,16 +10,22 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpptoas_hip.so")
 
-PP_OK, PP_EINVAL, PP_EHIP, PP_ENOMEM, PP_ESTATE = 0, -1, -2, -3, -4
+PP_OK, PP_EINVAL, PP_EHIP, PP_ENOMEM, PP_ESTATE, PP_ENOTSUP = 0, -1, -2, -3, -4, -5
 PP_F64, PP_F32 = 0, 1
 PP_MAX_SLOTS = 64
 PP_RECORD_WIDTH = 18
-ABI_VERSION = 3
+ABI_VERSION = 4
 PP_METHOD_TRUST_NCG, PP_METHOD_NEWTON = 0, 1
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
 c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class SeedRef(C.Structure):
+    _fields_ = [("weights", c_double_p), ("model_profs", c_double_p), ("model_prof_stride", C.c_int64),
+                ("nu_mean", c_double_p), ("lo", C.c_double), ("hi", C.c_double), ("Ns", C.c_int32),
+                ("finish", C.c_int32), ("seed_phase", c_double_p)]
 
 
 class FitIn(C.Structure):
@@ -32,7 +38,8 @@ class FitIn(C.Structure):
                 ("init_params", c_double_p), ("nu_fits", c_double_p),
                 ("nu_outs", c_double_p), ("fit_flags", C.c_int32 * 5),
                 ("log10_tau", C.c_int32), ("option", C.c_int32),
-                ("is_toa", C.c_int32), ("method", C.c_int32), ("seed_ns", C.c_int32)]
+                ("is_toa", C.c_int32), ("method", C.c_int32), ("seed_ns", C.c_int32),
+                ("ref_seed", C.POINTER(SeedRef))]
 
 
 class FitOut(C.Structure):

@@ -785,6 +785,7 @@ struct FpsArgs {
     int Ns, M, nprof;
     int finish;            // 0: Newton polish to rounding; 1: SciPy brute's own finish (Nelder-Mead simplex)
     const cplx* specm;     // nullptr: rows of `spec` alternate data_i, model_i; else spec = data rows, specm = model rows
+    int mstride;           // elements between the model rows of `specm` (M + 1; 0 = one model row for all)
 };
 
 // sum_k X_k e^{2 pi i k phi} weighted by (1, k, k^2): returns Re-sum, k*Im-sum,
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
     __shared__ double shv[4];
     __shared__ int shj[4];
     const cplx* d = a.specm ? a.spec + (size_t)i * (M + 1) : a.spec + (size_t)(2 * i) * (M + 1);
-    const cplx* m = a.specm ? a.specm + (size_t)i * (M + 1) : a.spec + (size_t)(2 * i + 1) * (M + 1);
+    const cplx* m = a.specm ? a.specm + (size_t)i * a.mstride : a.spec + (size_t)(2 * i + 1) * (M + 1);
     cplx* X = xwork + (size_t)i * M;
     const int H = M + 1, kc = (int)(0.75 * H);
     double v[3] = {0.0, 0.0, 0.0};   // sum |d|^2, sum |m|^2, tail of |d|^2

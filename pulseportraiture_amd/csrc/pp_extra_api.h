@@ -54,7 +54,7 @@ extern "C" int pp_fit_phase_shift_batch(pp_ctx* c, const double* data, const dou
             if ((rc = upload(c, c->errs, noise, (size_t)nprof * 8))) return rc;
             dnoise = c->errs.as<double>();
         }
-        FpsArgs fa{spec, dnoise, c->o_params.as<double>(), lo, hi, Ns, M, nprof, c->fps_finish, nullptr};
+        FpsArgs fa{spec, dnoise, c->o_params.as<double>(), lo, hi, Ns, M, nprof, c->fps_finish, nullptr, M + 1};
         hipLaunchKernelGGL(k_fps, dim3(nprof), dim3(256), 0, c->stream, fa, xwork);
     }
     HIP_TRY(hipGetLastError());
@@ -145,7 +145,7 @@ extern "C" int pp_reference_phase_seed(pp_ctx* c, const void* src, int dtype, in
             hipLaunchKernelGGL((k_rfft_rows<MM, double>), dim3(fft_grid(T, nsub)), dim3(T), 0, c->stream,
                                (const void*)c->errs.p, mspec, tw, nsub);
         });
-        FpsArgs fa{dspec, nullptr, c->o_params.as<double>(), lo, hi, Ns, M, nsub, c->fps_finish, mspec};
+        FpsArgs fa{dspec, nullptr, c->o_params.as<double>(), lo, hi, Ns, M, nsub, c->fps_finish, mspec, M + 1};
         hipLaunchKernelGGL(k_fps, dim3(nsub), dim3(256), 0, c->stream, fa, xwork);
     }
     HIP_TRY(hipGetLastError());

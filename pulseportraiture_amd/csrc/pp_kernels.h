@@ -119,6 +119,9 @@ struct FitArgs {
     int recentre;
     double* x0w;              // [nsub][5] the expansion points k_phase0 reads (writable view of x0)
     int x_f32;                // the cross-spectrum is stored as pairs of floats (k_eval<true, true> only)
+    // reference-seed flow (pp_xspec1024r.h): the Taylor model was taken about x0 (the pilot seed's
+    // phase), the iteration starts from xstart (the reference's own guess, known only after the pass)
+    const double* xstart;     // [nsub][5] or nullptr (= start at the expansion point)
 };
 
 __device__ __forceinline__ int sub_of(const int* act, int j) { return act ? act[j] : j; }
@@ -1625,6 +1628,11 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
         }
     };
     double dx[3] = {0.0, 0.0, 0.0};      // accepted displacement from x0 in (phi, DM, GM)
+    // (the reference-seed flow starts the iteration off centre: at the reference's own guess)
+    const bool off_centre = (a.xstart != nullptr) && st.recentred == 0;
+    if (off_centre)
+        for (int j = 0; j < 3; ++j) dx[j] = fl[j] ? a.xstart[i * 5 + j] - st.xe[j] : 0.0;
+    const double dx0[3] = {dx[0], dx[1], dx[2]};
     double f, g[3], H[9];
     bool ok = true;
     int it = 0, nfev = 1;                // objective evaluations as SciPy's nfev counts them
@@ -1647,7 +1655,7 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
         // reference's own rounding (its nfeval is k or k + 1 on it); the displacements kept
         // here resolve 1e-21, so the closing proposal is always a new point and is counted,
         // which is also what the reference does more often than not.)
-        double xl[3] = {0.0, 0.0, 0.0}, f2 = f, g2[3] = {g[0], g[1], g[2]}, H2[9];
+        double xl[3] = {dx0[0], dx0[1], dx0[2]}, f2 = f, g2[3] = {g[0], g[1], g[2]}, H2[9];
         for (int j = 0; j < 9; ++j) H2[j] = H[j];
         for (;;) {
             double gs[3], Hs[9], p[3];
@@ -1785,7 +1793,14 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
         // belong to another maximum of the correlation altogether)
         bool fin = isfinite(dpath) && dpath < 0.02;
         for (int j = 0; j < 3; ++j) fin = fin && isfinite(dx[j]);
-        if (st.recentred < a.recentre && fin) {
+        if (off_centre) {
+            // reference-seed flow: the model about the pilot's phase did not carry the walk from
+            // the reference's guess -- expand again about that guess itself (one more pass over
+            // this subint's rows), which is the ordinary one-pass flow from there on: the walk
+            // restarts at its own expansion point, whatever the fit family
+            for (int j = 0; j < 5; ++j) { st.xe[j] = a.xstart[i * 5 + j]; st.x[j] = st.xe[j]; a.x0w[i * 5 + j] = st.xe[j]; }
+            st.recentred = 1;
+        } else if (st.recentred < a.recentre && fin) {
             st.nfev += nfev;             // (the evaluations of the first expansion stay counted)
             for (int j = 0; j < 3; ++j) st.xe[j] += dx[j];
             for (int j = 0; j < 5; ++j) { st.x[j] = st.xe[j]; a.x0w[i * 5 + j] = st.xe[j]; }

@@ -17,6 +17,7 @@
 
 #include "pp_kernels.h"
 #include "pp_extra.h"
+#include "pp_xspec1024r.h"
 
 using namespace pp;
 
@@ -87,6 +88,7 @@ struct pp_ctx {
     DevBuf ticket;                          // k_xspec's chunk counter (RowWalk); never reset,
     unsigned ticket_base = 0;               // ... its value before the next launch (wraps)
     int ncu = 0;                            // compute units of the device
+    DevBuf refbuf;   // reference-seed flow: partial channel sums, spectra, profiles, start points
     DevBuf inpack;   // per-batch small inputs (freqs, P, x0, nu_fit, nu_out, slot): one H2D copy
     void* in_host = nullptr; size_t in_host_cap = 0;   // pinned staging of inpack
     DevBuf o_pack;   // per-subint scalar outputs, one allocation -> one D2H copy
@@ -215,6 +217,7 @@ extern "C" int pp_destroy(pp_ctx* c) {
     if (c->o_host) (void)hipHostFree(c->o_host);
     if (c->in_host) (void)hipHostFree(c->in_host);
     c->inpack.release();
+    c->refbuf.release();
     DevBuf* bufs[] = {&c->ticket, &c->o_pack, &c->mft_table, &c->msum_table, &c->kt_table, &c->mdc_table, &c->msq_table, &c->data, &c->X, &c->sdraw, &c->noise, &c->wts, &c->freqs,
                       &c->errs, &c->mask, &c->P, &c->x0, &c->nufit, &c->nuout, &c->slot, &c->state, &c->csum,
                       &c->partial, &c->o_params, &c->o_errs, &c->o_nu, &c->o_cov, &c->o_chi2, &c->o_rchi2,
@@ -550,6 +553,9 @@ static void launch_xspec(pp_ctx* c, const XspecArgs& xa_in, bool tail, int mode)
 
 static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, int ns, int Kt, bool scat,
                      const std::vector<double>& nufit_h, const std::vector<double>& nuout_h) {
+    const pp_seed_ref* rs = in->ref_seed;        // (applicability was checked by the caller)
+    const bool refseed = (rs != nullptr);
+    const int seed_ns = refseed ? rs->Ns : in->seed_ns;
     const int C = in->nchan, B = in->nbin, M = B / 2;
     const size_t esz = in->data_dtype == PP_F64 ? 8 : 4;
     int rc;
@@ -607,7 +613,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // channel + a solve on it replace the evaluation loop (fallback: the loop below,
     // on the subints that need it); otherwise evaluate as usual
     const bool taylor = !scat && c->max_iter > 0 && c->use_taylor;
-    const bool seeded = in->seed_ns > 0;
+    const bool seeded = seed_ns > 0;
     // Phase seed.  The Taylor flow wants the phase BEFORE its single pass, so the seed
     // comes from a pilot pass over every cstep-th channel (1/cstep of the rows and of
     // the bytes), certified by the significance of its correlation peak; subints whose
@@ -797,7 +803,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
                 hipLaunchKernelGGL(k_seed_accum, dim3(f.nact, f.nchunk), dim3(256), 0, c->stream, f, ypart, Ks,
                                    (const double*)xb, off);
                 hipLaunchKernelGGL(k_seed_fit, dim3(f.nact), dim3(256), 0, c->stream, f, (const cplx*)ypart, ywork,
-                                   d_x0, (int)in->seed_ns, Ks, (double*)nullptr, (const double*)xb, off,
+                                   d_x0, seed_ns, Ks, (double*)nullptr, (const double*)xb, off,
                                    pk, t, ndm);
             }
             hipLaunchKernelGGL(k_seed_dm_pick, dim3((f.nact + 63) / 64), dim3(64), 0, c->stream, f.act, f.nact,
@@ -806,7 +812,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         }
         hipLaunchKernelGGL(k_seed_accum, dim3(f.nact, f.nchunk), dim3(256), 0, c->stream, f, ypart, Ks, xbase, 0.0);
         hipLaunchKernelGGL(k_seed_fit, dim3(f.nact), dim3(256), 0, c->stream, f, (const cplx*)ypart, ywork,
-                           d_x0, (int)in->seed_ns, Ks, seedq, xbase, 0.0, (double*)nullptr, 0, 1);
+                           d_x0, seed_ns, Ks, seedq, xbase, 0.0, (double*)nullptr, 0, 1);
         HIP_TRY(hipGetLastError());
         return PP_OK;
     };
@@ -868,7 +874,89 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
                            wts_early ? d_errs : (const double*)nullptr, d_mask, c->wts.as<double>(),
                            xmode != 0 ? c->ph0.as<double>() : (double*)nullptr, seed_full ? 0 : 1);
     }
-    if (seed_full) {
+    // ---- reference-seed flow: Taylor model about the pilot's phase + the rotated channel sums in
+    // one pass, then the reference's fit_phase_shift on the channel mean, then the start points
+    auto run_refseed_pass = [&]() -> int {
+        const int ncc = C / PP_ROW_CHUNK;
+        const size_t H = (size_t)M + 1;
+        const size_t nprof = rs->model_prof_stride ? (size_t)ns : 1;
+        const bool w_host = rs->weights && !in->aux_on_device;
+        const size_t n_part = (size_t)ns * ncc * RS_NACC * 64;
+        const size_t n_cplx = n_part + (size_t)ns * H + nprof * H + (size_t)ns * M;
+        const size_t n_dbl = nprof * B + (size_t)ns * (1 + 1 + 1 + 7 + 5) + (w_host ? nc : 0);
+        if ((rc = c->refbuf.reserve(n_cplx * sizeof(cplx) + n_dbl * 8))) return rc;
+        cplx* part = c->refbuf.as<cplx>();
+        cplx* dspec = part + n_part;
+        cplx* mspec = dspec + (size_t)ns * H;
+        cplx* xwork = mspec + nprof * H;
+        double* mprof = reinterpret_cast<double*>(xwork + (size_t)ns * M);
+        double* d_numean = mprof + nprof * B;
+        double* d_delta = d_numean + ns;
+        double* d_wsum = d_delta + ns;
+        double* d_out7 = d_wsum + ns;
+        double* d_xs = d_out7 + (size_t)ns * 7;
+        double* d_wh = d_xs + (size_t)ns * 5;
+        HIP_TRY(hipMemcpyAsync(mprof, rs->model_profs + (rs->model_prof_stride ? (size_t)s0 * B : 0), nprof * B * 8,
+                               hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_numean, rs->nu_mean + s0, (size_t)ns * 8, hipMemcpyHostToDevice, c->stream));
+        const double* d_w = nullptr;
+        if (w_host) {
+            HIP_TRY(hipMemcpyAsync(d_wh, rs->weights + (size_t)s0 * C, nc * 8, hipMemcpyHostToDevice, c->stream));
+            d_w = d_wh;
+        } else if (rs->weights) d_w = rs->weights + (size_t)s0 * C;
+        const long long nrows = (long long)ns * C;
+        XspecArgs x = xa;
+        x.ticket = c->ticket.as<unsigned>();
+        x.ticket_base = c->ticket_base;
+        c->ticket_base += (unsigned)((nrows + PP_ROW_CHUNK - 1) / PP_ROW_CHUNK);
+        RefSeedArgs ra{d_w, part, ncc};
+        {
+            Prof pr(c, KF_XSPEC);
+            if (in->data_dtype == PP_F64) {
+                const dim3 grid(resident_grid(c, k_xspec_qr1024<double>, 64, nrows, fft_grid(64, nrows)));
+                hipLaunchKernelGGL((k_xspec_qr1024<double>), grid, dim3(64), 0, c->stream, x, ra);
+            } else {
+                const dim3 grid(resident_grid(c, k_xspec_qr1024<float>, 64, nrows, fft_grid(64, nrows)));
+                hipLaunchKernelGGL((k_xspec_qr1024<float>), grid, dim3(64), 0, c->stream, x, ra);
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        {
+            Prof pr(c, KF_FPS);
+            hipLaunchKernelGGL((k_rfft_rows<1024, double>), dim3(fft_grid(64, (long long)nprof)), dim3(64), 0, c->stream,
+                               (const void*)mprof, mspec, tw, (int)nprof);
+            hipLaunchKernelGGL(k_refseed_prep, dim3(ns), dim3(256), 0, c->stream, (const double*)d_x0, (const double*)d_P,
+                               (const double*)d_nufit, (const double*)d_numean, d_w, C, d_delta, d_wsum);
+            hipLaunchKernelGGL(k_refseed_finish, dim3((unsigned)((H + 255) / 256), ns), dim3(256), 0, c->stream,
+                               (const cplx*)part, ncc, (const double*)d_delta, (const double*)d_wsum, ns, dspec);
+            FpsArgs f{dspec, nullptr, d_out7, rs->lo, rs->hi, rs->Ns, M, ns, rs->finish, mspec,
+                      rs->model_prof_stride ? (int)H : 0};
+            hipLaunchKernelGGL(k_fps, dim3(ns), dim3(256), 0, c->stream, f, xwork);
+        }
+        HIP_TRY(hipGetLastError());
+        std::vector<double> o7((size_t)ns * 7), xs((size_t)ns * 5);
+        HIP_TRY(hipMemcpyAsync(o7.data(), d_out7, o7.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        // phase_transform(phi, DM, nu_mean, nu_fit, P, mod=True) (pplib.py:2592-2616), NumPy's
+        // order of operations and libm's pow; the other parameters start as given
+        for (int i = 0; i < ns; ++i) {
+            const double* x0i = in->init_params + (size_t)(s0 + i) * 5;
+            const double P = in->P[s0 + i], nu1 = rs->nu_mean[s0 + i], nu2 = nufit_h[(size_t)(s0 + i) * 3];
+            double ph = o7[(size_t)i * 7] + (PP_DCONST * x0i[1] * pow(P, -1.0) * (pow(nu2, -2.0) - pow(nu1, -2.0)));
+            if (fabs(ph) >= 0.5) { ph = fmod(ph, 1.0); if (ph != 0.0 && ph < 0.0) ph += 1.0; }
+            if (ph >= 0.5) ph -= 1.0;
+            xs[(size_t)i * 5] = ph;
+            for (int j = 1; j < 5; ++j) xs[(size_t)i * 5 + j] = x0i[j];
+            if (rs->seed_phase) rs->seed_phase[s0 + i] = ph;
+        }
+        HIP_TRY(hipMemcpyAsync(d_xs, xs.data(), xs.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));      // (xs is a local)
+        fa.xstart = d_xs;
+        return PP_OK;
+    };
+    if (refseed) {
+        if ((rc = run_refseed_pass())) return rc;
+    } else if (seed_full) {
         // the seed needs the cross-spectrum at a phase not known yet: store it, seed,
         // then take the Taylor moments (or iterate) in a second pass over it
         if ((rc = run_xspec(xa, 0))) return rc;
@@ -940,7 +1028,10 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         if ((rc = finalize_and_fetch())) return rc;
         all_done = (unfinished() <= 0);
         if (all_done) { unpack_outputs(); return PP_OK; }
-        for (int rep = 0; rep < fa.recentre && !all_done; ++rep) {
+        // (reference-seed flow: a subint whose walk left the model taken about the pilot's phase is
+        // expanded again about the reference's guess itself -- the ordinary flow from there)
+        const int nrep = std::max(fa.recentre, refseed ? 1 : 0);
+        for (int rep = 0; rep < nrep && !all_done; ++rep) {
             // some subints failed the certificate (poor guesses): k_taylor_solve moved
             // their expansion points to its tentative answers -- take the Taylor model of
             // THOSE again (one more pass over their rows, nothing stored) and solve again
@@ -1033,6 +1124,19 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
     bool scat = in->fit_flags[3] || in->fit_flags[4] || in->log10_tau;
     if (!scat)
         for (int i = 0; i < N; ++i) if (in->init_params[(size_t)i * 5 + 3] != 0.0) { scat = true; break; }
+    if (in->ref_seed) {
+        const pp_seed_ref* rs = in->ref_seed;
+        const int cstep = std::max(1, c->seed_chan_stride);
+        bool ok = !scat && c->max_iter > 0 && c->use_taylor && c->moments_in_xspec && c->one_exchange &&
+                  B == 2048 && 2 * Kt < B / 2 && C % PP_ROW_CHUNK == 0 && cstep > 1 && C / cstep >= 16 &&
+                  in->errs && in->seed_ns == 0 && rs->model_profs && rs->nu_mean && rs->Ns >= 1 &&
+                  (rs->model_prof_stride == 0 || rs->model_prof_stride == B);
+        for (int i = 0; ok && i < N; ++i) ok = (in->init_params[(size_t)i * 5 + 2] == 0.0);
+        if (!ok)
+            return fail(PP_ENOTSUP, "ref_seed: no single-pass path for this batch (needs 2048-bin portraits, no "
+                                    "scattering, a template that keeps < 512 harmonics, nchan a multiple of %d and >= %d, "
+                                    "errs given, GM guesses 0)", PP_ROW_CHUNK, 16 * cstep);
+    }
     // default reference frequencies: mean of the (unmasked) channel frequencies
     std::vector<double> nufit((size_t)N * 3), nuout((size_t)N * 3);
     // the masked mean needs the mask on the host: a device-resident mask is

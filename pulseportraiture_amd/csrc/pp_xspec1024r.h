@@ -1,0 +1,357 @@
+// k_xspec_qr1024: the transform of 2048-bin rows (k_xspec_q1024: one-exchange FFT, the 12
+// Taylor sums of every channel, nothing stored) that ALSO leaves what the reference's own
+// initial phase guess needs, so that get_TOAs' default flow reads the portraits once:
+//
+//   pptoas.py:421-457   rot_prof   = average(rotate_data(portx, 0, DM_guess, P, freqsx, nu_mean),
+//                                            axis=0, weights=weightsx)
+//                       phi_guess  = fit_phase_shift(rot_prof, model_prof, Ns=100).phase
+//
+// rot_prof is a sum over the channels of a subint, phi_guess is only known after it -- and
+// the Taylor model wants its expansion point BEFORE the pass.  But the model holds within
+// ~1e-3 rot of its centre, so any centre phi_c that close to phi_guess will do: the pilot
+// seed (a pass over every 16th channel, pp_toas.hip) supplies it, this pass expands about
+// (phi_c, DM_guess), and the solve then starts SciPy's walk from the reference's
+// (phi_guess, DM_guess) as a displacement from that centre (k_taylor_solve, FitArgs::xstart).
+//
+// The rotated spectrum needs no second phasor: with phi_n = phi_c + DM p1_n (the Taylor
+// phase) and phi'_n = Dconst DM (nu_n^-2 - nu_mean^-2) / P (the reference's rotation),
+// phi_n - phi'_n = Delta is the same for every channel of the subint, so
+//   R_k = sum_n w_n d_nk e^{i kap phi'_n} = e^{-i kap Delta} sum_n w_n d_nk e^{i kap phi_n}
+// and the per-harmonic factor is applied once per subint afterwards (k_refseed_finish).
+// fit_phase_shift measures its noise from the top quarter of rot_prof's power spectrum
+// (that decides where SciPy's simplex stops), so besides the harmonics the template keeps
+// (k <= 448: slots 0..6) the channel sum is also taken for k = 768..1024 (slots 12..15 and
+// the Nyquist term): 12 complex accumulators per lane, in registers.
+//
+// Rows are dealt in chunks of PP_ROW_CHUNK consecutive CHANNELS of one subint (chunk c =
+// channel block c / nsub of subint c % nsub: the waves in flight work on the same few channel
+// blocks of different subints, so the template rows they read stay in L2); a chunk's
+// accumulators are written out as one partial sum and k_refseed_finish adds the partials of
+// a subint in a fixed order (deterministic).  The template row is read per row (L2), after
+// the transform and before the second half of the next row's prefetch.
+#pragma once
+#include "pp_xspec1024q.h"
+
+namespace pp {
+
+#ifndef PP_R_TAILFIRST
+#define PP_R_TAILFIRST 0
+#endif
+
+struct RefSeedArgs {
+    const double* w;      // [nsub][nchan_full] channel weights of the mean, or nullptr (= 1)
+    cplx* part;           // [nsub][ncc][RS_NACC][64] partial channel sums
+    int ncc;              // channel blocks per subint (nchan / PP_ROW_CHUNK)
+};
+constexpr int RS_NACC = 12;     // slots 0..6 (kept), 12..15 (noise tail), Nyquist (lane of lam = 0)
+
+template <typename Tin>
+__global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs rs) {
+    constexpr int M = 1024, T = 64, R1 = 16, PER1 = 1;
+    constexpr int NSL = 7;
+    typedef typename RawOf<Tin>::type Raw;
+    constexpr int NRED = PP_TSTRIDE + 1;
+    static_assert(PP_TJ == 10, "power ladder written for order 10");
+    constexpr int WRED = PP_WRED_DOUBLES(NRED) / 2;
+    constexpr int LDSN = WRED > FFTQ_LDS_ELEMS ? WRED : FFTQ_LDS_ELEMS;
+    __shared__ cplx lds[LDSN];
+    int tid = threadIdx.x;
+    // rows = (chunk, position in chunk); RowWalk deals chunks, its "subint" is the position
+    const long long nrows = (long long)a.nsub * a.nchan;
+    Raw cur[PER1][R1];
+    const cplx wbT = a.twB[64];
+    RowWalk<true> rw;
+    rw.start(nrows);
+    int r = 0, c = 0;                 // position in the chunk, chunk
+    int ia = 0, cc = 0;               // the chunk's subint and channel block (one division per chunk)
+    if (rw.more) {
+        c = __builtin_amdgcn_readfirstlane((int)(rw.row / PP_ROW_CHUNK));
+        ia = c % a.nsub; cc = c / a.nsub;
+        const size_t rc = (size_t)ia * a.nchan_full + (size_t)cc * PP_ROW_CHUNK;
+        stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rc * (2 * M), tid);
+    }
+    cplx acc[RS_NACC];
+    int r_nx = r, c_nx = c, ia_nx = ia, cc_nx = cc;
+    const int ktg = a.Kt;             // harmonics the widest template row keeps: the channel sum takes them all
+    for (; rw.more; rw.advance(), r = r_nx, c = c_nx, ia = ia_nx, cc = cc_nx) {
+        rw.draw(a.ticket);
+        asm volatile("" : "+v"(tid));
+        const int lam = fftq_lambda(tid);
+        const bool l0 = (lam == 0);
+        const int kb = l0 ? 64 : lam;
+        const cplx t1 = as_global(a.twB)[2 * tid], t2 = as_global(a.twB)[32 * (tid & 15)];
+        const cplx wb0 = as_global(a.twB)[kb];
+        const int ne = cc * PP_ROW_CHUNK + r;
+        const size_t rc = (size_t)ia * a.nchan_full + ne;
+        const cplx* mrow = as_global(a.slot ? a.mft[a.slot[ia]] : a.mft0) + (size_t)ne * M;
+        const int ktn = a.ktab ? as_global(a.slot ? a.ktab[a.slot[ia]] : a.kt0)[ne] : a.Kt;
+        const double phin = a.ph0[rc];
+        const double hw = 0.5 * (rs.w ? rs.w[rc] : 1.0);     // (2 d_k below: the half goes here, exact)
+        if (r == 0) {
+#pragma unroll
+            for (int j = 0; j < RS_NACC; ++j) acc[j] = make_double2(0.0, 0.0);
+        }
+        double sd = 0.0;
+        cplx v[R1];
+#pragma unroll
+        for (int k = 0; k < R1; ++k) v[k] = to_cplx(cur[0][k]);
+        constexpr bool HALVES = sizeof(Tin) == 8;
+        const Tin* nxrow = nullptr;
+        auto load_some = [&](int k0, int k1) {
+            const char* gb = reinterpret_cast<const char*>(nxrow);
+            const unsigned boff = (unsigned)tid * (unsigned)sizeof(Raw);
+#pragma unroll
+            for (int k = 0; k < R1; ++k)
+                if (k >= k0 && k < k1)
+                    cur[0][k] = load_row_once<Raw>(gb + (size_t)(k * 64) * sizeof(Raw) + boff);
+        };
+        auto prefetch = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            rw.next(r, c, r_nx, c_nx, nrows, PP_ROW_CHUNK, a.ticket_base);
+            size_t rn = rc;
+            ia_nx = ia; cc_nx = cc;
+            if (rw.more_nx) {
+                if (c_nx != c) { ia_nx = c_nx % a.nsub; cc_nx = c_nx / a.nsub; }
+                rn = (size_t)ia_nx * a.nchan_full + (size_t)(cc_nx * PP_ROW_CHUNK + r_nx);
+            }
+            nxrow = reinterpret_cast<const Tin*>(a.data) + rn * (2 * M);
+            load_some(0, HALVES ? R1 / 2 : R1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#ifndef PP_R_FENCE
+#define PP_R_FENCE 1
+#endif
+        fftq1024<(sizeof(Tin) == 8 ? PP_Q_PREFETCH_F64 : PP_Q_PREFETCH_F32), PP_R_FENCE != 0>(v, lds, t1, t2, tid, &sd, prefetch);
+        __builtin_amdgcn_sched_barrier(0);
+        // this row's template values: read now (L2), behind the first half of the prefetch --
+        // which has had the whole transform to arrive -- and in front of the second half
+        cplx mv2[NSL];
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) mv2[j] = mrow[kb + 64 * j - 1];
+        // ---- partners through LDS: registers 9..15 and 0..4 out ----
+        {
+            cplx* pub = lds + tid;
+#pragma unroll
+            for (int s = 0; s < NSL; ++s) pub[64 * s] = v[9 + s];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) pub[64 * (NSL + q)] = v[q];
+            lds_sync<T>();
+        }
+        const cplx* pc = lds + fftq_lane_of((64 - lam) & 63);   // slot j: register 15 - j -> pc[64 (6 - j)]
+        // ---- phasors: e^{2 pi i kb phi}; lane 0 (kb = 64) holds the step ----
+        const cplx el = unit_phasor<true>((double)kb, phin);
+        const cplx wst = make_double2(bcast_lane0(el.x), bcast_lane0(el.y));
+#if PP_R_TAILFIRST
+#ifndef PP_R_NOTAIL
+        // ---- the noise tail of the channel sum first (its four registers are then free):
+        // k = lam + 64 kd, kd = 12..15 (lam = 0: k = 64 kd, partner = own register 16 - kd) and the
+        // Nyquist term.  e^{2 pi i (kb + 64 s) phi} and W^(kb + 64 s) for s = 12 (lam = 0: kb = 64,
+        // one step ahead -- s = 11).
+        {
+            const cplx e2 = cmul(wst, wst), e4 = cmul(e2, e2), e8 = cmul(e4, e4);
+            const cplx e12 = cmul(e8, e4), e11 = cmul(e8, cmul(e2, wst));
+            // W_2048^(64 * 12) = exp(-3 pi i / 4), W_2048^(64 * 11) = exp(-11 pi i / 16)
+            const cplx w12 = make_double2(-0.70710678118654752440, -0.70710678118654752440);
+            const cplx w11 = make_double2(-0.55557023301960222474, -0.83146961230254523708);
+            cplx et = cmul(el, csel(l0, e11, e12)), wt = cmul(wb0, csel(l0, w11, w12));
+            const cplx* pt = lds + fftq_lane_of((64 - lam) & 63) + (l0 ? 64 : 0);
+#pragma unroll
+            for (int kd = 12; kd < 16; ++kd) {
+                const cplx zk = v[kd];
+                cplx zc = pt[64 * (NSL + 15 - kd)];
+                zc.y = -zc.y;
+                const cplx E = make_double2(zk.x + zc.x, zk.y + zc.y);
+                const cplx O = make_double2(zk.x - zc.x, zk.y - zc.y);
+                const cplx wo = cmul(wt, O);
+                const cplx y = cmul(make_double2(E.x + wo.y, E.y - wo.x), et);
+                acc[7 + kd - 12].x = fma(hw, y.x, acc[7 + kd - 12].x);
+                acc[7 + kd - 12].y = fma(hw, y.y, acc[7 + kd - 12].y);
+                wt = cmul(wt, wbT);
+                et = cmul(et, wst);
+            }
+            // Nyquist (the lane of lam = 0, where et is now e^{2 pi i 1024 phi}): d_M = Re Z_0 - Im Z_0
+            const double dM = 2.0 * (v[0].x - v[0].y);
+            acc[11].x = fma(hw * dM, et.x, acc[11].x);
+            acc[11].y = fma(hw * dM, et.y, acc[11].y);
+        }
+#endif
+#endif
+        cplx e = el, wb = wb0;
+        const int ktu = __builtin_amdgcn_readfirstlane(ktn);
+        const double kap0 = PP_TWO_PI * (double)kb;
+        double tm[PP_TSTRIDE];
+        cplx zc_nx = pc[64 * 6];
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            cplx zc = zc_nx;
+            if (j + 1 < NSL) zc_nx = pc[64 * (5 - j)];
+#ifndef PP_R_LATE2
+#define PP_R_LATE2 6
+#endif
+            if (HALVES && j == PP_R_LATE2) {
+                // the second half of the next row: queued once four slots' registers are free
+                __builtin_amdgcn_sched_barrier(0);
+                load_some(R1 / 2, R1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // (the channel sum takes every harmonic ANY template row keeps; the Taylor sums only
+            // those this channel's row keeps -- both cuts are multiples of 64, wave-uniform)
+            if (j == 0 || 64 * j < ktg) {
+                const cplx zk = csel(l0, v[j + 1], v[j]);
+                zc.y = -zc.y;
+                const cplx E = make_double2(zk.x + zc.x, zk.y + zc.y);
+                const cplx O = make_double2(zk.x - zc.x, zk.y - zc.y);
+                const cplx wo = cmul(wb, O);
+                const cplx dd = make_double2(E.x + wo.y, E.y - wo.x);     // 2 d_k = E - i W^k O
+                // the rotated channel sum: w_n d_k e^{i kap phi_n}
+                const cplx y = cmul(dd, e);
+                acc[j].x = fma(hw, y.x, acc[j].x);
+                acc[j].y = fma(hw, y.y, acc[j].y);
+              if (j == 0 || 64 * j < ktu) {
+                // the cross-spectrum's Taylor sums, exactly as k_xspec_q1024 forms them
+                const cplx x = cmulc(dd, mv2[j]);
+                const cplx z = cmul(x, e);
+                const double kap = j == 0 ? kap0 : kap0 + kconst<true>(PP_TWO_PI * (double)(64 * j));
+                const double p2 = kap * kap, p4 = p2 * p2, p6 = p4 * p2, p8 = p4 * p4, p10 = p8 * p2;
+                const double ui = z.y * kap;
+                const double ax = fabs(x.x) + fabs(x.y);
+                if (j == 0) {
+                    tm[0] = z.x;
+                    tm[1] = ui;
+                    tm[2] = p2 * z.x;
+                    tm[3] = p2 * ui;
+                    tm[4] = p4 * z.x;
+                    tm[5] = p4 * ui;
+                    tm[6] = p6 * z.x;
+                    tm[7] = p6 * ui;
+                    tm[8] = p8 * z.x;
+                    tm[9] = p8 * ui;
+                    tm[10] = p10 * z.x;
+                    tm[11] = (p10 * kap) * ax;
+                } else {
+                    tm[0] += z.x;
+                    tm[1] += ui;
+                    tm[2] = fma(p2, z.x, tm[2]);
+                    tm[3] = fma(p2, ui, tm[3]);
+                    tm[4] = fma(p4, z.x, tm[4]);
+                    tm[5] = fma(p4, ui, tm[5]);
+                    tm[6] = fma(p6, z.x, tm[6]);
+                    tm[7] = fma(p6, ui, tm[7]);
+                    tm[8] = fma(p8, z.x, tm[8]);
+                    tm[9] = fma(p8, ui, tm[9]);
+                    tm[10] = fma(p10, z.x, tm[10]);
+                    tm[11] = fma(p10 * kap, ax, tm[11]);
+                }
+              }
+            }
+            wb = cmul(wb, wbT);
+            e = cmul(e, wst);
+        }
+#if !PP_R_TAILFIRST && !defined(PP_R_NOTAIL)
+        // ---- the noise tail of the channel sum: k = lam + 64 kd, kd = 12..15 (lam = 0: k = 64 kd,
+        // partner = own register 16 - kd) and the Nyquist term.  After the loop above
+        // e = e^{2 pi i (kb + 448) phi}, wb = W^(kb + 448): five more steps reach kd = 12
+        // (lam = 0: kb = 64, one step ahead -- four steps).
+        {
+            cplx e4 = cmul(wst, wst);
+            e4 = cmul(e4, e4);                       // e^{2 pi i 256 phi}
+            const cplx w4 = make_double2(0.70710678118654752440, -0.70710678118654752440);   // W_2048^256
+            cplx et = cmul(e, e4), wt = cmul(wb, w4);                 // + 4 steps
+            const cplx et1 = cmul(et, wst), wt1 = cmul(wt, wbT);      // + 5 steps
+            et = csel(l0, et, et1);
+            wt = csel(l0, wt, wt1);
+            const cplx* pt = lds + fftq_lane_of((64 - lam) & 63) + (l0 ? 64 : 0);
+#pragma unroll
+            for (int kd = 12; kd < 16; ++kd) {
+                const cplx zk = v[kd];
+                cplx zc = pt[64 * (NSL + 15 - kd)];
+                zc.y = -zc.y;
+                const cplx E = make_double2(zk.x + zc.x, zk.y + zc.y);
+                const cplx O = make_double2(zk.x - zc.x, zk.y - zc.y);
+                const cplx wo = cmul(wt, O);
+                const cplx y = cmul(make_double2(E.x + wo.y, E.y - wo.x), et);
+                acc[7 + kd - 12].x = fma(hw, y.x, acc[7 + kd - 12].x);
+                acc[7 + kd - 12].y = fma(hw, y.y, acc[7 + kd - 12].y);
+                wt = cmul(wt, wbT);
+                et = cmul(et, wst);
+            }
+            const double dM = 2.0 * (v[0].x - v[0].y);
+            acc[11].x = fma(hw * dM, et.x, acc[11].x);
+            acc[11].y = fma(hw * dM, et.y, acc[11].y);
+        }
+#endif
+        // ---- the 12 sums and S_d: one reduction through LDS ----
+        double tr[NRED];
+#pragma unroll
+        for (int j = 0; j < PP_TSTRIDE; ++j) tr[j] = tm[j];
+        tr[PP_TSTRIDE] = sd;
+        lds_sync<T>();
+        double tv = wave_reduce_lds(tr, tid, reinterpret_cast<double*>(lds));
+        if ((tid & 3) == 0) {
+            const int q = wave_reduce16_index(tid);
+            if (q < PP_TSTRIDE) {
+                tv *= 0.5;
+                a.tay[rc * PP_TSTRIDE + q] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
+            }
+        }
+        if (tid == 4 * PP_TSTRIDE) a.sdraw[rc] = tv;
+        if (r == PP_ROW_CHUNK - 1) {
+            // the chunk's share of the channel sums of subint ia
+            cplx* out = rs.part + (((size_t)ia * rs.ncc + cc) * RS_NACC) * 64 + tid;
+#pragma unroll
+            for (int j = 0; j < RS_NACC; ++j) out[64 * j] = acc[j];
+        }
+        lds_sync<T>();
+    }
+}
+
+// per subint: Delta_i = phi_c + Dconst DM (nu_mean^-2 - nu_fit^-2) / P, the constant by which the
+// Taylor phase of every channel exceeds the reference's rotation phase, and the summed weights
+// (fixed-order block reduction).  x0: [nsub][5] expansion points (the pilot seed wrote the phases).
+__global__ __launch_bounds__(256) void k_refseed_prep(const double* x0, const double* P, const double* nu_fit,
+                                                      const double* nu_mean, const double* w, int nchan,
+                                                      double* delta, double* wsum) {
+    const int i = blockIdx.x, tid = threadIdx.x;
+    __shared__ double scratch[4];
+    double s[1] = {0.0};
+    if (w) { for (int n = tid; n < nchan; n += 256) s[0] += w[(size_t)i * nchan + n]; }
+    else if (tid == 0) s[0] = (double)nchan;
+    block_sum<1>(s, scratch);
+    if (tid == 0) {
+        const double nf = nu_fit[i * 3], nm = nu_mean[i];
+        delta[i] = x0[i * 5] + PP_DCONST * x0[i * 5 + 1] * (1.0 / (nm * nm) - 1.0 / (nf * nf)) / P[i];
+        wsum[i] = s[0];
+    }
+}
+
+// rot_prof's spectrum of every subint from the partial channel sums: fixed-order sum over the
+// channel blocks, the per-harmonic factor e^{-i kap Delta_i} that turns the Taylor phase into the
+// reference's rotation phase, division by the summed weights; harmonics the pass did not
+// accumulate (448 < k < 768, and 0) are zero.  spec[i][0..M].
+__global__ __launch_bounds__(256) void k_refseed_finish(const cplx* part, int ncc, const double* delta,
+                                                        const double* wsum, int nsub, cplx* spec) {
+    constexpr int M = 1024;
+    const int i = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k > M) return;
+    const int lam = k & 63, kd = k >> 6;
+    int slot = -1;
+    if (k == M) slot = 11;
+    else if (lam != 0) slot = (kd <= 6) ? kd : (kd >= 12 ? 7 + kd - 12 : -1);
+    else slot = (kd >= 1 && kd <= 7) ? kd - 1 : (kd >= 12 ? 7 + kd - 12 : -1);
+    cplx s = make_double2(0.0, 0.0);
+    if (slot >= 0) {
+        const int lane = fftq_lane_of(k == M ? 0 : lam);
+        for (int cc = 0; cc < ncc; ++cc) {
+            const cplx v = part[(((size_t)i * ncc + cc) * RS_NACC + slot) * 64 + lane];
+            s.x += v.x; s.y += v.y;
+        }
+        const cplx rot = unit_phasor((double)k, -delta[i]);
+        s = cmul(s, rot);
+        const double inv = wsum[i] > 0.0 ? 1.0 / wsum[i] : 0.0;
+        s.x *= inv; s.y *= inv;
+        if (k == M) s.y = 0.0;          // (irfft keeps the real part of the Nyquist term only)
+    }
+    spec[(size_t)i * (M + 1) + k] = s;
+}
+
+}  // namespace pp

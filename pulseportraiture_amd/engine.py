@@ -10,8 +10,8 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import (FitIn, FitOut, PP_F32, PP_F64, PP_METHOD_NEWTON, PP_METHOD_TRUST_NCG,
-                   c_double_p, c_int32_p, c_uint8_p)
+from ._lib import (FitIn, FitOut, PP_ENOTSUP, PP_F32, PP_F64, PP_METHOD_NEWTON, PP_METHOD_TRUST_NCG,
+                   SeedRef, c_double_p, c_int32_p, c_uint8_p)
 
 # the reference's minimiser names (pptoaslib.py:993-1010) -> device solver
 METHODS = {'trust-ncg': PP_METHOD_TRUST_NCG, 'Newton-CG': PP_METHOD_NEWTON,
@@ -22,7 +22,14 @@ class EngineError(RuntimeError):
     pass
 
 
+class EngineNotSupported(EngineError):
+    """The library has no device path for this request in this shape (PP_ENOTSUP): nothing
+    was done; the caller takes its general route."""
+
+
 def _check(rc, what):
+    if rc == PP_ENOTSUP:
+        raise EngineNotSupported("%s: %s" % (what, _lib.last_error()))
     if rc != 0:
         raise EngineError("%s failed (%d): %s" % (what, rc, _lib.last_error()))
 
@@ -155,7 +162,7 @@ class Engine(object):
                   nu_outs=None, fit_flags=(1, 1, 0, 0, 0), log10_tau=False,
                   option=0, is_toa=True, model_slot=None, chan_mask=None,
                   per_channel=True, objective=False, seed_ns=0, method='trust-ncg',
-                  records=None, _submit=False):
+                  records=None, ref_seed=None, _submit=False):
         """Fit nsub subints.  data: [nsub,nchan,nbin] numpy array (f64/f32) or
         CUDA tensor.  freqs: [nchan] or [nsub,nchan].  Returns a dict of arrays
         (see include/pp_toas.h pp_fit_out).  errs / chan_mask may be CUDA
@@ -166,7 +173,13 @@ class Engine(object):
         seed_ns > 0 replaces init_params[:, 0] by a phase seeded on the device.
         method: 'trust-ncg' follows SciPy's trust-ncg iteration to the very point
         where the reference stops; 'newton' ('Newton-CG', 'TNC') converges to the
-        rounding of the objective in fewer evaluations."""
+        rounding of the objective in fewer evaluations.
+        ref_seed: dict(weights=[nsub,nchan] (array, CUDA tensor or None), model_profs=[nsub,nbin]
+        or [nbin], nu_mean=[nsub], Ns=100, bounds=(-0.5, 0.5), finish='simplex') -- the
+        reference's own phase guess (pptoas.py:421-457) is formed inside the fit, from the same
+        single pass over the portraits, and replaces init_params[:, 0]; the result gains
+        "seed_phase".  Raises EngineNotSupported when the batch has no single-pass path
+        (include/pp_toas.h pp_seed_ref): form the guess with reference_phase_seed then."""
         if method not in METHODS:
             raise EngineError("unknown method %r" % (method,))
         if records is not None and not (
@@ -247,6 +260,42 @@ class Engine(object):
         fin.option, fin.is_toa = int(option), int(bool(is_toa))
         fin.seed_ns = int(seed_ns)
         fin.method = METHODS[method]
+        seed_keep = None
+        if ref_seed is not None:
+            sr = SeedRef()
+            w = ref_seed.get("weights")
+            if w is not None and _is_device_array(w):
+                if not aux_dev and (errs is not None or chan_mask is not None):
+                    raise EngineError("ref_seed weights on the device need errs / chan_mask there too")
+                if not (w.is_contiguous() and w.element_size() == 8 and tuple(w.shape) == (nsub, nchan)):
+                    raise EngineError("device ref_seed weights must be a contiguous float64 tensor [nsub,nchan]")
+                fin.aux_on_device = 1
+                sr.weights = C.cast(w.data_ptr(), c_double_p)
+            elif w is not None:
+                if aux_dev:
+                    raise EngineError("ref_seed weights must be a CUDA tensor when errs / chan_mask are")
+                w = _f64(w, (nsub, nchan))
+                sr.weights = _dp(w)
+            mp = np.ascontiguousarray(ref_seed["model_profs"], dtype=np.float64)
+            if mp.ndim == 1:
+                sr.model_prof_stride = 0
+            elif mp.shape == (nsub, nbin):
+                sr.model_prof_stride = nbin
+            else:
+                raise EngineError("ref_seed model_profs must be [nbin] or [nsub,nbin]")
+            if mp.shape[-1] != nbin:
+                raise EngineError("ref_seed model_profs has %d bins, the data %d" % (mp.shape[-1], nbin))
+            sr.model_profs = _dp(mp)
+            numean = _f64(ref_seed["nu_mean"], (nsub,))
+            sr.nu_mean = _dp(numean)
+            lo_hi = ref_seed.get("bounds", (-0.5, 0.5))
+            sr.lo, sr.hi = float(lo_hi[0]), float(lo_hi[1])
+            sr.Ns = int(ref_seed.get("Ns", 100))
+            sr.finish = 1 if ref_seed.get("finish", "simplex") == "simplex" else 0
+            sphase = np.empty(nsub)
+            sr.seed_phase = _dp(sphase)
+            fin.ref_seed = C.pointer(sr)
+            seed_keep = (sr, w, mp, numean, sphase)
 
         res = dict(params=np.empty((nsub, 5)), param_errs=np.empty((nsub, 5)),
                    nu_refs=np.empty((nsub, 3)), cov=np.empty((nsub, 5, 5)),
@@ -287,18 +336,20 @@ class Engine(object):
             else:
                 setattr(fout, name, arr.ctypes.data_as(c_double_p))
         res["fit_flags"] = [1 if f else 0 for f in fit_flags]
+        if seed_keep is not None:
+            res["seed_phase"] = seed_keep[4]
         if _submit:
             if getattr(self, "_pending", None) is not None:
                 raise EngineError("a submitted batch is pending: wait() first")
             _check(self._lib.pp_fit_submit(self._ctx, C.byref(fin), C.byref(fout)), "pp_fit_submit")
             # every array the argument blocks point to stays alive until wait()
             self._pending = (res, (keep, freqs, P, x0, errs, nu_fits, nu_outs, slot, mask, chan_mask,
-                                   records, fin, fout))
+                                   records, fin, fout, seed_keep))
             return None
         _check(self._lib.pp_fit_portrait_batch(self._ctx, C.byref(fin),
                                                C.byref(fout)),
                "pp_fit_portrait_batch")
-        del keep
+        del keep, seed_keep
         res["duration"] = float(res["duration"][0])
         return res
 

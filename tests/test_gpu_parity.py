@@ -1800,6 +1800,70 @@ def test_float_cross_spectrum_option(name):
     assert a.npass == b.npass
 
 
+@pytest.mark.parametrize("dtype,flags", [("f64", [1, 1, 0, 0, 0]), ("f32", [1, 1, 0, 0, 0]), ("f64", [1, 0, 0, 0, 0])])
+def test_reference_seed_formed_inside_the_single_pass(dtype, flags):
+    """pp_seed_ref: the reference's own phase guess (pptoas.py:421-457: dedisperse to nu_mean,
+    weighted channel mean, fit_phase_shift with the simplex finish, phase_transform to nu_fit)
+    formed from the SAME pass over the portraits as the fit -- the transform takes the Taylor
+    model about the pilot seed's phase together with the rotated channel sums, and SciPy's
+    walk starts off-centre, at the reference's guess -- against the two-pass flow (the guess
+    from pp_reference_phase_seed, then the fit from it): the same guesses, the same raw
+    answers."""
+    import torch
+    from pulseportraiture_amd.pplib import phase_transform
+    from pulseportraiture_amd.engine import EngineNotSupported
+    C, B, nsub = 256, 2048, 12
+    e, data, freqs, model, P, x0, errs, nu_fit, kw = _full_shape_case(C, B, flags, False, nsub=nsub, seed=23)
+    if dtype == "f32":
+        data = data.to(torch.float32)
+    rng = np.random.default_rng(5)
+    w = rng.uniform(0.5, 1.5, (nsub, C))
+    w[:, rng.choice(C, 20, replace=False)] = 0.0          # zapped channels
+    mask = (w > 0).astype(np.uint8)
+    nu_mean = np.array([freqs[mask[i] > 0].mean() for i in range(nsub)])
+    mprof = model.mean(axis=0)
+    DM0 = x0[0, 1]
+    kw = dict(kw, chan_mask=mask)
+    # two passes: the guess, then the fit
+    out = e.reference_phase_seed(data, freqs, P, w, np.tile(mprof, (nsub, 1)), phi=-Dconst_() * DM0 / P * nu_mean ** -2.0,
+                                 DM=np.full(nsub, DM0), nu_DM=np.inf, Ns=100, finish='simplex')
+    g2 = np.array([phase_transform(out[i, 0], DM0, nu_mean[i], nu_fit, P[i], mod=True) for i in range(nsub)])
+    xa = x0.copy(); xa[:, 0] = g2
+    two = e.fit_batch(data, freqs, P, xa, **kw)
+    # one pass
+    xb = x0.copy(); xb[:, 0] = 0.123                      # (ignored)
+    rs = dict(weights=w, model_profs=mprof, nu_mean=nu_mean, Ns=100, finish='simplex')
+    e.set_option("profile", 1); e.kernel_times(reset=True)
+    one = e.fit_batch(data, freqs, P, xb, ref_seed=rs, **kw)
+    kt = e.kernel_times(reset=True); e.set_option("profile", 0)
+    assert kt["xspec"][1] == 2 and kt.get("eval", (0, 0))[1] == 0        # the pilot + ONE pass over the portraits
+    assert np.abs(_dphi_arr(one["seed_phase"], g2)).max() < 1e-12, (one["seed_phase"], g2)
+    # (raw: the same iterates; a phase-only walk has marginal exits -- a last step worth one ulp of
+    # f taken or not -- that the rounding of an off-centre model evaluation can flip)
+    dph = np.abs(_dphi_arr(one["params"][:, 0], two["params"][:, 0]))
+    assert (dph < 1e-12).mean() >= 0.8 and dph.max() < PHI_BAR, dph
+    assert np.abs(one["params"][:, 1] - two["params"][:, 1]).max() < 1e-9
+    np.testing.assert_allclose(one["param_errs"], two["param_errs"], rtol=1e-9)
+    np.testing.assert_allclose(one["chi2"], two["chi2"], rtol=1e-11)
+    np.testing.assert_allclose(one["nu_refs"], two["nu_refs"], rtol=1e-9)
+    assert (one["return_code"] == 2).all() and (one["npass"] == 1).all()
+    assert np.abs(one["nfeval"] - two["nfeval"]).max() <= 1
+    # the same with per-subint model profiles and a device-resident weight tensor
+    rs2 = dict(weights=torch.as_tensor(w, device=data.device), model_profs=np.tile(mprof, (nsub, 1)), nu_mean=nu_mean)
+    kw2 = dict(kw, errs=torch.as_tensor(errs, device=data.device), chan_mask=torch.as_tensor(mask, device=data.device))
+    one2 = e.fit_batch(data, freqs, P, xb, ref_seed=rs2, **kw2)
+    np.testing.assert_array_equal(one2["seed_phase"], one["seed_phase"])
+    np.testing.assert_array_equal(one2["params"], one["params"])
+    # shapes without a single-pass path say so and do nothing
+    with pytest.raises(EngineNotSupported):
+        e.fit_batch(data, freqs, P, xb, ref_seed=rs, **dict(kw, fit_flags=[1, 1, 0, 1, 1], log10_tau=True))
+
+
+def Dconst_():
+    from pulseportraiture_amd.pplib import Dconst
+    return Dconst
+
+
 def test_submit_and_wait_overlap_two_contexts():
     """pp_fit_submit / pp_fit_wait: a host-array batch started on one
     context runs on that context's worker thread while the calling thread fits another
