@@ -55,16 +55,13 @@ constexpr int FFTQ_LDS_ELEMS = 4 * 272;      // four rows of 16 lanes x (16 x 17
 // dead: WHEN = 0 a quarter into stage 1, 1 after the stage-1 twiddles (their powers no
 // longer live), 2 after the lane swaps, 3 after the transpose (before the last stage).  power (optional) += this lane's share of
 // sum_{k=1}^{M-1} |Z_k|^2 + (Re Z_0 - Im Z_0)^2.
-// FENCE: the scheduler may not move the stage-1 twiddle powers (60 registers) up beside the
-// butterflies -- for callers that hold more state across the transform than k_xspec_q1024
-template <int WHEN = 0, bool FENCE = false, typename Mid>
+template <int WHEN = 0, typename Mid>
 __device__ __forceinline__ void fftq1024(cplx (&v)[16], cplx* lds, const cplx t1, const cplx t2, int tid,
                                          double* power, Mid mid) {
     // ---- stage 1 ----
     dft16_first(v);
     if (WHEN == 0) mid();
     dft16_second(v);
-    if (FENCE) __builtin_amdgcn_sched_barrier(0);
     {
         // v[j] *= t1^j, every power formed once (product tree, as stage_finish<TREE>)
         cplx wq[16];

@@ -34,16 +34,15 @@
 
 namespace pp {
 
-#ifndef PP_R_TAILFIRST
-#define PP_R_TAILFIRST 0
-#endif
-
 struct RefSeedArgs {
     const double* w;      // [nsub][nchan_full] channel weights of the mean, or nullptr (= 1)
     cplx* part;           // [nsub][ncc][RS_NACC][64] partial channel sums
     int ncc;              // channel blocks per subint (nchan / PP_ROW_CHUNK)
 };
 constexpr int RS_NACC = 12;     // slots 0..6 (kept), 12..15 (noise tail), Nyquist (lane of lam = 0)
+constexpr int RS_NREG = 11;     // ... of which in registers; the Nyquist term (one lane's) sits in LDS
+constexpr int RS_NYQ = FFTQ_LDS_ELEMS - 1;    // ... in the one element of the transpose image no lane touches
+                                              // (highest index used: 3 * 272 + 17 * 15 + 15 = 1086)
 
 template <typename Tin>
 __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs rs) {
@@ -54,8 +53,13 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
     static_assert(PP_TJ == 10, "power ladder written for order 10");
     constexpr int WRED = PP_WRED_DOUBLES(NRED) / 2;
     constexpr int LDSN = WRED > FFTQ_LDS_ELEMS ? WRED : FFTQ_LDS_ELEMS;
-    __shared__ cplx lds[LDSN];
+    // f64 rows: three of the four tail accumulators live in the LDS a wave has left beside its
+    // image (8 waves x 20 KB = the CU's 160 KB) -- with a whole f64 row in flight (64 registers)
+    // there is no room for them in the register file
+    constexpr int NLA = (sizeof(Tin) == 8) ? 3 : 0;
+    __shared__ cplx lds[LDSN + 64 * NLA];
     int tid = threadIdx.x;
+    cplx* const lacc = lds + LDSN + threadIdx.x;
     // rows = (chunk, position in chunk); RowWalk deals chunks, its "subint" is the position
     const long long nrows = (long long)a.nsub * a.nchan;
     Raw cur[PER1][R1];
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
         const size_t rc = (size_t)ia * a.nchan_full + (size_t)cc * PP_ROW_CHUNK;
         stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rc * (2 * M), tid);
     }
-    cplx acc[RS_NACC];
+    cplx acc[RS_NREG - NLA];      // (slots 0..6, tail slot 12 [.. 15 for f32 rows])
     int r_nx = r, c_nx = c, ia_nx = ia, cc_nx = cc;
     const int ktg = a.Kt;             // harmonics the widest template row keeps: the channel sum takes them all
     for (; rw.more; rw.advance(), r = r_nx, c = c_nx, ia = ia_nx, cc = cc_nx) {
@@ -89,7 +93,10 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
         const double hw = 0.5 * (rs.w ? rs.w[rc] : 1.0);     // (2 d_k below: the half goes here, exact)
         if (r == 0) {
 #pragma unroll
-            for (int j = 0; j < RS_NACC; ++j) acc[j] = make_double2(0.0, 0.0);
+            for (int j = 0; j < RS_NREG - NLA; ++j) acc[j] = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int j = 0; j < NLA; ++j) lacc[64 * j] = make_double2(0.0, 0.0);
+            if (tid == 0) lds[RS_NYQ] = make_double2(0.0, 0.0);
         }
         double sd = 0.0;
         cplx v[R1];
@@ -118,10 +125,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
             load_some(0, HALVES ? R1 / 2 : R1);
             __builtin_amdgcn_sched_barrier(0);
         };
-#ifndef PP_R_FENCE
-#define PP_R_FENCE 1
-#endif
-        fftq1024<(sizeof(Tin) == 8 ? PP_Q_PREFETCH_F64 : PP_Q_PREFETCH_F32), PP_R_FENCE != 0>(v, lds, t1, t2, tid, &sd, prefetch);
+        fftq1024<(sizeof(Tin) == 8 ? PP_Q_PREFETCH_F64 : PP_Q_PREFETCH_F32)>(v, lds, t1, t2, tid, &sd, prefetch);
         __builtin_amdgcn_sched_barrier(0);
         // this row's template values: read now (L2), behind the first half of the prefetch --
         // which has had the whole transform to arrive -- and in front of the second half
@@ -141,41 +145,6 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
         // ---- phasors: e^{2 pi i kb phi}; lane 0 (kb = 64) holds the step ----
         const cplx el = unit_phasor<true>((double)kb, phin);
         const cplx wst = make_double2(bcast_lane0(el.x), bcast_lane0(el.y));
-#if PP_R_TAILFIRST
-#ifndef PP_R_NOTAIL
-        // ---- the noise tail of the channel sum first (its four registers are then free):
-        // k = lam + 64 kd, kd = 12..15 (lam = 0: k = 64 kd, partner = own register 16 - kd) and the
-        // Nyquist term.  e^{2 pi i (kb + 64 s) phi} and W^(kb + 64 s) for s = 12 (lam = 0: kb = 64,
-        // one step ahead -- s = 11).
-        {
-            const cplx e2 = cmul(wst, wst), e4 = cmul(e2, e2), e8 = cmul(e4, e4);
-            const cplx e12 = cmul(e8, e4), e11 = cmul(e8, cmul(e2, wst));
-            // W_2048^(64 * 12) = exp(-3 pi i / 4), W_2048^(64 * 11) = exp(-11 pi i / 16)
-            const cplx w12 = make_double2(-0.70710678118654752440, -0.70710678118654752440);
-            const cplx w11 = make_double2(-0.55557023301960222474, -0.83146961230254523708);
-            cplx et = cmul(el, csel(l0, e11, e12)), wt = cmul(wb0, csel(l0, w11, w12));
-            const cplx* pt = lds + fftq_lane_of((64 - lam) & 63) + (l0 ? 64 : 0);
-#pragma unroll
-            for (int kd = 12; kd < 16; ++kd) {
-                const cplx zk = v[kd];
-                cplx zc = pt[64 * (NSL + 15 - kd)];
-                zc.y = -zc.y;
-                const cplx E = make_double2(zk.x + zc.x, zk.y + zc.y);
-                const cplx O = make_double2(zk.x - zc.x, zk.y - zc.y);
-                const cplx wo = cmul(wt, O);
-                const cplx y = cmul(make_double2(E.x + wo.y, E.y - wo.x), et);
-                acc[7 + kd - 12].x = fma(hw, y.x, acc[7 + kd - 12].x);
-                acc[7 + kd - 12].y = fma(hw, y.y, acc[7 + kd - 12].y);
-                wt = cmul(wt, wbT);
-                et = cmul(et, wst);
-            }
-            // Nyquist (the lane of lam = 0, where et is now e^{2 pi i 1024 phi}): d_M = Re Z_0 - Im Z_0
-            const double dM = 2.0 * (v[0].x - v[0].y);
-            acc[11].x = fma(hw * dM, et.x, acc[11].x);
-            acc[11].y = fma(hw * dM, et.y, acc[11].y);
-        }
-#endif
-#endif
         cplx e = el, wb = wb0;
         const int ktu = __builtin_amdgcn_readfirstlane(ktn);
         const double kap0 = PP_TWO_PI * (double)kb;
@@ -185,11 +154,9 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
         for (int j = 0; j < NSL; ++j) {
             cplx zc = zc_nx;
             if (j + 1 < NSL) zc_nx = pc[64 * (5 - j)];
-#ifndef PP_R_LATE2
-#define PP_R_LATE2 6
-#endif
-            if (HALVES && j == PP_R_LATE2) {
-                // the second half of the next row: queued once four slots' registers are free
+            if (HALVES && j == NSL - 1) {
+                // the second half of the next row: queued before the last kept slot (earlier, the
+                // 64 registers of a whole f64 row in flight do not fit beside the accumulators)
                 __builtin_amdgcn_sched_barrier(0);
                 load_some(R1 / 2, R1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -247,7 +214,6 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
             wb = cmul(wb, wbT);
             e = cmul(e, wst);
         }
-#if !PP_R_TAILFIRST && !defined(PP_R_NOTAIL)
         // ---- the noise tail of the channel sum: k = lam + 64 kd, kd = 12..15 (lam = 0: k = 64 kd,
         // partner = own register 16 - kd) and the Nyquist term.  After the loop above
         // e = e^{2 pi i (kb + 448) phi}, wb = W^(kb + 448): five more steps reach kd = 12
@@ -270,16 +236,27 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
                 const cplx O = make_double2(zk.x - zc.x, zk.y - zc.y);
                 const cplx wo = cmul(wt, O);
                 const cplx y = cmul(make_double2(E.x + wo.y, E.y - wo.x), et);
-                acc[7 + kd - 12].x = fma(hw, y.x, acc[7 + kd - 12].x);
-                acc[7 + kd - 12].y = fma(hw, y.y, acc[7 + kd - 12].y);
+                constexpr int NRT = 4 - NLA;      // tail accumulators in registers
+                if (kd - 12 < NRT) {
+                    acc[7 + kd - 12].x = fma(hw, y.x, acc[7 + kd - 12].x);
+                    acc[7 + kd - 12].y = fma(hw, y.y, acc[7 + kd - 12].y);
+                } else {
+                    cplx t = lacc[64 * (kd - 12 - NRT)];
+                    t.x = fma(hw, y.x, t.x);
+                    t.y = fma(hw, y.y, t.y);
+                    lacc[64 * (kd - 12 - NRT)] = t;
+                }
                 wt = cmul(wt, wbT);
                 et = cmul(et, wst);
             }
-            const double dM = 2.0 * (v[0].x - v[0].y);
-            acc[11].x = fma(hw * dM, et.x, acc[11].x);
-            acc[11].y = fma(hw * dM, et.y, acc[11].y);
+            if (tid == 0) {
+                const double dM = 2.0 * (v[0].x - v[0].y);
+                cplx t = lds[RS_NYQ];
+                t.x = fma(hw * dM, et.x, t.x);
+                t.y = fma(hw * dM, et.y, t.y);
+                lds[RS_NYQ] = t;
+            }
         }
-#endif
         // ---- the 12 sums and S_d: one reduction through LDS ----
         double tr[NRED];
 #pragma unroll
@@ -299,7 +276,10 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
             // the chunk's share of the channel sums of subint ia
             cplx* out = rs.part + (((size_t)ia * rs.ncc + cc) * RS_NACC) * 64 + tid;
 #pragma unroll
-            for (int j = 0; j < RS_NACC; ++j) out[64 * j] = acc[j];
+            for (int j = 0; j < RS_NREG - NLA; ++j) out[64 * j] = acc[j];
+#pragma unroll
+            for (int j = 0; j < NLA; ++j) out[64 * (RS_NREG - NLA + j)] = lacc[64 * j];
+            if (tid == 0) out[64 * RS_NREG] = lds[RS_NYQ];
         }
         lds_sync<T>();
     }

@@ -17,7 +17,7 @@ import time
 import numpy as np
 
 from . import gmodel
-from .engine import default_engine
+from .engine import EngineNotSupported, default_engine
 from .pplib import DataBunch, guess_fit_freq, scattering_alpha, weighted_mean
 
 max_nfile = 999
@@ -331,20 +331,15 @@ class GetTOAs(object):
             mdl["params"][1] = 0.0
         eng.set_model_gaussian(mdl, freqs_row, nbin, P, slot=slot)
 
-    def _reference_phase_seeds(self, eng, port, d, ok_isubs, mask, nu_fit_DM, DM_guess, tau_lin,
-                               nu_fit_tau, fit_scat, use_ird):
-        """phi_guess of every good subint exactly as the reference forms it
-        (pptoas.py:421-457): rot_prof = weighted mean over the good channels of the
-        portrait dedispersed at DM_guess to their mean frequency (device: rotation +
-        mean), fitted against the mean of the template's good channels (scattered by
-        the guessed tau when fitting scattering) with fit_phase_shift(Ns=100) -- brute
-        grid + SciPy's simplex finish retraced on the device --, then moved from
-        nu_mean to nu_fit_DM."""
-        from .pplib import Dconst, phase_transform
+    def _reference_seed_inputs(self, port, d, ok_isubs, mask, tau_lin, nu_fit_tau, fit_scat, use_ird):
+        """What the reference's phase guess is formed from (pptoas.py:421-457), per good
+        subint: the weights of the channel mean, the mean frequency of the good channels and
+        the template's mean profile over them (scattered by the guessed tau when fitting
+        scattering): (w, nu_mean, mprofs)."""
         isubs = np.asarray(ok_isubs, dtype=int)
         nok, nchan, nbin = port.shape
-        freqs, P = d.freqs[isubs], np.asarray(d.Ps, dtype=np.float64)[isubs]
         w = np.asarray(d.weights, dtype=np.float64)[isubs] * mask
+        freqs = d.freqs[isubs]
         nu_mean = np.array([freqs[j, mask[j] > 0].mean() for j in range(nok)])
         mprofs, cache = np.empty((nok, nbin)), {}
         for j, isub in enumerate(isubs):
@@ -364,6 +359,18 @@ class GetTOAs(object):
                     mprof = np.fft.irfft(np.fft.rfft(mprof) / (1.0 + 2.0j * np.pi * k * tau_lin[j]))
                 cache[key] = mprof
             mprofs[j] = cache[key]
+        return w, nu_mean, mprofs
+
+    def _reference_phase_seeds(self, eng, port, freqs, P, w, nu_mean, mprofs, nu_fit_DM, DM_guess):
+        """phi_guess of every subint exactly as the reference forms it (pptoas.py:421-457), in
+        a pass of its own over the portraits: rot_prof = weighted mean over the good channels
+        of the portrait dedispersed at DM_guess to their mean frequency (device: rotation +
+        mean), fitted against the template's mean profile with fit_phase_shift(Ns=100) -- brute
+        grid + SciPy's simplex finish retraced on the device --, then moved from nu_mean to
+        nu_fit_DM.  (The route for batches without a single-pass path, Engine.fit_batch's
+        ref_seed.)"""
+        from .pplib import Dconst, phase_transform
+        nok = len(P)
         # rotate_data(portx, 0.0, DM_guess, P, freqsx, nu_mean): the nu_mean term is the
         # same for every channel of a subint and rides on the phase argument; rotation,
         # weighted channel mean (channels of zero weight are not read) and the fit run
@@ -524,12 +531,13 @@ class GetTOAs(object):
                     fl = list(self.fit_flags)
                 flags_per.append(tuple(fl))
             port = _dededisperse(eng, _take_subints(d.subints, ok_isubs), d, ok_isubs)
+            ref_in = None
             if seed == 'reference':
-                # the portraits are read twice (seed, fit): hand them to the device once
+                # (batches without a single-pass path read the portraits twice -- seed, fit --:
+                # hand them to the device once)
                 port = _to_device_once(eng, port)
-                x0[:, 0] = self._reference_phase_seeds(eng, port, d, ok_isubs, mask, nu_fit_arr[:, 0],
-                                                       DM_stored, tau_lin, nu_fit_arr[:, 2], fit_scat,
-                                                       use_ird)
+                ref_in = self._reference_seed_inputs(port, d, ok_isubs, mask, tau_lin, nu_fit_arr[:, 2],
+                                                     fit_scat, use_ird)
             # ---- one device call per distinct flag set (normally one) ----
             res = None
             for fl in sorted(set(flags_per)):
@@ -542,14 +550,24 @@ class GetTOAs(object):
                     psel = port[torch.as_tensor(sel, device=port.device)].contiguous()
                 else:
                     psel = np.ascontiguousarray(port[sel])
-                r = eng.fit_batch(psel, d.freqs[ok_isubs][sel], d.Ps[ok_isubs][sel],
-                                  x0[sel], errs=None if errs is None else errs[sel],
-                                  nu_fits=nu_fit_arr[sel], nu_outs=nu_ref_arr[sel],
-                                  fit_flags=fl, log10_tau=log10_tau, option=0,
-                                  is_toa=True, model_slot=slot_of[sel],
-                                  chan_mask=mask[sel],
-                                  seed_ns=100 if seed == 'device' else 0,
-                                  method='newton' if seed == 'device' else method)
+                fkw = dict(errs=None if errs is None else errs[sel], nu_fits=nu_fit_arr[sel],
+                           nu_outs=nu_ref_arr[sel], fit_flags=fl, log10_tau=log10_tau, option=0, is_toa=True,
+                           model_slot=slot_of[sel], chan_mask=mask[sel], seed_ns=100 if seed == 'device' else 0,
+                           method='newton' if seed == 'device' else method)
+                fsel, Psel = d.freqs[ok_isubs][sel], np.asarray(d.Ps, dtype=np.float64)[ok_isubs][sel]
+                r = None
+                if ref_in is not None:
+                    # the reference's own guess: formed inside the fit's single pass over the
+                    # portraits where the library has that path, else in a pass of its own
+                    w_, numean_, mprofs_ = (a[sel] for a in ref_in)
+                    try:
+                        r = eng.fit_batch(psel, fsel, Psel, x0[sel], ref_seed=dict(
+                            weights=w_, model_profs=mprofs_, nu_mean=numean_, Ns=100, finish='simplex'), **fkw)
+                    except EngineNotSupported:
+                        x0[sel, 0] = self._reference_phase_seeds(eng, psel, fsel, Psel, w_, numean_, mprofs_,
+                                                                 nu_fit_arr[sel, 0], DM_stored)
+                if r is None:
+                    r = eng.fit_batch(psel, fsel, Psel, x0[sel], **fkw)
                 if res is None:
                     res = {k: (np.zeros((nok,) + v.shape[1:], dtype=v.dtype)
                                if isinstance(v, np.ndarray) else v) for k, v in r.items()}

@@ -1859,6 +1859,61 @@ def test_reference_seed_formed_inside_the_single_pass(dtype, flags):
         e.fit_batch(data, freqs, P, xb, ref_seed=rs, **dict(kw, fit_flags=[1, 1, 0, 1, 1], log10_tau=True))
 
 
+def test_get_TOAs_default_flow_reads_the_portraits_once_at_2048_bins():
+    """Caller level: GetTOAs.get_TOAs (seed='reference', the default) on an archive of
+    2048-bin, 256-channel subints takes the single-pass path (pilot + ONE transform over
+    the portraits, the reference's guess formed inside it) and returns what the two-pass
+    route returns (one_exchange = 0 leaves the library without the single-pass kernel:
+    PP_ENOTSUP -> the guess from a pass of its own), raw; a zapped subint and zapped
+    channels included."""
+    from pulseportraiture_amd.pptoas import GetTOAs, MJD, data_from_arrays
+    from pulseportraiture_amd.engine import default_engine
+    from tests.synth_host import make_inputs, model_portrait
+    C, B, nsub = 256, 2048, 4
+    rng = np.random.default_rng(77)
+    freqs1, model = model_portrait(C, B)
+    subints = np.empty((nsub, 1, C, B))
+    for i in range(nsub):
+        subints[i, 0] = make_inputs(C, B, 900 + i, DM0=34.56789, model=model)["data"]
+    weights = np.ones((nsub, C))
+    weights[:, rng.choice(C, 9, replace=False)] = 0.0
+    weights[2] = 0.0
+    P0 = 1.0 / 345.67890123456789
+    epochs = [MJD(55000 + i, 0.25 + 1e-3 * i) for i in range(nsub)]
+    data = data_from_arrays(subints, np.tile(freqs1, (nsub, 1)), np.full(nsub, P0), epochs, weights=weights,
+                            noise_stds=np.full((nsub, 1, C), 0.05), SNRs=rng.uniform(5, 50, (nsub, 1, C)),
+                            DM=34.56789, doppler_factors=np.ones(nsub), backend_delay=0.0, telescope="GBT",
+                            telescope_code="1", backend="GUPPI", frontend="Rcvr1_2", bw=800.0, nu0=1500.0,
+                            subtimes=np.full(nsub, 60.0), source="J1234-5678", filename="fake.fits")
+    eng = default_engine()
+    runs = []
+    for single in (True, False):
+        eng.set_option("one_exchange", 1 if single else 0)
+        eng.set_option("profile", 1); eng.kernel_times(reset=True)
+        try:
+            gt = GetTOAs(data, os.path.join(GOLDEN, "example.gmodel"), quiet=True)
+            gt.get_TOAs(quiet=True)
+            kt = eng.kernel_times(reset=True)
+        finally:
+            eng.set_option("profile", 0)
+            eng.set_option("one_exchange", 1)
+        runs.append((gt, kt))
+    (a, kta), (b, ktb) = runs
+    assert kta["xspec"][1] == 2 and kta["fit_phase_shift"][1] == 1      # pilot + the one pass; fps on the channel mean
+    assert ktb["xspec"][1] == 1 and ktb["fit_phase_shift"][1] == 1      # the fit's pass + the seed's own pass
+    ok = a.ok_isubs[0]
+    np.testing.assert_array_equal(ok, [0, 1, 3])
+    assert np.abs(_dphi_arr(np.asarray(a.phis[0])[ok], np.asarray(b.phis[0])[ok])).max() < 1e-11
+    np.testing.assert_allclose(np.asarray(a.DMs[0])[ok], np.asarray(b.DMs[0])[ok], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(np.asarray(a.phi_errs[0])[ok], np.asarray(b.phi_errs[0])[ok], rtol=1e-9)
+    np.testing.assert_allclose(np.asarray(a.red_chi2s[0])[ok], np.asarray(b.red_chi2s[0])[ok], rtol=1e-11)
+    np.testing.assert_allclose(a.scales[0][ok], b.scales[0][ok], rtol=1e-9, atol=1e-12)
+    assert np.abs(np.asarray(a.nfevals[0]) - np.asarray(b.nfevals[0])).max() <= 1
+    for isub in ok:
+        ta, tb = a.TOAs[0][isub], b.TOAs[0][isub]
+        assert abs((ta.intday() - tb.intday()) + (ta.fracday() - tb.fracday())) * 86400.0 < 1e-11 * P0
+
+
 def Dconst_():
     from pulseportraiture_amd.pplib import Dconst
     return Dconst
