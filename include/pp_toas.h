@@ -126,6 +126,10 @@ void* pp_stream(pp_ctx* ctx);
  *                  each with a truncation certificate (DESIGN.md "Scattering fits");
  *                  2 = also for method 'newton' (whose few closing iterations do not
  *                  repay the pass); 0 = every evaluation is a pass over the cross-spectrum
+ *   "fuse_scat"    1 (default) = scattering fits of 2048-bin portraits (template cut below 512
+ *                  harmonics, noise given) take the transform that stores the cross-spectrum AND
+ *                  forms the first evaluation's sums while it is in registers (one pass over the
+ *                  stored cross-spectrum fewer); 0 = the general transform + an evaluation pass
  *   "x_f32"        1 = scattering fits keep their stored cross-spectrum X_nk = d_nk m_nk* as
  *                  pairs of floats (half the bytes of every evaluation pass, all arithmetic f64;
  *                  without the closing model).  Off by default: it buys 8 % on configs[3] and

@@ -708,6 +708,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
 }  // namespace pp
 #include "pp_xspec1024.h"
 #include "pp_xspec1024q.h"
+#include "pp_xspec1024s.h"
 namespace pp {
 
 // plain rFFT of rows (parity hook): out[row][0..M] complex
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(256) void k_phase0(int nsub, int nchan, const doubl
 // k_prep; measured noise only exists after the transform) and the solver state (do_init:
 // k_init_state).
 __global__ __launch_bounds__(256) void k_setup(FitArgs a, const double* errs, const unsigned char* mask,
-                                               double* wts, double* ph0, int do_init) {
+                                               double* wts, double* ph0, double* tau0, int do_init) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)a.nsub * a.nchan) return;
     const int i = (int)(idx / a.nchan), n = (int)(idx % a.nchan);
@@ -837,6 +838,14 @@ __global__ __launch_bounds__(256) void k_setup(FitArgs a, const double* errs, co
         double p1, p2;
         phase_geom(a.freqs[(size_t)i * a.freqs_stride + n], a.P[i], a.nu_fit[i * 3], a.nu_fit[i * 3 + 1], p1, p2);
         ph0[idx] = a.x0[i * 5] + a.x0[i * 5 + 1] * p1 + a.x0[i * 5 + 2] * p2;
+    }
+    if (tau0) {
+        // tau_n at the initial parameters (scattering fits whose first evaluation rides in the transform)
+        const double tau = a.log10_tau ? pow(10.0, a.x0[i * 5 + 3]) : a.x0[i * 5 + 3];
+        ChanGeom cg;
+        chan_geom(a.freqs[(size_t)i * a.freqs_stride + n], a.P[i], a.nu_fit[i * 3], a.nu_fit[i * 3 + 1], a.nu_fit[i * 3 + 2],
+                  tau, a.x0[i * 5 + 4], a.log10_tau, tau != 0.0, cg);
+        tau0[idx] = cg.taun;
     }
     if (errs) {
         const double e = errs[idx];
@@ -1054,6 +1063,26 @@ __global__ __launch_bounds__(256) void k_accum(FitArgs a) {
 #pragma unroll
     for (int j = 0; j < PP_NACC; ++j) acc[j] = 0.0;
     const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan_x);
+    if (a.scat) {
+        // the nine sums of a scattering fit (k_xspec_qs1024): the whole chain rule of k_eval<true>
+        const double tau = a.log10_tau ? pow(10.0, st.xe[3]) : st.xe[3];
+        const double nutau = a.nu_fit[i * 3 + 2], alpha = st.xe[4];
+        for (int nn = n0 + tid; nn < n1; nn += 256) {
+            const int n = a.coff + nn * a.cstep;
+            const double w = wts[n];
+            if (w == 0.0) continue;
+            double cs[PP_NCS];
+#pragma unroll
+            for (int j = 0; j < PP_NCS; ++j) cs[j] = csum[(size_t)n * PP_NCS + j];
+            ChanGeom cg;
+            chan_geom(freqs[n], P, nuDM, nuGM, nutau, tau, alpha, a.log10_tau, tau != 0.0, cg);
+            const Local L = local_terms(cs, w);
+            double c[PP_NACC];
+            accumulate_channel(L, cg, c);
+#pragma unroll
+            for (int j = 0; j < PP_NACC; ++j) acc[j] += c[j];
+        }
+    } else
     for (int nn = n0 + tid; nn < n1; nn += 256) {
         const int n = a.coff + nn * a.cstep;
         const double w = wts[n];

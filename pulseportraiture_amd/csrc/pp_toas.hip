@@ -106,6 +106,7 @@ struct pp_ctx {
     int scat_model = 1;         // scattering fits: closing iterations on the per-channel model (pp_scatmodel.h)
     double scat_model_tol = 1e-10;
     int scat_model_bet = 1;
+    int fuse_scat = 1;          // scattering fits: first evaluation inside the transform (k_xspec_qs1024) where it applies
     int x_f32 = 0;              // 1 = scattering fits store the cross-spectrum as float pairs (measured: not worth it)
     int taylor_recentre = 1;    // one-pass flow: re-expansions about the tentative answer when the certificate fails
                                 // (0 = none; a second one rarely rescues what the first did not)
@@ -256,6 +257,7 @@ extern "C" int pp_set_option(pp_ctx* c, const char* name, double value) {
     else if (n == "scat_model_tol") c->scat_model_tol = value;
     else if (n == "scat_model_bet") c->scat_model_bet = (int)value;
     else if (n == "x_f32") c->x_f32 = (int)value;
+    else if (n == "fuse_scat") c->fuse_scat = (int)value;
     else if (n == "fps_finish") c->fps_finish = (int)value;
     else if (n == "debug_poison") c->debug_poison = (int)value;
     else if (n == "taylor_recentre") c->taylor_recentre = (int)value;
@@ -622,7 +624,12 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     const int cstep = std::max(1, c->seed_chan_stride);
     const bool pilot = seeded && taylor && c->moments_in_xspec && cstep > 1 && C / cstep >= 16;
     const bool seed_full = seeded && !pilot;
-    const bool fuse = !scat && !taylor && !seeded;   // first evaluation folded into k_xspec
+    // scattering fits of 2048-bin rows (template cut 2 Kt < M): the transform built on the
+    // one-exchange FFT stores the cross-spectrum and takes the first evaluation's nine sums
+    // while X is in registers (k_xspec_qs1024) -- one pass over the stored cross-spectrum fewer
+    const bool fuse_scat = scat && !seeded && c->max_iter > 0 && c->one_exchange && c->fuse_scat && M == 1024 &&
+                           2 * Kt < M && !(c->x_f32 > 0) && in->errs != nullptr;
+    const bool fuse = (!scat && !taylor && !seeded) || fuse_scat;   // first evaluation folded into the transform
     // k_xspec mode: 2/3 = Taylor model only, no cross-spectrum stored;
     // 2 while every thread owns single harmonics (2 Kt < M), else 3 (pairs k, M-k)
     const bool xmom = taylor && c->moments_in_xspec && !seed_full;
@@ -656,7 +663,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // floor -- while chi2 loses its 1e-10 agreement with the reference (6e-8 of every |X_nk|
     // moves f by ~1e-6 of itself; the optimum by ~1e-11 rot).  Kept for experiments.
     const bool xf32 = scat && !seeded && !smodel && c->max_iter > 0 && c->x_f32 > 0;
-    if (xmode != 0) if ((rc = c->ph0.reserve(nc * 8))) return rc;
+    if (xmode != 0 || fuse_scat) if ((rc = c->ph0.reserve(nc * 8 * (fuse_scat ? 2 : 1)))) return rc;
     if ((rc = c->misc.reserve(256))) return rc;
     if ((rc = c->act.reserve((size_t)ns * 4))) return rc;
     // per-subint scalar outputs: blocks of one allocation (params 5, errs 5, nu 3,
@@ -872,7 +879,8 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         Prof pr(c, KF_PREP);
         hipLaunchKernelGGL(k_setup, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, fa,
                            wts_early ? d_errs : (const double*)nullptr, d_mask, c->wts.as<double>(),
-                           xmode != 0 ? c->ph0.as<double>() : (double*)nullptr, seed_full ? 0 : 1);
+                           (xmode != 0 || fuse_scat) ? c->ph0.as<double>() : (double*)nullptr,
+                           fuse_scat ? c->ph0.as<double>() + nc : (double*)nullptr, seed_full ? 0 : 1);
     }
     // ---- reference-seed flow: Taylor model about the pilot's phase + the rotated channel sums in
     // one pass, then the reference's fit_phase_shift on the channel mean, then the start points
@@ -963,6 +971,25 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         if (!wts_early) if ((rc = run_prep())) return rc;
         if ((rc = run_seed(fa, nullptr))) return rc;
         hipLaunchKernelGGL(k_init_state, dim3((ns + 63) / 64), dim3(64), 0, c->stream, fa);
+    } else if (fuse_scat) {
+        const long long nrows = (long long)ns * C;
+        XspecArgs x = xa;
+        x.ticket = c->ticket.as<unsigned>();
+        x.ticket_base = c->ticket_base;
+        c->ticket_base += (unsigned)((nrows + PP_ROW_CHUNK - 1) / PP_ROW_CHUNK);
+        {
+            Prof pr(c, KF_XSPEC);
+            if (in->data_dtype == PP_F64) {
+                const dim3 grid(resident_grid(c, k_xspec_qs1024<double>, 64, nrows, fft_grid(64, nrows)));
+                hipLaunchKernelGGL((k_xspec_qs1024<double>), grid, dim3(64), 0, c->stream, x,
+                                   (const double*)(c->ph0.as<double>() + nc), c->csum.as<double>());
+            } else {
+                const dim3 grid(resident_grid(c, k_xspec_qs1024<float>, 64, nrows, fft_grid(64, nrows)));
+                hipLaunchKernelGGL((k_xspec_qs1024<float>), grid, dim3(64), 0, c->stream, x,
+                                   (const double*)(c->ph0.as<double>() + nc), c->csum.as<double>());
+            }
+        }
+        if (!wts_early) if ((rc = run_prep())) return rc;
     } else {
         if ((rc = run_xspec(xa, xmode))) return rc;
         if (!wts_early) if ((rc = run_prep())) return rc;

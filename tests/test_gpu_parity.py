@@ -1919,6 +1919,45 @@ def Dconst_():
     return Dconst
 
 
+@pytest.mark.parametrize("flags,l10", [([1, 1, 0, 1, 1], True), ([1, 1, 0, 1, 0], False), ([1, 1, 1, 1, 1], True)])
+def test_first_evaluation_of_a_scattering_fit_rides_in_the_transform(flags, l10):
+    """2048-bin scattering fits: k_xspec_qs1024 stores the cross-spectrum and takes the
+    nine sums of the first evaluation while X is in registers (option fuse_scat) -- against
+    the general transform followed by an evaluation pass: the same objective, gradient and
+    Hessian at the initial parameters, the same iterates (raw), one pass fewer."""
+    from oracle import pptoas_oracle as orc
+    nsub = 6
+    e, data, freqs, model, P, x0, errs, nu_fit, kw = _full_shape_case(64, 2048, flags, l10, nsub=nsub, tau_us=25.0,
+                                                                      gm=bool(flags[2]), seed=31)
+    e.set_option("profile", 1); e.kernel_times(reset=True)
+    a = e.fit_batch(data, freqs, P, x0, objective=True, **kw)
+    kta = e.kernel_times(reset=True)
+    e.set_option("fuse_scat", 0)
+    try:
+        b = e.fit_batch(data, freqs, P, x0, objective=True, **kw)
+    finally:
+        e.set_option("fuse_scat", 1)
+    ktb = e.kernel_times(reset=True); e.set_option("profile", 0)
+    assert kta["accum"][1] == 1 and ktb.get("accum", (0, 0))[1] == 0
+    assert kta["eval"][1] + kta["scat_model"][1] // 2 == ktb["eval"][1] + ktb["scat_model"][1] // 2 - 1
+    np.testing.assert_allclose(a["obj_f"], b["obj_f"], rtol=1e-13)
+    np.testing.assert_allclose(a["obj_grad"], b["obj_grad"], rtol=1e-9, atol=1e-6 * np.abs(b["obj_grad"]).max())
+    np.testing.assert_allclose(a["obj_hess"], b["obj_hess"], rtol=1e-9, atol=1e-9 * np.abs(b["obj_hess"]).max())
+    dph = np.abs(_dphi_arr(a["params"][:, 0], b["params"][:, 0]))
+    # (the five-parameter problem is nearly degenerate: a last-bit difference in f moves SciPy's
+    # exit point by ~1e-10 rot; the four-parameter walks are the same to rounding)
+    assert dph.max() < PHI_BAR and (flags[2] or (dph < 1e-12).mean() >= 0.6), dph
+    assert np.abs(a["params"][:, 1] - b["params"][:, 1]).max() < DM_BAR
+    np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-10)
+    assert (a["return_code"] == 2).all() and np.abs(a["nfeval"] - b["nfeval"]).max() <= 3
+    assert (a["npass"] <= b["npass"]).all()
+    # ... and against the oracle, raw, on one subint
+    o = orc.fit_portrait_full(data[0].cpu().numpy(), model, x0[0], P[0], freqs, [nu_fit] * 3, [None] * 3, errs[0],
+                              flags, log10_tau=l10)
+    assert _dphi(a["params"][0, 0], o.phi) < PHI_BAR and abs(a["params"][0, 1] - o.DM) < DM_BAR
+    np.testing.assert_allclose(a["chi2"][0], o.chi2, rtol=1e-10)
+
+
 def test_submit_and_wait_overlap_two_contexts():
     """pp_fit_submit / pp_fit_wait: a host-array batch started on one
     context runs on that context's worker thread while the calling thread fits another
