@@ -13,10 +13,6 @@
 #pragma once
 #include "pp_common.h"
 
-#ifndef PP_SB_STAGES
-#define PP_SB_STAGES 1
-#endif
-
 namespace pp {
 
 __device__ __forceinline__ void dft2(cplx& a, cplx& b) {
@@ -304,22 +300,10 @@ __device__ __forceinline__ void stage_finish(cplx (&v)[PER][R], cplx* lds, const
             // pad(ob) + j
             cplx* wbase = lds + lds_pad<PADLOG>(ob);
             constexpr int JSTEP = (S % (1 << PADLOG) == 0) ? S + (S >> PADLOG) : ((S == 1 && R == (1 << PADLOG)) ? 1 : 0);
-#ifndef PP_ABL_LDSW
-#define PP_ABL_LDSW 0     // timing experiments: 1 = no stores in the last stage, 2 = every stage's stores twice
-#endif
-            if (PP_ABL_LDSW == 1 && LAST) continue;
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 if (JSTEP) wbase[j * JSTEP] = v[i][j];
                 else lds[lds_pad<PADLOG>(ob + S * j)] = v[i][j];
-            }
-            if (PP_ABL_LDSW == 2) {
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    if (JSTEP) wbase[j * JSTEP] = v[i][j];
-                    else lds[lds_pad<PADLOG>(ob + S * j)] = v[i][j];
-                }
             }
         }
     }
@@ -428,13 +412,9 @@ __device__ __forceinline__ void fft_later_stages(cplx* lds, const RowTwiddles<M>
                                                  double* power = nullptr) {
     typedef FftPlan<M> P;
     stage_lds<M, P::T, P::R2, P::R1, P::PADLOG>(lds, tw.t2, tid, power);
-#if PP_SB_STAGES
     __builtin_amdgcn_sched_barrier(0);
-#endif
     if constexpr (P::R3 > 1) stage_lds<M, P::T, P::R3, P::R1 * P::R2, P::PADLOG>(lds, tw.t3, tid, power);
-#if PP_SB_STAGES
     __builtin_amdgcn_sched_barrier(0);
-#endif
     if constexpr (P::R4 > 1) stage_lds<M, P::T, P::R4, P::R1 * P::R2 * P::R3, P::PADLOG>(lds, tw.t3, tid, power);
 }
 

@@ -262,22 +262,6 @@ struct RowWalk {
 #ifndef PP_SPLIT_U
 #define PP_SPLIT_U 4          // harmonics per thread processed together in the split loop
 #endif
-#ifndef PP_SD_FUSED
-#define PP_SD_FUSED 1         // S_d from the last stage's registers (else an LDS pass)
-#endif
-#ifndef PP_XSPEC_ABLATE
-#define PP_XSPEC_ABLATE 0     // timing-only builds: 1 = loads only, 2 = + stage 1, 3 = + all stages
-#endif
-// scheduling fences around the prefetch / after the FFT (experiments: no effect either way)
-#ifndef PP_SB_PREFETCH
-#define PP_SB_PREFETCH 1
-#endif
-#ifndef PP_SB_LATE
-#define PP_SB_LATE 1
-#endif
-#ifndef PP_PREFETCH_MID
-#define PP_PREFETCH_MID 1       // next row's loads queued inside the first stage (0: after it)
-#endif
 #ifndef PP_OPAQUE_ROW
 #define PP_OPAQUE_ROW 2         // 0 never, 1 always, 2 only in MODE 2 (register-bound)
 #endif
@@ -288,23 +272,8 @@ struct RowWalk {
 // MODE 2 requires 2 Kt < M (each thread then owns harmonics k only); MODE 3 is
 // the same for any Kt <= M: harmonic M-k is formed with k from the same two
 // transform outputs.
-#ifndef PP_XSPEC_STAMPS
-#define PP_XSPEC_STAMPS 0     // diagnostic builds: per-workgroup wall / shader clocks and placement
-#endif
-#if PP_XSPEC_STAMPS
-__device__ unsigned long long g_xspec_stamps[8192 * 6];
-#endif
 template <int M, typename Tin, bool TAIL, int MODE>
 __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void k_xspec(XspecArgs a) {
-#if PP_XSPEC_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x < 8192) {
-        unsigned long long* st = g_xspec_stamps + 6 * blockIdx.x;
-        st[0] = __builtin_amdgcn_s_memrealtime();
-        st[2] = __builtin_amdgcn_s_memtime();
-        st[4] = __builtin_amdgcn_s_getreg((3 << 11) | 20);        // XCC_ID
-        st[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID
-    }
-#endif
     constexpr bool FUSE = (MODE != 0);
     constexpr bool M2 = (MODE == 2 || MODE == 3), PAIR = (MODE == 3);
     constexpr int T = FftPlan<M>::T, R1 = FftPlan<M>::R1, PER1 = FftPlan<M>::PER1;
@@ -408,64 +377,23 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             // every use of an earlier load, because on the path without it no younger
             // loads exist)
             auto prefetch = [&]() {
-#if PP_SB_PREFETCH
                 __builtin_amdgcn_sched_barrier(0);
-#endif
                 rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base);
                 const size_t rn = rw.more_nx
                     ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
                 stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);
-#if PP_SB_PREFETCH
                 __builtin_amdgcn_sched_barrier(0);
-#endif
             };
-#if PP_XSPEC_ABLATE == 1
-            double keep = 0.0;
-#pragma unroll
-            for (int ii = 0; ii < PER1; ++ii)
-#pragma unroll
-                for (int k = 0; k < R1; ++k) keep += v[ii][k].x * v[ii][k].y;
-            if (keep == 1.2345e300) a.sdraw[0] = keep;
-            prefetch();
-#else
-#if PP_PREFETCH_MID
             fft_first_stage<M, M2>(lds, v, tw, tid, prefetch);
-#else
-            fft_first_stage<M, M2>(lds, v, tw, tid);
-            prefetch();
-#endif
-#endif
         }
-#if PP_XSPEC_ABLATE == 1 || PP_XSPEC_ABLATE == 2
-        lds_sync<T>();
-        continue;
-#endif
         // ---- S_d comes out of the last stage's registers ----
         double sd = 0.0, tail = 0.0;
-#if PP_SD_FUSED
         fft_later_stages<M>(lds, tw, tid, &sd);
-#else
-        fft_later_stages<M>(lds, tw, tid);
-        for (int k = tid; k < M; k += T) {
-            const cplx z = lds[lds_pad<PL>(k)];
-            if (k == 0) { const double dM = z.x - z.y; sd += dM * dM; }
-            else sd += cnorm(z);
-        }
-#endif
-#if PP_SB_LATE
         __builtin_amdgcn_sched_barrier(0);
-#endif
         if (TAIL) {
             for (int k = kc + tid; k <= M; k += T) tail += cnorm(rfft_harmonic<M>(lds, a.twB, k));
         }
-#if PP_XSPEC_ABLATE == 3
-        if (tid == 0) a.sdraw[rc] = sd;
-        lds_sync<T>();
-        continue;
-#endif
-#if PP_SB_LATE
         __builtin_amdgcn_sched_barrier(0);
-#endif
         // ---- cross-spectrum (and the first evaluation's sums) ----
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         cplx e = make_double2(1.0, 0.0), wst = make_double2(1.0, 0.0);
@@ -696,13 +624,6 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         }
         lds_sync<T>();
     }
-#if PP_XSPEC_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x < 8192) {
-        unsigned long long* st = g_xspec_stamps + 6 * blockIdx.x;
-        st[1] = __builtin_amdgcn_s_memrealtime();
-        st[3] = __builtin_amdgcn_s_memtime();
-    }
-#endif
 }
 
 }  // namespace pp

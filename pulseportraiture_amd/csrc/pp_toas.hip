@@ -1261,12 +1261,3 @@ extern "C" int pp_fit_wait(pp_ctx* c) {
 }
 
 #include "pp_extra_api.h"
-
-#if PP_XSPEC_STAMPS
-// diagnostic builds only: the stamps of the last k_xspec launch (6 words per workgroup)
-extern "C" int pp_debug_xspec_stamps(unsigned long long* out, int nwg) {
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp::g_xspec_stamps), sizeof(unsigned long long) * 6 * (size_t)nwg)
-               == hipSuccess ? 0 : -1;
-}
-#endif

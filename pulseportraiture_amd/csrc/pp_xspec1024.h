@@ -47,9 +47,6 @@ __device__ __forceinline__ cplx w128(int j) {
     }
 }
 
-#ifndef PP_SB_SLOTS
-#define PP_SB_SLOTS 1
-#endif
 template <typename Tin, bool TAIL, int MODE>
 __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
     constexpr int M = 1024, T = 64;
@@ -122,22 +119,16 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
                 for (int k = 0; k < R1; ++k) v[ii][k] = to_cplx(cur[ii][k]);
             fft_first_stage<M, true>(lds, v, tw, tid);
         }
-#if PP_SB_PREFETCH
         __builtin_amdgcn_sched_barrier(0);
-#endif
         {
             rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base);
             const size_t rn = rw.more_nx ? (size_t)i_nx * a.nchan + n_nx : rc;
             stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);
         }
-#if PP_SB_PREFETCH
         __builtin_amdgcn_sched_barrier(0);
-#endif
         // ---- stage 2 through LDS, stage 3 in registers ----
         stage_lds<M, T, P::R2, P::R1, PL>(lds, tw.t2, tid);
-#if PP_SB_STAGES
         __builtin_amdgcn_sched_barrier(0);
-#endif
         cplx va[8], vb[8];
         {
             constexpr int KSTEP = 128 + (128 >> PL);
@@ -158,9 +149,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) sd += cnorm(vb[j]);
         }
-#if PP_SB_LATE
         __builtin_amdgcn_sched_barrier(0);
-#endif
         const cplx wB = csel(l0, make_double2(0.98078528040323044913, -0.19509032201612826785),
                              cmulc(w128(1), wA));
         // 2 d_k = E - i W^k O,  E, O = Z_k +- conj Z_{M-k}
@@ -242,11 +231,9 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
                 consume(x, eB, tb + 128 * j);
             }
             if (FUSE && j + 1 < NS) { eA = cmul(eA, e128); eB = cmul(eB, e128); }
-#if PP_SB_SLOTS
             // keep the slots apart: interleaving them for ILP costs more registers
             // than the file has left here
             __builtin_amdgcn_sched_barrier(0);
-#endif
         }
         sd = group_sum<64>(sd);
         if (TAIL) tail = group_sum<64>(tail);

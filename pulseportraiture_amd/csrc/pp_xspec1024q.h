@@ -24,21 +24,12 @@
 
 namespace pp {
 
-#ifndef PP_Q_ABLATE
-#define PP_Q_ABLATE 0      // timing experiments: 1 = no row loads, 2 = row loads only
-#endif
-#ifndef PP_Q_SPLIT_PREFETCH
-#define PP_Q_SPLIT_PREFETCH 1    // f64 rows: the next row is fetched in two halves
-#endif
-#ifndef PP_Q_TW_RELOAD
-#define PP_Q_TW_RELOAD 1       // f64 rows only
-#endif
-#ifndef PP_Q_PREFETCH_F64
-#define PP_Q_PREFETCH_F64 1     // where the next row's loads are queued (fftq1024's WHEN)
-#endif
-#ifndef PP_Q_PREFETCH_F32
-#define PP_Q_PREFETCH_F32 0
-#endif
+// Where the next row's loads are queued (measured choices, profiles/README.md): f64 rows in two
+// halves -- eight registers' worth after the stage-1 twiddles (fftq1024's WHEN = 1), the rest
+// behind the partner exchange -- and with the stage twiddles re-read per row; f32 rows whole, a
+// quarter into stage 1 (WHEN = 0), twiddles held.
+constexpr bool Q_SPLIT_PREFETCH = true, Q_TW_RELOAD = true;
+constexpr int Q_PREFETCH_F64 = 1, Q_PREFETCH_F32 = 0;
 // TAIL: also measure the noise from the top quarter of the power spectrum (errs == NULL,
 // get_noise_PS): harmonics 768..1023 are this lane's registers 12..15 against the
 // partner's registers 3..0 (five more registers published, four more read back), the
@@ -63,7 +54,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
     // template values spill to scratch, and a scratch reload queues BEHIND the prefetched
     // row (vector memory returns in order) -- the split then waits for the next row's HBM
     // data (15.1 -> 14.1 ms per 1024 fits)
-    constexpr bool TWR = PP_Q_TW_RELOAD && sizeof(Tin) == 8;
+    constexpr bool TWR = Q_TW_RELOAD && sizeof(Tin) == 8;
     cplx t1 = a.twB[2 * tid], t2 = a.twB[32 * (tid & 15)];
     // this lane's harmonics k = kb + 64 j; split twiddle W_B^kb, stepped by W_B^64
     const int lam0 = fftq_lambda(tid);
@@ -121,7 +112,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
         // rest once the second half of this row's outputs has been published: with the
         // whole next row in flight from the start, 64 + 64 row registers on top of the
         // template row and the sums do not fit the 256 of two waves per SIMD
-        constexpr bool HALVES = PP_Q_SPLIT_PREFETCH && sizeof(Tin) == 8;
+        constexpr bool HALVES = Q_SPLIT_PREFETCH && sizeof(Tin) == 8;
         const Tin* nxrow = nullptr;
         auto load_some = [&](int k0, int k1) {
             const char* gb = reinterpret_cast<const char*>(nxrow);
@@ -137,28 +128,10 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
             const size_t rn = rw.more_nx
                 ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
             nxrow = reinterpret_cast<const Tin*>(a.data) + rn * (2 * M);
-#if PP_Q_ABLATE == 1
-            // timing experiment: no HBM traffic, the same row again (made opaque)
-#pragma unroll
-            for (int k = 0; k < R1; ++k) asm volatile("" : "+v"(cur[0][k].x), "+v"(cur[0][k].y));
-            if (rn == 0x7fffffffffffull) a.sdraw[0] = 0.0;
-#else
             load_some(0, HALVES ? R1 / 2 : R1);
-#endif
             __builtin_amdgcn_sched_barrier(0);
         };
-#if PP_Q_ABLATE == 2
-        // timing experiment: the loads and nothing else
-        {
-            double keep = 0.0;
-#pragma unroll
-            for (int k = 0; k < R1; ++k) keep += v[k].x * v[k].y;
-            if (keep == 1.2345e300) a.sdraw[0] = keep;
-            prefetch();
-            continue;
-        }
-#endif
-        fftq1024<(sizeof(Tin) == 8 ? PP_Q_PREFETCH_F64 : PP_Q_PREFETCH_F32)>(v, lds, t1, t2, tid, &sd, prefetch);
+        fftq1024<(sizeof(Tin) == 8 ? Q_PREFETCH_F64 : Q_PREFETCH_F32)>(v, lds, t1, t2, tid, &sd, prefetch);
         __builtin_amdgcn_sched_barrier(0);
         // ---- partners through LDS: registers 9..15 out, seven values back ----
         {
@@ -195,13 +168,11 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
             tail *= 0.25;
             if (tid == 0) { const double dM = v[0].x - v[0].y; tail += dM * dM; }
         }
-#if PP_Q_ABLATE != 1
         if (HALVES) {
             __builtin_amdgcn_sched_barrier(0);
             load_some(R1 / 2, R1);
             __builtin_amdgcn_sched_barrier(0);
         }
-#endif
         const cplx* pc = lds + fftq_lane_of((64 - lam) & 63);   // slot j: register 15 - j -> pc[64 (6 - j)]
         // ---- phasors: e^{2 pi i kb phi}; lane 0 (kb = 64) holds the step ----
         const cplx el = unit_phasor<true>((double)kb, phin);

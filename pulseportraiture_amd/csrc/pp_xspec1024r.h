@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
             load_some(0, HALVES ? R1 / 2 : R1);
             __builtin_amdgcn_sched_barrier(0);
         };
-        fftq1024<(sizeof(Tin) == 8 ? PP_Q_PREFETCH_F64 : PP_Q_PREFETCH_F32)>(v, lds, t1, t2, tid, &sd, prefetch);
+        fftq1024<(sizeof(Tin) == 8 ? Q_PREFETCH_F64 : Q_PREFETCH_F32)>(v, lds, t1, t2, tid, &sd, prefetch);
         __builtin_amdgcn_sched_barrier(0);
         // this row's template values: read now (L2), behind the first half of the prefetch --
         // which has had the whole transform to arrive -- and in front of the second half

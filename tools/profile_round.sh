@@ -21,8 +21,11 @@ W4="--workload cfg4-2048x2048-scat"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/trace_cfg4 -- $B $W4 --steps 3 --warmup 1 > $O/raw/bench_cfg4_under_rocprof.json 2> $O/raw/trace4.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_fetch_cfg4 -- $B $W4 --steps 1 --warmup 0 > /dev/null 2> $O/raw/fetch4.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_write_cfg4 -- $B $W4 --steps 1 --warmup 0 > /dev/null 2> $O/raw/write4.err
-# the seeded (get_TOAs) flow
+# the seeded (get_TOAs) flows: the device seed, and the reference's own guess formed inside the single pass
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/trace_seeded -- $B --seed-ns 100 --steps 3 --warmup 1 > $O/raw/bench_seeded_under_rocprof.json 2> $O/raw/trace_s.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/trace_refseed -- $B --seed-ns -1 --steps 3 --warmup 1 > $O/raw/bench_refseed_under_rocprof.json 2> $O/raw/trace_r.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_fetch_refseed -- $B --seed-ns -1 --steps 1 --warmup 0 > /dev/null 2> $O/raw/fetch_r.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_write_refseed -- $B --seed-ns -1 --steps 1 --warmup 0 > /dev/null 2> $O/raw/write_r.err
 python3 - $O $R <<'PY'
 import csv, glob, json, sys, collections, os
 O, R = sys.argv[1], sys.argv[2]
@@ -81,7 +84,7 @@ if fb > 0:
 def first(pat):
     fs = glob.glob(pat)
     return fs[0] if fs else None
-for tag in ("cfg4", "seeded"):
+for tag in ("cfg4", "seeded", "refseed"):
     f = first(f"{O}/raw/trace_{tag}/*/*_kernel_stats.csv")
     if f:
         open(f"{O}/{R}_{tag}_kernel_stats.csv", "w").write(open(f).read())
@@ -92,7 +95,7 @@ if f4:
         n4 = b4["config"]["nsub_per_gpu_per_step"]
         alg = b4["roofline"]["algorithmic_bytes_per_fit"]
         rows = {}
-        for kn in ("k_eval", "k_xspec", "k_scat_model(", "k_scat_model_solve", "k_step", "k_finalize"):
+        for kn in ("k_eval", "k_xspec", "k_accum", "k_scat_model(", "k_scat_model_solve", "k_step", "k_finalize"):
             fb = sum(v["sum_KiB"] for k, v in f4.items() if kn in k) * 2048
             wb = sum(v["sum_KiB"] for k, v in w4.items() if kn in k) * 1024
             nd = sum(v["dispatches"] for k, v in f4.items() if kn in k)
@@ -106,8 +109,35 @@ if f4:
                   open(f"{O}/{R}_cfg4_traffic.json", "w"), indent=1)
     except Exception as ex:
         print("cfg4 traffic summary failed:", ex)
+# the reference-seed flow: traffic of its one pass (and of everything else in the step)
+fr, wr = counters("pmc_fetch_refseed", "FETCH_SIZE"), counters("pmc_write_refseed", "WRITE_SIZE")
+if fr:
+    try:
+        br = json.loads(open(f"{O}/raw/bench_refseed_under_rocprof.json").read().strip().splitlines()[-1])
+        nr = br["config"]["nsub_per_gpu_per_step"]
+        rows = {}
+        for k in sorted(set(fr) | set(wr)):
+            # (not the untimed batch generation: k_synth, the template, the generation's own guesses)
+            if any(x in k for x in ("k_synth", "k_model_", "k_rot_mean", "vectorized_elementwise")):
+                continue
+            fb = fr.get(k, {"sum_KiB": 0.0})["sum_KiB"] * 2048
+            wb = wr.get(k, {"sum_KiB": 0.0})["sum_KiB"] * 1024
+            nd = fr.get(k, wr.get(k))["dispatches"]
+            if ("k_fps" in k or "k_rfft_rows" in k) and nd == 2:    # (one of the two belongs to the generation)
+                fb, wb, nd = fb / 2, wb / 2, 1
+            if fb + wb > 1e6 * nr * 0.01:
+                rows[k[:60]] = {"hbm_bytes_per_fit": (fb + wb) / nr, "dispatches": nd}
+        tot = sum(r["hbm_bytes_per_fit"] for r in rows.values())
+        alg = br["roofline"]["algorithmic_bytes_per_fit"]
+        json.dump({"workload": br["config"]["workload"], "phase_guesses": br["config"]["phase_guesses"], "nsub": nr,
+                   "fits_per_s_under_profiler": br["value"], "algorithmic_bytes_per_fit": alg,
+                   "hbm_bytes_per_fit_all_kernels": tot, "traffic_over_algorithmic": tot / alg, "kernels": rows,
+                   "note": "FETCH_SIZE x2 + WRITE_SIZE of one step (separate --pmc passes)"},
+                  open(f"{O}/{R}_refseed_traffic.json", "w"), indent=1)
+    except Exception as ex:
+        print("refseed traffic summary failed:", ex)
 PY
 ls -la $O
 # shader clock under the transform kernels (power cap) and the one-exchange kernel against the general one
-./tools/run_clock_probe.sh "--opt one_exchange=0" "--opt one_exchange=1" "--input-dtype f32 --opt one_exchange=0" "--input-dtype f32 --opt one_exchange=1" > $O/${R}_clock_probe.txt 2>&1
+./tools/run_clock_probe.sh "--opt one_exchange=0" "--opt one_exchange=1" "--input-dtype f32 --opt one_exchange=1" "--seed-ns -1" "--seed-ns -1 --input-dtype f32" > $O/${R}_clock_probe.txt 2>&1
 ./tools/run_ab_option.sh one_exchange > $O/${R}_one_exchange_ab.txt 2>&1
