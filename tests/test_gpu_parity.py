@@ -1859,6 +1859,49 @@ def test_reference_seed_formed_inside_the_single_pass(dtype, flags):
         e.fit_batch(data, freqs, P, xb, ref_seed=rs, **dict(kw, fit_flags=[1, 1, 0, 1, 1], log10_tau=True))
 
 
+@pytest.mark.parametrize("case", ["GM", "poor_dm"])
+def test_reference_seed_single_pass_off_the_easy_path(case):
+    """pp_seed_ref where the walk is longer than the model about the pilot's phase carries:
+    'GM' -- phase + DM + GM fitted from a GM guess of 0 (SciPy's path for a GM fit depends on
+    where it starts: the off-centre start must be the reference's guess exactly); 'poor_dm' --
+    header DMs 4e-3 pc cm^-3 off, so the certificate fails and the subints are expanded again
+    about the reference's guess itself, then (still too far) handed to evaluations over the
+    cross-spectrum.  Either way: the two-pass route's answers."""
+    from pulseportraiture_amd.pplib import phase_transform
+    C, B, nsub = 256, 2048, 8
+    gm = (case == "GM")
+    flags = [1, 1, 1, 0, 0] if gm else [1, 1, 0, 0, 0]
+    e, data, freqs, model, P, x0, errs, nu_fit, kw = _full_shape_case(C, B, flags, False, nsub=nsub, gm=gm, seed=41)
+    if not gm:
+        x0 = x0.copy(); x0[:, 1] += 4e-3
+    w = np.ones((nsub, C))
+    nu_mean = np.full(nsub, freqs.mean())
+    mprof = model.mean(axis=0)
+    g2 = np.empty(nsub)
+    for i in range(nsub):
+        out = e.reference_phase_seed(data[i:i + 1], freqs, P[i:i + 1], w[i:i + 1], mprof[None],
+                                     phi=-Dconst_() * x0[i, 1] / P[i] * nu_mean[i] ** -2.0, DM=x0[i:i + 1, 1],
+                                     nu_DM=np.inf, Ns=100, finish='simplex')
+        g2[i] = phase_transform(out[0, 0], x0[i, 1], nu_mean[i], nu_fit, P[i], mod=True)
+    xa = x0.copy(); xa[:, 0] = g2
+    # (phases compared at the fit's own reference frequency: the zero-covariance frequency of a GM
+    # fit is itself only good to ~1e-8 and moves phi(nu_out) by more than the raw agreement)
+    kw = dict(kw, nu_outs=np.full((nsub, 3), nu_fit))
+    two = e.fit_batch(data, freqs, P, xa, **kw)
+    one = e.fit_batch(data, freqs, P, x0, ref_seed=dict(weights=w, model_profs=mprof, nu_mean=nu_mean), **kw)
+    assert np.abs(_dphi_arr(one["seed_phase"], g2)).max() < 1e-12
+    dph = np.abs(_dphi_arr(one["params"][:, 0], two["params"][:, 0]))
+    assert dph.max() < PHI_BAR and np.median(dph) < 1e-11, dph
+    assert np.abs(one["params"][:, 1] - two["params"][:, 1]).max() < DM_BAR
+    np.testing.assert_allclose(one["chi2"], two["chi2"], rtol=1e-10)
+    assert (one["return_code"] == 2).all()
+    if gm:
+        np.testing.assert_allclose(one["params"][:, 2], two["params"][:, 2], rtol=0, atol=1e-8)
+        assert (one["npass"] == 1).all()
+    else:
+        assert (one["npass"] >= 2).all() and (two["npass"] >= 2).all()      # (the model alone did not carry these)
+
+
 def test_get_TOAs_default_flow_reads_the_portraits_once_at_2048_bins():
     """Caller level: GetTOAs.get_TOAs (seed='reference', the default) on an archive of
     2048-bin, 256-channel subints takes the single-pass path (pilot + ONE transform over
