@@ -486,6 +486,8 @@ def main():
         plan = [("seeded", args.workload, args.input_dtype, 100, None),
                 ("reference_seed_in_step", args.workload, args.input_dtype, -1, None),
                 ("f32", args.workload, "f32", 0, None),
+                # a template that keeps every harmonic (data-derived spline / PCA templates do: harm_eps = 0)
+                ("full_spectrum_template", args.workload, "f64", 0, "full"),
                 ("cfg2-512x1024-phiDM", "cfg2-512x1024-phiDM", "f64", 0, None),
                 ("cfg3-4096x2048-phiDMGM", "cfg3-4096x2048-phiDMGM", "f64", 0, None),
                 ("cfg4-2048x2048-scat", "cfg4-2048x2048-scat", "f64", 0, None),
@@ -493,6 +495,12 @@ def main():
         for key, wl, dt, sns, meth in plan:
             if wl == args.workload and dt == args.input_dtype and sns == args.seed_ns and meth is None:
                 continue
+            full = (meth == "full")
+            if full:
+                meth = None
+                if args.harm_eps is not None:
+                    continue
+                eng.set_option("harm_eps", 0.0)
             try:
                 b = Batch(eng, args, device, wl, 0, dt, 0, seed_ns=max(sns, 0), reseed=(sns < 0))
                 if sns < 0:
@@ -506,10 +514,15 @@ def main():
                 # recovered values against the injected ones, in units of the errors
                 sm["max_abs_dDM_over_err"] = float(np.max(np.abs(r["params"][:, 1] - b.inj[:, 1]) /
                                                           r["param_errs"][:, 1]))
+                if full:
+                    sm["model_harmonics_kept"] = b.nharm
                 others[key] = sm
                 b.free()
             except Exception as exc:      # a secondary workload must not lose the headline
                 others[key] = {"error": repr(exc)}
+            finally:
+                if full:
+                    eng.set_option("harm_eps", 2.0 ** -50)
         # configs[4]'s flow (contiguous shard, device-generated sub-batches, ragged last one, one
         # gather) at a size one GPU finishes in seconds
         try:
