@@ -491,7 +491,8 @@ def main():
                 ("cfg2-512x1024-phiDM", "cfg2-512x1024-phiDM", "f64", 0, None),
                 ("cfg3-4096x2048-phiDMGM", "cfg3-4096x2048-phiDMGM", "f64", 0, None),
                 ("cfg4-2048x2048-scat", "cfg4-2048x2048-scat", "f64", 0, None),
-                ("cfg4-2048x2048-scat-newton", "cfg4-2048x2048-scat", "f64", 0, "newton")]
+                ("cfg4-2048x2048-scat-newton", "cfg4-2048x2048-scat", "f64", 0, "newton"),
+                ("cfg4_reference_seed_in_step", "cfg4-2048x2048-scat", "f64", -1, None)]
         for key, wl, dt, sns, meth in plan:
             if wl == args.workload and dt == args.input_dtype and sns == args.seed_ns and meth is None:
                 continue
@@ -516,6 +517,8 @@ def main():
                                                           r["param_errs"][:, 1]))
                 if full:
                     sm["model_harmonics_kept"] = b.nharm
+                if sns < 0:
+                    sm["single_pass"] = not b.fused_unavailable
                 others[key] = sm
                 b.free()
             except Exception as exc:      # a secondary workload must not lose the headline

@@ -216,9 +216,12 @@ int pp_model_apply_response(pp_ctx* ctx, int slot, const double* rconst,
  * and the fit then starts from there (init_params[.][0] as given is ignored).  The transform
  * kernel takes the per-channel Taylor model about a provisional phase (a pilot pass over every
  * 16th channel) together with the rotated channel sums; the iteration starts off-centre, at the
- * reference's guess.  Available for 2048-bin portraits fitted without scattering whose template
- * keeps fewer than 512 harmonics, nchan a multiple of 32 and >= 256, errs given, GM guesses 0:
- * otherwise pp_fit_portrait_batch returns PP_ENOTSUP and nothing has been done. */
+ * reference's guess.  A scattering fit iterates over the stored cross-spectrum instead: the
+ * transform that stores it takes the rotated channel sums as well (rotation by the DM guess
+ * alone, no pilot) and the iteration starts AT the reference's guess.  Available for 2048-bin
+ * portraits whose template keeps fewer than 512 harmonics, nchan a multiple of 32 (and >= 256
+ * without scattering), errs given, GM guesses 0: otherwise pp_fit_portrait_batch returns
+ * PP_ENOTSUP and nothing has been done. */
 typedef struct {
     const double* weights;       /* [nsub][nchan] weights of the channel mean (0 = channel not used);
                                     host, or device when pp_fit_in.aux_on_device; NULL = all 1 */

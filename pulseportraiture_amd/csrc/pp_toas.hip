@@ -595,7 +595,11 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         double* h = reinterpret_cast<double*>(c->in_host);
         memcpy(h, in->freqs + (in->freqs_stride ? (size_t)s0 * C : 0), nfreq * 8); h += nfreq;
         memcpy(h, in->P + s0, (size_t)ns * 8); h += ns;
-        memcpy(h, in->init_params + (size_t)s0 * 5, (size_t)ns * 40); h += (size_t)ns * 5;
+        memcpy(h, in->init_params + (size_t)s0 * 5, (size_t)ns * 40);
+        // (reference seed of a scattering fit: the pass rotates by the DM guess alone -- phase 0 --
+        // and the phases the reference's guess gives are written before the state is set)
+        if (refseed && scat) for (int i = 0; i < ns; ++i) h[(size_t)i * 5] = 0.0;
+        h += (size_t)ns * 5;
         memcpy(h, nufit_h.data() + (size_t)s0 * 3, (size_t)ns * 24); h += (size_t)ns * 3;
         memcpy(h, nuout_h.data() + (size_t)s0 * 3, (size_t)ns * 24); h += (size_t)ns * 3;
         if (in->model_slot) memcpy(h, in->model_slot + s0, (size_t)ns * 4);
@@ -663,7 +667,8 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // floor -- while chi2 loses its 1e-10 agreement with the reference (6e-8 of every |X_nk|
     // moves f by ~1e-6 of itself; the optimum by ~1e-11 rot).  Kept for experiments.
     const bool xf32 = scat && !seeded && !smodel && c->max_iter > 0 && c->x_f32 > 0;
-    if (xmode != 0 || fuse_scat) if ((rc = c->ph0.reserve(nc * 8 * (fuse_scat ? 2 : 1)))) return rc;
+    const bool want_ph0 = xmode != 0 || fuse_scat || refseed;
+    if (want_ph0) if ((rc = c->ph0.reserve(nc * 8 * (fuse_scat ? 2 : 1)))) return rc;
     if ((rc = c->misc.reserve(256))) return rc;
     if ((rc = c->act.reserve((size_t)ns * 4))) return rc;
     // per-subint scalar outputs: blocks of one allocation (params 5, errs 5, nu 3,
@@ -697,7 +702,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         if (pz & 4) HIP_TRY(hipMemsetAsync(c->noise.p, 0xFF, nc * 8, c->stream));
         if (pz & 8) HIP_TRY(hipMemsetAsync(c->wts.p, 0xFF, nc * 8, c->stream));
         if (pz & 16) HIP_TRY(hipMemsetAsync(c->csum.p, 0xFF, 2 * nc * ncs * 8, c->stream));
-        if ((pz & 32) && xmode != 0) HIP_TRY(hipMemsetAsync(c->ph0.p, 0xFF, nc * 8, c->stream));
+        if ((pz & 32) && want_ph0) HIP_TRY(hipMemsetAsync(c->ph0.p, 0xFF, nc * 8, c->stream));
         if ((pz & 64) && xstore) HIP_TRY(hipMemsetAsync(c->X.p, 0xFF, nc * Kt * sizeof(cplx), c->stream));
         if ((pz & 128) && smodel) HIP_TRY(hipMemsetAsync(c->mdl.p, 0xFF, nc * PP_MROW * 8, c->stream));
     }
@@ -879,7 +884,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         Prof pr(c, KF_PREP);
         hipLaunchKernelGGL(k_setup, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, fa,
                            wts_early ? d_errs : (const double*)nullptr, d_mask, c->wts.as<double>(),
-                           (xmode != 0 || fuse_scat) ? c->ph0.as<double>() : (double*)nullptr,
+                           want_ph0 ? c->ph0.as<double>() : (double*)nullptr,
                            fuse_scat ? c->ph0.as<double>() + nc : (double*)nullptr, seed_full ? 0 : 1);
     }
     // ---- reference-seed flow: Taylor model about the pilot's phase + the rotated channel sums in
@@ -920,13 +925,14 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         RefSeedArgs ra{d_w, part, ncc};
         {
             Prof pr(c, KF_XSPEC);
-            if (in->data_dtype == PP_F64) {
-                const dim3 grid(resident_grid(c, k_xspec_qr1024<double>, 64, nrows, fft_grid(64, nrows)));
-                hipLaunchKernelGGL((k_xspec_qr1024<double>), grid, dim3(64), 0, c->stream, x, ra);
-            } else {
-                const dim3 grid(resident_grid(c, k_xspec_qr1024<float>, 64, nrows, fft_grid(64, nrows)));
-                hipLaunchKernelGGL((k_xspec_qr1024<float>), grid, dim3(64), 0, c->stream, x, ra);
-            }
+#define PP_QR(TIN, ST)                                                                                     \
+    do {                                                                                                   \
+        const dim3 grid(resident_grid(c, k_xspec_qr1024<TIN, ST>, 64, nrows, fft_grid(64, nrows)));        \
+        hipLaunchKernelGGL((k_xspec_qr1024<TIN, ST>), grid, dim3(64), 0, c->stream, x, ra);               \
+    } while (0)
+            if (in->data_dtype == PP_F64) { if (scat) PP_QR(double, true); else PP_QR(double, false); }
+            else { if (scat) PP_QR(float, true); else PP_QR(float, false); }
+#undef PP_QR
         }
         HIP_TRY(hipGetLastError());
         {
@@ -959,7 +965,12 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         }
         HIP_TRY(hipMemcpyAsync(d_xs, xs.data(), xs.size() * 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));      // (xs is a local)
-        fa.xstart = d_xs;
+        if (scat) {
+            // stored cross-spectrum: the iteration starts AT the reference's guess
+            HIP_TRY(hipMemcpyAsync(d_x0, d_xs, (size_t)ns * 40, hipMemcpyDeviceToDevice, c->stream));
+            hipLaunchKernelGGL(k_init_state, dim3((ns + 63) / 64), dim3(64), 0, c->stream, fa);
+            HIP_TRY(hipGetLastError());
+        } else fa.xstart = d_xs;       // Taylor model about the pilot's phase: the walk starts off-centre
         return PP_OK;
     };
     if (refseed) {
@@ -1154,15 +1165,17 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
     if (in->ref_seed) {
         const pp_seed_ref* rs = in->ref_seed;
         const int cstep = std::max(1, c->seed_chan_stride);
-        bool ok = !scat && c->max_iter > 0 && c->use_taylor && c->moments_in_xspec && c->one_exchange &&
-                  B == 2048 && 2 * Kt < B / 2 && C % PP_ROW_CHUNK == 0 && cstep > 1 && C / cstep >= 16 &&
+        // (no scattering: Taylor model about the pilot seed's phase; scattering: cross-spectrum stored)
+        const bool path = scat ? true : (c->use_taylor && c->moments_in_xspec && cstep > 1 && C / cstep >= 16);
+        bool ok = path && c->max_iter > 0 && c->one_exchange &&
+                  B == 2048 && 2 * Kt < B / 2 && C % PP_ROW_CHUNK == 0 &&
                   in->errs && in->seed_ns == 0 && rs->model_profs && rs->nu_mean && rs->Ns >= 1 &&
                   (rs->model_prof_stride == 0 || rs->model_prof_stride == B);
         for (int i = 0; ok && i < N; ++i) ok = (in->init_params[(size_t)i * 5 + 2] == 0.0);
         if (!ok)
-            return fail(PP_ENOTSUP, "ref_seed: no single-pass path for this batch (needs 2048-bin portraits, no "
-                                    "scattering, a template that keeps < 512 harmonics, nchan a multiple of %d and >= %d, "
-                                    "errs given, GM guesses 0)", PP_ROW_CHUNK, 16 * cstep);
+            return fail(PP_ENOTSUP, "ref_seed: no single-pass path for this batch (needs 2048-bin portraits, "
+                                    "a template that keeps < 512 harmonics, nchan a multiple of %d (and >= %d without "
+                                    "scattering), errs given, GM guesses 0)", PP_ROW_CHUNK, 16 * cstep);
     }
     // default reference frequencies: mean of the (unmasked) channel frequencies
     std::vector<double> nufit((size_t)N * 3), nuout((size_t)N * 3);

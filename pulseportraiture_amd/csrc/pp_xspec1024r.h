@@ -44,7 +44,11 @@ constexpr int RS_NREG = 11;     // ... of which in registers; the Nyquist term (
 constexpr int RS_NYQ = FFTQ_LDS_ELEMS - 1;    // ... in the one element of the transpose image no lane touches
                                               // (highest index used: 3 * 272 + 17 * 15 + 15 = 1086)
 
-template <typename Tin>
+// STORE (scattering fits): no Taylor model -- the evaluation loop iterates over the stored
+// cross-spectrum, so X_nk of the kept harmonics is stored instead (as k_xspec's MODE 0); the
+// phase a.ph0 then holds is the rotation alone (phase guess 0: the pass needs no centre, hence
+// no pilot) and the iteration starts at the reference's guess with an ordinary first evaluation.
+template <typename Tin, bool STORE = false>
 __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs rs) {
     constexpr int M = 1024, T = 64, R1 = 16, PER1 = 1;
     constexpr int NSL = 7;
@@ -174,7 +178,14 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
                 const cplx y = cmul(dd, e);
                 acc[j].x = fma(hw, y.x, acc[j].x);
                 acc[j].y = fma(hw, y.y, acc[j].y);
-              if (j == 0 || 64 * j < ktu) {
+              if (STORE) {
+                if (j == 0 || 64 * j < ktu) {
+                    // X_k = d_k conj(m_k) (the half of 2 d_k is exact), as k_xspec's MODE 0 stores it
+                    cplx x = cmulc(dd, mv2[j]);
+                    x.x *= 0.5; x.y *= 0.5;
+                    store_x(a, rc, kb + 64 * j, x);
+                }
+              } else if (j == 0 || 64 * j < ktu) {
                 // the cross-spectrum's Taylor sums, exactly as k_xspec_q1024 forms them
                 const cplx x = cmulc(dd, mv2[j]);
                 const cplx z = cmul(x, e);
@@ -257,21 +268,27 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
                 lds[RS_NYQ] = t;
             }
         }
-        // ---- the 12 sums and S_d: one reduction through LDS ----
-        double tr[NRED];
-#pragma unroll
-        for (int j = 0; j < PP_TSTRIDE; ++j) tr[j] = tm[j];
-        tr[PP_TSTRIDE] = sd;
-        lds_sync<T>();
-        double tv = wave_reduce_lds(tr, tid, reinterpret_cast<double*>(lds));
-        if ((tid & 3) == 0) {
-            const int q = wave_reduce16_index(tid);
-            if (q < PP_TSTRIDE) {
-                tv *= 0.5;
-                a.tay[rc * PP_TSTRIDE + q] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
+        if constexpr (STORE) {
+            sd = group_sum<64>(sd);
+            if (tid == 0) a.sdraw[rc] = sd;
+            lds_sync<T>();
+        } else {
+            // ---- the 12 sums and S_d: one reduction through LDS ----
+            double tr[NRED];
+    #pragma unroll
+            for (int j = 0; j < PP_TSTRIDE; ++j) tr[j] = tm[j];
+            tr[PP_TSTRIDE] = sd;
+            lds_sync<T>();
+            double tv = wave_reduce_lds(tr, tid, reinterpret_cast<double*>(lds));
+            if ((tid & 3) == 0) {
+                const int q = wave_reduce16_index(tid);
+                if (q < PP_TSTRIDE) {
+                    tv *= 0.5;
+                    a.tay[rc * PP_TSTRIDE + q] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
+                }
             }
+            if (tid == 4 * PP_TSTRIDE) a.sdraw[rc] = tv;
         }
-        if (tid == 4 * PP_TSTRIDE) a.sdraw[rc] = tv;
         if (r == PP_ROW_CHUNK - 1) {
             // the chunk's share of the channel sums of subint ia
             cplx* out = rs.part + (((size_t)ia * rs.ncc + cc) * RS_NACC) * 64 + tid;

@@ -1855,8 +1855,59 @@ def test_reference_seed_formed_inside_the_single_pass(dtype, flags):
     np.testing.assert_array_equal(one2["seed_phase"], one["seed_phase"])
     np.testing.assert_array_equal(one2["params"], one["params"])
     # shapes without a single-pass path say so and do nothing
+    xg = xb.copy(); xg[:, 2] = 1e-5                       # (a GM guess: the rotation is no longer the DM's alone)
     with pytest.raises(EngineNotSupported):
-        e.fit_batch(data, freqs, P, xb, ref_seed=rs, **dict(kw, fit_flags=[1, 1, 0, 1, 1], log10_tau=True))
+        e.fit_batch(data, freqs, P, xg, ref_seed=rs, **dict(kw, fit_flags=[1, 1, 1, 0, 0]))
+    with pytest.raises(EngineNotSupported):
+        e.fit_batch(data, freqs, P, xb, ref_seed=rs, **dict(kw, errs=None))       # (noise to be measured)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("l10", [True, False])
+def test_reference_seed_single_pass_scattering_fit(dtype, l10):
+    """pp_seed_ref for a scattering fit (phase, DM, tau, alpha): the transform that stores the
+    cross-spectrum (k_xspec_qr1024<., true>) also takes the rotated channel sums -- rotation by
+    the DM guess alone --, the reference's guess is formed from them and the iteration starts at
+    it: ONE read of the portraits.  Against the two-pass route (pp_reference_phase_seed, then
+    the fit from its guess): the same guess, the same raw answers, the same evaluation counts."""
+    import torch
+    from pulseportraiture_amd.pplib import phase_transform
+    C, B, nsub = 256, 2048, 10
+    e, data, freqs, model, P, x0, errs, nu_fit, kw = _full_shape_case(C, B, [1, 1, 0, 1, 1], l10, nsub=nsub,
+                                                                      tau_us=80.0, seed=31)
+    if dtype == "f32":
+        data = data.to(torch.float32)
+    rng = np.random.default_rng(6)
+    w = rng.uniform(0.5, 1.5, (nsub, C))
+    w[:, rng.choice(C, 17, replace=False)] = 0.0
+    mask = (w > 0).astype(np.uint8)
+    nu_mean = np.array([freqs[mask[i] > 0].mean() for i in range(nsub)])
+    # (the reference fits the channel mean against the template's mean profile scattered by the guess)
+    tau_lin = 10.0 ** x0[0, 3] if l10 else x0[0, 3]
+    k = np.arange(B // 2 + 1)
+    mprof = np.fft.irfft(np.fft.rfft(model.mean(axis=0)) / (1.0 + 2.0j * np.pi * k * tau_lin))
+    DM0 = x0[0, 1]
+    kw = dict(kw, chan_mask=mask)
+    out = e.reference_phase_seed(data, freqs, P, w, np.tile(mprof, (nsub, 1)), phi=-Dconst_() * DM0 / P * nu_mean ** -2.0,
+                                 DM=np.full(nsub, DM0), nu_DM=np.inf, Ns=100, finish='simplex')
+    g2 = np.array([phase_transform(out[i, 0], DM0, nu_mean[i], nu_fit, P[i], mod=True) for i in range(nsub)])
+    xa = x0.copy(); xa[:, 0] = g2
+    two = e.fit_batch(data, freqs, P, xa, **kw)
+    xb = x0.copy(); xb[:, 0] = -0.321                     # (ignored)
+    rs = dict(weights=w, model_profs=mprof, nu_mean=nu_mean, Ns=100, finish='simplex')
+    e.set_option("profile", 1); e.kernel_times(reset=True)
+    one = e.fit_batch(data, freqs, P, xb, ref_seed=rs, **kw)
+    kt = e.kernel_times(reset=True); e.set_option("profile", 0)
+    assert kt["xspec"][1] == 1                            # ONE pass over the portraits
+    assert np.abs(_dphi_arr(one["seed_phase"], g2)).max() < 1e-12, (one["seed_phase"], g2)
+    assert np.abs(_dphi_arr(one["params"][:, 0], two["params"][:, 0])).max() < 1e-11
+    np.testing.assert_allclose(one["params"][:, 1], two["params"][:, 1], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(one["params"][:, 3:], two["params"][:, 3:], rtol=1e-8)
+    np.testing.assert_allclose(one["param_errs"], two["param_errs"], rtol=1e-8)
+    np.testing.assert_allclose(one["chi2"], two["chi2"], rtol=1e-11)
+    assert (one["return_code"] == two["return_code"]).all()
+    assert np.abs(one["nfeval"] - two["nfeval"]).max() <= 1
 
 
 @pytest.mark.parametrize("case", ["GM", "poor_dm"])
@@ -1902,13 +1953,15 @@ def test_reference_seed_single_pass_off_the_easy_path(case):
         assert (one["npass"] >= 2).all() and (two["npass"] >= 2).all()      # (the model alone did not carry these)
 
 
-def test_get_TOAs_default_flow_reads_the_portraits_once_at_2048_bins():
+@pytest.mark.parametrize("fit_scat", [False, True])
+def test_get_TOAs_default_flow_reads_the_portraits_once_at_2048_bins(fit_scat):
     """Caller level: GetTOAs.get_TOAs (seed='reference', the default) on an archive of
     2048-bin, 256-channel subints takes the single-pass path (pilot + ONE transform over
     the portraits, the reference's guess formed inside it) and returns what the two-pass
     route returns (one_exchange = 0 leaves the library without the single-pass kernel:
     PP_ENOTSUP -> the guess from a pass of its own), raw; a zapped subint and zapped
-    channels included."""
+    channels included.  fit_scat: phase, DM, log10 tau and alpha fitted on scattered data --
+    the single pass is then the transform that stores the cross-spectrum (no pilot)."""
     from pulseportraiture_amd.pptoas import GetTOAs, MJD, data_from_arrays
     from pulseportraiture_amd.engine import default_engine
     from tests.synth_host import make_inputs, model_portrait
@@ -1917,7 +1970,8 @@ def test_get_TOAs_default_flow_reads_the_portraits_once_at_2048_bins():
     freqs1, model = model_portrait(C, B)
     subints = np.empty((nsub, 1, C, B))
     for i in range(nsub):
-        subints[i, 0] = make_inputs(C, B, 900 + i, DM0=34.56789, model=model)["data"]
+        subints[i, 0] = make_inputs(C, B, 900 + i, DM0=34.56789, model=model,
+                                    tau_us=60.0 if fit_scat else None)["data"]
     weights = np.ones((nsub, C))
     weights[:, rng.choice(C, 9, replace=False)] = 0.0
     weights[2] = 0.0
@@ -1935,14 +1989,18 @@ def test_get_TOAs_default_flow_reads_the_portraits_once_at_2048_bins():
         eng.set_option("profile", 1); eng.kernel_times(reset=True)
         try:
             gt = GetTOAs(data, os.path.join(GOLDEN, "example.gmodel"), quiet=True)
-            gt.get_TOAs(quiet=True)
+            if fit_scat:
+                gt.get_TOAs(quiet=True, fit_scat=True, scat_guess=[75e-6, 1500.0, -4.0])
+            else:
+                gt.get_TOAs(quiet=True)
             kt = eng.kernel_times(reset=True)
         finally:
             eng.set_option("profile", 0)
             eng.set_option("one_exchange", 1)
         runs.append((gt, kt))
     (a, kta), (b, ktb) = runs
-    assert kta["xspec"][1] == 2 and kta["fit_phase_shift"][1] == 1      # pilot + the one pass; fps on the channel mean
+    # (pilot +) the one pass; fit_phase_shift on the channel mean
+    assert kta["xspec"][1] == (1 if fit_scat else 2) and kta["fit_phase_shift"][1] == 1
     assert ktb["xspec"][1] == 1 and ktb["fit_phase_shift"][1] == 1      # the fit's pass + the seed's own pass
     ok = a.ok_isubs[0]
     np.testing.assert_array_equal(ok, [0, 1, 3])
@@ -1952,6 +2010,10 @@ def test_get_TOAs_default_flow_reads_the_portraits_once_at_2048_bins():
     np.testing.assert_allclose(np.asarray(a.red_chi2s[0])[ok], np.asarray(b.red_chi2s[0])[ok], rtol=1e-11)
     np.testing.assert_allclose(a.scales[0][ok], b.scales[0][ok], rtol=1e-9, atol=1e-12)
     assert np.abs(np.asarray(a.nfevals[0]) - np.asarray(b.nfevals[0])).max() <= 1
+    if fit_scat:
+        np.testing.assert_allclose(np.asarray(a.taus[0])[ok], np.asarray(b.taus[0])[ok], rtol=1e-8)
+        np.testing.assert_allclose(np.asarray(a.alphas[0])[ok], np.asarray(b.alphas[0])[ok], rtol=1e-8)
+        assert np.isfinite(np.asarray(a.taus[0])[ok]).all()           # (log10 tau)
     for isub in ok:
         ta, tb = a.TOAs[0][isub], b.TOAs[0][isub]
         assert abs((ta.intday() - tb.intday()) + (ta.fracday() - tb.fracday())) * 86400.0 < 1e-11 * P0
