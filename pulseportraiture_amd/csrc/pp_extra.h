@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_seed_accum(FitArgs a, cplx* ypart, int 
         const double phin = DM * p1 + GM * p2;
         cplx e = unit_phasor((double)(lane + 1), phin);
         const cplx wst = make_double2(__shfl(e.x, 63, 64), __shfl(e.y, 63, 64));
-        const cplx* xrow = a.X + ((size_t)jx * a.nchan_x + nn) * a.Kt;
+        const cplx* xrow = a.X + ((size_t)jx * a.nchan_x + nn) * a.Xs;
         const int ktn = min(ktv ? ktv[n] : a.Kt, Ks);
         // all of the row's loads first (independent, 1 KB per wave-instruction)
         cplx xv[PP_SEED_KPT];

@@ -41,11 +41,12 @@ struct XspecArgs {
     const int* const* ktab;   // [nslot] per-channel kept-harmonic counts, or nullptr (= Kt)
     const int* kt0;           // slot 0's
     const int* slot;          // [nsub] or nullptr
-    cplx* X;                  // [nsub][nchan][Kt]
+    cplx* X;                  // [nsub][nchan][Xs], harmonics 1..Kt in the first Kt places of a row
     double* sdraw;            // [nsub][nchan] sum_{k>=1} |d|^2
     double* noise;            // [nsub][nchan] get_noise_PS estimate
     const cplx* twB;
     int nsub, nchan, Kt;
+    int Xs;                   // pitch of X's rows (elements): Kt + the optional pad
     // fused first evaluation (phase/DM/GM model at the initial parameters)
     const double* x0;         // [nsub][5]
     const double* P;          // [nsub]
@@ -68,14 +69,15 @@ struct XspecArgs {
     int x_f32;                // the cross-spectrum is stored as pairs of floats (8 B per harmonic)
 };
 
-// one harmonic of the stored cross-spectrum (row pitch Kt elements of 16 or 8 bytes)
+// one harmonic of the stored cross-spectrum (row pitch Xs elements of 16 or 8 bytes)
 __device__ __forceinline__ void store_x(const XspecArgs& a, size_t row, int k, const cplx& x) {
-    if (a.x_f32) reinterpret_cast<float2*>(a.X)[row * a.Kt + (k - 1)] = make_float2((float)x.x, (float)x.y);
-    else a.X[row * a.Kt + (k - 1)] = x;
+    if (a.x_f32) reinterpret_cast<float2*>(a.X)[row * a.Xs + (k - 1)] = make_float2((float)x.x, (float)x.y);
+    else a.X[row * a.Xs + (k - 1)] = x;
 }
 
 struct FitArgs {
     int nsub, nchan, nbin, M, Kt;
+    int Xs;                   // pitch of X's rows (elements)
     int flags[5];
     int log10_tau, option, is_toa, max_iter, scat;
     int method;               // PP_METHOD_*: 0 = SciPy trust-ncg, step for step; 1 = Newton to rounding
@@ -118,7 +120,7 @@ struct FitArgs {
     // up to `recentre` times
     int recentre;
     double* x0w;              // [nsub][5] the expansion points k_phase0 reads (writable view of x0)
-    int x_f32;                // the cross-spectrum is stored as pairs of floats (k_eval<true, true> only)
+    int x_f32;                // the cross-spectrum is stored as pairs of floats (k_eval_scat<., true> only)
     // reference-seed flow (pp_xspec1024r.h): the Taylor model was taken about x0 (the pilot seed's
     // phase), the iteration starts from xstart (the reference's own guess, known only after the pass)
     const double* xstart;     // [nsub][5] or nullptr (= start at the expansion point)
@@ -814,157 +816,11 @@ __device__ __forceinline__ void accumulate_channel(const Local& L, const ChanGeo
 }
 
 // --------------------------------------------------------------------------
-// chi^2 evaluator.  grid = (nsub, nchunk) -- the subint runs fastest, so the
-// workgroups in flight together work on the SAME channels of different subints and
-// share the template's |m_nk|^2 rows in their XCD's L2 --, 256 threads; 16 lanes per
-// channel.
-// Each lane owns harmonics k = l+1, l+17, ... and advances its phasor by
-// e^{2 pi i 16 phi_n} (taken from lane 15's start phasor, k = 16).
+// chi^2 evaluators: k_eval_fast below (no scattering) and k_eval_scat (pp_evalscat.h).
 // --------------------------------------------------------------------------
 #ifndef PP_FAST_RECIP
 #define PP_FAST_RECIP 1       // |B_nk|^2 = 1/(1 + u^2) by rcp + 2 Newton steps (~1 ulp)
 #endif
-#ifndef PP_EVAL_UNROLL
-#define PP_EVAL_UNROLL 2      // independent 16-byte loads in flight per lane
-#endif
-// The stored cross-spectrum is streamed once per evaluation pass: non-temporal, so that it does
-// not displace the template power rows the co-resident workgroups share (k_eval 6.87 -> 6.73 ms
-// per 6 passes of configs[3], 8.21 -> 7.93 with the Newton solver)
-#ifndef PP_NT_X_LOADS
-#define PP_NT_X_LOADS 1
-#endif
-template <bool SCAT, bool XF32 = false>
-__global__ __launch_bounds__(256) void k_eval(FitArgs a) {
-    constexpr int LPC = 16;
-    const int jx = blockIdx.x, i = sub_of(a.act, jx), chunk = blockIdx.y;
-    SubState& st = a.st[i];
-    if (st.done || st.model == 1) return;    // (model == 1: this evaluation is k_scat_model's)
-    __shared__ double red[(256 / LPC) * PP_NACC];
-    const int tid = threadIdx.x, g = tid / LPC, l = tid % LPC;
-    const double phi = st.xe[0], DM = st.xe[1], GM = st.xe[2], alpha = st.xe[4];
-    const double tau = a.log10_tau ? pow(10.0, st.xe[3]) : st.xe[3];
-    const bool scat_on = SCAT && (tau != 0.0);
-    const double P = a.P[i];
-    const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1], nutau = a.nu_fit[i * 3 + 2];
-    const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
-    const double* wts = a.wts + (size_t)i * a.nchan;
-    const int slot = a.slot ? a.slot[i] : 0;
-    const double* msum = as_global(a.msum[slot]);
-    const double* msq = as_global(a.msq[slot]);
-    const int trial = 1 - st.cur;
-    double* csum = a.csum + ((size_t)trial * a.nsub + i) * a.nchan * a.ncs;
-    double accA = 0.0, accB = 0.0;   // lane l of a group owns sums l and 16+l of the 21
-    const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan_x);
-    for (int nn = n0 + g; nn < n1; nn += 256 / LPC) {
-        const int n = a.coff + nn * a.cstep;
-        const double w = wts[n];
-        ChanGeom cg;
-        chan_geom(freqs[n], P, nuDM, nuGM, nutau, tau, alpha, a.log10_tau, scat_on, cg);
-        // reference order of operations: phi + Dconst*DM*(f^-2 - nu^-2)/P + ...
-        const double phin = phi + DM * cg.p1 + GM * cg.p2;
-        cplx e = unit_phasor((double)(l + 1), phin);
-        const int src = ((tid & 63) & ~(LPC - 1)) | (LPC - 1);
-        const cplx wst = make_double2(__shfl(e.x, src, 64), __shfl(e.y, src, 64));
-        const size_t xoff = ((size_t)jx * a.nchan_x + nn) * a.Kt;
-        const cplx* xrow = a.X + xoff;
-        const float2* xrow32 = reinterpret_cast<const float2*>(a.X) + xoff;
-        double s0 = 0, s1 = 0, s2 = 0, t1 = 0, t2 = 0, a1t = 0, S0 = 0, S1 = 0, S2 = 0;
-        double k = (double)(l + 1);
-        // harmonics beyond the template's kept range carry |m_nk|^2 < 2^-100 of
-        // the channel's power: they drop out of S_n(tau) and of C_n alike
-        const int ktn = a.ktab ? as_global(a.ktab[slot])[n] : a.Kt;
-        if (w != 0.0) {
-#pragma unroll PP_EVAL_UNROLL
-            for (int j = l; j < ktn; j += LPC) {
-                cplx x;
-                if (XF32) {
-                    const float2 xf = PP_NT_X_LOADS ? load_row_once<float2>(reinterpret_cast<const char*>(xrow32 + j))
-                                                    : xrow32[j];
-                    x = make_double2((double)xf.x, (double)xf.y);
-                } else {
-                    x = PP_NT_X_LOADS ? load_row_once<cplx>(reinterpret_cast<const char*>(xrow + j)) : xrow[j];
-                }
-                const cplx z = cmul(x, e);
-                if (!SCAT) {
-                    s0 += z.x;
-                    s1 = fma(k, z.y, s1);
-                    s2 = fma(k * k, z.x, s2);
-                } else {
-                    const double kap = PP_TWO_PI * k, u = kap * cg.taun;
-                    const double D = PP_FAST_RECIP ? recip_ge1(fma(u, u, 1.0)) : 1.0 / fma(u, u, 1.0);
-                    const cplx b = make_double2(D, u * D);      // conj(B)
-                    const cplx zb = cmul(z, b);
-                    s0 += zb.x;
-                    s1 = fma(kap, zb.y, s1);                    // A1 = -sum kap Im(zb)
-                    s2 = fma(kap * kap, zb.x, s2);              // A2 = -sum kap^2 Re(zb)
-                    const double Mk = msq[(size_t)n * a.M + j];
-                    S0 = fma(D, Mk, S0);
-                    if (scat_on) {
-                        const cplx zb2 = cmul(zb, b);
-                        const cplx zb3 = cmul(zb2, b);
-                        t1 = fma(kap, zb2.y, t1);               // T1 = -sum kap Im(z b^2)
-                        a1t = fma(kap * kap, zb2.x, a1t);       // A1T = -sum kap^2 Re(z b^2)
-                        t2 = fma(kap * kap, zb3.x, t2);         // T2 = -2 sum kap^2 Re(z b^3)
-                        const double D2 = D * D;
-                        S1 = fma(kap * u * D2, Mk, S1);         // S1 = -2 sum kap u D^2 M
-                        S2 = fma(kap * kap * D2 * fma(4.0 * u * u, D, -1.0), Mk, S2);  // *2
-                    }
-                }
-                e = cmul(e, wst);
-                k += (double)LPC;
-            }
-        }
-        double cs[PP_NCS];
-        if (!SCAT) {
-            cs[0] = group_sum<LPC>(s0);
-            cs[1] = -PP_TWO_PI * group_sum<LPC>(s1);
-            cs[2] = -PP_TWO_PI * PP_TWO_PI * group_sum<LPC>(s2);
-            cs[3] = cs[4] = cs[5] = 0.0;
-            cs[6] = msum[n];
-            cs[7] = cs[8] = 0.0;
-        } else {
-            cs[0] = group_sum<LPC>(s0);
-            cs[1] = -group_sum<LPC>(s1);
-            cs[2] = -group_sum<LPC>(s2);
-            cs[3] = -group_sum<LPC>(t1);
-            cs[4] = -2.0 * group_sum<LPC>(t2);
-            cs[5] = -group_sum<LPC>(a1t);
-            cs[6] = group_sum<LPC>(S0);
-            cs[7] = -2.0 * group_sum<LPC>(S1);
-            cs[8] = 2.0 * group_sum<LPC>(S2);
-        }
-        if (l < PP_NCS) {
-            double* co = csum + (size_t)n * a.ncs;
-            if (a.ncs == 3) { if (l < 3) co[l] = (l == 0) ? cs[0] : (l == 1 ? cs[1] : cs[2]); }
-            else {
-                double v = cs[0];
-#pragma unroll
-                for (int j = 1; j < PP_NCS; ++j) v = (l == j) ? cs[j] : v;
-                co[l] = v;
-            }
-        }
-        if (w != 0.0) {
-            const Local L = local_terms(cs, w);
-            double c[PP_NACC];
-            accumulate_channel(L, cg, c);
-            double ca = c[0], cb = c[16];
-#pragma unroll
-            for (int u = 1; u < 16; ++u) ca = (l == u) ? c[u] : ca;
-#pragma unroll
-            for (int u = 1; u < PP_NACC - 16; ++u) cb = (l == u) ? c[16 + u] : cb;
-            accA += ca;
-            accB += cb;
-        }
-    }
-    red[g * PP_NACC + l] = accA;
-    if (l < PP_NACC - 16) red[g * PP_NACC + 16 + l] = accB;
-    __syncthreads();
-    if (tid < PP_NACC) {
-        double s = 0.0;
-        for (int gg = 0; gg < 256 / LPC; ++gg) s += red[gg * PP_NACC + tid];
-        a.partial[((size_t)i * a.nchunk + chunk) * PP_NACC + tid] = s;
-    }
-}
 
 // First evaluation when k_xspec already produced the per-channel sums (FUSE):
 // only the O(nchan) chain rule + reduction remains.  grid = (nchunk, nsub).
@@ -985,7 +841,7 @@ __global__ __launch_bounds__(256) void k_accum(FitArgs a) {
     for (int j = 0; j < PP_NACC; ++j) acc[j] = 0.0;
     const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan_x);
     if (a.scat) {
-        // the nine sums of a scattering fit (k_xspec_qs1024): the whole chain rule of k_eval<true>
+        // the nine sums of a scattering fit (k_xspec_qs1024): the whole chain rule of k_eval_scat
         const double tau = a.log10_tau ? pow(10.0, st.xe[3]) : st.xe[3];
         const double nutau = a.nu_fit[i * 3 + 2], alpha = st.xe[4];
         for (int nn = n0 + tid; nn < n1; nn += 256) {
@@ -1060,7 +916,7 @@ __global__ __launch_bounds__(256) void k_eval_fast(FitArgs a) {
         cplx e0 = unit_phasor((double)(l + 1), phin);
         const cplx w1 = make_double2(__shfl(e0.x, src, 64), __shfl(e0.y, src, 64));
         const cplx w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
-        const cplx* xrow = a.X + ((size_t)jx * a.nchan_x + nn) * a.Kt;
+        const cplx* xrow = a.X + ((size_t)jx * a.nchan_x + nn) * a.Xs;
         double s0a = 0, s1a = 0, s2a = 0, s0b = 0, s1b = 0, s2b = 0;
         double k = (double)(l + 1);
         const int ktn = ktv ? ktv[n] : a.Kt;
@@ -1390,7 +1246,7 @@ __global__ __launch_bounds__(256) void k_eval_moments(FitArgs a) {
         cplx e0 = unit_phasor((double)(l + 1), phin);
         const cplx w1 = make_double2(__shfl(e0.x, src, 64), __shfl(e0.y, src, 64));
         const cplx w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
-        const cplx* xrow = a.X + ((size_t)jx * a.nchan_x + nn) * a.Kt;
+        const cplx* xrow = a.X + ((size_t)jx * a.nchan_x + nn) * a.Xs;
         const int ktn = ktv ? ktv[n] : a.Kt;
         double s[PP_TSTRIDE];
 #pragma unroll
@@ -1937,6 +1793,7 @@ __device__ inline bool step_logic(const FitArgs& a, SubState& s, double f, const
 }
 
 #include "pp_scatmodel.h"
+#include "pp_evalscat.h"
 
 // one trust-region iteration per subint (64 threads, lane 0 decides)
 __global__ __launch_bounds__(64) void k_step(FitArgs a) {

@@ -173,7 +173,7 @@ __device__ inline void scat_model_request(const FitArgs& a, SubState& s) {
 }
 
 // --------------------------------------------------------------------------
-// The model pass.  Same work layout as k_eval<true> (grid (nsub, nchunk), 16 lanes
+// The model pass.  Same grid as k_eval_scat ((nsub, nchunk)), 16 lanes
 // per channel), for the subints whose state asks for it.  Leaves the PP_MROW
 // coefficients of every channel in a.mdl and the nine sums of the centre in the
 // trial csum buffer, exactly as k_eval would.
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_scat_model(FitArgs a) {
         const double phin = phi + DM * cg.p1 + GM * cg.p2;
         cplx e = unit_phasor((double)(l + 1), phin);
         const cplx wst = make_double2(__shfl(e.x, src, 64), __shfl(e.y, src, 64));
-        const cplx* xrow = a.X + ((size_t)jx * a.nchan_x + nn) * a.Kt;
+        const cplx* xrow = a.X + ((size_t)jx * a.nchan_x + nn) * a.Xs;
         const int ktn = a.ktab ? as_global(a.ktab[slot])[n] : a.Kt;
         double G[PP_MNG], Sc[P_ + 1], An = 0.0, Wp = 0.0;
 #pragma unroll
@@ -215,14 +215,14 @@ __global__ __launch_bounds__(256) void k_scat_model(FitArgs a) {
         if (w != 0.0 && l < ktn) {
             // the next harmonic's loads are issued before this one's arithmetic
             const double* mrow = msq + (size_t)n * a.M;
-            cplx xn = PP_NT_X_LOADS ? load_row_once<cplx>(reinterpret_cast<const char*>(xrow + l)) : xrow[l];
+            cplx xn = load_row_once<cplx>(reinterpret_cast<const char*>(xrow + l));
             double Mn = mrow[l];
 #pragma unroll 1
             for (int j = l; j < ktn; j += LPC) {
                 const cplx x = xn;
                 const double Mk = Mn;
                 if (j + LPC < ktn) {
-                    xn = PP_NT_X_LOADS ? load_row_once<cplx>(reinterpret_cast<const char*>(xrow + j + LPC)) : xrow[j + LPC];
+                    xn = load_row_once<cplx>(reinterpret_cast<const char*>(xrow + j + LPC));
                     Mn = mrow[j + LPC];
                 }
                 const cplx z = cmul(x, e);

@@ -106,6 +106,7 @@ struct pp_ctx {
     int scat_model = 1;         // scattering fits: closing iterations on the per-channel model (pp_scatmodel.h)
     double scat_model_tol = 1e-10;
     int scat_model_bet = 1;
+    int x_pad = 0;              // pad of the stored cross-spectrum's rows (elements); measured neutral
     int fuse_scat = 1;          // scattering fits: first evaluation inside the transform (k_xspec_qs1024) where it applies
     int x_f32 = 0;              // 1 = scattering fits store the cross-spectrum as float pairs (measured: not worth it)
     int taylor_recentre = 1;    // one-pass flow: re-expansions about the tentative answer when the certificate fails
@@ -258,6 +259,7 @@ extern "C" int pp_set_option(pp_ctx* c, const char* name, double value) {
     else if (n == "scat_model_bet") c->scat_model_bet = (int)value;
     else if (n == "x_f32") c->x_f32 = (int)value;
     else if (n == "fuse_scat") c->fuse_scat = (int)value;
+    else if (n == "x_pad") c->x_pad = (int)value;
     else if (n == "fps_finish") c->fps_finish = (int)value;
     else if (n == "debug_poison") c->debug_poison = (int)value;
     else if (n == "taylor_recentre") c->taylor_recentre = (int)value;
@@ -648,7 +650,12 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     };
     int nchunk, cpc;
     chunking(C, ns, nchunk, cpc);
-    if (xstore) if ((rc = c->X.reserve(nc * Kt * sizeof(cplx)))) return rc;
+    // pitch of the stored cross-spectrum's rows: Kt harmonics + an optional pad (option x_pad, elements).
+    // Kt x 16 B is a multiple of 1 KB and the evaluators stream 32 rows per workgroup at the same
+    // pace, which looked like a recipe for memory-channel camping: measured, pads of 8 / 16 / 48
+    // elements change nothing (profiles/README.md, round 3) -- the default stays 0
+    const size_t Xs = (size_t)Kt + (size_t)std::max(0, c->x_pad);
+    if (xstore) if ((rc = c->X.reserve(nc * Xs * sizeof(cplx)))) return rc;
     if ((rc = c->sdraw.reserve(nc * 8))) return rc;
     if ((rc = c->noise.reserve(nc * 8))) return rc;
     if ((rc = c->wts.reserve(nc * 8))) return rc;
@@ -662,9 +669,9 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     if (smodel) if ((rc = c->mdl.reserve(nc * PP_MROW * 8))) return rc;
     // Option x_f32 (off by default): the stored cross-spectrum of a scattering fit kept as float
     // pairs, half the bytes of every evaluation pass.  Measured on configs[3] with the Newton
-    // solver (profiles/README.md, round 3): the six passes go from 7.92 to 7.28 ms only -- at
-    // ~48 f64 instructions per harmonic k_eval<true> is as close to its VALU floor as to its HBM
-    // floor -- while chi2 loses its 1e-10 agreement with the reference (6e-8 of every |X_nk|
+    // solver (profiles/README.md, round 3, with the first evaluator, which was not HBM-bound: the
+    // six passes went from 7.92 to 7.28 ms only; k_eval_scat is, so the gain would be larger now)
+    // -- but chi2 loses its 1e-10 agreement with the reference (6e-8 of every |X_nk|
     // moves f by ~1e-6 of itself; the optimum by ~1e-11 rot).  Kept for experiments.
     const bool xf32 = scat && !seeded && !smodel && c->max_iter > 0 && c->x_f32 > 0;
     const bool want_ph0 = xmode != 0 || fuse_scat || refseed;
@@ -703,7 +710,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         if (pz & 8) HIP_TRY(hipMemsetAsync(c->wts.p, 0xFF, nc * 8, c->stream));
         if (pz & 16) HIP_TRY(hipMemsetAsync(c->csum.p, 0xFF, 2 * nc * ncs * 8, c->stream));
         if ((pz & 32) && want_ph0) HIP_TRY(hipMemsetAsync(c->ph0.p, 0xFF, nc * 8, c->stream));
-        if ((pz & 64) && xstore) HIP_TRY(hipMemsetAsync(c->X.p, 0xFF, nc * Kt * sizeof(cplx), c->stream));
+        if ((pz & 64) && xstore) HIP_TRY(hipMemsetAsync(c->X.p, 0xFF, nc * Xs * sizeof(cplx), c->stream));
         if ((pz & 128) && smodel) HIP_TRY(hipMemsetAsync(c->mdl.p, 0xFF, nc * PP_MROW * 8, c->stream));
     }
     // ---- argument blocks ----
@@ -716,7 +723,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     xa.kt0 = c->slots[0].kt.as<int>();
     xa.slot = in->model_slot ? d_slot : nullptr;
     xa.X = c->X.as<cplx>(); xa.sdraw = c->sdraw.as<double>(); xa.noise = c->noise.as<double>();
-    xa.twB = tw; xa.nsub = ns; xa.nchan = C; xa.Kt = Kt;
+    xa.twB = tw; xa.nsub = ns; xa.nchan = C; xa.Kt = Kt; xa.Xs = (int)Xs;
     xa.x0 = d_x0; xa.P = d_P; xa.nu_fit = d_nufit;
     xa.freqs = d_freqs; xa.freqs_stride = in->freqs_stride ? C : 0;
     xa.csum0 = c->csum.as<double>();
@@ -726,7 +733,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     xa.x_f32 = xf32 ? 1 : 0;
     FitArgs fa;
     memset(&fa, 0, sizeof fa);
-    fa.nsub = ns; fa.nchan = C; fa.nbin = B; fa.M = M; fa.Kt = Kt;
+    fa.nsub = ns; fa.nchan = C; fa.nbin = B; fa.M = M; fa.Kt = Kt; fa.Xs = (int)Xs;
     for (int j = 0; j < 5; ++j) fa.flags[j] = in->fit_flags[j] ? 1 : 0;
     fa.log10_tau = in->log10_tau ? 1 : 0; fa.option = in->option; fa.is_toa = in->is_toa ? 1 : 0;
     fa.max_iter = c->max_iter; fa.scat = scat ? 1 : 0;
@@ -841,7 +848,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // transform every channel of the listed subints again with the cross-spectrum
     // stored (compact in the list index), and point the evaluators at the list
     auto store_x_for_list = [&](int count) -> int {
-        if ((rc = c->X.reserve((size_t)count * C * Kt * sizeof(cplx)))) return rc;
+        if ((rc = c->X.reserve((size_t)count * C * Xs * sizeof(cplx)))) return rc;
         XspecArgs xl = xa;
         xl.X = c->X.as<cplx>(); xl.act = c->act.as<int>(); xl.nsub = count;
         if ((rc = run_xspec(xl, 0))) return rc;
@@ -855,7 +862,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // ---- phase seed from a pilot pass ----
     if (pilot) {
         const int Cp = (C + cstep - 1) / cstep;
-        if ((rc = c->X.reserve((size_t)ns * Cp * Kt * sizeof(cplx)))) return rc;
+        if ((rc = c->X.reserve((size_t)ns * Cp * Xs * sizeof(cplx)))) return rc;
         if ((rc = c->seedq.reserve((size_t)ns * 8))) return rc;
         XspecArgs xp = xa;
         xp.X = c->X.as<cplx>(); xp.nchan = Cp; xp.cstep = cstep;
@@ -1108,8 +1115,9 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             hipLaunchKernelGGL(k_accum, dim3(fa.nact, fa.nchunk), dim3(256), 0, c->stream, fa);
         } else {
             Prof pr(c, KF_EVAL);
-            if (scat && fa.x_f32) hipLaunchKernelGGL((k_eval<true, true>), dim3(fa.nact, fa.nchunk), dim3(256), 0, c->stream, fa);
-            else if (scat) hipLaunchKernelGGL(k_eval<true>, dim3(fa.nact, fa.nchunk), dim3(256), 0, c->stream, fa);
+            const dim3 eg(fa.nact, fa.nchunk);
+            if (scat && fa.x_f32) hipLaunchKernelGGL((k_eval_scat<8, true>), eg, dim3(256), 0, c->stream, fa);
+            else if (scat) hipLaunchKernelGGL((k_eval_scat<8, false>), eg, dim3(256), 0, c->stream, fa);
             else hipLaunchKernelGGL(k_eval_fast, dim3(fa.nact, fa.nchunk), dim3(256), 0, c->stream, fa);
         }
         if (smodel && it >= 2) {
@@ -1214,7 +1222,7 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
     // sub-batches sized to the work-memory budget
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const double per_sub = (double)C * Kt * 16.0 + (in->data_on_device ? 0.0 : (double)C * B * (in->data_dtype == PP_F64 ? 8 : 4)) +
+    const double per_sub = (double)C * (Kt + std::max(0, c->x_pad)) * 16.0 + (in->data_on_device ? 0.0 : (double)C * B * (in->data_dtype == PP_F64 ? 8 : 4)) +
                            (double)C * (8.0 * 12 + 2 * 9 * 8.0) + 4096.0 +
                            ((scat && c->scat_model) ? (double)C * PP_MROW * 8.0 : 0.0);
     double budget = std::min(c->max_work_bytes, 0.85 * ((double)free_b + (double)c->X.cap + (double)c->data.cap + (double)c->csum.cap));

@@ -5,7 +5,7 @@
 // one-exchange FFT (pp_fftq.h); same row walk, template row in registers and partner split as
 // k_xspec_q1024 (template cut 2 Kt < M: slots k = kb + 64 j, j = 0..6).
 //
-// Per harmonic (k_eval<true>'s arithmetic): z = X e^{i kap phi_n}, b = conj(B) = D (1 + i u),
+// Per harmonic (k_eval_scat's arithmetic): z = X e^{i kap phi_n}, b = conj(B) = D (1 + i u),
 // u = kap tau_n, D = 1 / (1 + u^2):
 //   A0 = Re z b, A1 = -kap Im z b, A2 = -kap^2 Re z b, T1 = -kap Im z b^2, A1T = -kap^2 Re z b^2,
 //   T2 = -2 kap^2 Re z b^3, S0 = D M, S1 = -2 kap u D^2 M, S2 = 2 kap^2 D^2 (4 u^2 D - 1) M.

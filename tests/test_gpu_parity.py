@@ -2195,7 +2195,8 @@ def test_scattering_model_of_the_closing_iterations_walks_the_same_iteration(l10
     e.set_option("profile", 0)
     a, b = res[0], res[1]
     assert passes[0] == 0 and passes[1] > 0
-    assert evals[1] < evals[0], (evals, "the model never took over")
+    # (launches are counted while ANY subint iterates; passes per subint say who took the model)
+    assert evals[1] <= evals[0] and b["npass"].sum() < 0.8 * a["npass"].sum(), (evals, "the model never took over")
     assert (b["return_code"] == 2).all()
     # Identical iterates -- except in the last step or two of some subints: once the
     # optimum is reached to the last bit of f, SciPy's ratio test compares an actual
