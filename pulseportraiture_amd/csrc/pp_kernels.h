@@ -1792,8 +1792,8 @@ __device__ inline bool step_logic(const FitArgs& a, SubState& s, double f, const
     return done;
 }
 
-#include "pp_scatmodel.h"
 #include "pp_evalscat.h"
+#include "pp_scatmodel.h"
 
 // one trust-region iteration per subint (64 threads, lane 0 decides)
 __global__ __launch_bounds__(64) void k_step(FitArgs a) {

@@ -52,27 +52,6 @@ __device__ inline double series_tail(int m, double x, double rho) {
     return fma(x, x, 1.0 + x) * fma(rc, fma(2.0, rho, 1.0), total);
 }
 
-// Sum 64 per-lane values over an aligned group of 16 lanes, leaving lane l of the
-// group with the totals of v[4l .. 4l+3] (in v[0..3]): every xor step halves what a
-// lane carries (it keeps the half its lane bit selects and adds the partner's copy of
-// it), 60 exchanges instead of 256.
-__device__ __forceinline__ void group16_reduce_scatter64(double (&v)[64], int lane) {
-#define PP_RS_STEP(HALF, BIT)                                             \
-    {                                                                    \
-        const bool up = (lane & (BIT)) != 0;                             \
-        _Pragma("unroll") for (int j = 0; j < (HALF); ++j) {             \
-            const double keep = up ? v[(HALF) + j] : v[j];               \
-            const double send = up ? v[j] : v[(HALF) + j];               \
-            v[j] = keep + __shfl_xor(send, (BIT), 64);                   \
-        }                                                                \
-    }
-    PP_RS_STEP(32, 8)
-    PP_RS_STEP(16, 4)
-    PP_RS_STEP(8, 2)
-    PP_RS_STEP(4, 1)
-#undef PP_RS_STEP
-}
-
 // largest |d phi_n / d DM|, |d phi_n / d GM|, |ln(nu_n / nu_tau)| of a subint's
 // channels, and the effective harmonic scale keff of the template (from |m_nk|, the
 // weighting of a noise-dominated cross-spectrum, on 16 channels across the band) -- 64 lanes;
@@ -173,16 +152,39 @@ __device__ inline void scat_model_request(const FitArgs& a, SubState& s) {
 }
 
 // --------------------------------------------------------------------------
-// The model pass.  Same grid as k_eval_scat ((nsub, nchunk)), 16 lanes
-// per channel), for the subints whose state asks for it.  Leaves the PP_MROW
-// coefficients of every channel in a.mdl and the nine sums of the centre in the
-// trial csum buffer, exactly as k_eval would.
+// The model pass.  Same grid and phases as k_eval_scat ((nsub, nchunk); A: one thread per
+// channel for the geometry, B: 8 lanes per channel on the harmonics), for the subints
+// whose state asks for it.  Leaves the PP_MROW coefficients of every channel in a.mdl and
+// the nine sums of the centre in the trial csum buffer, exactly as k_eval_scat would.
+// f64 VALU bound (~165 instructions per harmonic: two power chains in b_k, 54 FMAs): with 8
+// lanes per channel the per-channel part (phasor, zeroing and reducing 58 accumulators) is
+// 8 % of the instructions (16 lanes, geometry repeated by every lane: 24 %).
 // --------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_scat_model(FitArgs a) {
-    constexpr int LPC = 16, P_ = PP_MP;
+// Sum 64 per-lane values over an aligned group of 8 lanes, leaving lane l of the group with
+// the totals of v[8l .. 8l+7] (in v[0..7]): 56 exchanges (DPP / swizzle, no LDS traffic)
+__device__ __forceinline__ void group8_reduce_scatter64(double (&v)[64], int lane) {
+#define PP_RS8_STEP(HALF, BIT)                                            \
+    {                                                                    \
+        const bool up = (lane & (BIT)) != 0;                             \
+        _Pragma("unroll") for (int j = 0; j < (HALF); ++j) {             \
+            const double keep = up ? v[(HALF) + j] : v[j];               \
+            const double send = up ? v[j] : v[(HALF) + j];               \
+            v[j] = keep + lane_xor16<BIT>(send);                         \
+        }                                                                \
+    }
+    PP_RS8_STEP(32, 4)
+    PP_RS8_STEP(16, 2)
+    PP_RS8_STEP(8, 1)
+#undef PP_RS8_STEP
+}
+
+__global__ __launch_bounds__(256, 2) void k_scat_model(FitArgs a) {
+    constexpr int LPC = 8, G_ = 256 / LPC, P_ = PP_MP;
     const int jx = blockIdx.x, i = sub_of(a.act, jx), chunk = blockIdx.y;
     const SubState& st = a.st[i];
     if (st.done || st.model != 1) return;
+    __shared__ double s_phi[256], s_tau[256];
+    __shared__ int s_kt[256];
     const int tid = threadIdx.x, g = tid / LPC, l = tid % LPC;
     const double phi = st.xe[0], DM = st.xe[1], GM = st.xe[2], alpha = st.xe[4];
     const double tau = a.log10_tau ? pow(10.0, st.xe[3]) : st.xe[3];
@@ -192,101 +194,116 @@ __global__ __launch_bounds__(256) void k_scat_model(FitArgs a) {
     const double* wts = a.wts + (size_t)i * a.nchan;
     const int slot = a.slot ? a.slot[i] : 0;
     const double* msq = as_global(a.msq[slot]);
+    const int* ktab = a.ktab ? as_global(a.ktab[slot]) : nullptr;
     double* mdl = a.mdl + (size_t)i * a.nchan * PP_MROW;
     double* csum = a.csum + ((size_t)(1 - st.cur) * a.nsub + i) * a.nchan * a.ncs;
     const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan_x);
     const int src = ((tid & 63) & ~(LPC - 1)) | (LPC - 1);
-    for (int nn = n0 + g; nn < n1; nn += 256 / LPC) {
-        const int n = a.coff + nn * a.cstep;
-        const double w = wts[n];
-        ChanGeom cg;
-        chan_geom(freqs[n], P, nuDM, nuGM, nutau, tau, alpha, a.log10_tau, true, cg);
-        const double phin = phi + DM * cg.p1 + GM * cg.p2;
-        cplx e = unit_phasor((double)(l + 1), phin);
-        const cplx wst = make_double2(__shfl(e.x, src, 64), __shfl(e.y, src, 64));
-        const cplx* xrow = a.X + ((size_t)jx * a.nchan_x + nn) * a.Xs;
-        const int ktn = a.ktab ? as_global(a.ktab[slot])[n] : a.Kt;
-        double G[PP_MNG], Sc[P_ + 1], An = 0.0, Wp = 0.0;
+    for (int base = n0; base < n1; base += 256) {
+        const int cnt = min(256, n1 - base);
+        // ---- A: geometry of channel base + tid ----
+        if (tid < cnt) {
+            const int nt = a.coff + (base + tid) * a.cstep;
+            ChanGeom cg;
+            chan_geom(freqs[nt], P, nuDM, nuGM, nutau, tau, alpha, a.log10_tau, true, cg);
+            s_phi[tid] = phi + DM * cg.p1 + GM * cg.p2;
+            s_tau[tid] = cg.taun;
+            s_kt[tid] = (wts[nt] != 0.0) ? (ktab ? ktab[nt] : a.Kt) : 0;
+        }
+        __syncthreads();
+        // ---- B: the coefficients of every channel ----
+        for (int t = g; t < cnt; t += G_) {
+            const int nn = base + t, n = a.coff + nn * a.cstep;
+            const double taun = s_tau[t];
+            const int ktn = s_kt[t];
+            double G[PP_MNG], Sc[P_ + 1], An = 0.0, Wp = 0.0;
 #pragma unroll
-        for (int j = 0; j < PP_MNG; ++j) G[j] = 0.0;
+            for (int j = 0; j < PP_MNG; ++j) G[j] = 0.0;
 #pragma unroll
-        for (int j = 0; j <= P_; ++j) Sc[j] = 0.0;
-        double k = (double)(l + 1);
-        if (w != 0.0 && l < ktn) {
-            // the next harmonic's loads are issued before this one's arithmetic
-            const double* mrow = msq + (size_t)n * a.M;
-            cplx xn = load_row_once<cplx>(reinterpret_cast<const char*>(xrow + l));
-            double Mn = mrow[l];
+            for (int j = 0; j <= P_; ++j) Sc[j] = 0.0;
+            if (l < ktn) {
+                cplx e = unit_phasor((double)(l + 1), s_phi[t]);
+                const cplx wst = make_double2(__shfl(e.x, src, 64), __shfl(e.y, src, 64));
+                const cplx* xrow = a.X + ((size_t)jx * a.nchan_x + nn) * a.Xs;
+                const double* mrow = msq + (size_t)n * a.M;
+                double k = (double)(l + 1);
+                // the next harmonic's loads are issued before this one's arithmetic
+                cplx xn = load_row_once<cplx>(reinterpret_cast<const char*>(xrow + l));
+                double Mn = mrow[l];
 #pragma unroll 1
-            for (int j = l; j < ktn; j += LPC) {
-                const cplx x = xn;
-                const double Mk = Mn;
-                if (j + LPC < ktn) {
-                    xn = load_row_once<cplx>(reinterpret_cast<const char*>(xrow + j + LPC));
-                    Mn = mrow[j + LPC];
+                for (int j = l; j < ktn; j += LPC) {
+                    const cplx x = xn;
+                    const double Mk = Mn;
+                    if (j + LPC < ktn) {
+                        xn = load_row_once<cplx>(reinterpret_cast<const char*>(xrow + j + LPC));
+                        Mn = mrow[j + LPC];
+                    }
+                    const cplx z = cmul(x, e);
+                    const double kap = PP_TWO_PI * k, u = kap * taun;
+                    const double D = recip_ge1(fma(u, u, 1.0));
+                    const cplx b = make_double2(D, u * D);
+                    double kp[P_ + 1];
+                    kp[0] = 1.0;
+#pragma unroll
+                    for (int q = 1; q <= P_; ++q) kp[q] = kp[q - 1] * kap;
+                    cplx zb = cmul(z, b);                           // z b^(c+1)
+                    cplx bp = make_double2(Mk * b.x, Mk * b.y);     // |m_nk|^2 b^(c+1)
+#pragma unroll
+                    for (int c = 0; c <= P_; ++c) {
+                        if (c > 0) { zb = cmul(zb, b); bp = cmul(bp, b); }
+                        // Re(i^q v): +Re, -Im, -Re, +Im; the sign goes on at the end
+#pragma unroll
+                        for (int q = c; q <= P_; ++q)
+                            G[q * (q + 1) / 2 + c] = fma(kp[q], (q & 1) ? zb.y : zb.x, G[q * (q + 1) / 2 + c]);
+                        Sc[c] = fma(kp[c], (c & 1) ? bp.y : bp.x, Sc[c]);
+                    }
+                    // |b_k| from above: a single-precision rsqrt, widened by its error
+                    const float rs = __builtin_amdgcn_rsqf((float)fma(u, u, 1.0)) * 1.0001f;
+                    const double ax = (fabs(x.x) + fabs(x.y)) * (double)rs;
+                    An += ax;
+                    Wp = fma(ax, kp[P_] * kap, Wp);
+                    e = cmul(e, wst);
+                    k += (double)LPC;
                 }
-                const cplx z = cmul(x, e);
-                const double kap = PP_TWO_PI * k, u = kap * cg.taun;
-                const double D = recip_ge1(fma(u, u, 1.0));
-                const cplx b = make_double2(D, u * D);
-                double kp[P_ + 1];
-                kp[0] = 1.0;
+            }
+            // signs of Re(i^q v), then one reduce-scatter of the whole row over the 8 lanes
+            double V[64];
 #pragma unroll
-                for (int q = 1; q <= P_; ++q) kp[q] = kp[q - 1] * kap;
-                cplx zb = cmul(z, b);                           // z b^(c+1)
-                cplx bp = make_double2(Mk * b.x, Mk * b.y);     // |m_nk|^2 b^(c+1)
+            for (int q = 0; q <= P_; ++q)
 #pragma unroll
-                for (int c = 0; c <= P_; ++c) {
-                    if (c > 0) { zb = cmul(zb, b); bp = cmul(bp, b); }
-                    // Re(i^q v): +Re, -Im, -Re, +Im; the sign goes on at the end
-#pragma unroll
-                    for (int q = c; q <= P_; ++q)
-                        G[q * (q + 1) / 2 + c] = fma(kp[q], (q & 1) ? zb.y : zb.x, G[q * (q + 1) / 2 + c]);
-                    Sc[c] = fma(kp[c], (c & 1) ? bp.y : bp.x, Sc[c]);
+                for (int c = 0; c <= q; ++c) {
+                    const int j = q * (q + 1) / 2 + c;
+                    V[j] = ((q & 3) == 1 || (q & 3) == 2) ? -G[j] : G[j];
                 }
-                // |b_k| from above: a single-precision rsqrt, widened by its error
-                const float rs = __builtin_amdgcn_rsqf((float)fma(u, u, 1.0)) * 1.0001f;
-                const double ax = (fabs(x.x) + fabs(x.y)) * (double)rs;
-                An += ax;
-                Wp = fma(ax, kp[P_] * kap, Wp);
-                e = cmul(e, wst);
-                k += (double)LPC;
+#pragma unroll
+            for (int c = 0; c <= P_; ++c) V[PP_MNG + c] = ((c & 3) == 1 || (c & 3) == 2) ? -Sc[c] : Sc[c];
+            V[PP_MNG + P_ + 1] = An;
+            V[PP_MNG + P_ + 2] = 0.0;                 // (tau_n goes here)
+            V[PP_MNG + P_ + 3] = Wp;
+#pragma unroll
+            for (int j = PP_MNG + P_ + 4; j < 64; ++j) V[j] = 0.0;
+            group8_reduce_scatter64(V, l);
+            constexpr int JT = PP_MNG + P_ + 2;       // tau_n's place in the row
+            if (l == JT / 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (q == JT % 8) V[q] = taun;
+            }
+            // coefficient j of channel n goes to mdl[j * nchan + n] (the 32 channels a
+            // workgroup has in flight are neighbours: 256 B per coefficient)
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (8 * l + q < PP_MROW) mdl[(size_t)(8 * l + q) * a.nchan + n] = V[q];
+            // the nine sums of the centre for the post-fit stage:
+            // A0 = G00, A1 = G10, T1 = G11, A2 = G20, A1T = G21, T2 = 2 G22; S0, S1 = Sc1, S2 = 2 Sc2
+            double* co = csum + (size_t)n * a.ncs;
+            if (l == 0) { co[0] = V[0]; co[1] = V[1]; co[3] = V[2]; co[2] = V[3]; co[5] = V[4]; co[4] = 2.0 * V[5]; }
+            static_assert(PP_MNG % 8 <= 5, "Sc[0..2] sit in one lane's octet");
+            if (l == PP_MNG / 8) {
+                constexpr int o = PP_MNG % 8;
+                co[6] = V[o]; co[7] = V[o + 1]; co[8] = 2.0 * V[o + 2];
             }
         }
-        // signs of Re(i^q v), then one reduce-scatter of the whole row over the 16 lanes
-        double V[64];
-#pragma unroll
-        for (int q = 0; q <= P_; ++q)
-#pragma unroll
-            for (int c = 0; c <= q; ++c) {
-                const int j = q * (q + 1) / 2 + c;
-                V[j] = ((q & 3) == 1 || (q & 3) == 2) ? -G[j] : G[j];
-            }
-#pragma unroll
-        for (int c = 0; c <= P_; ++c) V[PP_MNG + c] = ((c & 3) == 1 || (c & 3) == 2) ? -Sc[c] : Sc[c];
-        V[PP_MNG + P_ + 1] = An;
-        V[PP_MNG + P_ + 2] = 0.0;                 // (tau_n goes here)
-        V[PP_MNG + P_ + 3] = Wp;
-#pragma unroll
-        for (int j = PP_MNG + P_ + 4; j < 64; ++j) V[j] = 0.0;
-        group16_reduce_scatter64(V, l);
-        constexpr int JT = PP_MNG + P_ + 2;       // tau_n's place in the row
-        if (l == JT / 4) V[JT % 4] = cg.taun;
-        // coefficient j of channel n goes to mdl[j * nchan + n] (the 16 channels a
-        // workgroup has in flight are neighbours: 128 B per coefficient)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (4 * l + q < PP_MROW) mdl[(size_t)(4 * l + q) * a.nchan + n] = V[q];
-        // the nine sums of the centre for the post-fit stage:
-        // A0 = G00, A1 = G10, T1 = G11, A2 = G20, A1T = G21, T2 = 2 G22; S0, S1 = Sc1, S2 = 2 Sc2
-        double* co = csum + (size_t)n * a.ncs;
-        if (l == 0) { co[0] = V[0]; co[1] = V[1]; co[3] = V[2]; co[2] = V[3]; }
-        if (l == 1) { co[5] = V[0]; co[4] = 2.0 * V[1]; }
-        static_assert(PP_MNG % 4 == 1 || PP_MNG % 4 == 0, "Sc[0..2] sit in one lane's quartet");
-        if (l == PP_MNG / 4) {
-            constexpr int o = PP_MNG % 4;
-            co[6] = V[o]; co[7] = V[o + 1]; co[8] = 2.0 * V[o + 2];
-        }
+        __syncthreads();          // (s_phi, s_tau, s_kt are reused)
     }
 }
 
