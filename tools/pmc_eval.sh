@@ -13,7 +13,7 @@ for set in \
   "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
   "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" ; do
   i=$((i+1))
-  timeout -k 5 ${PP_PMC_TIMEOUT:-60} rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/p$i -- python3 tools/scratch/eval_pass_time.py "$@" > $out/p$i.log 2>&1
+  timeout -k 5 ${PP_PMC_TIMEOUT:-60} rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/p$i -- python3 tools/dev_eval_pass_time.py "$@" > $out/p$i.log 2>&1
 done
 python3 - $out <<'PY' | tee $out/summary.txt
 import csv,glob,collections,sys
