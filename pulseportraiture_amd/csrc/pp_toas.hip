@@ -521,11 +521,25 @@ static void launch_xspec(pp_ctx* c, const XspecArgs& xa_in, bool tail, int mode)
         // ... and with a template that keeps 512 harmonics or more (mode 3)
         if (c->one_exchange && mode == 3) {
             if (tail) {
-                const dim3 grid(resident_grid(c, k_xspec_qf1024<TIN, true>, T, nrows, fft_grid(T, nrows)));
-                hipLaunchKernelGGL((k_xspec_qf1024<TIN, true>), grid, blk, 0, c->stream, xa);
+                const dim3 grid(resident_grid(c, k_xspec_qf<1024, TIN, true>, T, nrows, fft_grid(T, nrows)));
+                hipLaunchKernelGGL((k_xspec_qf<1024, TIN, true>), grid, blk, 0, c->stream, xa);
             } else {
-                const dim3 grid(resident_grid(c, k_xspec_qf1024<TIN, false>, T, nrows, fft_grid(T, nrows)));
-                hipLaunchKernelGGL((k_xspec_qf1024<TIN, false>), grid, blk, 0, c->stream, xa);
+                const dim3 grid(resident_grid(c, k_xspec_qf<1024, TIN, false>, T, nrows, fft_grid(T, nrows)));
+                hipLaunchKernelGGL((k_xspec_qf<1024, TIN, false>), grid, blk, 0, c->stream, xa);
+            }
+            return;
+        }
+    }
+    if constexpr (MM == 512) {
+        // 1024-bin rows, Taylor sums only: the one-exchange transform of pp_fftq.h (plan 8.4.2.8),
+        // whatever the template keeps
+        if (c->one_exchange && (mode == 2 || mode == 3)) {
+            if (tail) {
+                const dim3 grid(resident_grid(c, k_xspec_qf<512, TIN, true>, T, nrows, fft_grid(T, nrows)));
+                hipLaunchKernelGGL((k_xspec_qf<512, TIN, true>), grid, blk, 0, c->stream, xa);
+            } else {
+                const dim3 grid(resident_grid(c, k_xspec_qf<512, TIN, false>, T, nrows, fft_grid(T, nrows)));
+                hipLaunchKernelGGL((k_xspec_qf<512, TIN, false>), grid, blk, 0, c->stream, xa);
             }
             return;
         }

@@ -273,14 +273,23 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
 // TAIL (errs == NULL): harmonics 768..1024 are slots 12..15 (11..15 for the lane that owns
 // lam = 0, whose slot 15 is the Nyquist harmonic); their split is formed whether or not the
 // template keeps them.
-template <typename Tin, bool TAIL>
-__global__ __launch_bounds__(64, 2) void k_xspec_qf1024(XspecArgs a) {
-    constexpr int M = 1024, T = 64, R1 = 16, PER1 = 1;
-    constexpr int NSL = 16;
+// M = 512 (1024-bin rows, plan 8.4.2.8 of pp_fftq.h): the same with 8 harmonics per lane; serves every
+// template cut (slots beyond it are skipped) -- configs[1]'s template keeps 448 of 512 harmonics.
+#ifndef PP_QF512_WPS
+#define PP_QF512_WPS 3
+#endif
+template <int M, typename Tin, bool TAIL>
+__global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf(XspecArgs a) {
+    typedef FftQ<M> Q;
+    constexpr int T = 64, R1 = Q::R, PER1 = 1;
+    constexpr int NSL = R1;
+    constexpr int JT = (3 * NSL) / 4;        // first slot of the noise tail (k >= int(0.75 (M + 1)) = 64 JT)
+    static_assert((int)(0.75 * (M + 1)) == 64 * JT, "the noise tail starts on a slot boundary");
     typedef typename RawOf<Tin>::type Raw;
     constexpr int NRED = PP_TSTRIDE + (TAIL ? 2 : 1);       // the 12 Taylor sums, S_d (and the noise tail)
     constexpr int WRED = PP_WRED_DOUBLES(NRED) / 2;   // in cplx
-    constexpr int LDSN = WRED > FFTQ_LDS_ELEMS ? WRED : FFTQ_LDS_ELEMS;
+    constexpr int LDSN0 = Q::LDS_ELEMS > 64 * NSL ? Q::LDS_ELEMS : 64 * NSL;     // transpose image | published registers
+    constexpr int LDSN = WRED > LDSN0 ? WRED : LDSN0;
     __shared__ cplx lds[LDSN];
     int tid = threadIdx.x;
     const long long nrows = (long long)a.nsub * a.nchan;
@@ -300,10 +309,9 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qf1024(XspecArgs a) {
     for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
         rw.draw(a.ticket);
         asm volatile("" : "+v"(tid));
-        const int lam = fftq_lambda(tid);
+        const int lam = Q::lambda(tid);
         const bool l0 = (lam == 0);
         const int kb = l0 ? 64 : lam;
-        const cplx t1 = as_global(a.twB)[2 * tid], t2 = as_global(a.twB)[32 * (tid & 15)];
         const cplx wb0 = as_global(a.twB)[kb];
         const int ia = sub_of(a.act, i), ne = a.coff + n * a.cstep;   // true subint, channel
         const size_t rc = (size_t)ia * a.nchan_full + ne;
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qf1024(XspecArgs a) {
             for (int j = 0; j < NSL; ++j) mv[j] = mrow[kb + 64 * j - 1];   // k <= 1024: inside the row
             __builtin_amdgcn_sched_barrier(0);
         };
-        fftq1024<3>(v, lds, t1, t2, tid, &sd, template_loads);
+        Q::template run<3>(v, lds, as_global(a.twB), tid, &sd, template_loads);
         __builtin_amdgcn_sched_barrier(0);
         // ---- partners through LDS: all 16 registers out, 16 values back ----
         {
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qf1024(XspecArgs a) {
             load_some(0, R1 / 2);
             __builtin_amdgcn_sched_barrier(0);
         }
-        const cplx* pc = lds + fftq_lane_of((64 - lam) & 63);   // slot j: register 15 - j of the partner
+        const cplx* pc = lds + Q::lane_of((64 - lam) & 63);   // slot j: register NSL - 1 - j of the partner
         const cplx el = unit_phasor<true>((double)kb, phin);
         const cplx wst = make_double2(bcast_lane0(el.x), bcast_lane0(el.y));
         cplx e = el, wb = wb0;
@@ -357,11 +365,11 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qf1024(XspecArgs a) {
         const double kap0 = PP_TWO_PI * (double)kb;
         double tm[PP_TSTRIDE];
         double tail = 0.0;
-        cplx zc_nx = pc[64 * 15];
+        cplx zc_nx = pc[64 * (NSL - 1)];
 #pragma unroll
         for (int j = 0; j < NSL; ++j) {
             cplx zc = zc_nx;
-            if (j + 1 < NSL) zc_nx = pc[64 * (14 - j)];
+            if (j + 1 < NSL) zc_nx = pc[64 * (NSL - 2 - j)];
             if (j == NSL / 2) {
                 __builtin_amdgcn_sched_barrier(0);
                 load_some(R1 / 2, R1);
@@ -369,17 +377,17 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qf1024(XspecArgs a) {
             }
             // the template cut is a multiple of 64: a slot is kept or dropped as a whole
             const bool keep = (j == 0 || 64 * j < ktu);
-            if (keep || (TAIL && j >= 11)) {
-                const cplx zk = csel(l0, v[(j + 1) & 15], v[j]);
+            if (keep || (TAIL && j >= JT - 1)) {
+                const cplx zk = csel(l0, v[(j + 1) & (NSL - 1)], v[j]);
                 zc.y = -zc.y;
                 const cplx E = make_double2(zk.x + zc.x, zk.y + zc.y);
                 const cplx O = make_double2(zk.x - zc.x, zk.y - zc.y);
                 const cplx wo = cmul(wb, O);
                 // 2 d_k = E - i W^k O
                 const cplx dd = make_double2(E.x + wo.y, E.y - wo.x);
-                if (TAIL && j >= 11) {
+                if (TAIL && j >= JT - 1) {
                     const double pw = cnorm(dd);
-                    tail += (j >= 12 || l0) ? pw : 0.0;
+                    tail += (j >= JT || l0) ? pw : 0.0;
                 }
               if (keep) {
                 const cplx x = cmulc(dd, mv[j]);

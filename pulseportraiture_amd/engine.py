@@ -47,12 +47,25 @@ def _is_device_array(x):
     return False
 
 
+_WAITED = set()      # devices whose producer stream this engine call has already waited for
+
+
+def _new_call():
+    """Start of an engine call: every device array handed over was produced before it, so
+    one wait per device and call covers them all (seven waits per fit cost ~50 us)."""
+    _WAITED.clear()
+
+
 def _wait_for_producer(x):
+    key = str(x.device)
+    if key in _WAITED:
+        return
     try:
         import torch
         torch.cuda.current_stream(x.device).synchronize()
     except ImportError:      # (another array library: its arrays must be complete when handed over)
         pass
+    _WAITED.add(key)
 
 
 def _dp(a):
@@ -656,3 +669,19 @@ def default_engine(device=0):
     if eng is None:
         eng = _default[device] = Engine(device)
     return eng
+
+
+def _fresh_waits(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def call(self, *args, **kwargs):
+        _new_call()
+        return fn(self, *args, **kwargs)
+    return call
+
+
+# every entry point that may be handed device arrays starts a new round of producer waits
+for _name in [n for n, f in vars(Engine).items() if callable(f) and not n.startswith("_")]:
+    setattr(Engine, _name, _fresh_waits(getattr(Engine, _name)))
+

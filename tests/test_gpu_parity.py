@@ -2609,23 +2609,27 @@ def test_fused_reference_seed_2048_bins_one_exchange_kernel(eng, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-def test_one_exchange_transform_full_spectrum_template(dtype):
+@pytest.mark.parametrize("B", [2048, 1024])
+def test_one_exchange_transform_full_spectrum_template(dtype, B):
     """A template that keeps every harmonic (harm_eps = 0: k_xspec's paired mode 3 /
-    k_xspec_qf1024, all 16 harmonics of every lane, the Nyquist harmonic as slot 15 of the
+    k_xspec_qf<1024>, all 16 harmonics of every lane, the Nyquist harmonic as slot 15 of the
     lane that owns lambda = 0) and one cut at 512..960 harmonics: the one-exchange kernel
-    against the general kernel on the same batch and against the CPU oracle."""
+    against the general kernel on the same batch and against the CPU oracle.  B = 1024:
+    k_xspec_qf<512> (plan 8.4.2.8, 8 harmonics per lane), which serves every cut of a
+    1024-bin row -- all 512 harmonics, a cut in the upper half, and the example template's
+    own (the lower slots only)."""
     import torch
     from oracle import pptoas_oracle as orc
     from pulseportraiture_amd.engine import Engine
     from pulseportraiture_amd import gmodel
     from pulseportraiture_amd.pplib import guess_fit_freq, Dconst
-    C, B, nsub = 96, 2048, 36
-    for eps in (0.0, 1e-9):
+    C, nsub = 96, 36
+    for eps in ((0.0, 1e-9) if B == 2048 else (0.0, 1e-9, 2.0 ** -50)):
         e = Engine(0)
         e.set_option("harm_eps", eps)
         freqs, model, P0 = gmodel.example_model(C, B)
-        if eps:
-            # white "template noise": the cut then falls between 512 and 1024 harmonics
+        if eps == 1e-9:
+            # white "template noise": the cut then falls in the upper half of the harmonics
             model = model + 2e-6 * np.random.default_rng(5).standard_normal(model.shape)
         e.set_model(model)
         rng = np.random.default_rng(77)
