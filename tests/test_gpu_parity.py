@@ -2608,6 +2608,36 @@ def test_fused_reference_seed_2048_bins_one_exchange_kernel(eng, dtype):
 
 
 @pytest.mark.gpu
+def test_one_exchange_1024_bin_rows_in_the_list_and_seed_flows(eng):
+    """k_xspec_qf<512> where the rows come through a list of subints (poor DM guesses: the
+    Taylor model is taken again about the first solve's answer, for THOSE subints only) and
+    behind the pilot seed (device phase seed inside the fit): the same decisions and answers
+    as the general kernel (one_exchange = 0)."""
+    nsub = 48
+    data, freqs, P, x0, kw = _medium_batch(eng, nsub, C=256, B=1024, seed=13)
+    poor = np.arange(3, nsub, 7)
+    x1 = x0.copy()
+    x1[poor, 1] += np.where(np.arange(len(poor)) % 2, 5e-3, -4.5e-3)
+    runs = {}
+    for oe in (0, 1):
+        eng.set_option("one_exchange", oe)
+        try:
+            runs[oe] = (eng.fit_batch(data, freqs, P, x1, **kw),
+                        eng.fit_batch(data, freqs, P, x0, seed_ns=100, method="newton", **kw))
+        finally:
+            eng.set_option("one_exchange", 1)
+    for a, b in zip(runs[0], runs[1]):
+        assert (a["return_code"] == 2).all() and (b["return_code"] == 2).all()
+        np.testing.assert_array_equal(a["npass"], b["npass"])
+        assert np.abs(a["nfeval"] - b["nfeval"]).max() <= 1
+        assert _dphi_arr(a["params"][:, 0], b["params"][:, 0]).max() < PHI_BAR
+        assert np.abs(a["params"][:, 1] - b["params"][:, 1]).max() < DM_BAR
+        np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-10)
+        np.testing.assert_allclose(a["param_errs"][:, :2], b["param_errs"][:, :2], rtol=1e-9)
+    assert (runs[1][0]["npass"][poor] == 2).all()          # (the list flow was taken)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("B", [2048, 1024])
 def test_one_exchange_transform_full_spectrum_template(dtype, B):
