@@ -323,8 +323,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d"
                              % args.gpus)
+    # PP_BENCH_SHARE_GPU=1 (tests on a one-GPU box): the ranks share the GPUs there are and talk
+    # over gloo -- the whole N > 1 path (shards, barriers, max over ranks, the gather) with the
+    # real engine, minus RCCL, which wants one device per rank
+    share = os.environ.get("PP_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if share else device      # where the small collectives' tensors live
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # launched by torchrun
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -335,8 +342,10 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=device)
+            if share:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -376,7 +385,7 @@ def main():
         elapsed = time.perf_counter() - t0
         eng.set_option("profile", 0)
         if use_dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return res, gathered, elapsed, eng.kernel_times()
@@ -600,7 +609,8 @@ def strong_scaling(args, make_batch, sync, fence, device, rank, world, use_dist)
     gather_s = time.perf_counter() - t0
     total_s = fit_s + gather_s
     if use_dist:
-        t = torch.tensor([total_s, worst], dtype=torch.float64, device=device)
+        t = torch.tensor([total_s, worst], dtype=torch.float64,
+                         device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         total_s, worst = float(t[0].item()), float(t[1].item())
     guess = batch.guess

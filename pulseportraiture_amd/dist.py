@@ -57,8 +57,9 @@ def gather_records(rec, counts=None, device=None, dst=0):
     nmax = max(counts)
     as_tensor = torch.is_tensor(rec)
     if as_tensor:
-        dev = rec.device
-        src = rec.to(torch.float64)
+        # (gloo gathers host tensors only: a world of ranks sharing one GPU, in tests)
+        dev = torch.device("cpu") if dist.get_backend() == "gloo" else rec.device
+        src = rec.to(device=dev, dtype=torch.float64)
     else:
         dev = device if device is not None else "cpu"
         src = torch.from_numpy(np.ascontiguousarray(rec, dtype=np.float64)).to(dev)

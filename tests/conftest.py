@@ -24,8 +24,9 @@ def pytest_configure(config):
 
 
 def pytest_collection_finish(session):
-    # only when the test that collects the child is going to run
-    if not any("test_strong_scaling_bench_in_a_child_process" in it.nodeid for it in session.items):
+    # only when a test that collects a child is going to run
+    want = ("test_strong_scaling_bench_in_a_child_process", "test_two_ranks_sharing_the_gpu")
+    if not any(w in it.nodeid for it in session.items for w in want) or os.environ.get("PP_NO_BENCH_CHILD"):
         return
     try:
         import torch
@@ -34,18 +35,39 @@ def pytest_collection_finish(session):
     except Exception:
         return
     tmp = tempfile.mkdtemp(prefix="pp_bench_child_")
-    out, err = open(os.path.join(tmp, "line.json"), "w"), open(os.path.join(tmp, "stderr.txt"), "w")
-    recs = os.path.join(tmp, "records.npy")
-    proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + BENCH_CHILD_ARGS +
-                            ["--dump-records", recs], stdout=out, stderr=err, cwd=ROOT)
-    BENCH_CHILD.update(proc=proc, tmp=tmp, records=recs, out=out, err=err)
+    BENCH_CHILD.update(tmp=tmp)
+    if any(want[0] in it.nodeid for it in session.items):
+        out, err = open(os.path.join(tmp, "line.json"), "w"), open(os.path.join(tmp, "stderr.txt"), "w")
+        recs = os.path.join(tmp, "records.npy")
+        proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + BENCH_CHILD_ARGS +
+                                ["--dump-records", recs], stdout=out, stderr=err, cwd=ROOT)
+        BENCH_CHILD.update(proc=proc, records=recs, out=out, err=err)
+
+
+    # ... and the N = 2 path with the real engine: two ranks under torch.distributed.run that share
+    # this box's GPU and talk over gloo (PP_BENCH_SHARE_GPU=1), strong and weak scaling
+    if any("test_two_ranks_sharing_the_gpu" in it.nodeid for it in session.items):
+        import socket
+        for tag, extra in (("strong", ["--total-nsub", "600", "--nsub", "256"]), ("weak", ["--nsub", "128", "--steps", "2"])):
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            o = open(os.path.join(tmp, "line2_%s.json" % tag), "w")
+            e = open(os.path.join(tmp, "stderr2_%s.txt" % tag), "w")
+            r2 = os.path.join(tmp, "records2_%s.npy" % tag)
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                   "--gpus", "2", "--workload", "cfg2-512x1024-phiDM", "--no-cpu-baseline"] + extra
+            if tag == "strong":
+                cmd += ["--dump-records", r2]
+            p2 = subprocess.Popen(cmd, stdout=o, stderr=e, cwd=ROOT, env=dict(os.environ, PP_BENCH_SHARE_GPU="1"))
+            BENCH_CHILD["two_" + tag] = dict(proc=p2, out=o, err=e, records=r2)
 
 
 def pytest_sessionfinish(session, exitstatus):
-    proc = BENCH_CHILD.get("proc")
-    if proc is not None and proc.poll() is None:
-        proc.kill()
-        proc.wait()
+    procs = [BENCH_CHILD.get("proc")] + [v.get("proc") for k, v in BENCH_CHILD.items() if k.startswith("two_")]
+    for proc in procs:
+        if proc is not None and proc.poll() is None:
+            proc.kill()
+            proc.wait()
 
 
 @pytest.fixture(scope="session")

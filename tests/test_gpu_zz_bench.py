@@ -21,6 +21,8 @@ def test_strong_scaling_bench_in_a_child_process():
     import bench
     from pulseportraiture_amd import dist as ppdist
     from pulseportraiture_amd.engine import Engine
+    if os.environ.get("PP_NO_BENCH_CHILD"):
+        pytest.skip("PP_NO_BENCH_CHILD")
     assert BENCH_CHILD.get("proc") is not None, "conftest did not start the bench child (GPU visible?)"
     rc = BENCH_CHILD["proc"].wait(timeout=800)
     BENCH_CHILD["out"].close(); BENCH_CHILD["err"].close()
@@ -54,3 +56,53 @@ def test_strong_scaling_bench_in_a_child_process():
         np.testing.assert_allclose(r["params"], rec[first:first + n, :5], rtol=1e-13, atol=1e-15)
         b.free()
     eng.close()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_sharing_the_gpu():
+    """bench.py --gpus 2 under torch.distributed.run, the two ranks sharing this box's GPU and
+    talking over gloo (PP_BENCH_SHARE_GPU=1; RCCL wants one device per rank): the N > 1 path of
+    both modes with the real engine.  Strong scaling (600 subints of configs[1] in contiguous
+    shards of 300, sub-batches 256 + 44, ONE gather): every gathered record against fits made
+    directly in this process.  Weak scaling (128 subints per rank and step): the line's
+    bookkeeping."""
+    import torch
+    from tests.conftest import BENCH_CHILD
+    import bench
+    from pulseportraiture_amd import dist as ppdist
+    from pulseportraiture_amd.engine import Engine
+    if os.environ.get("PP_NO_BENCH_CHILD"):
+        pytest.skip("PP_NO_BENCH_CHILD")
+    lines = {}
+    for tag in ("strong", "weak"):
+        ch = BENCH_CHILD.get("two_" + tag)
+        assert ch is not None, "conftest did not start the two-rank bench (GPU visible?)"
+        rc = ch["proc"].wait(timeout=800)
+        ch["out"].close(); ch["err"].close()
+        text = open(os.path.join(BENCH_CHILD["tmp"], "line2_%s.json" % tag)).read().strip()
+        assert rc == 0 and text, open(os.path.join(BENCH_CHILD["tmp"], "stderr2_%s.txt" % tag)).read()[-3000:]
+        lines[tag] = json.loads(text.splitlines()[-1])
+    line = lines["strong"]
+    total = 600
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2
+    cfg = line["config"]
+    assert cfg["fits_per_rank"] == [300, 300] and cfg["sub_batches_rank0"] == [256, 44]
+    assert line["gathered_records"]["rows"] == total and line["value"] > 0
+    rec = np.load(BENCH_CHILD["two_strong"]["records"])
+    assert rec.shape == (total, ppdist.RECORD_WIDTH) and (rec[:, 17] == 2).all()
+    ns = argparse.Namespace(seed=20260101, dm0=34.56789, dm_offset=[3e-4, 2e-4], sigma=0.05,
+                            truth_guesses=False, measured_noise=False, method="trust-ncg")
+    eng = Engine(0)
+    dev = torch.device("cuda", 0)
+    b = bench.Batch(eng, ns, dev, cfg["workload"], total, "f64", 0)       # (subints by their global indices)
+    out = torch.zeros((total, ppdist.RECORD_WIDTH), dtype=torch.float64, device=dev)
+    b.fit(records=out)
+    mine = out.cpu().numpy()
+    np.testing.assert_array_equal(mine[:, 16:], rec[:, 16:])            # nfeval, return_code: rank 0's and rank 1's
+    np.testing.assert_allclose(mine[:, :16], rec[:, :16], rtol=1e-13, atol=1e-15)
+    b.free(); eng.close()
+    w = lines["weak"]
+    assert w["scaling"] == "weak" and w["n_gpus"] == 2 and w["steps"] == 2
+    assert w["config"]["nsub_per_gpu_per_step"] == 128
+    assert abs(w["value"] - 2 * 128 * 2 / (w["ms_per_step"] * 2e-3)) < 5e-3 * w["value"]     # all ranks' fits / max time (ms rounded)
+    assert w["gathered_records"]["rows"] == 2 * 2 * 128
