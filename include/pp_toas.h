@@ -92,6 +92,11 @@ void* pp_stream(pp_ctx* ctx);
  *   "max_iter"     trust-region iteration limit (default 64; reference: 1000)
  *   "profile"      1 = record HIP events around every kernel (pp_kernel_times)
  *   "check_every"  iterations between host checks of the active count
+ *   "lagged_check" 1 (default) = evaluation loops without the scattering model read that count
+ *                  one iteration behind, so the GPU never waits for the host's look at it
+ *                  (one extra, empty iteration is queued at the end); 0 = synchronous checks
+ *   "x_pad"        pad (elements) of the rows of a stored cross-spectrum (default 0: measured
+ *                  neutral)
  *   "max_work_bytes"  cap on device scratch per call (larger batches are split)
  *   "taylor"       1 (default) = fits without scattering first try the
  *                  per-channel Taylor-model solve; 0 = always iterate
@@ -114,11 +119,11 @@ void* pp_stream(pp_ctx* ctx);
  *   "paired_split" 1 (default) = 2048-bin rows whose template keeps fewer than 512
  *                  harmonics take the transform kernel that does the last FFT stage
  *                  and the even/odd split in registers; 0 = the generic kernel
- *   "one_exchange" 1 (default) = 2048-bin rows whose template keeps fewer than 512
- *                  harmonics, fitted without scattering (noise given or measured), take the
- *                  transform kernel whose FFT crosses the LDS once (lane-swap first
- *                  exchange) and whose split reads only the partner harmonics;
- *                  0 = the kernels above
+ *   "one_exchange" 1 (default) = 2048- and 1024-bin rows fitted without scattering (noise
+ *                  given or measured) take the transform kernels whose FFT crosses the LDS
+ *                  once (first exchange by lane swaps) and whose split reads only the partner
+ *                  harmonics -- k_xspec_q1024 / k_xspec_qf<1024> / k_xspec_qf<512> --, and the
+ *                  single-pass reference seed (pp_seed_ref) exists; 0 = the kernels above
  *   "scat_model"   scattering fits: 1 (default) = once the trust-ncg iteration is
  *                  predicted to stay within its range, ONE more pass over the
  *                  cross-spectrum leaves a degree-8 polynomial model of every channel's
