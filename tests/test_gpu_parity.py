@@ -831,6 +831,34 @@ def test_max_nbin_8192(eng):
     np.testing.assert_allclose(r["red_chi2"][0], o.red_chi2, rtol=1e-9)
 
 
+@pytest.mark.parametrize("nbin", [32, 64, 4096, 8192])
+def test_scattering_fit_at_the_ends_of_the_nbin_range(eng, nbin):
+    """phase + DM + log10 tau + alpha at the smallest and largest profile lengths (kept
+    harmonics 16 ... 4096 per row: one to 256 stages of k_eval_scat's walk, the model pass
+    and its rounds) against the oracle: raw answers, errors, chi^2, evaluation count."""
+    from oracle import pptoas_oracle as orc
+    from tests.synth_host import make_inputs, caller_guess, model_portrait
+    C = 12 if nbin <= 64 else 6
+    freqs, model = model_portrait(C, nbin)
+    tau_us = 300.0 if nbin <= 64 else 40.0          # (a scattering tail the profile resolves)
+    inp = make_inputs(C, nbin, 77 + nbin, model=model, sigma=0.05, tau_us=tau_us)
+    tau_rot = tau_us * 1e-6 / inp["P"]
+    gss = caller_guess(inp, fit_scat=True, log10_tau=True, tau_guess_rot=1.3 * tau_rot)
+    eng.set_model(model)
+    flags = [1, 1, 0, 1, 1]
+    r = eng.fit_batch(inp["data"][None], freqs, inp["P"], gss["init_params"], errs=inp["errs"],
+                      nu_fits=[[gss["nu_fit"]] * 3], fit_flags=flags, log10_tau=True)
+    o = orc.fit_portrait_full(inp["data"], model, gss["init_params"], inp["P"], freqs,
+                              [gss["nu_fit"]] * 3, [None] * 3, inp["errs"], flags, log10_tau=True)
+    assert r["return_code"][0] == o.return_code == 2
+    assert _dphi(r["params"][0, 0], o.phi) < PHI_BAR
+    assert abs(r["params"][0, 1] - o.DM) < DM_BAR
+    np.testing.assert_allclose(r["params"][0, 3:], [o.tau, o.alpha], rtol=1e-7)
+    np.testing.assert_allclose(r["param_errs"][0], o.param_errs, rtol=1e-6)
+    np.testing.assert_allclose(r["red_chi2"][0], o.red_chi2, rtol=1e-9)
+    assert abs(int(r["nfeval"][0]) - int(o.nfeval)) <= 1
+
+
 def test_get_TOAs_with_spline_model():
     """A .spl (PCA + B-spline) template goes through the same path; compare with
     the oracle fed the same template portrait."""
