@@ -152,8 +152,20 @@ class Batch(object):
     measured_noise, method -- bench's argparse namespace or a stand-in); device: the
     torch device of the resident portraits."""
 
-    def __init__(self, eng, args, device, workload, nsub, input_dtype, first_subint, seed_ns=0, reseed=False):
+    def __init__(self, eng, args, device, workload, nsub, input_dtype, first_subint, seed_ns=0, reseed=False,
+                 variant=None):
+        """variant (SURVEY 8d's other regimes): dict(sigma=1.5) the low-S/N recipe of examples/example.py:28;
+        dict(scint=True) per-channel scintillation gains (add_scintillation, pplib.py:1146-1174, nsin = 3,
+        amax = 1, wmax = 5); dict(measured_noise=True) errs=None, the noise of every channel measured from
+        the top quarter of its power spectrum as load_data always does (pplib.py:2227-2247);
+        dict(mask_frac=0.2) an independent random channel mask per subint (zapped archives: the fit does
+        C_i channels' work, pptoas.py:384-397)."""
         import torch
+        v = dict(variant or {})
+        self.sigma = float(v.get("sigma", args.sigma))
+        self.scint = bool(v.get("scint", False))
+        self.measured_noise = bool(v.get("measured_noise", getattr(args, "measured_noise", False)))
+        self.mask_frac = float(v.get("mask_frac", 0.0))
         from pulseportraiture_amd import gmodel
         from pulseportraiture_amd.pplib import guess_fit_freq
         self.eng, self.args, self.device = eng, args, device
@@ -187,8 +199,9 @@ class Batch(object):
             self.seed_prof = np.fft.irfft(np.fft.rfft(self.seed_prof) / (1.0 + 2j * np.pi * k * tg))
         self.data = torch.empty((self.nsub, C, B), device=self.device,
                                 dtype=torch.float64 if input_dtype == "f64" else torch.float32)
-        self.errs_dev = torch.full((self.nsub, C), self.args.sigma, dtype=torch.float64, device=self.device)
+        self.errs_dev = torch.full((self.nsub, C), self.sigma, dtype=torch.float64, device=self.device)
         self.P = np.full(self.nsub, self.P0)
+        self.mask_host, self.mask_dev = None, None
         self.generate(first_subint)
 
     def generate(self, first_subint):
@@ -197,8 +210,23 @@ class Batch(object):
         nsub, flags = self.nsub, self.flags
         inj, unit = injected_params(self.args.seed, first_subint, nsub, flags, self.args.dm0, self.args.dm_offset)
         self.inj = inj
-        self.eng.synth_portraits(self.data, self.freqs, self.P, inj, self.args.sigma, self.args.seed,
-                                 first_subint, slot=self.gen_slot)
+        gains = None
+        if self.scint:
+            # add_scintillation(random=True): sum of nsin sin^2 patterns across the band, per subint
+            rng = np.random.default_rng([self.args.seed, 424242, first_subint])
+            a, w, p = rng.uniform(0, 1.0, (nsub, 3)), rng.chisquare(5.0, (nsub, 3)), rng.uniform(0, 1, (nsub, 3))
+            ramp = np.linspace(0.0, np.pi, self.C)
+            gains = (a[:, :, None] * np.sin(w[:, :, None] * ramp[None, None, :] + p[:, :, None] * np.pi) ** 2).sum(axis=1)
+        if self.mask_frac > 0.0:
+            import torch
+            rng = np.random.default_rng([self.args.seed, 535353, first_subint])
+            self.mask_host = (rng.random((nsub, self.C)) >= self.mask_frac).astype(np.uint8)
+            self.mask_dev = torch.from_numpy(self.mask_host).to(self.device)
+        # mean frequency of the channels in use, per subint (pptoas.py:399)
+        self.nu_mean = np.full(nsub, float(self.freqs.mean())) if self.mask_host is None else \
+            (self.mask_host @ self.freqs) / self.mask_host.sum(axis=1)
+        self.eng.synth_portraits(self.data, self.freqs, self.P, inj, self.sigma, self.args.seed,
+                                 first_subint, slot=self.gen_slot, gains=gains)
         x0 = np.zeros((nsub, 5))
         x0[:, 1] = self.args.dm0
         if self.args.truth_guesses:
@@ -223,7 +251,8 @@ class Batch(object):
         template's mean profile (Ns = 100 grid + SciPy's simplex finish, retraced:
         the guess the reference itself would start from), move the phase to nu_fit."""
         nu_mean = float(self.freqs.mean())
-        out = self.eng.reference_phase_seed(self.data, self.freqs, self.P, np.ones((self.nsub, self.C)),
+        w = np.ones((self.nsub, self.C)) if self.mask_host is None else self.mask_host.astype(np.float64)
+        out = self.eng.reference_phase_seed(self.data, self.freqs, self.P, w,
                                             self.seed_prof, DM=np.full(self.nsub, self.args.dm0), nu_DM=nu_mean,
                                             Ns=100, finish='simplex')
         phi = out[:, 0] + DCONST * self.args.dm0 / self.P * (self.nu_fit ** -2 - nu_mean ** -2)
@@ -235,7 +264,8 @@ class Batch(object):
         if self.reseed and not getattr(self.args, "two_pass_seed", False) and not self.fused_unavailable:
             # the reference's own preamble inside the timed step, formed from the SAME pass over
             # the portraits as the fit (pp_seed_ref); batches without that path fall through
-            ref_seed = dict(weights=None, model_profs=self.seed_prof, nu_mean=np.full(n, float(self.freqs.mean())),
+            numean = self.nu_mean[:n]
+            ref_seed = dict(weights=None, model_profs=self.seed_prof, nu_mean=numean,
                             Ns=100, finish='simplex')
         elif self.reseed:
             # ... or with one more read of the portraits (rotation + channel mean +
@@ -249,7 +279,8 @@ class Batch(object):
 
     def _fit(self, n, records, method, ref_seed):
         return self.eng.fit_batch(self.data[:n], self.freqs, self.P[:n], self.x0[:n],
-                                  errs=None if self.args.measured_noise else self.errs_dev[:n],
+                                  errs=None if self.measured_noise else self.errs_dev[:n],
+                                  chan_mask=None if self.mask_dev is None else self.mask_dev[:n],
                                   nu_fits=np.full((n, 3), self.nu_fit), fit_flags=self.flags,
                                   log10_tau=self.log10_tau, per_channel="device",
                                   seed_ns=self.seed_ns, method=method or self.args.method, records=records,
@@ -258,6 +289,7 @@ class Batch(object):
     def free(self):
         import torch
         del self.data, self.errs_dev
+        self.mask_dev = None
         torch.cuda.empty_cache()
 
 
@@ -394,6 +426,11 @@ def main():
         fam = max((k for k in ktimes if ktimes[k][1] > 0), key=lambda k: ktimes[k][0])
         per_step_s = ktimes[fam][0] / steps
         abytes = algorithmic_bytes_per_fit(batch.C, batch.B, batch.s_bytes, batch.nsub)
+        if getattr(batch, "mask_host", None) is not None:
+            # the fit of a zapped subint does C_i channels' work (pptoas.py:384-397): the data term counts
+            # the channels in use, the shared template and the per-channel arrays all of them
+            c_eff = float(batch.mask_host.sum()) / batch.nsub
+            abytes += (c_eff - batch.C) * batch.B * batch.s_bytes
         achieved = abytes * batch.nsub / per_step_s / 1e9
         return fam, per_step_s, abytes, achieved, {
             "fits_per_s": round(nfits / elapsed, 2),
@@ -403,6 +440,7 @@ def main():
             "kernels_ms_per_step": {k: round(1e3 * v[0] / steps, 4) for k, v in ktimes.items() if v[1] > 0},
             "nfeval_mean": float(np.mean(res["nfeval"])), "nfeval_max": int(np.max(res["nfeval"])),
             "npass_mean": float(np.mean(res["npass"])), "npass_max": int(np.max(res["npass"])),
+            "left_one_pass_flow": int(np.sum(res["npass"] > 1)),
             "return_codes": {str(k): int(v) for k, v in zip(*np.unique(res["return_code"],
                                                                       return_counts=True))}}
 
@@ -495,6 +533,12 @@ def main():
         plan = [("seeded", args.workload, args.input_dtype, 100, None),
                 ("reference_seed_in_step", args.workload, args.input_dtype, -1, None),
                 ("f32", args.workload, "f32", 0, None),
+                # SURVEY 8(d)'s other regimes of the headline shape (Batch.__init__)
+                ("lowsnr_sigma1.5", args.workload, args.input_dtype, 0, None, dict(sigma=1.5)),
+                ("scint", args.workload, args.input_dtype, 0, None, dict(scint=True)),
+                ("measured_noise", args.workload, args.input_dtype, 0, None, dict(measured_noise=True)),
+                ("masked20", args.workload, args.input_dtype, 0, None, dict(mask_frac=0.2)),
+                ("masked20_reference_seed_in_step", args.workload, args.input_dtype, -1, None, dict(mask_frac=0.2)),
                 # a template that keeps every harmonic (data-derived spline / PCA templates do: harm_eps = 0)
                 ("full_spectrum_template", args.workload, "f64", 0, "full"),
                 ("cfg2-512x1024-phiDM", "cfg2-512x1024-phiDM", "f64", 0, None),
@@ -502,8 +546,10 @@ def main():
                 ("cfg4-2048x2048-scat", "cfg4-2048x2048-scat", "f64", 0, None),
                 ("cfg4-2048x2048-scat-newton", "cfg4-2048x2048-scat", "f64", 0, "newton"),
                 ("cfg4_reference_seed_in_step", "cfg4-2048x2048-scat", "f64", -1, None)]
-        for key, wl, dt, sns, meth in plan:
-            if wl == args.workload and dt == args.input_dtype and sns == args.seed_ns and meth is None:
+        for entry in plan:
+            key, wl, dt, sns, meth = entry[:5]
+            variant = entry[5] if len(entry) > 5 else None
+            if wl == args.workload and dt == args.input_dtype and sns == args.seed_ns and meth is None and not variant:
                 continue
             full = (meth == "full")
             if full:
@@ -512,7 +558,7 @@ def main():
                     continue
                 eng.set_option("harm_eps", 0.0)
             try:
-                b = Batch(eng, args, device, wl, 0, dt, 0, seed_ns=max(sns, 0), reseed=(sns < 0))
+                b = Batch(eng, args, device, wl, 0, dt, 0, seed_ns=max(sns, 0), reseed=(sns < 0), variant=variant)
                 if sns < 0:
                     b.guess = "the reference's preamble INSIDE the timed step (rotation + channel mean + fit_phase_shift " \
                               "with the simplex finish, from the fit's own single pass over the portraits), then " \
@@ -526,6 +572,10 @@ def main():
                                                           r["param_errs"][:, 1]))
                 if full:
                     sm["model_harmonics_kept"] = b.nharm
+                if variant:
+                    sm["variant"] = variant
+                    if b.mask_host is not None:
+                        sm["mean_channels_in_use"] = float(b.mask_host.sum()) / b.nsub
                 if sns < 0:
                     sm["single_pass"] = not b.fused_unavailable
                 others[key] = sm

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 4
+#define PP_ABI_VERSION 5
 
 /* status codes */
 #define PP_OK 0
@@ -145,11 +145,24 @@ void* pp_stream(pp_ctx* ctx);
  *                  the exact local optimum; 1 = what scipy.optimize.brute does by default
  *                  and the reference therefore returns (pplib.py:2085): the Nelder-Mead
  *                  simplex to xtol = ftol = 1e-4, operation by operation
+ *   "skip_masked"  1 (default) = channels a subint's chan_mask removes are not transformed at
+ *                  all: the transform walks a compact list of the (subint, channel) rows in use,
+ *                  as the reference slices the good channels away before its fit
+ *                  (pptoas.py:384-397); 0 = every row is transformed and masked ones get weight 0
+ *   "nfev_shadow"  one-pass flow, method trust-ncg: how SciPy's one-point cache is mirrored when nfeval is
+ *                  counted.  0 (default): proposals are compared as displacements from the expansion
+ *                  point (resolution 1e-21: the closing proposal p = -H^-1 g is always a new point and
+ *                  counts, which is what the reference does in most fits); 1: on the absolute iterate
+ *                  fl(x + p) as SciPy forms it -- exact in principle, but the closing p is the
+ *                  device's own rounding noise, not the reference's (measured: DESIGN.md section 2)
  *   "moments_in_xspec"  1 (default) = the Taylor moments are accumulated inside
  *                  the transform kernel and no cross-spectrum is stored; 0 = store
  *                  the cross-spectrum and take the moments in a second pass
  */
 int pp_set_option(pp_ctx* ctx, const char* name, double value);
+/* the current value of an option (a caller that changes one for a call -- max_iter = 0 to
+ * evaluate only -- reads it first and puts it back) */
+int pp_get_option(pp_ctx* ctx, const char* name, double* value);
 
 /* ---- model portraits ---------------------------------------------------- */
 /* Upload an nchan x nbin template into slot `slot` (0..PP_MAX_SLOTS-1), rFFT it
@@ -390,12 +403,14 @@ int pp_channel_red_chi2(pp_ctx* ctx, const void* src, int dtype, int on_device,
                         const double* scales, const double* errs, double* red_chi2);
 
 /* Fill dst[nsub][nchan][nbin] (device pointer, dtype) with
- *   gain[i][n] * rotate(model slot, -phi_i, -DM_i, -GM_i) + N(0, sigma)
+ *   gains[i][n] * rotate(model slot, -phi_i, -DM_i, -GM_i) + N(0, sigma)
  * using a counter-based RNG keyed on (seed, first_subint + i, channel, bin).
- * inj is host [nsub][3] (phi, DM, GM injected, reference frequency infinity). */
+ * inj is host [nsub][3] (phi, DM, GM injected, reference frequency infinity); gains is host
+ * [nsub][nchan] -- per-channel amplitudes, e.g. the scintillation pattern of add_scintillation
+ * (pplib.py:1146-1174) -- or NULL (= 1 everywhere).  The synthetic inputs of SURVEY 8(d). */
 int pp_synth_portraits(pp_ctx* ctx, int slot, void* dst, int dtype, int nsub,
                        const double* freqs, const double* P, const double* inj,
-                       double sigma, uint64_t seed, int64_t first_subint);
+                       const double* gains, double sigma, uint64_t seed, int64_t first_subint);
 
 /* ---- measurement --------------------------------------------------------- */
 /* Accumulated HIP-event time per kernel family since the last reset (only

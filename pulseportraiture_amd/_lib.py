@@ -8,13 +8,15 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpptoas_hip.so")
+# PP_TOAS_LIB: another build of the same library (kernel experiments, trace builds under variants/);
+# like the default it must exist and carry the binding's ABI -- there is no fallback either way
+LIB_PATH = os.environ.get("PP_TOAS_LIB") or os.path.join(_HERE, "csrc", "libpptoas_hip.so")
 
 PP_OK, PP_EINVAL, PP_EHIP, PP_ENOMEM, PP_ESTATE, PP_ENOTSUP = 0, -1, -2, -3, -4, -5
 PP_F64, PP_F32 = 0, 1
 PP_MAX_SLOTS = 64
 PP_RECORD_WIDTH = 18
-ABI_VERSION = 4
+ABI_VERSION = 5
 PP_METHOD_TRUST_NCG, PP_METHOD_NEWTON = 0, 1
 
 c_double_p = C.POINTER(C.c_double)
@@ -62,6 +64,7 @@ SYMBOLS = {
     "pp_synchronize": (C.c_int, [C.c_void_p]),
     "pp_stream": (C.c_void_p, [C.c_void_p]),
     "pp_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "pp_get_option": (C.c_int, [C.c_void_p, C.c_char_p, c_double_p]),
     "pp_model_set": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                C.c_int, C.c_int]),
     "pp_model_nharm": (C.c_int, [C.c_void_p, C.c_int]),
@@ -86,7 +89,7 @@ SYMBOLS = {
                                       C.c_int64, c_double_p, c_double_p, C.c_double,
                                       C.c_double]),
     "pp_synth_portraits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int,
-                                     C.c_int, c_double_p, c_double_p, c_double_p,
+                                     C.c_int, c_double_p, c_double_p, c_double_p, c_double_p,
                                      C.c_double, C.c_uint64, C.c_int64]),
     "pp_gaussian_portrait": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, C.c_char_p,
                                        C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,

@@ -1,0 +1,179 @@
+// Rows of ANY even length (numpy.fft.rfft takes every nbin: pptoaslib.py:976-979).
+//
+// The tuned transforms of pp_kernels.h / pp_xspec1024*.h are plans for powers of two.  Every
+// other even row length B = 2 M (M <= 2048) goes through Bluestein's identity here: the complex
+// DFT of the M packed pairs z_j = x_2j + i x_2j+1,
+//     Z_k = w_k sum_j (z_j w_j) conj(w_{k-j}),      w_j = exp(-i pi j^2 / M),
+// is a circular convolution of length L = 2^n >= 2 M - 1, taken with the power-of-two transform
+// of pp_fft.h (two transforms of L points per row; the transform of the chirp is a per-length
+// table built on the host in extended precision, j^2 reduced mod 2 M in integers), followed by
+// the usual even/odd split d_k = E - i W_B^k O.  One workgroup per row; the harmonics are used
+// straight from LDS by the same sums the tuned kernels form (S_d, the noise tail, the stored
+// cross-spectrum, the first evaluation's sums or the 12 Taylor sums), so everything downstream
+// of the transform -- solvers, post-fit stage, seeds -- is shared.  The template spectrum of such
+// a slot is pitched to Mp = M rounded up to 64 with zeros beyond M: the kept-harmonic counts stay
+// multiples of 64 as the evaluators assume, and the padding contributes nothing.
+// A compatibility path: ~3 x the LDS traffic and instructions of a tuned plan per sample.
+#pragma once
+#include "pp_kernels.h"
+
+namespace pp {
+
+struct AnyArgs {
+    int nbin, M, Mp;          // true row length, harmonics M = nbin / 2, pitch of the slot's spectrum rows
+    const cplx* chirp;        // [M]  w_j
+    const cplx* bft;          // [L]  transform of the wrapped conj chirp
+    const cplx* twL;          // twiddles of the L-point transform (table of 2 L)
+    const cplx* twB;          // [M + 1] W_B^k of the true row length (the split)
+    int mode;                 // -1: harmonics 0..M to hout; 0..3 as k_xspec's MODE
+    int tail;                 // measure the noise from the top quarter of the power spectrum
+    cplx* hout;               // mode -1: [nrows][M + 1]
+    const unsigned char* mask;   // [nsub][nchan_full] rows to skip, or nullptr
+};
+
+template <int L, typename Tin>
+__global__ __launch_bounds__(FftPlan<L>::T) void k_any(XspecArgs a, AnyArgs g) {
+    constexpr int T = FftPlan<L>::T, PL = FftPlan<L>::PADLOG, NW = T / 64;
+    __shared__ cplx lds[FftPlan<L>::LDS_ELEMS];
+    __shared__ cplx buf[L];
+    __shared__ double red[NW * 16];
+    const int tid = threadIdx.x;
+    const int M = g.M, H = M + 1;
+    const int kc = (int)(0.75 * H);          // get_noise_PS: int((1 - 1/4) * len(pows))
+    const long long nrows = (long long)a.nsub * a.nchan;
+    const double invL = 1.0 / (double)L;
+    for (long long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int n = (int)(row / a.nsub), i = (int)(row % a.nsub);
+        const int ia = sub_of(a.act, i), ne = a.coff + n * a.cstep;      // true subint, channel
+        const size_t rc = (size_t)ia * a.nchan_full + ne;
+        const size_t rx = (size_t)i * a.nchan + n;                       // compact row of X
+        if (g.mask && !g.mask[rc]) continue;                             // (uniform over the workgroup)
+        const Tin* x = reinterpret_cast<const Tin*>(a.data) + rc * (size_t)g.nbin;
+        // ---- a_j = z_j w_j, zero-padded ----
+        for (int j = tid; j < L; j += T) {
+            cplx v = make_double2(0.0, 0.0);
+            if (j < M) v = cmul(make_double2((double)x[2 * j], (double)x[2 * j + 1]), g.chirp[j]);
+            buf[j] = v;
+        }
+        __syncthreads();
+        fft_row<L, cplx>(lds, buf, g.twL, tid);
+        __syncthreads();
+        // ---- convolution with the chirp: conj(A_k Bf_k), transformed again ----
+        for (int k = tid; k < L; k += T) {
+            const cplx p = cmul(lds[lds_pad<PL>(k)], g.bft[k]);
+            buf[k] = make_double2(p.x, -p.y);
+        }
+        __syncthreads();
+        fft_row<L, cplx>(lds, buf, g.twL, tid);
+        __syncthreads();
+        // ---- Z_k = w_k conj(.) / L ----
+        for (int k = tid; k < M; k += T) {
+            const cplx c = lds[lds_pad<PL>(k)];
+            buf[k] = cmul(make_double2(c.x * invL, -c.y * invL), g.chirp[k]);
+        }
+        __syncthreads();
+        // harmonic k of the real transform: d_k = E - i W_B^k O; d_0, d_M from Z_0
+        auto harm = [&](int k) -> cplx {
+            const cplx z0 = buf[0];
+            if (k == 0) return make_double2(z0.x + z0.y, 0.0);
+            if (k == M) return make_double2(z0.x - z0.y, 0.0);
+            const cplx zk = buf[k];
+            cplx zc = buf[M - k];
+            zc.y = -zc.y;
+            const cplx E = make_double2(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
+            const cplx O = make_double2(0.5 * (zk.x - zc.x), 0.5 * (zk.y - zc.y));
+            const cplx wo = cmul(g.twB[k], O);
+            return make_double2(E.x + wo.y, E.y - wo.x);
+        };
+        if (g.mode < 0) {
+            for (int k = tid; k <= M; k += T) g.hout[(size_t)row * H + k] = harm(k);
+            __syncthreads();
+            continue;
+        }
+        const cplx* mrow = as_global(a.slot ? a.mft[a.slot[ia]] : a.mft0) + (size_t)ne * g.Mp;
+        const int ktn = min(M, a.ktab ? as_global(a.slot ? a.ktab[a.slot[ia]] : a.kt0)[ne] : a.Kt);
+        const double phin = (g.mode != 0) ? a.ph0[rc] : 0.0;
+        double acc[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+        // acc: 0..11 Taylor sums (modes 2, 3) or 0..2 = s0, s1, s2 (mode 1); 12 = S_d; 13 = noise tail
+        for (int k = 1 + tid; k <= M; k += T) {
+            const cplx d = harm(k);
+            const double pw = cnorm(d);
+            acc[12] += pw;
+            if (g.tail && k >= kc) acc[13] += pw;
+            if (k > ktn) continue;
+            const cplx xk = cmulc(d, mrow[k - 1]);
+            if (g.mode <= 1) store_x(a, rx, k, xk);
+            if (g.mode == 0) continue;
+            const cplx z = cmul(xk, unit_phasor((double)k, phin));
+            if (g.mode == 1) {
+                const double kk = (double)k;
+                acc[0] += z.x;
+                acc[1] = fma(kk, z.y, acc[1]);
+                acc[2] = fma(kk * kk, z.x, acc[2]);
+            } else {
+                static_assert(PP_TJ == 10, "power ladder written for order 10");
+                const double kap = PP_TWO_PI * (double)k;
+                const double p2 = kap * kap, p4 = p2 * p2, p6 = p4 * p2, p8 = p4 * p4, p10 = p8 * p2;
+                const double ui = z.y * kap;
+                acc[0] += z.x;
+                acc[1] += ui;
+                acc[2] = fma(p2, z.x, acc[2]);
+                acc[3] = fma(p2, ui, acc[3]);
+                acc[4] = fma(p4, z.x, acc[4]);
+                acc[5] = fma(p4, ui, acc[5]);
+                acc[6] = fma(p6, z.x, acc[6]);
+                acc[7] = fma(p6, ui, acc[7]);
+                acc[8] = fma(p8, z.x, acc[8]);
+                acc[9] = fma(p8, ui, acc[9]);
+                acc[10] = fma(p10, z.x, acc[10]);
+                acc[11] = fma(p10 * kap, fabs(xk.x) + fabs(xk.y), acc[11]);
+            }
+        }
+        // ---- workgroup totals (fixed order: deterministic) ----
+#pragma unroll
+        for (int q = 0; q < 14; ++q) acc[q] = group_sum<64>(acc[q]);
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < 14; ++q) red[(tid >> 6) * 16 + q] = acc[q];
+        }
+        __syncthreads();
+        if (tid < 14) {
+            double v = 0.0;
+            for (int w = 0; w < NW; ++w) v += red[w * 16 + tid];
+            if (tid == 12) a.sdraw[rc] = v;
+            else if (tid == 13) { if (g.tail) a.noise[rc] = sqrt(v / (2.0 * M) / (double)(H - kc)); }
+            else if (g.mode >= 2) {
+                // Re(i^q z): +Re, -Im, -Re, +Im, ...
+                if (tid < PP_TSTRIDE)
+                    a.tay[rc * PP_TSTRIDE + tid] = (tid <= PP_TJ && ((tid & 3) == 1 || (tid & 3) == 2)) ? -v : v;
+            } else if (g.mode == 1 && tid < 3) {
+                a.csum0[rc * 3 + tid] = (tid == 0) ? v : (tid == 1 ? -PP_TWO_PI * v : -PP_TWO_PI * PP_TWO_PI * v);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// template spectrum of a slot from the harmonics k_any left in hout[nchan][M + 1]: rows pitched
+// to Mp with zeros beyond M, |m|^2, its sum and maximum, the DC term
+__global__ __launch_bounds__(64) void k_model_from_harm(const cplx* hout, int M, int Mp, cplx* mft, double* msq, double* msum,
+                                                        double* mmax, double* mdc) {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const cplx* h = hout + (size_t)n * (M + 1);
+    double s = 0.0, mx = 0.0;
+    for (int k = 1 + tid; k <= Mp; k += 64) {
+        const cplx d = (k <= M) ? h[k] : make_double2(0.0, 0.0);
+        const double p = cnorm(d);
+        mft[(size_t)n * Mp + (k - 1)] = d;
+        msq[(size_t)n * Mp + (k - 1)] = p;
+        s += p;
+        mx = fmax(mx, p);
+    }
+    s = group_sum<64>(s);
+    mx = group_max<64>(mx);
+    if (tid == 0) { msum[n] = s; mmax[n] = mx; mdc[n] = h[0].x; }
+}
+
+}  // namespace pp

@@ -47,9 +47,10 @@ struct SynthArgs {
     uint64_t seed;
     int64_t first_subint;
     int nsub, nchan;
+    const double* gain;   // [nsub][nchan] amplitude of the template in every channel (scintillation), or nullptr = 1
 };
 
-// dst = irfft(m_k e^{2 pi i k phi_n}) + sigma N(0,1); phi_n = -(phi + DM and GM
+// dst = gain irfft(m_k e^{2 pi i k phi_n}) + sigma N(0,1); phi_n = -(phi + DM and GM
 // delays): data "delayed by" the injected values (pptoaslib.py:52-81, 57-58)
 template <int M, typename Tout>
 __global__ __launch_bounds__(FftPlan<M>::T) void k_synth(SynthArgs a) {
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(FftPlan<M>::T) void k_synth(SynthArgs a) {
         __syncthreads();
         fft_row<M, cplx>(lds, zin, a.twB, tid);
         Tout* out = reinterpret_cast<Tout*>(a.dst) + (size_t)row * (2 * M);
-        const double inv = 1.0 / (double)M;
+        const double inv = (a.gain ? a.gain[row] : 1.0) / (double)M;
         for (int j = tid; j < M; j += T) {
             const cplx r = lds[lds_pad<PL>(j)];
             double z0, z1;

@@ -13,7 +13,8 @@ static int aux_chunk_cap(pp_ctx* c, double per_sub, int nsub) {
 extern "C" int pp_fit_phase_shift_batch(pp_ctx* c, const double* data, const double* model, const double* noise,
                                         int nprof, int nbin, double lo, double hi, int Ns, double* out7) {
     if (!c || !data || !model || !out7) return fail(PP_EINVAL, "pp_fit_phase_shift_batch: null argument");
-    if (!nbin_ok(nbin) || nprof < 1) return fail(PP_EINVAL, "pp_fit_phase_shift_batch: bad shape %d x %d", nprof, nbin);
+    if (!nbin_ok(nbin)) return nbin_refuse("pp_fit_phase_shift_batch", nbin);
+    if (nprof < 1) return fail(PP_EINVAL, "pp_fit_phase_shift_batch: bad shape %d x %d", nprof, nbin);
     if (Ns < 1) return fail(PP_EINVAL, "pp_fit_phase_shift_batch: Ns %d", Ns);
     HIP_TRY(hipSetDevice(c->device));
     const int M = nbin / 2;
@@ -74,7 +75,8 @@ extern "C" int pp_reference_phase_seed(pp_ctx* c, const void* src, int dtype, in
                                        const double* model_profs, double lo, double hi, int Ns, double* out7) {
     if (!c || !src || !freqs || !P || !par3 || !weights || !model_profs || !out7)
         return fail(PP_EINVAL, "pp_reference_phase_seed: null argument");
-    if (!nbin_ok(nbin) || nsub < 1 || nchan < 1 || Ns < 1) return fail(PP_EINVAL, "pp_reference_phase_seed: bad shape");
+    if (!nbin_ok(nbin)) return nbin_refuse("pp_reference_phase_seed", nbin);
+    if (nsub < 1 || nchan < 1 || Ns < 1) return fail(PP_EINVAL, "pp_reference_phase_seed: bad shape");
     if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_reference_phase_seed: dtype %d", dtype);
     if (freqs_stride != 0 && freqs_stride != nchan) return fail(PP_EINVAL, "freqs_stride must be 0 or nchan");
     HIP_TRY(hipSetDevice(c->device));
@@ -159,12 +161,13 @@ extern "C" int pp_reference_phase_seed(pp_ctx* c, const void* src, int dtype, in
 }
 
 extern "C" int pp_synth_portraits(pp_ctx* c, int slot, void* dst, int dtype, int nsub, const double* freqs,
-                                  const double* P, const double* inj, double sigma, uint64_t seed,
-                                  int64_t first_subint) {
+                                  const double* P, const double* inj, const double* gains, double sigma,
+                                  uint64_t seed, int64_t first_subint) {
     if (!c || !dst || !freqs || !P || !inj) return fail(PP_EINVAL, "pp_synth_portraits: null argument");
     if (slot < 0 || slot >= PP_MAX_SLOTS || !c->slots[slot].set) return fail(PP_ESTATE, "pp_synth_portraits: slot %d not set", slot);
     if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_synth_portraits: dtype %d", dtype);
     if (nsub < 1) return fail(PP_EINVAL, "pp_synth_portraits: nsub %d", nsub);
+    if (!nbin_ok(c->slots[slot].nbin)) return nbin_refuse("pp_synth_portraits", c->slots[slot].nbin);
     HIP_TRY(hipSetDevice(c->device));
     ModelSlot& s = c->slots[slot];
     const int C = s.nchan, B = s.nbin, M = B / 2;
@@ -172,10 +175,12 @@ extern "C" int pp_synth_portraits(pp_ctx* c, int slot, void* dst, int dtype, int
     if ((rc = upload(c, c->freqs, freqs, (size_t)C * 8))) return rc;
     if ((rc = upload(c, c->P, P, (size_t)nsub * 8))) return rc;
     if ((rc = upload(c, c->x0, inj, (size_t)nsub * 24))) return rc;
+    if (gains) if ((rc = upload(c, c->errs, gains, (size_t)nsub * C * 8))) return rc;
     const cplx* tw = nullptr;
     if ((rc = get_twiddles(c, B, &tw))) return rc;
     SynthArgs a{s.mft.as<cplx>(), s.mdc.as<double>(), dst, c->freqs.as<double>(), c->P.as<double>(),
-                c->x0.as<double>(), tw, sigma, seed, first_subint, nsub, C};
+                c->x0.as<double>(), tw, sigma, seed, first_subint, nsub, C,
+                gains ? c->errs.as<double>() : (const double*)nullptr};
     {
         Prof pr(c, KF_SYNTH);
         PP_DISPATCH_M(M, {
@@ -194,7 +199,8 @@ extern "C" int pp_rotate_portraits(pp_ctx* c, const void* src, void* dst, int dt
                                    int nchan, int nbin, const double* freqs, int64_t freqs_stride,
                                    const double* P, const double* par3, double nu_DM, double nu_GM) {
     if (!c || !src || !dst || !freqs || !P || !par3) return fail(PP_EINVAL, "pp_rotate_portraits: null argument");
-    if (!nbin_ok(nbin) || nsub < 1 || nchan < 1) return fail(PP_EINVAL, "pp_rotate_portraits: bad shape");
+    if (!nbin_ok(nbin)) return nbin_refuse("pp_rotate_portraits", nbin);
+    if (nsub < 1 || nchan < 1) return fail(PP_EINVAL, "pp_rotate_portraits: bad shape");
     if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_rotate_portraits: dtype %d", dtype);
     if (freqs_stride != 0 && freqs_stride != nchan) return fail(PP_EINVAL, "freqs_stride must be 0 or nchan");
     HIP_TRY(hipSetDevice(c->device));
@@ -253,7 +259,8 @@ extern "C" int pp_align_accumulate(pp_ctx* c, const void* src, int dtype, int on
                                    double* total_weights) {
     if (!c || !src || !freqs || !P || !par3 || !weights || !aligned || !total_weights)
         return fail(PP_EINVAL, "pp_align_accumulate: null argument");
-    if (!nbin_ok(nbin) || nsub < 1 || nchan < 1) return fail(PP_EINVAL, "pp_align_accumulate: bad shape");
+    if (!nbin_ok(nbin)) return nbin_refuse("pp_align_accumulate", nbin);
+    if (nsub < 1 || nchan < 1) return fail(PP_EINVAL, "pp_align_accumulate: bad shape");
     if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_align_accumulate: dtype %d", dtype);
     if (freqs_stride != 0 && freqs_stride != nchan) return fail(PP_EINVAL, "freqs_stride must be 0 or nchan");
     HIP_TRY(hipSetDevice(c->device));
@@ -320,7 +327,8 @@ extern "C" int pp_channel_red_chi2(pp_ctx* c, const void* src, int dtype, int on
                                    double* red_chi2) {
     if (!c || !src || !freqs || !P || !params5 || !nu_refs3 || !scales || !errs || !red_chi2)
         return fail(PP_EINVAL, "pp_channel_red_chi2: null argument");
-    if (!nbin_ok(nbin) || nsub < 1 || nchan < 1) return fail(PP_EINVAL, "pp_channel_red_chi2: bad shape");
+    if (!nbin_ok(nbin)) return nbin_refuse("pp_channel_red_chi2", nbin);
+    if (nsub < 1 || nchan < 1) return fail(PP_EINVAL, "pp_channel_red_chi2: bad shape");
     if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_channel_red_chi2: dtype %d", dtype);
     if (freqs_stride != 0 && freqs_stride != nchan) return fail(PP_EINVAL, "freqs_stride must be 0 or nchan");
     HIP_TRY(hipSetDevice(c->device));
@@ -391,7 +399,8 @@ static int gauss_generate(pp_ctx* c, int nchan, int nbin, const double* freqs, c
                           double dc, double tau_rot, double alpha, int ngauss, const double* comps,
                           double* dev_out) {
     if (!freqs || !code || !comps) return fail(PP_EINVAL, "gaussian portrait: null argument");
-    if (!nbin_ok(nbin) || nchan < 1) return fail(PP_EINVAL, "gaussian portrait: bad shape");
+    if (!nbin_ok(nbin)) return nbin_refuse("gaussian portrait", nbin);
+    if (nchan < 1) return fail(PP_EINVAL, "gaussian portrait: bad shape");
     if (ngauss < 1 || ngauss > PP_MAX_GAUSS) return fail(PP_EINVAL, "gaussian portrait: 1..%d components", PP_MAX_GAUSS);
     for (int j = 0; j < 3; ++j)
         if (code[j] != '0' && code[j] != '1') return fail(PP_EINVAL, "gaussian portrait: model code '%.3s'", code);
@@ -496,7 +505,7 @@ extern "C" int pp_model_set_spline(pp_ctx* c, int slot, int nchan, int nbin, con
                                    const double* basis, int nknots, const double* t, const double* coefs,
                                    int degree) {
     if (!c) return fail(PP_EINVAL, "pp_model_set_spline: null context");
-    if (!nbin_ok(nbin)) return fail(PP_EINVAL, "pp_model_set_spline: nbin %d must be a power of two in [32,8192]", nbin);
+    if (!nbin_ok(nbin)) return nbin_refuse("pp_model_set_spline", nbin);
     HIP_TRY(hipSetDevice(c->device));
     int rc;
     if ((rc = c->X.reserve((size_t)nchan * nbin * 8))) return rc;     // scratch for the portrait
@@ -510,6 +519,7 @@ extern "C" int pp_model_apply_response(pp_ctx* c, int slot, const double* rconst
     if (!c || slot < 0 || slot >= PP_MAX_SLOTS || !c->slots[slot].set)
         return fail(PP_ESTATE, "pp_model_apply_response: slot not set");
     if (!rconst && !smear_wid) return PP_OK;
+    if (!nbin_ok(c->slots[slot].nbin)) return nbin_refuse("pp_model_apply_response", c->slots[slot].nbin);
     HIP_TRY(hipSetDevice(c->device));
     ModelSlot& s = c->slots[slot];
     const int M = s.nbin / 2;

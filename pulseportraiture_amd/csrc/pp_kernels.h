@@ -67,6 +67,9 @@ struct XspecArgs {
     unsigned* ticket;
     unsigned ticket_base;
     int x_f32;                // the cross-spectrum is stored as pairs of floats (8 B per harmonic)
+    // rows in use (RowWalk): one word per chunk of PP_ROW_CHUNK rows in the kernel's own row order,
+    // or nullptr = every row.  Only with act == nullptr, cstep == 1 (the main pass over a batch).
+    const unsigned* mwords;
 };
 
 // one harmonic of the stored cross-spectrum (row pitch Xs elements of 16 or 8 bytes)
@@ -124,6 +127,7 @@ struct FitArgs {
     // reference-seed flow (pp_xspec1024r.h): the Taylor model was taken about x0 (the pilot seed's
     // phase), the iteration starts from xstart (the reference's own guess, known only after the pass)
     const double* xstart;     // [nsub][5] or nullptr (= start at the expansion point)
+    int nfev_shadow;          // one-pass flow: SciPy's one-point cache compared on the absolute iterate fl(x + p)
 };
 
 __device__ __forceinline__ int sub_of(const int* act, int j) { return act ? act[j] : j; }
@@ -216,28 +220,122 @@ __global__ void k_model_kcut(const cplx* mft, const double* mmax, int /*nchan*/,
 #endif
 // DYN = false (workgroups of several waves: the ticket would have to cross waves):
 // chunk c goes to workgroup c mod G; the tickets are then not drawn at all.
+// Masked rows (XspecArgs::mwords): one 32-bit word per chunk, bit b set = row 32 c + b is in
+// use (k_mask_words builds them from the batch's chan_mask).  The walk visits the set bits of a
+// chunk's word only -- a channel the mask removes from a subint is neither read nor transformed,
+// as the reference slices the good channels away before its fit (pptoas.py:384-397).  All of it
+// is scalar work: the word of the NEXT chunk is fetched (one scalar load) while the current one
+// is walked, as soon as the ticket that names it has arrived; an empty chunk costs its visitor
+// one more (synchronous) ticket.  Every in-range chunk still draws exactly one ticket.
 template <bool DYN>
 struct RowWalk {
     long long row, row_nx, cstart, cend;
     unsigned tick;     // lane 0: the ticket; kept per-lane (not uniform) so that it stays
                        // in a VGPR and nothing waits for the atomic before next() reads it
     bool more, more_nx;
-    __device__ __forceinline__ void start(long long nrows) {
+    // masked walk
+    const unsigned* mw;        // nullptr: every row
+    unsigned bits;             // rows of this chunk still to come (after `row`)
+    unsigned wnx;              // the next chunk's word, once fetched
+    bool fresh, have_wnx;      // `row` is the first row visited of its chunk; wnx is valid
+    long long cnx;             // first row of the next chunk (valid with have_wnx)
+    __device__ __forceinline__ unsigned word_of(long long c0, long long nrows) const {
+        return (c0 < nrows) ? as_global(mw)[c0 / PP_ROW_CHUNK] : 0u;
+    }
+    // first row of the chunk a visitor of chunk start c0 moves on to (DYN: one synchronous ticket)
+    __device__ __forceinline__ long long chunk_after(long long c0, unsigned* ticket, unsigned base) {
+        if (DYN) {
+            unsigned t = 0;
+            if (threadIdx.x == 0) t = atomicAdd(ticket, 1u);
+            t = __builtin_amdgcn_readfirstlane(t) - base;
+            return ((long long)gridDim.x + (long long)t) * PP_ROW_CHUNK;
+        }
+        return c0 + (long long)gridDim.x * PP_ROW_CHUNK;
+    }
+    __device__ __forceinline__ void start(long long nrows, const unsigned* mwords = nullptr, unsigned* ticket = nullptr,
+                                          unsigned base = 0) {
+        static_assert(PP_ROW_CHUNK == 32, "one 32-bit mask word per chunk");
+        mw = mwords; bits = 0; wnx = 0; have_wnx = false; cnx = 0;
         cstart = (long long)blockIdx.x * PP_ROW_CHUNK;
         cend = min(nrows, cstart + PP_ROW_CHUNK);
         row = cstart;
-        more = row < nrows;
+        if (mw) {
+            // the first chunk with a row in use (an empty one still owes its ticket)
+            unsigned w = word_of(cstart, nrows);
+            while (w == 0u && cstart < nrows) {
+                cstart = chunk_after(cstart, ticket, base);
+                w = word_of(cstart, nrows);
+            }
+            w = __builtin_amdgcn_readfirstlane(w);
+            cend = min(nrows, cstart + PP_ROW_CHUNK);
+            row = cstart + (w ? __builtin_ctz(w) : 0);
+            bits = w & (w - 1u);
+        }
+        more = cstart < nrows;
         row_nx = row; more_nx = more;
         tick = threadIdx.x;
+        fresh = true;
     }
     // top of a row: draw the ticket of the chunk after this one
     __device__ __forceinline__ void draw(unsigned* ticket) {
-        if (DYN && row == cstart && threadIdx.x == 0) tick = atomicAdd(ticket, 1u);
+        if (DYN && fresh && threadIdx.x == 0) tick = atomicAdd(ticket, 1u);
+    }
+    // masked walk, top of a row that is not the first of its chunk: the ticket has long arrived --
+    // fetch the word of the chunk it names, to be looked at when this chunk runs out
+    __device__ __forceinline__ void peek(long long nrows, unsigned base) {
+        if (mw && !fresh && !have_wnx) {
+            if (DYN) {
+                const unsigned t = __builtin_amdgcn_readfirstlane(tick) - base;
+                cnx = ((long long)gridDim.x + (long long)t) * PP_ROW_CHUNK;
+            } else {
+                cnx = cstart + (long long)gridDim.x * PP_ROW_CHUNK;
+            }
+            wnx = word_of(cnx, nrows);
+            have_wnx = true;
+        }
     }
     // (subint, channel) of the row after this one: the next of the chunk, or the
     // first of the chunk the ticket names (one division per chunk, all scalar)
     __device__ __forceinline__ void next(int i, int n, int& i_nx, int& n_nx, long long nrows, int nsub,
-                                         unsigned base) {
+                                         unsigned base, unsigned* ticket = nullptr) {
+        if (mw) {
+            more_nx = true;
+            if (bits) {
+                // the next row in use of this chunk
+                const int b = __builtin_ctz(bits);
+                bits &= bits - 1u;
+                row_nx = cstart + b;
+                i_nx = i + (int)(row_nx - row); n_nx = n;
+                while (i_nx >= nsub) { i_nx -= nsub; ++n_nx; }
+                return;
+            }
+            // this chunk is done: the one its ticket names, or the first after it with a row in use
+            long long c0; unsigned w;
+            if (have_wnx) { c0 = cnx; w = wnx; }
+            else {
+                if (DYN) {
+                    const unsigned t = __builtin_amdgcn_readfirstlane(tick) - base;
+                    c0 = ((long long)gridDim.x + (long long)t) * PP_ROW_CHUNK;
+                } else c0 = cstart + (long long)gridDim.x * PP_ROW_CHUNK;
+                w = word_of(c0, nrows);
+            }
+            while (w == 0u && c0 < nrows) {
+                c0 = chunk_after(c0, ticket, base);
+                w = word_of(c0, nrows);
+            }
+            w = __builtin_amdgcn_readfirstlane(w);
+            have_wnx = false;
+            cstart = c0;
+            cend = min(nrows, cstart + PP_ROW_CHUNK);
+            more_nx = cstart < nrows;
+            row_nx = cstart + (w ? __builtin_ctz(w) : 0);
+            bits = w & (w - 1u);
+            if (more_nx) {
+                n_nx = __builtin_amdgcn_readfirstlane((int)(row_nx / nsub));
+                i_nx = __builtin_amdgcn_readfirstlane((int)(row_nx % nsub));
+            }
+            return;
+        }
         row_nx = row + 1;
         i_nx = i + 1; n_nx = n;
         if (i_nx == nsub) { i_nx = 0; ++n_nx; }
@@ -258,7 +356,11 @@ struct RowWalk {
             }
         }
     }
-    __device__ __forceinline__ void advance() { row = row_nx; more = more_nx; }
+    __device__ __forceinline__ void advance() {
+        // (a row is the first of its chunk when the walk has just changed chunks)
+        fresh = (row_nx / PP_ROW_CHUNK != row / PP_ROW_CHUNK);
+        row = row_nx; more = more_nx;
+    }
 };
 
 #ifndef PP_SPLIT_U
@@ -306,7 +408,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
     // channel -- hence the template row -- changes once per nsub rows, and the
     // (subint, channel) indices advance without divisions.
     RowWalk<(NW == 1)> rw;
-    rw.start(nrows);
+    rw.start(nrows, a.mwords, a.ticket, a.ticket_base);
     long long row = rw.row;
     int n = 0, i = 0;
     if (rw.more) {
@@ -327,6 +429,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
     int i_nx = i, n_nx = n;
     for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
         rw.draw(a.ticket);
+        rw.peek(nrows, a.ticket_base);
         // Everything derived from the thread index and the twiddles is invariant
         // over this loop, and the compiler hoists all of it (LDS addresses of every
         // stage, twiddle powers: ~50 VGPRs held across the whole row).  Recomputing
@@ -380,7 +483,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             // loads exist)
             auto prefetch = [&]() {
                 __builtin_amdgcn_sched_barrier(0);
-                rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base);
+                rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket);
                 const size_t rn = rw.more_nx
                     ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
                 stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);
@@ -776,6 +879,47 @@ __global__ __launch_bounds__(256) void k_setup(FitArgs a, const double* errs, co
         wts[idx] = (mask && !mask[idx]) ? 0.0 : w;
     }
     if (do_init && idx < a.nsub) init_state(a, (int)idx);
+}
+
+// The rows in use of a batch as RowWalk wants them: one 32-bit word per chunk of PP_ROW_CHUNK
+// rows, in two row orders -- `wmain`: row = n nsub + i (the transform kernels' channel-major
+// order); `wsub` (optional): row = (cb nsub + i) 32 + b for channel 32 cb + b of subint i
+// (k_xspec_qr1024's chunks of 32 channels of one subint: the mask's own layout).  A block takes
+// 32 subints x 256 channels of the mask through LDS (coalesced reads) and every thread assembles
+// the 32 subints of its channel; words that straddle two channels (nsub not a multiple of 32) are
+// merged with atomicOr, so both arrays must be zero on entry.  grid = (ceil(nchan / 256), ceil(nsub / 32)).
+__global__ __launch_bounds__(256) void k_mask_words(const unsigned char* mask, int nsub, int nchan, unsigned* wmain,
+                                                    unsigned* wsub) {
+    __shared__ unsigned char tile[32][256 + 4];
+    const int tid = threadIdx.x, n0 = blockIdx.x * 256, i0 = blockIdx.y * 32;
+    const int n = n0 + tid;
+    for (int b = 0; b < 32; ++b) {
+        const int i = i0 + b;
+        tile[b][tid] = (i < nsub && n < nchan) ? mask[(size_t)i * nchan + n] : (unsigned char)0;
+    }
+    __syncthreads();
+    if (n < nchan) {
+        unsigned w = 0;
+        for (int b = 0; b < 32; ++b) w |= (tile[b][tid] ? 1u : 0u) << b;
+        const long long r0 = (long long)n * nsub + i0;      // first row of these 32
+        const int sh = (int)(r0 & 31);
+        if (w) {
+            if (sh == 0) atomicOr(&wmain[r0 >> 5], w);
+            else {
+                atomicOr(&wmain[r0 >> 5], w << sh);
+                if (w >> (32 - sh)) atomicOr(&wmain[(r0 >> 5) + 1], w >> (32 - sh));
+            }
+        }
+    }
+    if (wsub && tid < 32 * 8) {
+        // (subint i0 + tid / 8, channel block (n0 / 32) + tid % 8): 32 consecutive channels of one subint
+        const int b = tid >> 3, q = tid & 7, i = i0 + b, cb = (n0 >> 5) + q;
+        if (i < nsub && cb * 32 < nchan) {
+            unsigned w = 0;
+            for (int k = 0; k < 32; ++k) w |= (tile[b][q * 32 + k] ? 1u : 0u) << k;
+            wsub[(size_t)cb * nsub + i] = w;
+        }
+    }
 }
 
 // local (phi_n, tau_n) derivatives of F_n = -C^2/S from weighted sums
@@ -1455,13 +1599,17 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
         // SciPy's ScalarFunction keeps the point it evaluated last: a proposal that IS that
         // point (a rejected step proposed again under a smaller radius, ~15 times in a row
         // at the end of the iteration) is answered from the cache and not counted in nfev.
-        // (SciPy compares absolute parameters, fl(x + p): its closing proposal -- p = -H^-1 g
-        // with g pure rounding noise by then, ~1e-15 -- also counts as cached when it happens
-        // to fall below half an ulp of x in every coordinate.  That is a coin toss of the
-        // reference's own rounding (its nfeval is k or k + 1 on it); the displacements kept
-        // here resolve 1e-21, so the closing proposal is always a new point and is counted,
-        // which is also what the reference does more often than not.)
-        double xl[3] = {dx0[0], dx0[1], dx0[2]}, f2 = f, g2[3] = {g[0], g[1], g[2]}, H2[9];
+        // SciPy iterates on ABSOLUTE parameters, x <- fl(x + p), and compares the proposal, bit for
+        // bit, with the point its ScalarFunction evaluated last.  The walk keeps that absolute iterate
+        // (xa) beside the displacement from the expansion point (dx) the model is evaluated at, so the
+        // cache decision -- including whether the closing proposal p = -H^-1 g ~ 1e-15 still changes
+        // x and therefore counts as an evaluation (pptoaslib.py:1017 `nfeval = results.nfev`) -- is
+        // taken on the reference's own numbers.  (The model itself is evaluated at the unrounded
+        // displacement: half an ulp of DM is worth ~1e-15 rot, the same size as the rounding of the
+        // reference's own phases at these DMs.)
+        double xa[3], xla[3], xld[3] = {dx0[0], dx0[1], dx0[2]};
+        for (int j = 0; j < 3; ++j) { xa[j] = off_centre ? (fl[j] ? a.xstart[i * 5 + j] : st.xe[j]) : st.xe[j]; xla[j] = xa[j]; }
+        double f2 = f, g2[3] = {g[0], g[1], g[2]}, H2[9];
         for (int j = 0; j < 9; ++j) H2[j] = H[j];
         for (;;) {
             double gs[3], Hs[9], p[3];
@@ -1469,9 +1617,12 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
             int hits = 0;
             tr_cg_steihaug_scipy(nf, f, gs, Hs, radius, p, &hits);
             const double pred = f - tr_model_value(nf, f, gs, Hs, p);
-            double xt[3] = {dx[0], dx[1], dx[2]};
-            for (int r_ = 0; r_ < nf; ++r_) xt[idx[r_]] += p[r_];
-            const bool cached = (xt[0] == xl[0] && xt[1] == xl[1] && xt[2] == xl[2]);
+            double xta[3] = {xa[0], xa[1], xa[2]}, xt[3] = {dx[0], dx[1], dx[2]};
+            for (int r_ = 0; r_ < nf; ++r_) { xta[idx[r_]] = xa[idx[r_]] + p[r_]; xt[idx[r_]] += p[r_]; }
+            // (a.nfev_shadow = 0: the comparison is made on the displacements, which resolve 1e-21 -- the
+            // closing proposal is then always a new point and is counted)
+            const bool cached = a.nfev_shadow ? (xta[0] == xla[0] && xta[1] == xla[1] && xta[2] == xla[2])
+                                              : (xt[0] == xld[0] && xt[1] == xld[1] && xt[2] == xld[2]);
             if (!(pred > 0.0)) {
                 // SciPy's status 2, the reference's normal exit -- taken AFTER it has evaluated
                 // the proposal (scipy/optimize/_trustregion.py: m_proposed.fun comes before the
@@ -1481,13 +1632,18 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
             }
             if (!cached) {
                 dpath = fmax(dpath, evalm(xt, f2, g2, H2));
-                for (int j = 0; j < 3; ++j) xl[j] = xt[j];
+                for (int j = 0; j < 3; ++j) { xla[j] = xta[j]; xld[j] = xt[j]; }
                 ++nfev;
             }
             bool finite = isfinite(f2);
             for (int j = 0; j < 3; ++j) finite = finite && isfinite(g2[j]);
+#if defined(PP_TAYLOR_TRACE) && PP_TAYLOR_TRACE >= 3
+            if (tid == 0)
+                printf("tay it %2d f %.17g f_new %.17g actual %.3e pred %.3e rho %.3f radius %.3e hits %d cached %d\n", it, f, f2,
+                       f - f2, pred, (f - f2) / pred, radius, hits, (int)cached);
+#endif
             if (tr_scipy_accept(f, f2, pred, hits, finite, &radius)) {
-                for (int j = 0; j < 3; ++j) dx[j] = xt[j];
+                for (int j = 0; j < 3; ++j) { dx[j] = xt[j]; xa[j] = xta[j]; }
                 f = f2;
                 for (int j = 0; j < 3; ++j) g[j] = g2[j];
                 for (int j = 0; j < 9; ++j) H[j] = H2[j];

@@ -6,8 +6,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdarg>
 #include <cstdio>
+#include <climits>
+#include <cstdint>
 #include <cstring>
 #include <map>
 #include <atomic>
@@ -18,6 +21,7 @@
 #include "pp_kernels.h"
 #include "pp_extra.h"
 #include "pp_xspec1024r.h"
+#include "pp_anybin.h"
 
 using namespace pp;
 
@@ -69,6 +73,7 @@ struct DevBuf {
 struct ModelSlot {
     bool set = false;
     int nchan = 0, nbin = 0, Kt = 0;
+    int Mp = 0;        // pitch of the spectrum rows: nbin / 2, rounded up to 64 for row lengths that are no power of two
     DevBuf mft, msum, mmax, mdc, kt, msq;
 };
 
@@ -80,6 +85,8 @@ struct pp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::map<int, DevBuf> twiddles;   // by nbin
+    struct AnyPlan { int L = 0; DevBuf chirp, bft; };
+    std::map<int, AnyPlan> anyplans;  // Bluestein tables of row lengths that are no power of two (pp_anybin.h)
     ModelSlot slots[PP_MAX_SLOTS];
     DevBuf mft_table, msum_table, kt_table, mdc_table, msq_table;   // device arrays of slot base pointers
     // work buffers
@@ -88,6 +95,7 @@ struct pp_ctx {
     DevBuf ticket;                          // k_xspec's chunk counter (RowWalk); never reset,
     unsigned ticket_base = 0;               // ... its value before the next launch (wraps)
     int ncu = 0;                            // compute units of the device
+    DevBuf mwords;   // rows in use of a masked batch, one word per chunk (k_mask_words), both row orders
     DevBuf refbuf;   // reference-seed flow: partial channel sums, spectra, profiles, start points
     DevBuf inpack;   // per-batch small inputs (freqs, P, x0, nu_fit, nu_out, slot): one H2D copy
     void* in_host = nullptr; size_t in_host_cap = 0;   // pinned staging of inpack
@@ -120,6 +128,8 @@ struct pp_ctx {
     int seed_ndm = 1;           // DM trials of the coarse (phi, DM) seed grid (1 = phase only, at the guessed DM)
     double seed_dm_step = 0.0;  // their spacing [pc cm^-3]
     double max_work_bytes = 96e9;
+    int nfev_shadow = 0;        // (measured: profiles/README.md round 4 -- see pp_set_option's table in include/pp_toas.h)
+    int skip_masked = 1;        // channels masked out of a subint are not transformed at all (compact row list)
     // profiling
     struct Span { int fam; hipEvent_t a, b; };
     std::vector<Span> spans;
@@ -218,11 +228,13 @@ extern "C" int pp_destroy(pp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     resolve_spans(c);
     for (auto& kv : c->twiddles) kv.second.release();
+    for (auto& kv : c->anyplans) { kv.second.chirp.release(); kv.second.bft.release(); }
     for (auto& s : c->slots) { s.mft.release(); s.msum.release(); s.mmax.release(); s.mdc.release(); s.kt.release(); s.msq.release(); }
     if (c->o_host) (void)hipHostFree(c->o_host);
     if (c->in_host) (void)hipHostFree(c->in_host);
     c->inpack.release();
     c->refbuf.release();
+    c->mwords.release();
     DevBuf* bufs[] = {&c->ticket, &c->o_pack, &c->mft_table, &c->msum_table, &c->kt_table, &c->mdc_table, &c->msq_table, &c->data, &c->X, &c->sdraw, &c->noise, &c->wts, &c->freqs,
                       &c->errs, &c->mask, &c->P, &c->x0, &c->nufit, &c->nuout, &c->slot, &c->state, &c->csum,
                       &c->partial, &c->o_params, &c->o_errs, &c->o_nu, &c->o_cov, &c->o_chi2, &c->o_rchi2,
@@ -246,33 +258,45 @@ extern "C" int pp_synchronize(pp_ctx* c) {
 
 extern "C" void* pp_stream(pp_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
+// one table for pp_set_option / pp_get_option: name, kind ('d' double, 'i' int), lower clamp of ints
+namespace {
+struct OptRef { const char* name; char kind; void* p; int imin; };
+}
+static bool option_ref(pp_ctx* c, const std::string& n, OptRef* out) {
+    const OptRef tab[] = {
+        {"harm_eps", 'd', &c->harm_eps, 0}, {"max_iter", 'i', &c->max_iter, INT32_MIN},
+        {"profile", 'i', &c->profile, INT32_MIN}, {"check_every", 'i', &c->check_every, 1},
+        {"lagged_check", 'i', &c->lagged_check, INT32_MIN}, {"max_work_bytes", 'd', &c->max_work_bytes, 0},
+        {"taylor", 'i', &c->use_taylor, INT32_MIN}, {"moments_in_xspec", 'i', &c->moments_in_xspec, INT32_MIN},
+        {"paired_split", 'i', &c->paired_split, INT32_MIN}, {"one_exchange", 'i', &c->one_exchange, INT32_MIN},
+        {"scat_model", 'i', &c->scat_model, INT32_MIN}, {"scat_model_tol", 'd', &c->scat_model_tol, 0},
+        {"scat_model_bet", 'i', &c->scat_model_bet, INT32_MIN}, {"x_f32", 'i', &c->x_f32, INT32_MIN},
+        {"fuse_scat", 'i', &c->fuse_scat, INT32_MIN}, {"x_pad", 'i', &c->x_pad, INT32_MIN},
+        {"fps_finish", 'i', &c->fps_finish, INT32_MIN}, {"debug_poison", 'i', &c->debug_poison, INT32_MIN},
+        {"taylor_recentre", 'i', &c->taylor_recentre, INT32_MIN}, {"seed_chan_stride", 'i', &c->seed_chan_stride, 1},
+        {"seed_min_snr", 'd', &c->seed_min_snr, 0}, {"seed_ndm", 'i', &c->seed_ndm, 1},
+        {"seed_dm_step", 'd', &c->seed_dm_step, 0}, {"skip_masked", 'i', &c->skip_masked, INT32_MIN},
+        {"nfev_shadow", 'i', &c->nfev_shadow, INT32_MIN},
+    };
+    for (const OptRef& o : tab)
+        if (n == o.name) { *out = o; return true; }
+    return false;
+}
+
 extern "C" int pp_set_option(pp_ctx* c, const char* name, double value) {
     if (!c || !name) return fail(PP_EINVAL, "pp_set_option: null argument");
-    std::string n(name);
-    if (n == "harm_eps") c->harm_eps = value;
-    else if (n == "max_iter") c->max_iter = (int)value;
-    else if (n == "profile") c->profile = (int)value;
-    else if (n == "check_every") c->check_every = std::max(1, (int)value);
-    else if (n == "lagged_check") c->lagged_check = (int)value;
-    else if (n == "max_work_bytes") c->max_work_bytes = value;
-    else if (n == "taylor") c->use_taylor = (int)value;
-    else if (n == "moments_in_xspec") c->moments_in_xspec = (int)value;
-    else if (n == "paired_split") c->paired_split = (int)value;
-    else if (n == "one_exchange") c->one_exchange = (int)value;
-    else if (n == "scat_model") c->scat_model = (int)value;
-    else if (n == "scat_model_tol") c->scat_model_tol = value;
-    else if (n == "scat_model_bet") c->scat_model_bet = (int)value;
-    else if (n == "x_f32") c->x_f32 = (int)value;
-    else if (n == "fuse_scat") c->fuse_scat = (int)value;
-    else if (n == "x_pad") c->x_pad = (int)value;
-    else if (n == "fps_finish") c->fps_finish = (int)value;
-    else if (n == "debug_poison") c->debug_poison = (int)value;
-    else if (n == "taylor_recentre") c->taylor_recentre = (int)value;
-    else if (n == "seed_chan_stride") c->seed_chan_stride = std::max(1, (int)value);
-    else if (n == "seed_min_snr") c->seed_min_snr = value;
-    else if (n == "seed_ndm") c->seed_ndm = std::max(1, (int)value);
-    else if (n == "seed_dm_step") c->seed_dm_step = value;
-    else return fail(PP_EINVAL, "pp_set_option: unknown option '%s'", name);
+    OptRef o;
+    if (!option_ref(c, name, &o)) return fail(PP_EINVAL, "pp_set_option: unknown option '%s'", name);
+    if (o.kind == 'd') *static_cast<double*>(o.p) = value;
+    else *static_cast<int*>(o.p) = std::max(o.imin, (int)value);
+    return PP_OK;
+}
+
+extern "C" int pp_get_option(pp_ctx* c, const char* name, double* value) {
+    if (!c || !name || !value) return fail(PP_EINVAL, "pp_get_option: null argument");
+    OptRef o;
+    if (!option_ref(c, name, &o)) return fail(PP_EINVAL, "pp_get_option: unknown option '%s'", name);
+    *value = o.kind == 'd' ? *static_cast<double*>(o.p) : (double)*static_cast<int*>(o.p);
     return PP_OK;
 }
 
@@ -324,12 +348,108 @@ static int get_twiddles(pp_ctx* c, int nbin, const cplx** out) {
     return PP_OK;
 }
 
+// row lengths with a tuned plan (every entry point), and every row length the fit itself takes:
+// the reference's numpy.fft.rfft accepts any (pptoaslib.py:976-979); even lengths up to 4096 that
+// are no power of two go through pp_anybin.h
 static bool nbin_ok(int nbin) { return nbin >= 32 && nbin <= 8192 && (nbin & (nbin - 1)) == 0; }
+static bool nbin_any_ok(int nbin) { return nbin_ok(nbin) || (nbin >= 8 && nbin <= 4096 && nbin % 2 == 0); }
+static int fail(int code, const char* fmt, ...);
+// what an entry point without a general-length path answers
+static int nbin_refuse(const char* who, int nbin) {
+    if (nbin_any_ok(nbin))
+        return fail(PP_ENOTSUP, "%s: nbin %d is no power of two: only pp_model_set, pp_fit_portrait_batch and pp_rfft_rows "
+                                "take general even row lengths", who, nbin);
+    return fail(PP_EINVAL, "%s: nbin %d must be a power of two in [32, 8192] (the fit also takes even lengths up to 4096)",
+                who, nbin);
+}
+
+// Bluestein tables of a row length B = 2 M that is no power of two
+static int get_twiddles(pp_ctx* c, int nbin, const cplx** out);
+static int get_any_plan(pp_ctx* c, int nbin, pp_ctx::AnyPlan** out) {
+    auto it = c->anyplans.find(nbin);
+    if (it != c->anyplans.end()) { *out = &it->second; return PP_OK; }
+    const int M = nbin / 2;
+    int L = 16;
+    while (L < 2 * M - 1) L <<= 1;
+    // (four transform sizes are instantiated: the next one up serves)
+    const int sizes[4] = {64, 256, 1024, 4096};
+    for (int sz : sizes) if (L <= sz) { L = sz; break; }
+    const long double pi = 3.141592653589793238462643383279502884L;
+    std::vector<double> w(2 * (size_t)M);
+    std::vector<std::complex<long double>> b((size_t)L, std::complex<long double>(0.0L, 0.0L));
+    for (int j = 0; j < M; ++j) {
+        const long long q = ((long long)j * j) % (2LL * M);        // j^2 mod 2 M, exactly
+        const long double ang = pi * (long double)q / (long double)M;
+        const long double cs = cosl(ang), sn = sinl(ang);
+        w[2 * (size_t)j] = (double)cs; w[2 * (size_t)j + 1] = (double)(-sn);           // w_j = exp(-i pi j^2 / M)
+        b[j] = std::complex<long double>(cs, sn);                                       // conj(w_j)
+        if (j) b[L - j] = b[j];
+    }
+    // transform of the wrapped chirp, radix 2 in extended precision (once per row length)
+    {
+        for (int i = 1, j = 0; i < L; ++i) {
+            int bit = L >> 1;
+            for (; j & bit; bit >>= 1) j ^= bit;
+            j ^= bit;
+            if (i < j) std::swap(b[i], b[j]);
+        }
+        for (int len = 2; len <= L; len <<= 1) {
+            for (int i = 0; i < L; i += len)
+                for (int k = 0; k < len / 2; ++k) {
+                    const long double ang = -2.0L * pi * (long double)k / (long double)len;
+                    const std::complex<long double> tw(cosl(ang), sinl(ang));
+                    const std::complex<long double> u = b[i + k], v = b[i + k + len / 2] * tw;
+                    b[i + k] = u + v; b[i + k + len / 2] = u - v;
+                }
+        }
+    }
+    std::vector<double> bf(2 * (size_t)L);
+    for (int k = 0; k < L; ++k) { bf[2 * (size_t)k] = (double)b[k].real(); bf[2 * (size_t)k + 1] = (double)b[k].imag(); }
+    pp_ctx::AnyPlan pl;
+    pl.L = L;
+    int rc;
+    if ((rc = pl.chirp.reserve(w.size() * 8))) return rc;
+    if ((rc = pl.bft.reserve(bf.size() * 8))) return rc;
+    HIP_TRY(hipMemcpy(pl.chirp.p, w.data(), w.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(pl.bft.p, bf.data(), bf.size() * 8, hipMemcpyHostToDevice));
+    c->anyplans[nbin] = pl;
+    *out = &c->anyplans[nbin];
+    return PP_OK;
+}
 
 static int fft_grid(int T, long long nrows) {
     // persistent workgroups: enough to fill 256 CUs at the LDS-limited residency
     long long g = 256LL * (T <= 128 ? 8 : (T == 256 ? 4 : 2));
     return (int)std::max(1LL, std::min(nrows, g));
+}
+
+// one launch of the general-length transform (pp_anybin.h): mode -1 = harmonics to hout, 0..3 = k_xspec's modes
+static int launch_any(pp_ctx* c, const XspecArgs& xa, int nbin, int Mp, int dtype, int mode, bool tail, cplx* hout,
+                      const unsigned char* mask) {
+    pp_ctx::AnyPlan* pl = nullptr;
+    int rc;
+    if ((rc = get_any_plan(c, nbin, &pl))) return rc;
+    const cplx *twL = nullptr, *twB = nullptr;
+    if ((rc = get_twiddles(c, 2 * pl->L, &twL))) return rc;
+    if ((rc = get_twiddles(c, nbin, &twB))) return rc;
+    AnyArgs g{nbin, nbin / 2, Mp, pl->chirp.as<cplx>(), pl->bft.as<cplx>(), twL, twB, mode, tail ? 1 : 0, hout, mask};
+    const long long nrows = (long long)xa.nsub * xa.nchan;
+    const int grid = (int)std::max(1LL, std::min(nrows, 2048LL));
+#define PP_ANY(LL)                                                                                            \
+    do {                                                                                                      \
+        if (dtype == PP_F64) hipLaunchKernelGGL((k_any<LL, double>), dim3(grid), dim3(FftPlan<LL>::T), 0, c->stream, xa, g); \
+        else hipLaunchKernelGGL((k_any<LL, float>), dim3(grid), dim3(FftPlan<LL>::T), 0, c->stream, xa, g);   \
+    } while (0)
+    switch (pl->L) {
+        case 64: PP_ANY(64); break;
+        case 256: PP_ANY(256); break;
+        case 1024: PP_ANY(1024); break;
+        case 4096: PP_ANY(4096); break;
+        default: return fail(PP_EINVAL, "no transform of %d points", pl->L);
+    }
+#undef PP_ANY
+    HIP_TRY(hipGetLastError());
+    return PP_OK;
 }
 
 // dispatch a templated kernel on (M, dtype)
@@ -354,7 +474,7 @@ static int fft_grid(int T, long long nrows) {
 // harmonics kt[n] and their maximum) and its entry in the device pointer tables
 static int model_publish(pp_ctx* c, int slot) {
     ModelSlot& s = c->slots[slot];
-    const int nchan = s.nchan, M = s.nbin / 2;
+    const int nchan = s.nchan, M = s.Mp;      // (rows pitched to Mp, zeros beyond nbin / 2)
     int rc;
     int Kt = M;
     {
@@ -381,25 +501,41 @@ extern "C" int pp_model_set(pp_ctx* c, int slot, const void* portrait, int dtype
                             int nbin) {
     if (!c || !portrait) return fail(PP_EINVAL, "pp_model_set: null argument");
     if (slot < 0 || slot >= PP_MAX_SLOTS) return fail(PP_EINVAL, "pp_model_set: slot %d", slot);
-    if (!nbin_ok(nbin)) return fail(PP_EINVAL, "pp_model_set: nbin %d must be a power of two in [32,8192]", nbin);
+    if (!nbin_any_ok(nbin))
+        return fail(PP_EINVAL, "pp_model_set: nbin %d must be a power of two in [32, 8192] or even in [8, 4096]", nbin);
     if (nchan < 1) return fail(PP_EINVAL, "pp_model_set: nchan %d", nchan);
     if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_model_set: dtype %d", dtype);
     HIP_TRY(hipSetDevice(c->device));
-    const int M = nbin / 2;
+    const bool anyb = !nbin_ok(nbin);
+    const int M = nbin / 2, Mp = anyb ? ((M + 63) / 64) * 64 : M;
     const size_t esz = dtype == PP_F64 ? 8 : 4;
     ModelSlot& s = c->slots[slot];
     int rc;
-    if ((rc = s.mft.reserve((size_t)nchan * M * sizeof(cplx)))) return rc;
+    if ((rc = s.mft.reserve((size_t)nchan * Mp * sizeof(cplx)))) return rc;
     if ((rc = s.msum.reserve((size_t)nchan * sizeof(double)))) return rc;
     if ((rc = s.mmax.reserve((size_t)nchan * sizeof(double)))) return rc;
     if ((rc = s.mdc.reserve((size_t)nchan * sizeof(double)))) return rc;
     if ((rc = s.kt.reserve((size_t)nchan * sizeof(int)))) return rc;
-    if ((rc = s.msq.reserve((size_t)nchan * M * sizeof(double)))) return rc;
+    if ((rc = s.msq.reserve((size_t)nchan * Mp * sizeof(double)))) return rc;
     const void* dport = portrait;
     if (!on_device) {
         if ((rc = c->data.reserve((size_t)nchan * nbin * esz))) return rc;
         HIP_TRY(hipMemcpyAsync(c->data.p, portrait, (size_t)nchan * nbin * esz, hipMemcpyHostToDevice, c->stream));
         dport = c->data.p;
+    }
+    if (anyb) {
+        // general row length: harmonics by the Bluestein path, then the slot's padded rows
+        if ((rc = c->X.reserve((size_t)nchan * (M + 1) * sizeof(cplx)))) return rc;
+        XspecArgs xa;
+        memset(&xa, 0, sizeof xa);
+        xa.data = dport; xa.nsub = 1; xa.nchan = nchan; xa.nchan_full = nchan; xa.cstep = 1;
+        Prof pr(c, KF_MODEL);
+        if ((rc = launch_any(c, xa, nbin, Mp, dtype, -1, false, c->X.as<cplx>(), nullptr))) return rc;
+        hipLaunchKernelGGL(k_model_from_harm, dim3(nchan), dim3(64), 0, c->stream, (const cplx*)c->X.p, M, Mp,
+                           s.mft.as<cplx>(), s.msq.as<double>(), s.msum.as<double>(), s.mmax.as<double>(), s.mdc.as<double>());
+        HIP_TRY(hipGetLastError());
+        s.nchan = nchan; s.nbin = nbin; s.Mp = Mp;
+        return model_publish(c, slot);
     }
     const cplx* tw = nullptr;
     if ((rc = get_twiddles(c, nbin, &tw))) return rc;
@@ -414,7 +550,7 @@ extern "C" int pp_model_set(pp_ctx* c, int slot, const void* portrait, int dtype
         });
     }
     HIP_TRY(hipGetLastError());
-    s.nchan = nchan; s.nbin = nbin;
+    s.nchan = nchan; s.nbin = nbin; s.Mp = M;
     return model_publish(c, slot);
 }
 
@@ -437,22 +573,29 @@ extern "C" int pp_model_nharm(pp_ctx* c, int slot) {
 // --------------------------------------------------------------------------
 extern "C" int pp_rfft_rows(pp_ctx* c, const void* rows, int dtype, int nrows, int nbin, double* out) {
     if (!c || !rows || !out) return fail(PP_EINVAL, "pp_rfft_rows: null argument");
-    if (!nbin_ok(nbin) || nrows < 1) return fail(PP_EINVAL, "pp_rfft_rows: bad shape %d x %d", nrows, nbin);
+    if (!nbin_any_ok(nbin) || nrows < 1) return fail(PP_EINVAL, "pp_rfft_rows: bad shape %d x %d", nrows, nbin);
     HIP_TRY(hipSetDevice(c->device));
     const int M = nbin / 2;
     const size_t esz = dtype == PP_F64 ? 8 : 4;
     int rc;
     if ((rc = c->data.reserve((size_t)nrows * nbin * esz))) return rc;
     if ((rc = c->X.reserve((size_t)nrows * (M + 1) * sizeof(cplx)))) return rc;
-    const cplx* tw = nullptr;
-    if ((rc = get_twiddles(c, nbin, &tw))) return rc;
     HIP_TRY(hipMemcpyAsync(c->data.p, rows, (size_t)nrows * nbin * esz, hipMemcpyHostToDevice, c->stream));
-    PP_DISPATCH_M(M, {
-        const int T = FftPlan<MM>::T;
-        if (dtype == PP_F64) hipLaunchKernelGGL((k_rfft_rows<MM, double>), dim3(fft_grid(T, nrows)), dim3(T), 0, c->stream, (const void*)c->data.p, c->X.as<cplx>(), tw, nrows);
-        else hipLaunchKernelGGL((k_rfft_rows<MM, float>), dim3(fft_grid(T, nrows)), dim3(T), 0, c->stream, (const void*)c->data.p, c->X.as<cplx>(), tw, nrows);
-    });
-    HIP_TRY(hipGetLastError());
+    if (!nbin_ok(nbin)) {
+        XspecArgs xa;
+        memset(&xa, 0, sizeof xa);
+        xa.data = c->data.p; xa.nsub = 1; xa.nchan = nrows; xa.nchan_full = nrows; xa.cstep = 1;
+        if ((rc = launch_any(c, xa, nbin, ((M + 63) / 64) * 64, dtype, -1, false, c->X.as<cplx>(), nullptr))) return rc;
+    } else {
+        const cplx* tw = nullptr;
+        if ((rc = get_twiddles(c, nbin, &tw))) return rc;
+        PP_DISPATCH_M(M, {
+            const int T = FftPlan<MM>::T;
+            if (dtype == PP_F64) hipLaunchKernelGGL((k_rfft_rows<MM, double>), dim3(fft_grid(T, nrows)), dim3(T), 0, c->stream, (const void*)c->data.p, c->X.as<cplx>(), tw, nrows);
+            else hipLaunchKernelGGL((k_rfft_rows<MM, float>), dim3(fft_grid(T, nrows)), dim3(T), 0, c->stream, (const void*)c->data.p, c->X.as<cplx>(), tw, nrows);
+        });
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipMemcpyAsync(out, c->X.p, (size_t)nrows * (M + 1) * sizeof(cplx), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PP_OK;
@@ -579,7 +722,11 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     const pp_seed_ref* rs = in->ref_seed;        // (applicability was checked by the caller)
     const bool refseed = (rs != nullptr);
     const int seed_ns = refseed ? rs->Ns : in->seed_ns;
-    const int C = in->nchan, B = in->nbin, M = B / 2;
+    const int C = in->nchan, B = in->nbin;
+    // row lengths without a tuned plan (pp_anybin.h): the slot's spectrum rows are pitched to Mp
+    const bool anyb = !nbin_ok(B);
+    const int Mp_any = c->slots[in->model_slot ? in->model_slot[s0] : 0].Mp;
+    const int M = anyb ? Mp_any : B / 2;
     const size_t esz = in->data_dtype == PP_F64 ? 8 : 4;
     int rc;
     const cplx* tw = nullptr;
@@ -634,6 +781,20 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     } else {
         if (in->errs) { if ((rc = upload(c, c->errs, in->errs + (size_t)s0 * C, nc * 8))) return rc; d_errs = c->errs.as<double>(); }
         if (in->chan_mask) { if ((rc = upload(c, c->mask, in->chan_mask + (size_t)s0 * C, nc))) return rc; d_mask = c->mask.as<unsigned char>(); }
+    }
+    // rows in use: channels the mask removes from a subint are not transformed at all (RowWalk)
+    const unsigned* mw_main = nullptr;
+    const unsigned* mw_sub = nullptr;
+    if (d_mask && c->skip_masked) {
+        const size_t nw_main = (nc + 31) / 32 + 1, nw_sub = (C % 32 == 0) ? nc / 32 : 0;
+        if ((rc = c->mwords.reserve((nw_main + nw_sub) * sizeof(unsigned)))) return rc;
+        HIP_TRY(hipMemsetAsync(c->mwords.p, 0, (nw_main + nw_sub) * sizeof(unsigned), c->stream));
+        unsigned* wm = c->mwords.as<unsigned>();
+        unsigned* ws = nw_sub ? wm + nw_main : nullptr;
+        hipLaunchKernelGGL(k_mask_words, dim3((unsigned)((C + 255) / 256), (unsigned)((ns + 31) / 32)), dim3(256), 0, c->stream,
+                           d_mask, ns, C, wm, ws);
+        HIP_TRY(hipGetLastError());
+        mw_main = wm; mw_sub = ws;
     }
     // ---- work ----
     // no scattering: one pass over the data that leaves a Taylor model of every
@@ -794,9 +955,11 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
                       ? std::max(0, c->taylor_recentre) : 0;
     fa.x0w = d_x0;
     fa.x_f32 = xf32 ? 1 : 0;
+    fa.nfev_shadow = c->nfev_shadow;
 
     auto run_xspec = [&](const XspecArgs& x, int mode) -> int {
         Prof pr(c, KF_XSPEC);
+        if (anyb) return launch_any(c, x, B, M, in->data_dtype, mode, tail, nullptr, c->skip_masked ? d_mask : nullptr);
         PP_DISPATCH_M(M, {
             if (in->data_dtype == PP_F64) launch_xspec<MM, double>(c, x, tail, mode);
             else launch_xspec<MM, float>(c, x, tail, mode);
@@ -947,8 +1110,9 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         XspecArgs x = xa;
         x.ticket = c->ticket.as<unsigned>();
         x.ticket_base = c->ticket_base;
+        x.mwords = mw_sub;
         c->ticket_base += (unsigned)((nrows + PP_ROW_CHUNK - 1) / PP_ROW_CHUNK);
-        RefSeedArgs ra{d_w, part, ncc};
+        RefSeedArgs ra{d_w, part, ncc, d_mask};
         {
             Prof pr(c, KF_XSPEC);
 #define PP_QR(TIN, ST)                                                                                     \
@@ -966,9 +1130,9 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             hipLaunchKernelGGL((k_rfft_rows<1024, double>), dim3(fft_grid(64, (long long)nprof)), dim3(64), 0, c->stream,
                                (const void*)mprof, mspec, tw, (int)nprof);
             hipLaunchKernelGGL(k_refseed_prep, dim3(ns), dim3(256), 0, c->stream, (const double*)d_x0, (const double*)d_P,
-                               (const double*)d_nufit, (const double*)d_numean, d_w, C, d_delta, d_wsum);
+                               (const double*)d_nufit, (const double*)d_numean, d_w, d_mask, C, d_delta, d_wsum);
             hipLaunchKernelGGL(k_refseed_finish, dim3((unsigned)((H + 255) / 256), ns), dim3(256), 0, c->stream,
-                               (const cplx*)part, ncc, (const double*)d_delta, (const double*)d_wsum, ns, dspec);
+                               (const cplx*)part, ncc, (const double*)d_delta, (const double*)d_wsum, ns, dspec, mw_sub);
             FpsArgs f{dspec, nullptr, d_out7, rs->lo, rs->hi, rs->Ns, M, ns, rs->finish, mspec,
                       rs->model_prof_stride ? (int)H : 0};
             hipLaunchKernelGGL(k_fps, dim3(ns), dim3(256), 0, c->stream, f, xwork);
@@ -1004,7 +1168,9 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     } else if (seed_full) {
         // the seed needs the cross-spectrum at a phase not known yet: store it, seed,
         // then take the Taylor moments (or iterate) in a second pass over it
-        if ((rc = run_xspec(xa, 0))) return rc;
+        XspecArgs xm = xa;
+        xm.mwords = mw_main;
+        if ((rc = run_xspec(xm, 0))) return rc;
         if (!wts_early) if ((rc = run_prep())) return rc;
         if ((rc = run_seed(fa, nullptr))) return rc;
         hipLaunchKernelGGL(k_init_state, dim3((ns + 63) / 64), dim3(64), 0, c->stream, fa);
@@ -1013,6 +1179,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         XspecArgs x = xa;
         x.ticket = c->ticket.as<unsigned>();
         x.ticket_base = c->ticket_base;
+        x.mwords = mw_main;
         c->ticket_base += (unsigned)((nrows + PP_ROW_CHUNK - 1) / PP_ROW_CHUNK);
         {
             Prof pr(c, KF_XSPEC);
@@ -1028,7 +1195,9 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         }
         if (!wts_early) if ((rc = run_prep())) return rc;
     } else {
-        if ((rc = run_xspec(xa, xmode))) return rc;
+        XspecArgs xm = xa;
+        xm.mwords = mw_main;
+        if ((rc = run_xspec(xm, xmode))) return rc;
         if (!wts_early) if ((rc = run_prep())) return rc;
     }
     HIP_TRY(hipGetLastError());
@@ -1183,8 +1352,12 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
 
 extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out) {
     if (!c || !in || !out) return fail(PP_EINVAL, "pp_fit_portrait_batch: null argument");
+    // a submitted batch owns the context (work buffers, stream, counters) until pp_fit_wait
+    if (c->job_active && std::this_thread::get_id() != c->job.get_id())
+        return fail(PP_ESTATE, "pp_fit_portrait_batch: a submitted fit is pending on this context (pp_fit_wait first)");
     if (in->nsub < 1 || in->nchan < 1) return fail(PP_EINVAL, "bad batch shape %d x %d", in->nsub, in->nchan);
-    if (!nbin_ok(in->nbin)) return fail(PP_EINVAL, "nbin %d must be a power of two in [32,8192]", in->nbin);
+    if (!nbin_any_ok(in->nbin))
+        return fail(PP_EINVAL, "nbin %d must be a power of two in [32, 8192] or an even number in [8, 4096]", in->nbin);
     if (!in->data || !in->freqs || !in->P || !in->init_params) return fail(PP_EINVAL, "missing input array");
     if (in->data_dtype != PP_F64 && in->data_dtype != PP_F32) return fail(PP_EINVAL, "data_dtype %d", in->data_dtype);
     if (in->freqs_stride != 0 && in->freqs_stride != in->nchan) return fail(PP_EINVAL, "freqs_stride must be 0 or nchan");

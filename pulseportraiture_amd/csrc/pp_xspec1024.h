@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
     const long long nrows = (long long)a.nsub * a.nchan;
     Raw cur[PER1][R1];
     RowWalk<true> rw;
-    rw.start(nrows);
+    rw.start(nrows, a.mwords, a.ticket, a.ticket_base);
     long long row = rw.row;
     int n = 0, i = 0;
     if (rw.more) {
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
     int i_nx = i, n_nx = n;
     for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
         rw.draw(a.ticket);
+        rw.peek(nrows, a.ticket_base);
         if (PP_OPAQUE_ROW == 1 || (PP_OPAQUE_ROW == 2 && M2)) asm volatile("" : "+v"(tid));
         // stage twiddles are re-read every row (three L1-resident loads, issued before
         // the prefetch) instead of living in 12 registers through the harmonic phase,
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         {
-            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base);
+            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket);
             const size_t rn = rw.more_nx ? (size_t)i_nx * a.nchan + n_nx : rc;
             stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);
         }

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
     cplx wb0 = a.twB[lam0 ? lam0 : 64];
     const cplx wbT = a.twB[64];
     RowWalk<true> rw;
-    rw.start(nrows);
+    rw.start(nrows, a.mwords, a.ticket, a.ticket_base);
     long long row = rw.row;
     int n = 0, i = 0;
     if (rw.more) {
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
     int i_nx = i, n_nx = n;
     for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
         rw.draw(a.ticket);
+        rw.peek(nrows, a.ticket_base);
         // (everything derived from the lane number is recomputed per row: held across
         // the row it would cost the registers the prefetched row needs)
         asm volatile("" : "+v"(tid));
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
         };
         auto prefetch = [&]() {
             __builtin_amdgcn_sched_barrier(0);
-            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base);
+            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket);
             const size_t rn = rw.more_nx
                 ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
             nxrow = reinterpret_cast<const Tin*>(a.data) + rn * (2 * M);
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
     Raw cur[PER1][R1];
     const cplx wbT = a.twB[64];
     RowWalk<true> rw;
-    rw.start(nrows);
+    rw.start(nrows, a.mwords, a.ticket, a.ticket_base);
     long long row = rw.row;
     int n = 0, i = 0;
     if (rw.more) {
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
     int i_nx = i, n_nx = n;
     for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
         rw.draw(a.ticket);
+        rw.peek(nrows, a.ticket_base);
         asm volatile("" : "+v"(tid));
         const int lam = Q::lambda(tid);
         const bool l0 = (lam == 0);
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
         };
         {
             __builtin_amdgcn_sched_barrier(0);
-            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base);
+            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket);
             const size_t rn = rw.more_nx
                 ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
             nxrow = reinterpret_cast<const Tin*>(a.data) + rn * (2 * M);

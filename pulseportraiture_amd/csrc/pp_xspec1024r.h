@@ -38,6 +38,9 @@ struct RefSeedArgs {
     const double* w;      // [nsub][nchan_full] channel weights of the mean, or nullptr (= 1)
     cplx* part;           // [nsub][ncc][RS_NACC][64] partial channel sums
     int ncc;              // channel blocks per subint (nchan / PP_ROW_CHUNK)
+    const unsigned char* mask;   // [nsub][nchan] the fit's channel mask or nullptr: the channel mean is taken over
+                                 // the channels in use only (the reference averages portx = port[ok_ichans],
+                                 // pptoas.py:384-397, 424), whatever weight a masked channel carries
 };
 constexpr int RS_NACC = 12;     // slots 0..6 (kept), 12..15 (noise tail), Nyquist (lane of lam = 0)
 constexpr int RS_NREG = 11;     // ... of which in registers; the Nyquist term (one lane's) sits in LDS
@@ -69,13 +72,14 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
     Raw cur[PER1][R1];
     const cplx wbT = a.twB[64];
     RowWalk<true> rw;
-    rw.start(nrows);
+    rw.start(nrows, a.mwords, a.ticket, a.ticket_base);
     int r = 0, c = 0;                 // position in the chunk, chunk
     int ia = 0, cc = 0;               // the chunk's subint and channel block (one division per chunk)
     if (rw.more) {
         c = __builtin_amdgcn_readfirstlane((int)(rw.row / PP_ROW_CHUNK));
+        r = __builtin_amdgcn_readfirstlane((int)(rw.row % PP_ROW_CHUNK));     // (0 unless the mask removes the chunk's first rows)
         ia = c % a.nsub; cc = c / a.nsub;
-        const size_t rc = (size_t)ia * a.nchan_full + (size_t)cc * PP_ROW_CHUNK;
+        const size_t rc = (size_t)ia * a.nchan_full + (size_t)cc * PP_ROW_CHUNK + r;
         stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rc * (2 * M), tid);
     }
     cplx acc[RS_NREG - NLA];      // (slots 0..6, tail slot 12 [.. 15 for f32 rows])
@@ -83,6 +87,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
     const int ktg = a.Kt;             // harmonics the widest template row keeps: the channel sum takes them all
     for (; rw.more; rw.advance(), r = r_nx, c = c_nx, ia = ia_nx, cc = cc_nx) {
         rw.draw(a.ticket);
+        rw.peek(nrows, a.ticket_base);
         asm volatile("" : "+v"(tid));
         const int lam = fftq_lambda(tid);
         const bool l0 = (lam == 0);
@@ -94,8 +99,9 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
         const cplx* mrow = as_global(a.slot ? a.mft[a.slot[ia]] : a.mft0) + (size_t)ne * M;
         const int ktn = a.ktab ? as_global(a.slot ? a.ktab[a.slot[ia]] : a.kt0)[ne] : a.Kt;
         const double phin = a.ph0[rc];
-        const double hw = 0.5 * (rs.w ? rs.w[rc] : 1.0);     // (2 d_k below: the half goes here, exact)
-        if (r == 0) {
+        const double hw = (rs.mask && !rs.mask[rc]) ? 0.0
+                                                    : 0.5 * (rs.w ? rs.w[rc] : 1.0);     // (2 d_k below: the half goes here, exact)
+        if (rw.fresh) {       // (the first row visited of this chunk)
 #pragma unroll
             for (int j = 0; j < RS_NREG - NLA; ++j) acc[j] = make_double2(0.0, 0.0);
 #pragma unroll
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
         };
         auto prefetch = [&]() {
             __builtin_amdgcn_sched_barrier(0);
-            rw.next(r, c, r_nx, c_nx, nrows, PP_ROW_CHUNK, a.ticket_base);
+            rw.next(r, c, r_nx, c_nx, nrows, PP_ROW_CHUNK, a.ticket_base, a.ticket);
             size_t rn = rc;
             ia_nx = ia; cc_nx = cc;
             if (rw.more_nx) {
@@ -289,8 +295,8 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
             }
             if (tid == 4 * PP_TSTRIDE) a.sdraw[rc] = tv;
         }
-        if (r == PP_ROW_CHUNK - 1) {
-            // the chunk's share of the channel sums of subint ia
+        if (!rw.more_nx || c_nx != c) {
+            // (the last row visited of this chunk:) the chunk's share of the channel sums of subint ia
             cplx* out = rs.part + (((size_t)ia * rs.ncc + cc) * RS_NACC) * 64 + tid;
 #pragma unroll
             for (int j = 0; j < RS_NREG - NLA; ++j) out[64 * j] = acc[j];
@@ -306,13 +312,15 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
 // Taylor phase of every channel exceeds the reference's rotation phase, and the summed weights
 // (fixed-order block reduction).  x0: [nsub][5] expansion points (the pilot seed wrote the phases).
 __global__ __launch_bounds__(256) void k_refseed_prep(const double* x0, const double* P, const double* nu_fit,
-                                                      const double* nu_mean, const double* w, int nchan,
-                                                      double* delta, double* wsum) {
+                                                      const double* nu_mean, const double* w, const unsigned char* mask,
+                                                      int nchan, double* delta, double* wsum) {
     const int i = blockIdx.x, tid = threadIdx.x;
     __shared__ double scratch[4];
     double s[1] = {0.0};
-    if (w) { for (int n = tid; n < nchan; n += 256) s[0] += w[(size_t)i * nchan + n]; }
-    else if (tid == 0) s[0] = (double)nchan;
+    if (w || mask) {
+        for (int n = tid; n < nchan; n += 256)
+            if (!mask || mask[(size_t)i * nchan + n]) s[0] += w ? w[(size_t)i * nchan + n] : 1.0;
+    } else if (tid == 0) s[0] = (double)nchan;
     block_sum<1>(s, scratch);
     if (tid == 0) {
         const double nf = nu_fit[i * 3], nm = nu_mean[i];
@@ -325,8 +333,10 @@ __global__ __launch_bounds__(256) void k_refseed_prep(const double* x0, const do
 // channel blocks, the per-harmonic factor e^{-i kap Delta_i} that turns the Taylor phase into the
 // reference's rotation phase, division by the summed weights; harmonics the pass did not
 // accumulate (448 < k < 768, and 0) are zero.  spec[i][0..M].
+// mws (optional): the rows-in-use words of the pass (k_mask_words' wsub): a chunk without a row in use
+// was never visited and left no partial.
 __global__ __launch_bounds__(256) void k_refseed_finish(const cplx* part, int ncc, const double* delta,
-                                                        const double* wsum, int nsub, cplx* spec) {
+                                                        const double* wsum, int nsub, cplx* spec, const unsigned* mws) {
     constexpr int M = 1024;
     const int i = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
     if (k > M) return;
@@ -339,6 +349,7 @@ __global__ __launch_bounds__(256) void k_refseed_finish(const cplx* part, int nc
     if (slot >= 0) {
         const int lane = fftq_lane_of(k == M ? 0 : lam);
         for (int cc = 0; cc < ncc; ++cc) {
+            if (mws && mws[(size_t)cc * nsub + i] == 0u) continue;
             const cplx v = part[(((size_t)i * ncc + cc) * RS_NACC + slot) * 64 + lane];
             s.x += v.x; s.y += v.y;
         }

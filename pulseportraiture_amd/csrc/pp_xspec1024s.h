@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qs1024(XspecArgs a, const doubl
     Raw cur[PER1][R1];
     const cplx wbT = a.twB[64];
     RowWalk<true> rw;
-    rw.start(nrows);
+    rw.start(nrows, a.mwords, a.ticket, a.ticket_base);
     long long row = rw.row;
     int n = 0, i = 0;
     if (rw.more) {
@@ -44,6 +44,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qs1024(XspecArgs a, const doubl
     int i_nx = i, n_nx = n;
     for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
         rw.draw(a.ticket);
+        rw.peek(nrows, a.ticket_base);
         asm volatile("" : "+v"(tid));
         const int lam = fftq_lambda(tid);
         const bool l0 = (lam == 0);
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qs1024(XspecArgs a, const doubl
         };
         auto prefetch = [&]() {
             __builtin_amdgcn_sched_barrier(0);
-            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base);
+            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket);
             const size_t rn = rw.more_nx ? (size_t)i_nx * a.nchan_full + n_nx : rc;
             nxrow = reinterpret_cast<const Tin*>(a.data) + rn * (2 * M);
             load_some(0, HALVES ? R1 / 2 : R1);

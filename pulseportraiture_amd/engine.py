@@ -6,6 +6,7 @@ into it.
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -47,25 +48,32 @@ def _is_device_array(x):
     return False
 
 
-_WAITED = set()      # devices whose producer stream this engine call has already waited for
+# Devices whose producer stream the engine call running on THIS thread has already waited for.
+# Per thread: engines are one per host thread, and a set shared between threads would let one
+# thread's call clear -- or pre-fill -- the record of another's while that one sits in
+# synchronize() with the GIL released.
+_TLS = threading.local()
 
 
 def _new_call():
     """Start of an engine call: every device array handed over was produced before it, so
     one wait per device and call covers them all (seven waits per fit cost ~50 us)."""
-    _WAITED.clear()
+    _TLS.waited = set()
 
 
 def _wait_for_producer(x):
+    waited = getattr(_TLS, "waited", None)
+    if waited is None:
+        waited = _TLS.waited = set()
     key = str(x.device)
-    if key in _WAITED:
+    if key in waited:
         return
     try:
         import torch
         torch.cuda.current_stream(x.device).synchronize()
     except ImportError:      # (another array library: its arrays must be complete when handed over)
         pass
-    _WAITED.add(key)
+    waited.add(key)
 
 
 def _dp(a):
@@ -126,6 +134,12 @@ class Engine(object):
                "pp_set_option(%s)" % name)
         if name == "harm_eps":
             self._digests.clear()      # truncation is decided when a template is set
+
+    def get_option(self, name):
+        """Current value of an engine option (pp_get_option)."""
+        v = C.c_double()
+        _check(self._lib.pp_get_option(self._ctx, name.encode(), C.byref(v)), "pp_get_option(%s)" % name)
+        return v.value
 
     def synchronize(self):
         _check(self._lib.pp_synchronize(self._ctx), "pp_synchronize")
@@ -352,8 +366,6 @@ class Engine(object):
         if seed_keep is not None:
             res["seed_phase"] = seed_keep[4]
         if _submit:
-            if getattr(self, "_pending", None) is not None:
-                raise EngineError("a submitted batch is pending: wait() first")
             _check(self._lib.pp_fit_submit(self._ctx, C.byref(fin), C.byref(fout)), "pp_fit_submit")
             # every array the argument blocks point to stays alive until wait()
             self._pending = (res, (keep, freqs, P, x0, errs, nu_fits, nu_outs, slot, mask, chan_mask,
@@ -634,18 +646,20 @@ class Engine(object):
         return out
 
     def synth_portraits(self, dst, freqs, P, inj, sigma, seed, first_subint=0,
-                        slot=0):
-        """Fill a CUDA tensor dst[nsub,nchan,nbin] with synthetic subints."""
+                        slot=0, gains=None):
+        """Fill a CUDA tensor dst[nsub,nchan,nbin] with synthetic subints; gains[nsub,nchan]
+        (optional) scales the template in every channel (scintillation)."""
         if not _is_device_array(dst):
             raise EngineError("synth_portraits needs a CUDA tensor destination")
         nsub = int(dst.shape[0])
         freqs = _f64(freqs)
         P = _f64(P, (nsub,))
         inj = _f64(inj, (nsub, 3))
+        gains = _f64(gains, (nsub, int(dst.shape[1])))
         _check(self._lib.pp_synth_portraits(
             self._ctx, int(slot), C.c_void_p(dst.data_ptr()),
             PP_F64 if dst.element_size() == 8 else PP_F32, nsub, _dp(freqs),
-            _dp(P), _dp(inj), float(sigma), C.c_uint64(int(seed)),
+            _dp(P), _dp(inj), _dp(gains), float(sigma), C.c_uint64(int(seed)),
             C.c_int64(int(first_subint))), "pp_synth_portraits")
 
     def kernel_times(self, reset=False):
@@ -671,11 +685,18 @@ def default_engine(device=0):
     return eng
 
 
+_WHILE_PENDING = ("poll", "wait", "close")      # what may be called while a submitted batch runs
+
+
 def _fresh_waits(fn):
     import functools
 
     @functools.wraps(fn)
     def call(self, *args, **kwargs):
+        # a submitted batch owns the context (its buffers, stream and counters) until wait():
+        # include/pp_toas.h forbids every other call meanwhile -- enforce it here
+        if getattr(self, "_pending", None) is not None and fn.__name__ not in _WHILE_PENDING:
+            raise EngineError("a submitted batch is pending on this engine: wait() before %s()" % fn.__name__)
         _new_call()
         return fn(self, *args, **kwargs)
     return call

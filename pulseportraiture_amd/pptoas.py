@@ -568,13 +568,20 @@ class GetTOAs(object):
                                                                  nu_fit_arr[sel, 0], DM_stored)
                 if r is None:
                     r = eng.fit_batch(psel, fsel, Psel, x0[sel], **fkw)
+                    if ref_in is not None:
+                        # (the fallback route formed the guess in a pass of its own: report it like
+                        # the single-pass route does, so every group carries the same keys)
+                        r["seed_phase"] = x0[sel, 0].copy()
                 if res is None:
-                    res = {k: (np.zeros((nok,) + v.shape[1:], dtype=v.dtype)
-                               if isinstance(v, np.ndarray) else v) for k, v in r.items()}
-                    res["duration"] = 0.0
+                    res = {"duration": 0.0}
                 for k, v in r.items():
                     if isinstance(v, np.ndarray):
+                        # (groups may return different key sets: allocate on first sight)
+                        if k not in res:
+                            res[k] = np.zeros((nok,) + v.shape[1:], dtype=v.dtype)
                         res[k][sel] = v
+                    elif k != "duration":
+                        res.setdefault(k, v)
                 res["duration"] += r["duration"]
             fit_duration = res["duration"]
             # template profile means per slot, for the flux estimate (the scattering

@@ -94,8 +94,16 @@ def _fit_with_bounds(eng, data, freqs, P, init_params, errs, nu_fits, nu_outs, f
     if np.any(lo > hi):
         raise ValueError("bounds: lower > upper")
     x = np.clip(np.asarray(init_params, dtype=np.float64).copy(), lo, hi)   # (TNC starts inside the box)
+    # The iteration works with RAW parameters -- phi, tau at the fit's own reference frequencies --
+    # so those must be concrete before the loop: a None entry means "the mean channel frequency"
+    # for the fit (pptoaslib.py:986-989) but "the zero-covariance frequency" as an OUTPUT frequency,
+    # and a phase returned there would be fed back as a guess at nu_fit.
+    fmean = float(np.mean(np.asarray(freqs, dtype=np.float64)))
+    nu_fits = [fmean if (v is None or (isinstance(v, float) and np.isnan(v))) else float(v) for v in nu_fits]
     common = dict(errs=errs, nu_fits=[nu_fits], log10_tau=log10_tau, option=option, is_toa=is_toa)
     active = {}
+    max_iter = eng.get_option("max_iter")       # (the caller's setting: restored after the evaluate-only calls)
+    nfeval, duration = 0, 0.0
     for _ in range(12):
         fl = [1 if (f and j not in active) else 0 for j, f in enumerate(flags)]
         for j, v in active.items():
@@ -103,6 +111,8 @@ def _fit_with_bounds(eng, data, freqs, P, init_params, errs, nu_fits, nu_outs, f
         if any(fl):
             # raw parameters: output frequencies = the fit's own
             r = eng.fit_batch(data, freqs, P, x, nu_outs=[nu_fits], fit_flags=fl, method='newton', **common)
+            nfeval += int(r["nfeval"][0])
+            duration += r["duration"]
             xs = r["params"][0].copy()
             xs[0] = x[0] + ((xs[0] - x[0] + 0.5) % 1.0 - 0.5)     # (the phase comes back wrapped)
         else:
@@ -117,10 +127,13 @@ def _fit_with_bounds(eng, data, freqs, P, init_params, errs, nu_fits, nu_outs, f
         # gradient of the full problem at x: may a fixed parameter move back inside?
         eng.set_option("max_iter", 0)
         try:
-            g = eng.fit_batch(data, freqs, P, x, nu_outs=[nu_fits], fit_flags=flags, objective=True,
-                              method='newton', **common)["obj_grad"][0]
+            r = eng.fit_batch(data, freqs, P, x, nu_outs=[nu_fits], fit_flags=flags, objective=True,
+                              method='newton', **common)
         finally:
-            eng.set_option("max_iter", 64)
+            eng.set_option("max_iter", max_iter)
+        g = r["obj_grad"][0]
+        nfeval += int(r["nfeval"][0])
+        duration += r["duration"]
         free = [j for j, v in active.items() if (v == lo[j] and g[j] < 0.0) or (v == hi[j] and g[j] > 0.0)]
         if not free:
             break
@@ -131,8 +144,11 @@ def _fit_with_bounds(eng, data, freqs, P, init_params, errs, nu_fits, nu_outs, f
     try:
         res = eng.fit_batch(data, freqs, P, x, nu_outs=[nu_outs], fit_flags=flags, method='newton', **common)
     finally:
-        eng.set_option("max_iter", 64)
+        eng.set_option("max_iter", max_iter)
     res["return_code"][:] = 2 if not active else 0     # (TNC's table: XCONVERGED / LOCALMINIMUM at a bound)
+    # what the whole bounded fit cost, not its closing evaluate-only call
+    res["nfeval"][:] = nfeval + int(res["nfeval"][0])
+    res["duration"] = duration + res["duration"]
     return res
 
 

@@ -25,7 +25,8 @@ def pytest_configure(config):
 
 def pytest_collection_finish(session):
     # only when a test that collects a child is going to run
-    want = ("test_strong_scaling_bench_in_a_child_process", "test_two_ranks_sharing_the_gpu")
+    want = ("test_strong_scaling_bench_in_a_child_process", "test_two_ranks_sharing_the_gpu",
+            "test_rccl_backend_with_one_rank")
     if not any(w in it.nodeid for it in session.items for w in want) or os.environ.get("PP_NO_BENCH_CHILD"):
         return
     try:
@@ -62,8 +63,31 @@ def pytest_collection_finish(session):
             BENCH_CHILD["two_" + tag] = dict(proc=p2, out=o, err=e, records=r2)
 
 
+    # ... and RCCL itself as far as one GPU allows: ONE rank under torch.distributed.run with the "nccl"
+    # backend (communicator creation with its banner kept off stdout, barriers, the gather of device
+    # tensors), weak and strong modes
+    if any("test_rccl_backend_with_one_rank" in it.nodeid for it in session.items):
+        import socket
+        for tag, extra in (("weak", ["--nsub", "256", "--steps", "2", "--no-other-workloads"]),
+                           ("strong", ["--total-nsub", "1500", "--nsub", "256"])):
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            o = open(os.path.join(tmp, "line1_%s.json" % tag), "w")
+            e = open(os.path.join(tmp, "stderr1_%s.txt" % tag), "w")
+            r1 = os.path.join(tmp, "records1_%s.npy" % tag)
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                   "--gpus", "1", "--no-cpu-baseline"] + extra
+            if tag == "strong":
+                cmd += ["--dump-records", r1]
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+            env.pop("PP_BENCH_SHARE_GPU", None)
+            p1 = subprocess.Popen(cmd, stdout=o, stderr=e, cwd=ROOT, env=env)
+            BENCH_CHILD["rccl_" + tag] = dict(proc=p1, out=o, err=e, records=r1)
+
+
 def pytest_sessionfinish(session, exitstatus):
-    procs = [BENCH_CHILD.get("proc")] + [v.get("proc") for k, v in BENCH_CHILD.items() if k.startswith("two_")]
+    procs = [BENCH_CHILD.get("proc")] + [v.get("proc") for k, v in BENCH_CHILD.items()
+                                         if k.startswith("two_") or k.startswith("rccl_")]
     for proc in procs:
         if proc is not None and proc.poll() is None:
             proc.kill()

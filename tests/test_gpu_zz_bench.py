@@ -106,3 +106,69 @@ def test_two_ranks_sharing_the_gpu():
     assert w["config"]["nsub_per_gpu_per_step"] == 128
     assert abs(w["value"] - 2 * 128 * 2 / (w["ms_per_step"] * 2e-3)) < 5e-3 * w["value"]     # all ranks' fits / max time (ms rounded)
     assert w["gathered_records"]["rows"] == 2 * 2 * 128
+
+
+@pytest.mark.timeout(900)
+def test_rccl_backend_with_one_rank():
+    """RCCL as far as one GPU allows: bench.py under torch.distributed.run with ONE rank and the
+    "nccl" backend (= RCCL on ROCm) -- process-group creation bound to the device, the barriers
+    around the timed region, the max-over-ranks all_reduce and the gather of DEVICE record tensors
+    all go through RCCL, and its version banner must not reach stdout, which carries exactly one
+    JSON line.  Weak mode (256 subints of the headline shape, 2 steps) and configs[4]'s strong
+    mode (1500 subints in sub-batches of 256, ragged tail, one gather): rows, bookkeeping, and
+    the records against fits made directly in this process."""
+    import torch
+    from tests.conftest import BENCH_CHILD
+    import bench
+    from pulseportraiture_amd import dist as ppdist
+    from pulseportraiture_amd.engine import Engine
+    if os.environ.get("PP_NO_BENCH_CHILD"):
+        pytest.skip("PP_NO_BENCH_CHILD")
+    lines = {}
+    for tag in ("weak", "strong"):
+        ch = BENCH_CHILD.get("rccl_" + tag)
+        assert ch is not None, "conftest did not start the one-rank RCCL bench (GPU visible?)"
+        rc = ch["proc"].wait(timeout=800)
+        ch["out"].close(); ch["err"].close()
+        text = open(os.path.join(BENCH_CHILD["tmp"], "line1_%s.json" % tag)).read().strip()
+        err = open(os.path.join(BENCH_CHILD["tmp"], "stderr1_%s.txt" % tag)).read()
+        assert rc == 0 and text, err[-3000:]
+        out_lines = [ln for ln in text.splitlines() if ln.strip()]
+        assert len(out_lines) == 1, out_lines[:5]            # (no RCCL banner, nothing but the line)
+        lines[tag] = json.loads(out_lines[0])
+    w = lines["weak"]
+    assert w["scaling"] == "weak" and w["n_gpus"] == 1 and w["steps"] == 2
+    assert w["config"]["nsub_per_gpu_per_step"] == 256 and "1 rank(s)" in w["config"]["parallelism"]
+    assert w["gathered_records"]["rows"] == 2 * 256 and w["value"] > 1e3
+    s = lines["strong"]
+    total = 1500
+    assert s["scaling"] == "strong" and s["n_gpus"] == 1
+    assert s["config"]["fits_per_rank"] == [total] and s["config"]["sub_batches_rank0"] == [256] * 5 + [220]
+    assert s["gathered_records"]["rows"] == total
+    rec = np.load(BENCH_CHILD["rccl_strong"]["records"])
+    assert rec.shape == (total, ppdist.RECORD_WIDTH) and (rec[:, 17] == 2).all()
+    np.testing.assert_allclose(rec.sum(axis=0), s["gathered_records"]["column_sums"], rtol=1e-12)
+    ns = argparse.Namespace(seed=20260101, dm0=34.56789, dm_offset=[3e-4, 2e-4], sigma=0.05,
+                            truth_guesses=False, measured_noise=False, method="trust-ncg")
+    eng = Engine(0)
+    dev = torch.device("cuda", 0)
+    # the weak job's records are those of subints [0, 256) (both steps fit the same resident batch):
+    # its checksum against a direct fit; the strong job's ragged tail [1280, 1500) record by record
+    b = bench.Batch(eng, ns, dev, w["config"]["workload"], 256, "f64", 0)
+    out = torch.zeros((256, ppdist.RECORD_WIDTH), dtype=torch.float64, device=dev)
+    b.fit(records=out)
+    mine = out.cpu().numpy()
+    np.testing.assert_allclose(2.0 * mine[:, :3].sum(axis=0), w["gathered_records"]["checksum"], rtol=1e-12)
+    np.testing.assert_allclose(mine[:, :13], rec[:256, :13], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(mine[:, 13:16], rec[:256, 13:16], rtol=1e-11)
+    b.free()
+    b = bench.Batch(eng, ns, dev, s["config"]["workload"], 220, "f64", 1280)
+    out = torch.zeros((220, ppdist.RECORD_WIDTH), dtype=torch.float64, device=dev)
+    b.fit(records=out)
+    mine = out.cpu().numpy()
+    np.testing.assert_array_equal(mine[:, 16:], rec[1280:, 16:])
+    # (chi2 = S_d + f is a difference of two numbers ~1e3 times its size: the child formed its guesses
+    # in batches of 256, this process in one of 220 -- last-bit differences of the guess show there)
+    np.testing.assert_allclose(mine[:, :13], rec[1280:, :13], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(mine[:, 13:16], rec[1280:, 13:16], rtol=1e-11)
+    b.free(); eng.close()

@@ -11,7 +11,11 @@ from oracle import pptoas_oracle as orc
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 FPF = sorted(os.path.basename(p)[:-4] for p in
              glob.glob(os.path.join(GOLDEN, "fpf_64x256_*.npz")) +
-             glob.glob(os.path.join(GOLDEN, "fpf_128x512_*.npz")))
+             glob.glob(os.path.join(GOLDEN, "fpf_128x512_*.npz")) +
+             # row lengths that are no power of two (tests/golden/make_golden_nbin.py)
+             glob.glob(os.path.join(GOLDEN, "fpf_48x1000_*.npz")) +
+             glob.glob(os.path.join(GOLDEN, "fpf_40x100_*.npz")) +
+             glob.glob(os.path.join(GOLDEN, "fpf_24x1536_*.npz")))
 
 # tolerances: north_star bar is 1e-9 (phase) / 1e-6 (DM); the oracle is held
 # tighter where the reference itself is reproducible to rounding
