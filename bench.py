@@ -277,14 +277,30 @@ class Batch(object):
             self.fused_unavailable = True
             return self.fit(records=records, method=method, n=n)
 
-    def _fit(self, n, records, method, ref_seed):
-        return self.eng.fit_batch(self.data[:n], self.freqs, self.P[:n], self.x0[:n],
-                                  errs=None if self.measured_noise else self.errs_dev[:n],
-                                  chan_mask=None if self.mask_dev is None else self.mask_dev[:n],
-                                  nu_fits=np.full((n, 3), self.nu_fit), fit_flags=self.flags,
-                                  log10_tau=self.log10_tau, per_channel="device",
-                                  seed_ns=self.seed_ns, method=method or self.args.method, records=records,
-                                  ref_seed=ref_seed)
+    def _fit(self, n, records, method, ref_seed, submit=False):
+        eng = self.eng
+        call = eng.enqueue if submit else eng.fit_batch
+        return call(self.data[:n], self.freqs, self.P[:n], self.x0[:n],
+                    errs=None if self.measured_noise else self.errs_dev[:n],
+                    chan_mask=None if self.mask_dev is None else self.mask_dev[:n],
+                    nu_fits=np.full((n, 3), self.nu_fit), fit_flags=self.flags,
+                    log10_tau=self.log10_tau, per_channel="device",
+                    seed_ns=self.seed_ns, method=method or self.args.method, records=records,
+                    ref_seed=ref_seed)
+
+    def can_pipeline(self):
+        """Steps may be enqueued (pp_fit_enqueue) unless every step needs a synchronous call of its own
+        first (the two-pass reference seed)."""
+        return not (self.reseed and (getattr(self.args, "two_pass_seed", False) or self.fused_unavailable))
+
+    def enqueue(self, records=None, method=None):
+        """Queue this batch's fit on the engine's stream (pp_fit_enqueue) and return at once;
+        eng.collect() returns the result."""
+        n = self.nsub
+        ref_seed = None
+        if self.reseed:
+            ref_seed = dict(weights=None, model_profs=self.seed_prof, nu_mean=self.nu_mean[:n], Ns=100, finish='simplex')
+        self._fit(n, records, method, ref_seed, submit=True)
 
     def free(self):
         import torch
@@ -325,6 +341,9 @@ def main():
                          "fit_phase_shift seed (experiments)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="engine option (pp_set_option), e.g. scat_model=0; repeatable")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="2 = step k + 1 is enqueued on the engine's stream (pp_fit_enqueue) before step k is "
+                         "collected: the host prepares a step while the previous one runs; 1 = synchronous calls")
     ap.add_argument("--measured-noise", action="store_true",
                     help="errs=None: the noise of every channel is measured from the top quarter of its "
                          "power spectrum inside the transform (get_noise_PS) instead of being given")
@@ -401,17 +420,29 @@ def main():
 
     def timed(batch, steps, warmup, method=None):
         """`steps` passes over the resident batch; records of all steps stay on the
-        device and are gathered once before the clock stops."""
+        device and are gathered once before the clock stops.  With --pipeline 2 (default) step
+        k + 1 is enqueued on the engine's stream (pp_fit_enqueue) before step k is collected:
+        while one step's kernels run the host marshals and queues the next, so the GPU never
+        waits for the host between steps.  One stream: kernels do not overlap, the per-kernel
+        HIP-event times stay exact; every step is still a whole fit of the whole batch."""
         recs = torch.zeros((steps, batch.nsub, ppdist.RECORD_WIDTH), dtype=torch.float64, device=device)
         for _ in range(warmup):
             batch.fit(method=method)
+        piped = args.pipeline > 1 and batch.can_pipeline()
         eng.set_option("profile", 1)
         eng.kernel_times(reset=True)
         fence()
         t0 = time.perf_counter()
         res = None
-        for k in range(steps):
-            res = batch.fit(records=recs[k], method=method)
+        if piped:
+            for k in range(steps):
+                batch.enqueue(records=recs[k], method=method)
+                if k > 0:
+                    res = eng.collect()
+            res = eng.collect()
+        else:
+            for k in range(steps):
+                res = batch.fit(records=recs[k], method=method)
         gathered = ppdist.gather_records(recs.view(-1, ppdist.RECORD_WIDTH))   # one RCCL gather
         fence()
         elapsed = time.perf_counter() - t0
@@ -420,6 +451,7 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        timed.piped = piped
         return res, gathered, elapsed, eng.kernel_times()
 
     def summary(batch, res, elapsed, ktimes, steps, nfits):
@@ -512,6 +544,7 @@ def main():
                            "sigma": args.sigma, "model_harmonics_kept": batch.nharm,
                            "method": args.method, "phase_guesses": batch.guess,
                            "device_phase_seed_ns": args.seed_ns,
+                           "steps_in_flight": 2 if getattr(timed, "piped", False) else 1,
                            "parallelism": "subint shards, %d rank(s), records kept in HBM, "
                                           "1 gather at the end" % world},
                 "roofline": roofline,
@@ -565,6 +598,7 @@ def main():
                               "trust-ncg from that guess"
                 r, _, el, kt = timed(b, 3, 1, method=meth)
                 _, _, _, _, sm = summary(b, r, el, kt, 3, b.nsub * 3)
+                sm["steps_in_flight"] = 2 if getattr(timed, "piped", False) else 1
                 sm.update(workload=wl, input_dtype=dt, seed_ns=max(sns, 0), nsub=b.nsub,
                           method=meth or args.method, phase_guesses=b.guess)
                 # recovered values against the injected ones, in units of the errors

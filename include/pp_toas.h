@@ -149,6 +149,13 @@ void* pp_stream(pp_ctx* ctx);
  *                  all: the transform walks a compact list of the (subint, channel) rows in use,
  *                  as the reference slices the good channels away before its fit
  *                  (pptoas.py:384-397); 0 = every row is transformed and masked ones get weight 0
+ *   "eager_flush"  1 (default) = the stream is queried once the transform has been queued, which makes the
+ *                  runtime hand what is queued to the GPU at once instead of with the next blocking call
+ *   "coarse_newton"  1 (default) = scattering fits with PP_METHOD_NEWTON first iterate on every 16th channel
+ *                  (each evaluation reads a sixteenth of the stored cross-spectrum) and start the
+ *                  full-channel iteration from that answer -- the optimum does not depend on the path --;
+ *                  0 = every evaluation over all channels.  nfeval includes the coarse evaluations, npass
+ *                  counts full passes.  (PP_METHOD_TRUST_NCG retraces SciPy's iterates and is not affected.)
  *   "nfev_shadow"  one-pass flow, method trust-ncg: how SciPy's one-point cache is mirrored when nfeval is
  *                  counted.  0 (default): proposals are compared as displacements from the expansion
  *                  point (resolution 1e-21: the closing proposal p = -H^-1 g is always a new point and
@@ -336,6 +343,24 @@ int pp_fit_portrait_batch(pp_ctx* ctx, const pp_fit_in* in, pp_fit_out* out);
 int pp_fit_submit(pp_ctx* ctx, const pp_fit_in* in, pp_fit_out* out);
 int pp_fit_poll(pp_ctx* ctx);
 int pp_fit_wait(pp_ctx* ctx);
+
+/* Stream-ordered batches (one context, one stream, no extra thread).  pp_fit_enqueue copies the two
+ * argument blocks and queues the WHOLE batch on the context's stream -- small inputs, every kernel,
+ * the outputs on their way to a pinned staging block -- and returns without waiting; pp_fit_collect
+ * completes the OLDEST enqueued batch (waits for it, fills the caller's output arrays) and returns what
+ * pp_fit_portrait_batch would have returned.  Up to two batches may be pending, so a caller that
+ * enqueues batch k + 1 before it collects batch k keeps the GPU busy while the host marshals: stream
+ * order keeps batch k's solve and post-fit stage ahead of batch k + 1's transform, on one set of
+ * device work buffers.  Batches whose flow needs a host decision in its middle (scattering fits,
+ * device seeds, pp_seed_ref, sub-batching) simply run to their end inside pp_fit_enqueue; a one-pass
+ * batch in which some subint fails its certificate (poor guesses) is fitted again by the general
+ * flow inside pp_fit_collect.  Every buffer the argument blocks point to (pp_seed_ref included) must
+ * stay valid and untouched until the batch has been collected; no other fit call may be made on the
+ * context while batches are pending (PP_ESTATE).  pp_fit_pending returns how many are.
+ * The reference has no counterpart: its loop over subints is serial (pptoas.py:344-489). */
+int pp_fit_enqueue(pp_ctx* ctx, const pp_fit_in* in, pp_fit_out* out);
+int pp_fit_collect(pp_ctx* ctx);
+int pp_fit_pending(pp_ctx* ctx);
 
 /* ---- building blocks exported for parity tests --------------------------- */
 /* rFFT of nrows real rows of length nbin (host pointers); out holds

@@ -73,6 +73,9 @@ SYMBOLS = {
                                         C.POINTER(FitOut)]),
     "pp_fit_submit": (C.c_int, [C.c_void_p, C.POINTER(FitIn), C.POINTER(FitOut)]),
     "pp_fit_poll": (C.c_int, [C.c_void_p]),
+    "pp_fit_enqueue": (C.c_int, [C.c_void_p, C.POINTER(FitIn), C.POINTER(FitOut)]),
+    "pp_fit_collect": (C.c_int, [C.c_void_p]),
+    "pp_fit_pending": (C.c_int, [C.c_void_p]),
     "pp_fit_wait": (C.c_int, [C.c_void_p]),
     "pp_rfft_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                c_double_p]),

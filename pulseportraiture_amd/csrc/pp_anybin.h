@@ -91,7 +91,8 @@ __global__ __launch_bounds__(FftPlan<L>::T) void k_any(XspecArgs a, AnyArgs g) {
             continue;
         }
         const cplx* mrow = as_global(a.slot ? a.mft[a.slot[ia]] : a.mft0) + (size_t)ne * g.Mp;
-        const int ktn = min(M, a.ktab ? as_global(a.slot ? a.ktab[a.slot[ia]] : a.kt0)[ne] : a.Kt);
+        const int ktp = a.ktab ? as_global(a.slot ? a.ktab[a.slot[ia]] : a.kt0)[ne] : a.Kt;     // (a multiple of 64, <= Mp)
+        const int ktn = min(M, ktp);
         const double phin = (g.mode != 0) ? a.ph0[rc] : 0.0;
         double acc[16];
 #pragma unroll
@@ -131,6 +132,9 @@ __global__ __launch_bounds__(FftPlan<L>::T) void k_any(XspecArgs a, AnyArgs g) {
                 acc[11] = fma(p10 * kap, fabs(xk.x) + fabs(xk.y), acc[11]);
             }
         }
+        // the stored row runs to the kept-harmonic count, which is rounded up past M: zeros there
+        if (g.mode <= 1)
+            for (int k = M + 1 + tid; k <= ktp; k += T) store_x(a, rx, k, make_double2(0.0, 0.0));
         // ---- workgroup totals (fixed order: deterministic) ----
 #pragma unroll
         for (int q = 0; q < 14; ++q) acc[q] = group_sum<64>(acc[q]);

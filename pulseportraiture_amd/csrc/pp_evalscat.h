@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_scat(FitArgs a) {
                     const int src = ((tid & 63) & ~(LPC - 1)) | (LPC - 1);
                     wst = make_double2(__shfl(e.x, src, 64), __shfl(e.y, src, 64));
                 }
-                const size_t xoff = ((size_t)jx * a.nchan_x + nn) * a.Xs;
+                const size_t xoff = a.x_full ? ((size_t)jx * a.nchan + n) * a.Xs : ((size_t)jx * a.nchan_x + nn) * a.Xs;
                 const cplx* xrow = a.X + xoff;
                 const float2* xrow32 = reinterpret_cast<const float2*>(a.X) + xoff;
                 const double* mrow = msq + (size_t)n * a.M;

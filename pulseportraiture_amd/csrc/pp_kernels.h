@@ -128,6 +128,8 @@ struct FitArgs {
     // phase), the iteration starts from xstart (the reference's own guess, known only after the pass)
     const double* xstart;     // [nsub][5] or nullptr (= start at the expansion point)
     int nfev_shadow;          // one-pass flow: SciPy's one-point cache compared on the absolute iterate fl(x + p)
+    int x_full;               // the channel subset (coff, cstep, nchan_x) is evaluated over a cross-spectrum stored for
+                              // ALL channels: X rows are addressed by the true channel (k_eval_scat)
 };
 
 __device__ __forceinline__ int sub_of(const int* act, int j) { return act ? act[j] : j; }
@@ -789,6 +791,21 @@ __device__ inline void init_state(const FitArgs& a, int i) {
 __global__ void k_init_state(FitArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.nsub) init_state(a, i);
+}
+
+// Newton solver, scattering fits: the iteration has first been run on every 16th channel (a
+// sixteenth of every evaluation pass); the full-channel iteration now starts from that answer.
+// Subints whose coarse solve did not end on its normal exit keep their initial parameters.
+__global__ void k_adopt_coarse(FitArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.nsub) return;
+    SubState& s = a.st[i];
+    bool ok = (s.done && s.status == PP_RC_STALL);
+    for (int j = 0; j < 5; ++j) ok = ok && isfinite(s.x[j]);
+    const int nf = s.nfev;
+    if (ok) for (int j = 0; j < 5; ++j) a.x0w[i * 5 + j] = s.x[j];
+    init_state(a, i);
+    a.st[i].nfev = nf;          // (the coarse evaluations stay counted; npass counts full passes only)
 }
 
 // per-channel geometry shared by evaluator and finaliser
@@ -1619,6 +1636,10 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
             const double pred = f - tr_model_value(nf, f, gs, Hs, p);
             double xta[3] = {xa[0], xa[1], xa[2]}, xt[3] = {dx[0], dx[1], dx[2]};
             for (int r_ = 0; r_ < nf; ++r_) { xta[idx[r_]] = xa[idx[r_]] + p[r_]; xt[idx[r_]] += p[r_]; }
+            // (nfev_shadow = 2: the model is evaluated AT the rounded point fl(x + p), as SciPy evaluates its
+            // objective there; xta - x0 is exact, the two are neighbours)
+            if (a.nfev_shadow >= 2)
+                for (int j = 0; j < 3; ++j) xt[j] = xta[j] - st.xe[j];
             // (a.nfev_shadow = 0: the comparison is made on the displacements, which resolve 1e-21 -- the
             // closing proposal is then always a new point and is counted)
             const bool cached = a.nfev_shadow ? (xta[0] == xla[0] && xta[1] == xla[1] && xta[2] == xla[2])

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <deque>
 #include <cstdarg>
 #include <cstdio>
 #include <climits>
@@ -98,9 +99,16 @@ struct pp_ctx {
     DevBuf mwords;   // rows in use of a masked batch, one word per chunk (k_mask_words), both row orders
     DevBuf refbuf;   // reference-seed flow: partial channel sums, spectra, profiles, start points
     DevBuf inpack;   // per-batch small inputs (freqs, P, x0, nu_fit, nu_out, slot): one H2D copy
-    void* in_host = nullptr; size_t in_host_cap = 0;   // pinned staging of inpack
+    // pinned host staging of the small inputs / the packed outputs of a batch: two sets, so that a
+    // deferred batch (pp_fit_enqueue) keeps its own while the next one is being queued
+    struct Stage { void* in_host = nullptr; size_t in_cap = 0; void* o_host = nullptr; size_t o_cap = 0;
+                   hipEvent_t t0 = nullptr, done = nullptr; };
+    Stage stage[2];
+    int cur_stage = 0;
+    // pp_fit_enqueue / pp_fit_collect: batches queued on the stream and not yet collected (oldest first)
+    struct Deferred { pp_fit_in in; pp_fit_out out; int stage; bool queued; int rc; std::string err; };
+    std::deque<Deferred> pending;
     DevBuf o_pack;   // per-subint scalar outputs, one allocation -> one D2H copy
-    void* o_host = nullptr; size_t o_host_cap = 0;   // pinned staging of o_pack
     DevBuf o_params, o_errs, o_nu, o_cov, o_chi2, o_rchi2, o_snr, o_nfev, o_rc, o_scales, o_serrs, o_csnr,
         o_f0, o_g0, o_H0, misc, seedbuf, tay, ph0, act, seedq, xbase, mdl;
     int* nactive_h = nullptr;   // pinned
@@ -128,11 +136,17 @@ struct pp_ctx {
     int seed_ndm = 1;           // DM trials of the coarse (phi, DM) seed grid (1 = phase only, at the guessed DM)
     double seed_dm_step = 0.0;  // their spacing [pc cm^-3]
     double max_work_bytes = 96e9;
+    int eager_flush = 1;        // poke the stream once the transform is queued (hipStreamQuery), so that the GPU starts
+                                // while the host is still queueing the rest of the batch
+    int coarse_newton = 1;      // Newton solver, scattering fits: iterate on every 16th channel first
     int nfev_shadow = 0;        // (measured: profiles/README.md round 4 -- see pp_set_option's table in include/pp_toas.h)
     int skip_masked = 1;        // channels masked out of a subint are not transformed at all (compact row list)
     // profiling
     struct Span { int fam; hipEvent_t a, b; };
     std::vector<Span> spans;
+    std::vector<hipEvent_t> ev_pool;       // recycled profiling events
+    std::vector<double> kx_host;           // reference-seed flow: host side of the start points
+    double known_ok_bytes = 0.0;           // largest work-memory demand a batch has already been granted
     double fam_sec[KF_COUNT] = {0};
     long long fam_n[KF_COUNT] = {0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -148,11 +162,20 @@ struct pp_ctx {
     pp_fit_out job_out;
 };
 
+// (events are recycled: creating and destroying ten of them per batch cost more than the solve
+// of a 512 x 1024 batch's launch)
+static hipEvent_t prof_event(pp_ctx* c) {
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
 struct Prof {
     pp_ctx* c; int fam; hipEvent_t a = nullptr, b = nullptr;
     Prof(pp_ctx* c_, int fam_) : c(c_), fam(fam_) {
         if (c->profile) {
-            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            a = prof_event(c); b = prof_event(c);
             (void)hipEventRecord(a, c->stream);
         }
     }
@@ -171,7 +194,7 @@ static void resolve_spans(pp_ctx* c) {
             c->fam_sec[s.fam] += 1e-3 * ms;
             c->fam_n[s.fam] += 1;
         }
-        (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
+        c->ev_pool.push_back(s.a); c->ev_pool.push_back(s.b);
     }
     c->spans.clear();
 }
@@ -185,6 +208,7 @@ static int ctx_init(pp_ctx* c) {
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
     for (auto& e : c->evq) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& sg : c->stage) { HIP_TRY(hipEventCreate(&sg.t0)); HIP_TRY(hipEventCreate(&sg.done)); }
     DevBuf* tables[] = {&c->mft_table, &c->msum_table, &c->kt_table, &c->mdc_table, &c->msq_table};
     for (DevBuf* t : tables) {
         int rc = t->reserve(sizeof(void*) * PP_MAX_SLOTS);
@@ -230,8 +254,12 @@ extern "C" int pp_destroy(pp_ctx* c) {
     for (auto& kv : c->twiddles) kv.second.release();
     for (auto& kv : c->anyplans) { kv.second.chirp.release(); kv.second.bft.release(); }
     for (auto& s : c->slots) { s.mft.release(); s.msum.release(); s.mmax.release(); s.mdc.release(); s.kt.release(); s.msq.release(); }
-    if (c->o_host) (void)hipHostFree(c->o_host);
-    if (c->in_host) (void)hipHostFree(c->in_host);
+    for (auto& sg : c->stage) {
+        if (sg.o_host) (void)hipHostFree(sg.o_host);
+        if (sg.in_host) (void)hipHostFree(sg.in_host);
+        if (sg.t0) (void)hipEventDestroy(sg.t0);
+        if (sg.done) (void)hipEventDestroy(sg.done);
+    }
     c->inpack.release();
     c->refbuf.release();
     c->mwords.release();
@@ -242,6 +270,8 @@ extern "C" int pp_destroy(pp_ctx* c) {
                       &c->o_H0, &c->misc, &c->seedbuf, &c->tay, &c->ph0, &c->act, &c->seedq, &c->xbase};
     for (DevBuf* b : bufs) b->release();
     if (c->nactive_h) (void)hipHostFree(c->nactive_h);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    c->ev_pool.clear();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto& e : c->evq) if (e) (void)hipEventDestroy(e);
@@ -276,7 +306,8 @@ static bool option_ref(pp_ctx* c, const std::string& n, OptRef* out) {
         {"taylor_recentre", 'i', &c->taylor_recentre, INT32_MIN}, {"seed_chan_stride", 'i', &c->seed_chan_stride, 1},
         {"seed_min_snr", 'd', &c->seed_min_snr, 0}, {"seed_ndm", 'i', &c->seed_ndm, 1},
         {"seed_dm_step", 'd', &c->seed_dm_step, 0}, {"skip_masked", 'i', &c->skip_masked, INT32_MIN},
-        {"nfev_shadow", 'i', &c->nfev_shadow, INT32_MIN},
+        {"nfev_shadow", 'i', &c->nfev_shadow, INT32_MIN}, {"coarse_newton", 'i', &c->coarse_newton, INT32_MIN},
+        {"eager_flush", 'i', &c->eager_flush, INT32_MIN},
     };
     for (const OptRef& o : tab)
         if (n == o.name) { *out = o; return true; }
@@ -717,8 +748,32 @@ static void launch_xspec(pp_ctx* c, const XspecArgs& xa_in, bool tail, int mode)
 #undef PP_XS
 }
 
+// the packed per-subint outputs of a batch, from its host staging block to the caller's arrays
+static void unpack_stage(const void* o_host, pp_fit_out* out, int s0, int ns) {
+    const double* h = reinterpret_cast<const double*>(o_host);
+    memcpy(out->params + (size_t)s0 * 5, h, (size_t)ns * 40);
+    memcpy(out->param_errs + (size_t)s0 * 5, h + (size_t)ns * 5, (size_t)ns * 40);
+    memcpy(out->nu_refs + (size_t)s0 * 3, h + (size_t)ns * 10, (size_t)ns * 24);
+    memcpy(out->cov + (size_t)s0 * 25, h + (size_t)ns * 13, (size_t)ns * 200);
+    memcpy(out->chi2 + s0, h + (size_t)ns * 38, (size_t)ns * 8);
+    memcpy(out->red_chi2 + s0, h + (size_t)ns * 39, (size_t)ns * 8);
+    memcpy(out->snr + s0, h + (size_t)ns * 40, (size_t)ns * 8);
+    const int32_t* hi = reinterpret_cast<const int32_t*>(h + (size_t)ns * 41);
+    memcpy(out->nfeval + s0, hi, (size_t)ns * 4);
+    memcpy(out->return_code + s0, hi + ns, (size_t)ns * 4);
+    if (out->npass) memcpy(out->npass + s0, hi + 2 * (size_t)ns, (size_t)ns * 4);
+}
+// subints the post-fit stage found unfinished (as k_finalize saw it)
+static int unfinished_in_stage(const void* o_host, int ns) {
+    return reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(o_host) + (size_t)ns * 41)[3 * (size_t)ns];
+}
+
+// `deferred` (pp_fit_enqueue): when non-null and the batch takes the one-pass flow without a host
+// decision in its middle, everything is queued -- outputs on their way to the staging block included --
+// and the call returns WITHOUT waiting (*deferred = true); pp_fit_collect finishes it.
 static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, int ns, int Kt, bool scat,
-                     const std::vector<double>& nufit_h, const std::vector<double>& nuout_h) {
+                     const std::vector<double>& nufit_h, const std::vector<double>& nuout_h, bool* deferred = nullptr) {
+    pp_ctx::Stage& sg = c->stage[c->cur_stage];
     const pp_seed_ref* rs = in->ref_seed;        // (applicability was checked by the caller)
     const bool refseed = (rs != nullptr);
     const int seed_ns = refseed ? rs->Ns : in->seed_ns;
@@ -747,11 +802,11 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     const size_t in_doubles = nfreq + (size_t)ns * (1 + 5 + 3 + 3);
     const size_t in_bytes = in_doubles * 8 + (size_t)ns * 4;
     if ((rc = c->inpack.reserve(in_bytes))) return rc;
-    if (c->in_host_cap < in_bytes) {
-        if (c->in_host) (void)hipHostFree(c->in_host);
-        c->in_host = nullptr; c->in_host_cap = 0;
-        HIP_TRY(hipHostMalloc(&c->in_host, in_bytes, hipHostMallocDefault));
-        c->in_host_cap = in_bytes;
+    if (sg.in_cap < in_bytes) {
+        if (sg.in_host) (void)hipHostFree(sg.in_host);
+        sg.in_host = nullptr; sg.in_cap = 0;
+        HIP_TRY(hipHostMalloc(&sg.in_host, in_bytes, hipHostMallocDefault));
+        sg.in_cap = in_bytes;
     }
     double* const d_freqs = c->inpack.as<double>();
     double* const d_P = d_freqs + nfreq;
@@ -760,7 +815,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     double* const d_nuout = d_nufit + (size_t)ns * 3;
     int* const d_slot = reinterpret_cast<int*>(d_nuout + (size_t)ns * 3);
     {
-        double* h = reinterpret_cast<double*>(c->in_host);
+        double* h = reinterpret_cast<double*>(sg.in_host);
         memcpy(h, in->freqs + (in->freqs_stride ? (size_t)s0 * C : 0), nfreq * 8); h += nfreq;
         memcpy(h, in->P + s0, (size_t)ns * 8); h += ns;
         memcpy(h, in->init_params + (size_t)s0 * 5, (size_t)ns * 40);
@@ -771,7 +826,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         memcpy(h, nufit_h.data() + (size_t)s0 * 3, (size_t)ns * 24); h += (size_t)ns * 3;
         memcpy(h, nuout_h.data() + (size_t)s0 * 3, (size_t)ns * 24); h += (size_t)ns * 3;
         if (in->model_slot) memcpy(h, in->model_slot + s0, (size_t)ns * 4);
-        HIP_TRY(hipMemcpyAsync(c->inpack.p, c->in_host, in_bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->inpack.p, sg.in_host, in_bytes, hipMemcpyHostToDevice, c->stream));
     }
     const double* d_errs = nullptr;
     const unsigned char* d_mask = nullptr;
@@ -807,13 +862,21 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // the bytes), certified by the significance of its correlation peak; subints whose
     // pilot seed is not convincing are seeded from all their channels.  Scattering
     // fits store the whole cross-spectrum anyway and seed from it.
-    const int cstep = std::max(1, c->seed_chan_stride);
+    // (reference-seed flow: the pilot only supplies the expansion point of the Taylor model, which the
+    // certificate guards -- wide bands take every 64th channel, a quarter of the pilot's rows)
+    const int cstep = (refseed && C / 64 >= 32) ? std::max(64, c->seed_chan_stride) : std::max(1, c->seed_chan_stride);
     const bool pilot = seeded && taylor && c->moments_in_xspec && cstep > 1 && C / cstep >= 16;
     const bool seed_full = seeded && !pilot;
     // scattering fits of 2048-bin rows (template cut 2 Kt < M): the transform built on the
     // one-exchange FFT stores the cross-spectrum and takes the first evaluation's nine sums
     // while X is in registers (k_xspec_qs1024) -- one pass over the stored cross-spectrum fewer
-    const bool fuse_scat = scat && !seeded && c->max_iter > 0 && c->one_exchange && c->fuse_scat && M == 1024 &&
+    // Newton solver on a scattering fit: the answer does not depend on the path, so the iteration is first
+    // run on every 16th channel -- a sixteenth of every evaluation pass over the stored cross-spectrum --
+    // and the full-channel iteration starts from there: two or three full passes instead of five or six
+    constexpr int kCoarseStep = 16;
+    const bool coarse = scat && in->method == PP_METHOD_NEWTON && !seeded && !refseed && c->max_iter > 0 &&
+                        c->coarse_newton && C / kCoarseStep >= 32 && !(c->x_f32 > 0);
+    const bool fuse_scat = scat && !seeded && !coarse && c->max_iter > 0 && c->one_exchange && c->fuse_scat && M == 1024 &&
                            2 * Kt < M && !(c->x_f32 > 0) && in->errs != nullptr;
     const bool fuse = (!scat && !taylor && !seeded) || fuse_scat;   // first evaluation folded into the transform
     // k_xspec mode: 2/3 = Taylor model only, no cross-spectrum stored;
@@ -862,11 +925,11 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // cov 25, chi2, red_chi2, snr doubles; nfeval, return_code, npass ints) = 340 B / subint
     const size_t o_bytes = (size_t)ns * 340 + 8;       // (+ the count of unfinished subints)
     if ((rc = c->o_pack.reserve(o_bytes))) return rc;
-    if (c->o_host_cap < o_bytes) {
-        if (c->o_host) (void)hipHostFree(c->o_host);
-        c->o_host = nullptr; c->o_host_cap = 0;
-        HIP_TRY(hipHostMalloc(&c->o_host, o_bytes, hipHostMallocDefault));
-        c->o_host_cap = o_bytes;
+    if (sg.o_cap < o_bytes) {
+        if (sg.o_host) (void)hipHostFree(sg.o_host);
+        sg.o_host = nullptr; sg.o_cap = 0;
+        HIP_TRY(hipHostMalloc(&sg.o_host, o_bytes, hipHostMallocDefault));
+        sg.o_cap = o_bytes;
     }
     double* const o_base = c->o_pack.as<double>();
     if ((rc = c->o_f0.reserve((size_t)ns * 8))) return rc;
@@ -1078,6 +1141,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     }
     // ---- reference-seed flow: Taylor model about the pilot's phase + the rotated channel sums in
     // one pass, then the reference's fit_phase_shift on the channel mean, then the start points
+    double* d_seedph = nullptr;      // [ns] the phase guesses the reference-seed flow formed (fetched with the outputs)
     auto run_refseed_pass = [&]() -> int {
         const int ncc = C / PP_ROW_CHUNK;
         const size_t H = (size_t)M + 1;
@@ -1085,7 +1149,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         const bool w_host = rs->weights && !in->aux_on_device;
         const size_t n_part = (size_t)ns * ncc * RS_NACC * 64;
         const size_t n_cplx = n_part + (size_t)ns * H + nprof * H + (size_t)ns * M;
-        const size_t n_dbl = nprof * B + (size_t)ns * (1 + 1 + 1 + 7 + 5) + (w_host ? nc : 0);
+        const size_t n_dbl = nprof * B + (size_t)ns * (1 + 1 + 1 + 7 + 5 + 1) + (w_host ? nc : 0);
         if ((rc = c->refbuf.reserve(n_cplx * sizeof(cplx) + n_dbl * 8))) return rc;
         cplx* part = c->refbuf.as<cplx>();
         cplx* dspec = part + n_part;
@@ -1097,7 +1161,8 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         double* d_wsum = d_delta + ns;
         double* d_out7 = d_wsum + ns;
         double* d_xs = d_out7 + (size_t)ns * 7;
-        double* d_wh = d_xs + (size_t)ns * 5;
+        double* d_sph = d_xs + (size_t)ns * 5;
+        double* d_wh = d_sph + ns;
         HIP_TRY(hipMemcpyAsync(mprof, rs->model_profs + (rs->model_prof_stride ? (size_t)s0 * B : 0), nprof * B * 8,
                                hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(d_numean, rs->nu_mean + s0, (size_t)ns * 8, hipMemcpyHostToDevice, c->stream));
@@ -1138,23 +1203,24 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             hipLaunchKernelGGL(k_fps, dim3(ns), dim3(256), 0, c->stream, f, xwork);
         }
         HIP_TRY(hipGetLastError());
-        std::vector<double> o7((size_t)ns * 7), xs((size_t)ns * 5);
-        HIP_TRY(hipMemcpyAsync(o7.data(), d_out7, o7.size() * 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        // phase_transform(phi, DM, nu_mean, nu_fit, P, mod=True) (pplib.py:2592-2616), NumPy's
-        // order of operations and libm's pow; the other parameters start as given
-        for (int i = 0; i < ns; ++i) {
-            const double* x0i = in->init_params + (size_t)(s0 + i) * 5;
-            const double P = in->P[s0 + i], nu1 = rs->nu_mean[s0 + i], nu2 = nufit_h[(size_t)(s0 + i) * 3];
-            double ph = o7[(size_t)i * 7] + (PP_DCONST * x0i[1] * pow(P, -1.0) * (pow(nu2, -2.0) - pow(nu1, -2.0)));
-            if (fabs(ph) >= 0.5) { ph = fmod(ph, 1.0); if (ph != 0.0 && ph < 0.0) ph += 1.0; }
-            if (ph >= 0.5) ph -= 1.0;
-            xs[(size_t)i * 5] = ph;
-            for (int j = 1; j < 5; ++j) xs[(size_t)i * 5 + j] = x0i[j];
-            if (rs->seed_phase) rs->seed_phase[s0 + i] = ph;
+        // phase_transform(phi, DM, nu_mean, nu_fit, P, mod=True) (pplib.py:2592-2616): the term it adds
+        // depends on the inputs alone -- formed here in NumPy's order of operations with libm's pow, as the
+        // reference forms it -- so the device only adds it to its fit_phase_shift result and wraps: no
+        // host round trip between the pass and the iteration.  The other parameters start as given.
+        {
+            std::vector<double>& kx = c->kx_host;       // (outlives the copy queued below)
+            kx.resize((size_t)ns * 5);
+            for (int i = 0; i < ns; ++i) {
+                const double* x0i = in->init_params + (size_t)(s0 + i) * 5;
+                const double P = in->P[s0 + i], nu1 = rs->nu_mean[s0 + i], nu2 = nufit_h[(size_t)(s0 + i) * 3];
+                kx[(size_t)i * 5] = PP_DCONST * x0i[1] * pow(P, -1.0) * (pow(nu2, -2.0) - pow(nu1, -2.0));
+                for (int j = 1; j < 5; ++j) kx[(size_t)i * 5 + j] = x0i[j];
+            }
+            HIP_TRY(hipMemcpyAsync(d_xs, kx.data(), kx.size() * 8, hipMemcpyHostToDevice, c->stream));
         }
-        HIP_TRY(hipMemcpyAsync(d_xs, xs.data(), xs.size() * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));      // (xs is a local)
+        hipLaunchKernelGGL(k_refseed_start, dim3((ns + 63) / 64), dim3(64), 0, c->stream, (const double*)d_out7, ns, d_xs, d_sph);
+        HIP_TRY(hipGetLastError());
+        d_seedph = d_sph;
         if (scat) {
             // stored cross-spectrum: the iteration starts AT the reference's guess
             HIP_TRY(hipMemcpyAsync(d_x0, d_xs, (size_t)ns * 40, hipMemcpyDeviceToDevice, c->stream));
@@ -1201,8 +1267,9 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         if (!wts_early) if ((rc = run_prep())) return rc;
     }
     HIP_TRY(hipGetLastError());
+    if (c->eager_flush) (void)hipStreamQuery(c->stream);
     // ---- post-fit stage + every output in one round trip ----
-    auto finalize_and_fetch = [&]() -> int {
+    auto finalize_and_fetch = [&](bool wait = true) -> int {
         FitArgs ff = fa;
         ff.act = nullptr; ff.nact = ns;
         {
@@ -1212,36 +1279,23 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         HIP_TRY(hipGetLastError());
 #define PP_D2H(dst, buf, off, bytes) \
     if (dst) HIP_TRY(hipMemcpyAsync((char*)(dst) + (off), (buf).p, (bytes), hipMemcpyDeviceToHost, c->stream))
-        HIP_TRY(hipMemcpyAsync(c->o_host, c->o_pack.p, o_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(sg.o_host, c->o_pack.p, o_bytes, hipMemcpyDeviceToHost, c->stream));
         if (!chan_dev) {
             PP_D2H(out->scales, c->o_scales, (size_t)s0 * C * 8, nc * 8);
             PP_D2H(out->scale_errs, c->o_serrs, (size_t)s0 * C * 8, nc * 8);
             PP_D2H(out->channel_snrs, c->o_csnr, (size_t)s0 * C * 8, nc * 8);
         }
+        if (d_seedph && rs->seed_phase)
+            HIP_TRY(hipMemcpyAsync(rs->seed_phase + s0, d_seedph, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
         PP_D2H(out->obj_f, c->o_f0, (size_t)s0 * 8, (size_t)ns * 8);
         PP_D2H(out->obj_grad, c->o_g0, (size_t)s0 * 40, (size_t)ns * 40);
         PP_D2H(out->obj_hess, c->o_H0, (size_t)s0 * 200, (size_t)ns * 200);
 #undef PP_D2H
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (wait) HIP_TRY(hipStreamSynchronize(c->stream));
         return PP_OK;
     };
-    auto unpack_outputs = [&]() {
-        const double* h = reinterpret_cast<const double*>(c->o_host);
-        memcpy(out->params + (size_t)s0 * 5, h, (size_t)ns * 40);
-        memcpy(out->param_errs + (size_t)s0 * 5, h + (size_t)ns * 5, (size_t)ns * 40);
-        memcpy(out->nu_refs + (size_t)s0 * 3, h + (size_t)ns * 10, (size_t)ns * 24);
-        memcpy(out->cov + (size_t)s0 * 25, h + (size_t)ns * 13, (size_t)ns * 200);
-        memcpy(out->chi2 + s0, h + (size_t)ns * 38, (size_t)ns * 8);
-        memcpy(out->red_chi2 + s0, h + (size_t)ns * 39, (size_t)ns * 8);
-        memcpy(out->snr + s0, h + (size_t)ns * 40, (size_t)ns * 8);
-        const int32_t* hi = reinterpret_cast<const int32_t*>(h + (size_t)ns * 41);
-        memcpy(out->nfeval + s0, hi, (size_t)ns * 4);
-        memcpy(out->return_code + s0, hi + ns, (size_t)ns * 4);
-        if (out->npass) memcpy(out->npass + s0, hi + 2 * (size_t)ns, (size_t)ns * 4);
-    };
-    auto unfinished = [&]() -> int {     // (as k_finalize saw it)
-        return reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(c->o_host) + (size_t)ns * 41)[3 * (size_t)ns];
-    };
+    auto unpack_outputs = [&]() { unpack_stage(sg.o_host, out, s0, ns); };
+    auto unfinished = [&]() -> int { return unfinished_in_stage(sg.o_host, ns); };
     bool all_done = false;
     if (taylor) {
         if (xstore) {
@@ -1258,6 +1312,14 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         // launched straight behind it and the count of unfinished subints comes back with the
         // outputs -- one host round trip per batch instead of two.  (When some are left, what
         // the post-fit stage wrote for them is overwritten below.)
+        if (deferred && !pilot && !seed_full && !refseed) {
+            // nothing left for the host to decide before the outputs are on their way: pp_fit_collect
+            // looks at the count of unfinished subints (and fits the batch again, synchronously, in the
+            // rare case that some are left -- their guesses were poor)
+            if ((rc = finalize_and_fetch(false))) return rc;
+            *deferred = true;
+            return PP_OK;
+        }
         if ((rc = finalize_and_fetch())) return rc;
         all_done = (unfinished() <= 0);
         if (all_done) { unpack_outputs(); return PP_OK; }
@@ -1294,6 +1356,21 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             if ((rc = list_active(nullptr, 0.0, &nleft))) return rc;
             if ((rc = store_x_for_list(nleft))) return rc;
         }
+    }
+    if (coarse && !all_done) {
+        FitArgs fs = fa;
+        fs.cstep = kCoarseStep; fs.coff = 0; fs.nchan_x = (C + kCoarseStep - 1) / kCoarseStep; fs.x_full = 1;
+        fs.use_model = 0;
+        chunking(fs.nchan_x, ns, fs.nchunk, fs.cpc);
+        // (a fixed number of iterations, no host check: subints that are done cost their kernels nothing)
+        for (int it = 0; it < 8; ++it) {
+            { Prof pr(c, KF_EVAL);
+              hipLaunchKernelGGL((k_eval_scat<8, false>), dim3(fs.nact, fs.nchunk), dim3(256), 0, c->stream, fs); }
+            { Prof pr(c, KF_STEP);
+              hipLaunchKernelGGL(k_step, dim3(fs.nact), dim3(64), 0, c->stream, fs); }
+        }
+        hipLaunchKernelGGL(k_adopt_coarse, dim3((ns + 63) / 64), dim3(64), 0, c->stream, fa);
+        HIP_TRY(hipGetLastError());
     }
     // ---- trust-region iterations: evaluation + step, until every subint is done
     const int max_evals = all_done ? 0 : std::max(1, c->max_iter + 1);
@@ -1350,11 +1427,16 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     return PP_OK;
 }
 
-extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out) {
-    if (!c || !in || !out) return fail(PP_EINVAL, "pp_fit_portrait_batch: null argument");
-    // a submitted batch owns the context (work buffers, stream, counters) until pp_fit_wait
-    if (c->job_active && std::this_thread::get_id() != c->job.get_id())
-        return fail(PP_ESTATE, "pp_fit_portrait_batch: a submitted fit is pending on this context (pp_fit_wait first)");
+// what a batch needs before its first sub-batch: validation, the models it uses, whether the scattering
+// path is needed, default reference frequencies, the sub-batch size the work-memory budget allows
+struct BatchPlan {
+    int Kt = 0, cap = 0;
+    bool scat = false;
+    double per_sub = 0.0;
+    std::vector<double> nufit, nuout;
+};
+
+static int plan_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, BatchPlan* bp) {
     if (in->nsub < 1 || in->nchan < 1) return fail(PP_EINVAL, "bad batch shape %d x %d", in->nsub, in->nchan);
     if (!nbin_any_ok(in->nbin))
         return fail(PP_EINVAL, "nbin %d must be a power of two in [32, 8192] or an even number in [8, 4096]", in->nbin);
@@ -1397,7 +1479,8 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
                                     "scattering), errs given, GM guesses 0)", PP_ROW_CHUNK, 16 * cstep);
     }
     // default reference frequencies: mean of the (unmasked) channel frequencies
-    std::vector<double> nufit((size_t)N * 3), nuout((size_t)N * 3);
+    bp->nufit.assign((size_t)N * 3, 0.0);
+    bp->nuout.assign((size_t)N * 3, 0.0);
     // the masked mean needs the mask on the host: a device-resident mask is
     // copied back once, and only if some reference frequency was left to default
     std::vector<uint8_t> mask_h;
@@ -1426,25 +1509,38 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
                 }
                 v = mean;
             }
-            nufit[(size_t)i * 3 + j] = v;
-            nuout[(size_t)i * 3 + j] = in->nu_outs ? in->nu_outs[(size_t)i * 3 + j] : NAN;
+            bp->nufit[(size_t)i * 3 + j] = v;
+            bp->nuout[(size_t)i * 3 + j] = in->nu_outs ? in->nu_outs[(size_t)i * 3 + j] : NAN;
         }
     }
     // sub-batches sized to the work-memory budget
     size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const double per_sub = (double)C * (Kt + std::max(0, c->x_pad)) * 16.0 + (in->data_on_device ? 0.0 : (double)C * B * (in->data_dtype == PP_F64 ? 8 : 4)) +
                            (double)C * (8.0 * 12 + 2 * 9 * 8.0) + 4096.0 +
                            ((scat && c->scat_model) ? (double)C * PP_MROW * 8.0 : 0.0);
-    double budget = std::min(c->max_work_bytes, 0.85 * ((double)free_b + (double)c->X.cap + (double)c->data.cap + (double)c->csum.cap));
-    int cap = (int)std::max(1.0, std::floor(budget / per_sub));
+    // (a batch no larger than one that already ran under this budget needs no look at the free
+    // memory: hipMemGetInfo costs as much as the post-fit stage of a 512 x 1024 batch)
+    int cap = N;
+    if (per_sub * N > std::min(c->max_work_bytes, c->known_ok_bytes)) {
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const double budget = std::min(c->max_work_bytes, 0.85 * ((double)free_b + (double)c->X.cap + (double)c->data.cap + (double)c->csum.cap));
+        cap = (int)std::max(1.0, std::floor(budget / per_sub));
+    }
     cap = std::min(std::min(cap, N), 65535);   // (subints index the grid's y dimension)
+    bp->Kt = Kt; bp->scat = scat; bp->cap = cap; bp->per_sub = per_sub;
+    return PP_OK;
+}
+
+// every sub-batch in turn, synchronously; device time of the whole into out->duration
+static int run_batch_sync(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, const BatchPlan& bp) {
+    const int N = in->nsub;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    for (int s0 = 0; s0 < N; s0 += cap) {
-        const int ns = std::min(cap, N - s0);
-        int rc = fit_chunk(c, in, out, s0, ns, Kt, scat, nufit, nuout);
+    for (int s0 = 0; s0 < N; s0 += bp.cap) {
+        const int ns = std::min(bp.cap, N - s0);
+        int rc = fit_chunk(c, in, out, s0, ns, bp.Kt, bp.scat, bp.nufit, bp.nuout);
         if (rc) return rc;
     }
+    c->known_ok_bytes = std::max(c->known_ok_bytes, bp.per_sub * std::min(bp.cap, N));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     if (out->duration) {
@@ -1454,6 +1550,101 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
     }
     if (c->profile) resolve_spans(c);
     return PP_OK;
+}
+
+extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out) {
+    if (!c || !in || !out) return fail(PP_EINVAL, "pp_fit_portrait_batch: null argument");
+    // a submitted batch owns the context (work buffers, stream, counters) until pp_fit_wait
+    if (c->job_active && std::this_thread::get_id() != c->job.get_id())
+        return fail(PP_ESTATE, "pp_fit_portrait_batch: a submitted fit is pending on this context (pp_fit_wait first)");
+    if (!c->pending.empty())
+        return fail(PP_ESTATE, "pp_fit_portrait_batch: %zu enqueued batch(es) not collected yet (pp_fit_collect first)", c->pending.size());
+    BatchPlan bp;
+    int rc = plan_batch(c, in, out, &bp);
+    if (rc) return rc;
+    return run_batch_sync(c, in, out, bp);
+}
+
+// --------------------------------------------------------------------------
+// stream-ordered batches: pp_fit_enqueue queues a whole batch -- inputs, kernels, outputs on their
+// way to a pinned staging block -- and returns without waiting; pp_fit_collect completes the oldest.
+// Two may be pending: while the GPU works on one batch the host marshals and queues the next, so
+// the stream never runs dry between batches.  One stream, one set of device work buffers: stream
+// order keeps a batch's solve and post-fit stage ahead of the next batch's transform.
+// --------------------------------------------------------------------------
+extern "C" int pp_fit_enqueue(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out) {
+    if (!c || !in || !out) return fail(PP_EINVAL, "pp_fit_enqueue: null argument");
+    if (c->job_active) return fail(PP_ESTATE, "pp_fit_enqueue: a submitted fit is pending on this context (pp_fit_wait first)");
+    if (c->pending.size() >= 2) return fail(PP_ESTATE, "pp_fit_enqueue: two batches are pending (pp_fit_collect first)");
+    BatchPlan bp;
+    int rc = plan_batch(c, in, out, &bp);
+    if (rc) return rc;
+    pp_ctx::Deferred d;
+    d.in = *in; d.out = *out; d.queued = false; d.rc = PP_OK;
+    d.stage = c->pending.empty() ? c->cur_stage : 1 - c->pending.front().stage;
+    c->cur_stage = d.stage;
+    pp_ctx::Stage& sg = c->stage[d.stage];
+    if (bp.cap >= in->nsub) {
+        HIP_TRY(hipEventRecord(sg.t0, c->stream));
+        bool deferred = false;
+        rc = fit_chunk(c, in, out, 0, in->nsub, bp.Kt, bp.scat, bp.nufit, bp.nuout, &deferred);
+        if (rc) return rc;
+        c->known_ok_bytes = std::max(c->known_ok_bytes, bp.per_sub * in->nsub);
+        HIP_TRY(hipEventRecord(sg.done, c->stream));
+        d.queued = deferred;
+        if (!deferred) {
+            // (a flow with host decisions in its middle: it has run to its end)
+            HIP_TRY(hipEventSynchronize(sg.done));
+            if (out->duration) {
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, sg.t0, sg.done));
+                out->duration[0] = 1e-3 * ms;
+            }
+            if (c->profile) resolve_spans(c);
+        }
+    } else {
+        // (more than the work-memory budget holds at once: sub-batches, synchronously -- only with
+        // nothing else pending, the sub-batches reuse the staging blocks)
+        if (!c->pending.empty()) return fail(PP_ESTATE, "pp_fit_enqueue: a batch that needs sub-batches cannot follow a pending one");
+        if ((rc = run_batch_sync(c, in, out, bp))) return rc;
+    }
+    c->pending.push_back(d);
+    return PP_OK;
+}
+
+extern "C" int pp_fit_pending(pp_ctx* c) {
+    if (!c) return fail(PP_EINVAL, "null context");
+    return (int)c->pending.size();
+}
+
+extern "C" int pp_fit_collect(pp_ctx* c) {
+    if (!c) return fail(PP_EINVAL, "null context");
+    if (c->pending.empty()) return fail(PP_ESTATE, "pp_fit_collect: nothing enqueued");
+    pp_ctx::Deferred d = c->pending.front();
+    c->pending.pop_front();
+    if (!d.queued) return d.rc;
+    HIP_TRY(hipSetDevice(c->device));
+    pp_ctx::Stage& sg = c->stage[d.stage];
+    HIP_TRY(hipEventSynchronize(sg.done));
+    const int ns = d.in.nsub;
+    if (unfinished_in_stage(sg.o_host, ns) <= 0) {
+        unpack_stage(sg.o_host, &d.out, 0, ns);
+        if (d.out.duration) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, sg.t0, sg.done));
+            d.out.duration[0] = 1e-3 * ms;
+        }
+        if (c->profile && c->pending.empty()) resolve_spans(c);
+        return PP_OK;
+    }
+    // some subints left the one-pass flow (poor guesses): the batch is fitted again, synchronously, by
+    // the general flow -- behind whatever has been queued since; its inputs are still the caller's
+    c->cur_stage = d.stage;
+    BatchPlan bp;
+    int rc = plan_batch(c, &d.in, &d.out, &bp);
+    if (rc) return rc;
+    // (run_batch_sync refuses nothing here: the check for pending batches is pp_fit_portrait_batch's)
+    return run_batch_sync(c, &d.in, &d.out, bp);
 }
 
 // --------------------------------------------------------------------------

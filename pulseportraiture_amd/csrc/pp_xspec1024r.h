@@ -329,6 +329,19 @@ __global__ __launch_bounds__(256) void k_refseed_prep(const double* x0, const do
     }
 }
 
+// the start points of the iteration: xs[i] holds {K_i, DM, GM, tau, alpha} on entry, K_i the term
+// phase_transform adds (formed on the host from the inputs alone); the phase becomes
+// wrap(fit_phase_shift's phase + K_i) with NumPy's two-step wrap to [-0.5, 0.5) (pplib.py:2612-2613)
+__global__ void k_refseed_start(const double* out7, int nsub, double* xs, double* seed_phase) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsub) return;
+    double ph = out7[(size_t)i * 7] + xs[(size_t)i * 5];
+    if (fabs(ph) >= 0.5) { ph = fmod(ph, 1.0); if (ph != 0.0 && ph < 0.0) ph += 1.0; }
+    if (ph >= 0.5) ph -= 1.0;
+    xs[(size_t)i * 5] = ph;
+    seed_phase[i] = ph;
+}
+
 // rot_prof's spectrum of every subint from the partial channel sums: fixed-order sum over the
 // channel blocks, the per-harmonic factor e^{-i kap Delta_i} that turns the Taylor phase into the
 // reference's rotation phase, division by the summed weights; harmonics the pass did not

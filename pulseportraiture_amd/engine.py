@@ -365,6 +365,14 @@ class Engine(object):
         res["fit_flags"] = [1 if f else 0 for f in fit_flags]
         if seed_keep is not None:
             res["seed_phase"] = seed_keep[4]
+        if _submit == "enqueue":
+            _check(self._lib.pp_fit_enqueue(self._ctx, C.byref(fin), C.byref(fout)), "pp_fit_enqueue")
+            # every array the argument blocks point to stays alive until collect()
+            if not hasattr(self, "_queue"):
+                self._queue = []
+            self._queue.append((res, (keep, freqs, P, x0, errs, nu_fits, nu_outs, slot, mask, chan_mask,
+                                      records, fin, fout, seed_keep)))
+            return None
         if _submit:
             _check(self._lib.pp_fit_submit(self._ctx, C.byref(fin), C.byref(fout)), "pp_fit_submit")
             # every array the argument blocks point to stays alive until wait()
@@ -384,6 +392,24 @@ class Engine(object):
         until then.  Two engines on one GPU overlap their copies and kernels."""
         kwargs["_submit"] = True
         self.fit_batch(*args, **kwargs)
+
+    def enqueue(self, *args, **kwargs):
+        """fit_batch queued on the engine's stream (pp_fit_enqueue): returns without waiting for the
+        GPU; collect() returns the result dict of the OLDEST enqueued batch.  Up to two batches may be
+        pending: enqueue batch k + 1, then collect batch k, and the GPU never waits for the host
+        between batches.  The caller's arrays must not be modified until the batch is collected."""
+        kwargs["_submit"] = "enqueue"
+        self.fit_batch(*args, **kwargs)
+
+    def collect(self):
+        """Complete the oldest enqueued batch; returns what fit_batch returns."""
+        if not getattr(self, "_queue", None):
+            raise EngineError("nothing enqueued")
+        res, keep = self._queue.pop(0)
+        _check(self._lib.pp_fit_collect(self._ctx), "pp_fit_collect")
+        del keep
+        res["duration"] = float(res["duration"][0])
+        return res
 
     def poll(self):
         """True once the submitted batch is complete."""
@@ -686,6 +712,7 @@ def default_engine(device=0):
 
 
 _WHILE_PENDING = ("poll", "wait", "close")      # what may be called while a submitted batch runs
+_WHILE_QUEUED = ("enqueue", "fit_batch", "collect", "close", "set_option", "get_option", "kernel_times", "synchronize")
 
 
 def _fresh_waits(fn):
@@ -697,6 +724,8 @@ def _fresh_waits(fn):
         # include/pp_toas.h forbids every other call meanwhile -- enforce it here
         if getattr(self, "_pending", None) is not None and fn.__name__ not in _WHILE_PENDING:
             raise EngineError("a submitted batch is pending on this engine: wait() before %s()" % fn.__name__)
+        if getattr(self, "_queue", None) and fn.__name__ not in _WHILE_QUEUED:
+            raise EngineError("enqueued batches are pending on this engine: collect() before %s()" % fn.__name__)
         _new_call()
         return fn(self, *args, **kwargs)
     return call

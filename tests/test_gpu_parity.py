@@ -2957,3 +2957,77 @@ def test_entry_points_without_a_general_length_path_refuse_loudly(eng):
         eng.rotate_portraits(x, np.linspace(1200., 1300., 3), 0.003, phi=0.1)
     with pytest.raises(EngineError):
         eng.rfft_rows(np.zeros((1, 1001)))            # odd lengths: not even the reference's nbin = 2 (nharm - 1) holds
+
+
+@pytest.mark.parametrize("flags,l10", [([1, 1, 0, 1, 1], True), ([1, 1, 0, 1, 0], False), ([1, 1, 1, 1, 1], True)])
+def test_newton_scattering_fit_iterates_on_a_channel_subset_first(flags, l10):
+    """method='newton' on a scattering fit: the iteration first runs on every 16th channel (a sixteenth
+    of each evaluation pass over the stored cross-spectrum) and the full-channel iteration starts from
+    that answer (option coarse_newton).  The optimum does not depend on the path: same parameters,
+    errors and chi2 as the all-channel iteration, in fewer full passes; the oracle's Newton step at the
+    answer vanishes."""
+    from oracle import pptoas_oracle as orc
+    C, B, nsub = 512, 2048, 6
+    e, data, freqs, model, P, x0, errs, nu_fit, kw = _full_shape_case(C, B, flags, l10, nsub=nsub, tau_us=30.0,
+                                                                      gm=bool(flags[2]), seed=41)
+    kw = dict(kw, method='newton', nu_outs=np.full((nsub, 3), nu_fit))
+    e.set_option("coarse_newton", 0)
+    full = e.fit_batch(data, freqs, P, x0, **kw)
+    e.set_option("coarse_newton", 1)
+    fast = e.fit_batch(data, freqs, P, x0, **kw)
+    assert (fast["return_code"] == 2).all() and (full["return_code"] == 2).all()
+    assert fast["npass"].mean() < full["npass"].mean() - 1.0, (fast["npass"], full["npass"])
+    assert np.abs(_dphi_arr(fast["params"][:, 0], full["params"][:, 0])).max() < 2e-10
+    np.testing.assert_allclose(fast["params"][:, 1:], full["params"][:, 1:], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(fast["param_errs"], full["param_errs"], rtol=1e-6)
+    np.testing.assert_allclose(fast["chi2"], full["chi2"], rtol=1e-10)
+    host = data[0].cpu().numpy()
+    dFT = np.fft.rfft(host, axis=-1); dFT[:, 0] = 0
+    mFT = np.fft.rfft(model, axis=-1); mFT[:, 0] = 0
+    args = (dFT, mFT, errs[0] * np.sqrt(B / 2.0), P[0], freqs, nu_fit, nu_fit, nu_fit, flags, l10)
+    step = _oracle_newton_step(args, fast["params"][0], flags)
+    assert abs(step[0]) < PHI_BAR, step
+    e.close()
+
+
+def test_enqueued_batches_equal_synchronous_fits(eng):
+    """pp_fit_enqueue / pp_fit_collect: batches queued on the engine's stream two deep return,
+    bitwise, what the synchronous call returns -- the one-pass flow (deferred: nothing waits until
+    collect), a batch with poor guesses (some subints fail their certificate: collect fits the batch
+    again by the general flow), a scattering fit (runs to its end inside enqueue) -- in the order
+    they were enqueued; a synchronous call while batches are pending is refused."""
+    from pulseportraiture_amd.engine import EngineError
+    nsub = 24
+    data, freqs, P, x0, kw = _medium_batch(eng, nsub, C=256, B=2048, seed=77)
+    x_poor = x0.copy()
+    x_poor[[3, 17], 0] = (x_poor[[3, 17], 0] + 0.03 + 0.5) % 1 - 0.5
+    x_b = x0.copy()
+    x_b[:, 0] = (x_b[:, 0] + 2e-5 + 0.5) % 1 - 0.5
+    jobs = [(x0, kw), (x_poor, kw), (x_b, dict(kw, fit_flags=[1, 0, 0, 0, 0])), (x0, dict(kw, method='newton'))]
+    sync = [eng.fit_batch(data, freqs, P, x, **k) for x, k in jobs]
+    assert (sync[1]["npass"][[3, 17]] > 1).all() and (sync[0]["npass"] == 1).all()
+    got = []
+    for j, (x, k) in enumerate(jobs):
+        eng.enqueue(data, freqs, P, x, **k)
+        if j == 1:
+            with pytest.raises(EngineError):
+                eng.fit_batch(data, freqs, P, x0, **kw)          # (two pending: the context is theirs)
+        if j > 0:
+            got.append(eng.collect())
+    got.append(eng.collect())
+    with pytest.raises(EngineError):
+        eng.collect()
+    for a, b in zip(sync, got):
+        for key in ("params", "param_errs", "nu_refs", "cov", "chi2", "red_chi2", "snr", "nfeval", "npass", "return_code",
+                    "scales", "scale_errs", "channel_snrs"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    # a scattering fit through the same door
+    e2, d2, f2, m2, P2, x2, er2, nf2, kw2 = _full_shape_case(64, 512, [1, 1, 0, 1, 1], True, nsub=5, tau_us=30.0, seed=8)
+    s2 = e2.fit_batch(d2, f2, P2, x2, **kw2)
+    e2.enqueue(d2, f2, P2, x2, **kw2)
+    e2.enqueue(d2, f2, P2, x2, **kw2)
+    for _ in range(2):
+        r2 = e2.collect()
+        for key in ("params", "chi2", "nfeval", "npass"):
+            np.testing.assert_array_equal(s2[key], r2[key], err_msg=key)
+    e2.close()
