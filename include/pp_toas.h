@@ -157,11 +157,13 @@ void* pp_stream(pp_ctx* ctx);
  *                  0 = every evaluation over all channels.  nfeval includes the coarse evaluations, npass
  *                  counts full passes.  (PP_METHOD_TRUST_NCG retraces SciPy's iterates and is not affected.)
  *   "nfev_shadow"  one-pass flow, method trust-ncg: how SciPy's one-point cache is mirrored when nfeval is
- *                  counted.  0 (default): proposals are compared as displacements from the expansion
- *                  point (resolution 1e-21: the closing proposal p = -H^-1 g is always a new point and
- *                  counts, which is what the reference does in most fits); 1: on the absolute iterate
- *                  fl(x + p) as SciPy forms it -- exact in principle, but the closing p is the
- *                  device's own rounding noise, not the reference's (measured: DESIGN.md section 2)
+ *                  counted.  0: proposals are compared as displacements from the expansion point
+ *                  (resolution 1e-21: the closing proposal p = -H^-1 g is always a new point and counts);
+ *                  1: on the absolute iterate fl(x + p) as SciPy forms it; 2: as 1, with the model evaluated
+ *                  at the rounded point; -1 (default): 1 for one-parameter fits, 0 otherwise -- the rule
+ *                  that agrees with the reference's count most often, family by family (3000 random fits,
+ *                  profiles/r04_parity_sweep.txt; the closing p is rounding noise of whoever computes it, so
+ *                  the last unit of nfeval is a coin toss of the reference's own arithmetic)
  *   "moments_in_xspec"  1 (default) = the Taylor moments are accumulated inside
  *                  the transform kernel and no cross-spectrum is stored; 0 = store
  *                  the cross-spectrum and take the moments in a second pass

@@ -139,7 +139,7 @@ struct pp_ctx {
     int eager_flush = 1;        // poke the stream once the transform is queued (hipStreamQuery), so that the GPU starts
                                 // while the host is still queueing the rest of the batch
     int coarse_newton = 1;      // Newton solver, scattering fits: iterate on every 16th channel first
-    int nfev_shadow = 0;        // (measured: profiles/README.md round 4 -- see pp_set_option's table in include/pp_toas.h)
+    int nfev_shadow = -1;       // (-1: by family, measured: profiles/README.md round 4 -- see pp_set_option's table in include/pp_toas.h)
     int skip_masked = 1;        // channels masked out of a subint are not transformed at all (compact row list)
     // profiling
     struct Span { int fam; hipEvent_t a, b; };
@@ -1363,7 +1363,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         fs.use_model = 0;
         chunking(fs.nchan_x, ns, fs.nchunk, fs.cpc);
         // (a fixed number of iterations, no host check: subints that are done cost their kernels nothing)
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < std::min(12, c->max_iter + 1); ++it) {
             { Prof pr(c, KF_EVAL);
               hipLaunchKernelGGL((k_eval_scat<8, false>), dim3(fs.nact, fs.nchunk), dim3(256), 0, c->stream, fs); }
             { Prof pr(c, KF_STEP);

@@ -21,6 +21,13 @@ W4="--workload cfg4-2048x2048-scat"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/trace_cfg4 -- $B $W4 --steps 3 --warmup 1 > $O/raw/bench_cfg4_under_rocprof.json 2> $O/raw/trace4.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_fetch_cfg4 -- $B $W4 --steps 1 --warmup 0 > /dev/null 2> $O/raw/fetch4.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_write_cfg4 -- $B $W4 --steps 1 --warmup 0 > /dev/null 2> $O/raw/write4.err
+# configs[1] (512 x 1024, k_xspec_qf<512>) and the masked regime (20 % of the rows skipped): kernel stats + HBM counters
+for tag in cfg2 masked20; do
+  if [ $tag = cfg2 ]; then WX="--workload cfg2-512x1024-phiDM"; else WX="--variant masked20"; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/trace_$tag -- $B $WX --steps 5 --warmup 1 > $O/raw/bench_${tag}_under_rocprof.json 2> $O/raw/trace_$tag.err
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_fetch_$tag -- $B $WX --steps 1 --warmup 0 > /dev/null 2> $O/raw/fetch_$tag.err
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_write_$tag -- $B $WX --steps 1 --warmup 0 > /dev/null 2> $O/raw/write_$tag.err
+done
 # the seeded (get_TOAs) flows: the device seed, and the reference's own guess formed inside the single pass
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/trace_seeded -- $B --seed-ns 100 --steps 3 --warmup 1 > $O/raw/bench_seeded_under_rocprof.json 2> $O/raw/trace_s.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/trace_refseed -- $B --seed-ns -1 --steps 3 --warmup 1 > $O/raw/bench_refseed_under_rocprof.json 2> $O/raw/trace_r.err
@@ -84,10 +91,31 @@ if fb > 0:
 def first(pat):
     fs = glob.glob(pat)
     return fs[0] if fs else None
-for tag in ("cfg4", "seeded", "refseed"):
+for tag in ("cfg4", "seeded", "refseed", "cfg2", "masked20"):
     f = first(f"{O}/raw/trace_{tag}/*/*_kernel_stats.csv")
     if f:
         open(f"{O}/{R}_{tag}_kernel_stats.csv", "w").write(open(f).read())
+# configs[1] and the masked regime: HBM traffic of the transform against the algorithmic bytes
+for tag in ("cfg2", "masked20"):
+    fx, wx = counters(f"pmc_fetch_{tag}", "FETCH_SIZE"), counters(f"pmc_write_{tag}", "WRITE_SIZE")
+    if not fx:
+        continue
+    try:
+        bx = json.loads(open(f"{O}/raw/bench_{tag}_under_rocprof.json").read().strip().splitlines()[-1])
+        nx = bx["config"]["nsub_per_gpu_per_step"]
+        fb = sum(v["sum_KiB"] for k, v in fx.items() if "k_xspec" in k) * 2048
+        wb = sum(v["sum_KiB"] for k, v in wx.items() if "k_xspec" in k) * 1024
+        kn = [k for k in fx if "k_xspec" in k]
+        json.dump({"workload": bx["config"]["workload"], "variant": bx["config"].get("variant"), "nsub": nx,
+                   "transform_kernels": kn, "fits_per_s_under_profiler": bx["value"],
+                   "algorithmic_bytes_per_fit": bx["roofline"]["algorithmic_bytes_per_fit"],
+                   "transform_hbm_bytes_per_fit": (fb + wb) / nx,
+                   "traffic_over_algorithmic": (fb + wb) / nx / bx["roofline"]["algorithmic_bytes_per_fit"],
+                   "roofline_under_profiler": {k: bx["roofline"][k] for k in ("achieved", "frac", "ms_per_step_in_kernel")},
+                   "note": "FETCH_SIZE x2 + WRITE_SIZE of the transform kernel of one step (separate --pmc passes)"},
+                  open(f"{O}/{R}_{tag}_traffic.json", "w"), indent=1)
+    except Exception as ex:
+        print(tag, "traffic summary failed:", ex)
 f4, w4 = counters("pmc_fetch_cfg4", "FETCH_SIZE"), counters("pmc_write_cfg4", "WRITE_SIZE")
 if f4:
     try:
