@@ -16,6 +16,7 @@
 // A compatibility path: ~3 x the LDS traffic and instructions of a tuned plan per sample.
 #pragma once
 #include "pp_kernels.h"
+#include "pp_extra.h"
 
 namespace pp {
 
@@ -178,6 +179,38 @@ __global__ __launch_bounds__(64) void k_model_from_harm(const cplx* hout, int M,
     s = group_sum<64>(s);
     mx = group_max<64>(mx);
     if (tid == 0) { msum[n] = s; mmax[n] = mx; mdc[n] = h[0].x; }
+}
+
+// The reference's rot_prof from the harmonics k_any left in hout (general row lengths; pp_reference_phase_seed):
+// spec[i][k] = sum_n w_n d_nk e^{2 pi i k phi'_n} / sum_n w_n, phi'_n the rotation of rotate_data
+// (pplib.py:2338-2426).  hout rows are channel-major (row = n nsub + i).  One thread per harmonic,
+// channels in order: a fixed summation order.
+__global__ __launch_bounds__(256) void k_rot_mean_harm(const cplx* hout, RotMeanArgs a, int M, cplx* spec) {
+    const int i = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > M) return;
+    const double P = a.P[i];
+    cplx s = make_double2(0.0, 0.0);
+    double wt = 0.0;
+    for (int n = 0; n < a.nchan; ++n) {
+        const double w = a.w[(size_t)i * a.nchan + n];
+        if (w == 0.0) continue;
+        wt += w;
+        const double nu = a.freqs[(size_t)i * a.freqs_stride + n];
+        const double a2 = 1.0 / (nu * nu);
+        const double phin = a.par[i * 3] + PP_DCONST * a.par[i * 3 + 1] * (a2 - a.inv_nuDM2) / P +
+                            PP_DCONST * PP_DCONST * a.par[i * 3 + 2] * (a2 * a2 - a.inv_nuGM4) / P;
+        const cplx d = hout[((size_t)n * a.nsub + i) * (M + 1) + k];
+        cplx y;
+        if (k == 0) y = d;
+        else {
+            const cplx e = unit_phasor((double)k, phin);
+            y = (k == M) ? make_double2(d.x * e.x, 0.0) : cmul(d, e);
+        }
+        s.x = fma(w, y.x, s.x);
+        s.y = fma(w, y.y, s.y);
+    }
+    const double inv = (wt > 0.0) ? 1.0 / wt : 0.0;
+    spec[(size_t)i * (M + 1) + k] = make_double2(s.x * inv, s.y * inv);
 }
 
 }  // namespace pp

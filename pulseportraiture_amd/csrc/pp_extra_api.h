@@ -13,7 +13,8 @@ static int aux_chunk_cap(pp_ctx* c, double per_sub, int nsub) {
 extern "C" int pp_fit_phase_shift_batch(pp_ctx* c, const double* data, const double* model, const double* noise,
                                         int nprof, int nbin, double lo, double hi, int Ns, double* out7) {
     if (!c || !data || !model || !out7) return fail(PP_EINVAL, "pp_fit_phase_shift_batch: null argument");
-    if (!nbin_ok(nbin)) return nbin_refuse("pp_fit_phase_shift_batch", nbin);
+    if (!nbin_any_ok(nbin)) return nbin_refuse("pp_fit_phase_shift_batch", nbin);
+    const bool anyb = !nbin_ok(nbin);
     if (nprof < 1) return fail(PP_EINVAL, "pp_fit_phase_shift_batch: bad shape %d x %d", nprof, nbin);
     if (Ns < 1) return fail(PP_EINVAL, "pp_fit_phase_shift_batch: Ns %d", Ns);
     HIP_TRY(hipSetDevice(c->device));
@@ -45,11 +46,19 @@ extern "C" int pp_fit_phase_shift_batch(pp_ctx* c, const double* data, const dou
     cplx* xwork = spec + 2 * (size_t)nprof * (M + 1);
     {
         Prof pr(c, KF_FPS);
+        if (anyb) {
+            // (row lengths without a tuned plan: the same spectra by the chirp-z path, pp_anybin.h)
+            XspecArgs xa;
+            memset(&xa, 0, sizeof xa);
+            xa.data = c->data.p; xa.nsub = 1; xa.nchan = 2 * nprof; xa.nchan_full = 2 * nprof; xa.cstep = 1;
+            if ((rc = launch_any(c, xa, nbin, ((M + 63) / 64) * 64, PP_F64, -1, false, spec, nullptr))) return rc;
+        } else {
         PP_DISPATCH_M(M, {
             const int T = FftPlan<MM>::T;
             hipLaunchKernelGGL((k_rfft_rows<MM, double>), dim3(fft_grid(T, 2 * nprof)), dim3(T), 0, c->stream,
                                (const void*)c->data.p, spec, tw, 2 * nprof);
         });
+        }
         const double* dnoise = nullptr;
         if (noise) {
             if ((rc = upload(c, c->errs, noise, (size_t)nprof * 8))) return rc;
@@ -75,7 +84,8 @@ extern "C" int pp_reference_phase_seed(pp_ctx* c, const void* src, int dtype, in
                                        const double* model_profs, double lo, double hi, int Ns, double* out7) {
     if (!c || !src || !freqs || !P || !par3 || !weights || !model_profs || !out7)
         return fail(PP_EINVAL, "pp_reference_phase_seed: null argument");
-    if (!nbin_ok(nbin)) return nbin_refuse("pp_reference_phase_seed", nbin);
+    if (!nbin_any_ok(nbin)) return nbin_refuse("pp_reference_phase_seed", nbin);
+    const bool anyb = !nbin_ok(nbin);
     if (nsub < 1 || nchan < 1 || Ns < 1) return fail(PP_EINVAL, "pp_reference_phase_seed: bad shape");
     if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_reference_phase_seed: dtype %d", dtype);
     if (freqs_stride != 0 && freqs_stride != nchan) return fail(PP_EINVAL, "freqs_stride must be 0 or nchan");
@@ -117,6 +127,8 @@ extern "C" int pp_reference_phase_seed(pp_ctx* c, const void* src, int dtype, in
     const int cpr = (nchan + nrun - 1) / nrun;
     nrun = (nchan + cpr - 1) / cpr;
     const size_t H = (size_t)M + 1;
+    // (general row lengths: the harmonics of every row are written out first -- nrun = nchan slots of H)
+    if (anyb) nrun = nchan;
     // X: [nsub][nrun][H] partial spectra | [nsub][H] data spectra | [nsub][H] model spectra | [nsub][M] k_fps work
     if ((rc = c->X.reserve(((size_t)nsub * nrun * H + 2 * (size_t)nsub * H + (size_t)nsub * M) * sizeof(cplx)))) return rc;
     if ((rc = c->sdraw.reserve((size_t)nsub * nrun * 8))) return rc;
@@ -132,7 +144,23 @@ extern "C" int pp_reference_phase_seed(pp_ctx* c, const void* src, int dtype, in
                    std::isinf(nu_GM) ? 0.0 : 1.0 / (nu_GM * nu_GM * nu_GM * nu_GM), part, c->sdraw.as<double>(),
                    nsub, nchan, nrun, cpr};
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    {
+    if (anyb) {
+        // row lengths without a tuned plan (pp_anybin.h): every row's harmonics by the chirp-z path, then
+        // the weighted, rotated channel sum per harmonic, and the template profiles' spectra the same way
+        Prof pr(c, KF_FPS);
+        XspecArgs xa;
+        memset(&xa, 0, sizeof xa);
+        xa.data = dsrc; xa.nsub = nsub; xa.nchan = nchan; xa.nchan_full = nchan; xa.cstep = 1;
+        const int Mp = ((M + 63) / 64) * 64;
+        if ((rc = launch_any(c, xa, nbin, Mp, dtype, -1, false, part, nullptr))) return rc;
+        hipLaunchKernelGGL(k_rot_mean_harm, dim3((unsigned)((M + 1 + 255) / 256), nsub), dim3(256), 0, c->stream,
+                           (const cplx*)part, ra, M, dspec);
+        memset(&xa, 0, sizeof xa);
+        xa.data = c->errs.p; xa.nsub = 1; xa.nchan = nsub; xa.nchan_full = nsub; xa.cstep = 1;
+        if ((rc = launch_any(c, xa, nbin, Mp, PP_F64, -1, false, mspec, nullptr))) return rc;
+        FpsArgs fa{dspec, nullptr, c->o_params.as<double>(), lo, hi, Ns, M, nsub, c->fps_finish, mspec, M + 1};
+        hipLaunchKernelGGL(k_fps, dim3(nsub), dim3(256), 0, c->stream, fa, xwork);
+    } else {
         Prof pr(c, KF_FPS);
         PP_DISPATCH_M(M, {
             const int T = FftPlan<MM>::T;

@@ -222,59 +222,60 @@ __global__ void k_model_kcut(const cplx* mft, const double* mmax, int /*nchan*/,
 #endif
 // DYN = false (workgroups of several waves: the ticket would have to cross waves):
 // chunk c goes to workgroup c mod G; the tickets are then not drawn at all.
-// Masked rows (XspecArgs::mwords): one 32-bit word per chunk, bit b set = row 32 c + b is in
-// use (k_mask_words builds them from the batch's chan_mask).  The walk visits the set bits of a
-// chunk's word only -- a channel the mask removes from a subint is neither read nor transformed,
-// as the reference slices the good channels away before its fit (pptoas.py:384-397).  All of it
-// is scalar work: the word of the NEXT chunk is fetched (one scalar load) while the current one
-// is walked, as soon as the ticket that names it has arrived; an empty chunk costs its visitor
-// one more (synchronous) ticket.  Every in-range chunk still draws exactly one ticket.
+// Rows in use (XspecArgs::mwords): one 32-bit word per chunk, bit b set = row 32 c + b is to be
+// transformed (k_mask_words builds them from the batch's chan_mask; nullptr = every row, i.e. full
+// words).  The walk visits the set bits of a chunk's word only -- a channel the mask removes from a
+// subint is neither read nor transformed, as the reference slices the good channels away before
+// its fit (pptoas.py:384-397).  All of it is scalar work on a handful of 32-bit registers (the
+// transform kernels have none to spare: rows are counted in 32 bits, nrows < 2^31): the word of the
+// NEXT chunk is fetched (one scalar load) while the current one is walked, as soon as the ticket
+// that names it has arrived; an empty chunk costs its visitor one more (synchronous) ticket.  Every
+// in-range chunk draws exactly one ticket.
 template <bool DYN>
 struct RowWalk {
-    long long row, row_nx, cstart, cend;
-    unsigned tick;     // lane 0: the ticket; kept per-lane (not uniform) so that it stays
-                       // in a VGPR and nothing waits for the atomic before next() reads it
-    bool more, more_nx;
-    // masked walk
-    const unsigned* mw;        // nullptr: every row
+    unsigned row, row_nx;      // this row, the row after it
     unsigned bits;             // rows of this chunk still to come (after `row`)
-    unsigned wnx;              // the next chunk's word, once fetched
-    bool fresh, have_wnx;      // `row` is the first row visited of its chunk; wnx is valid
-    long long cnx;             // first row of the next chunk (valid with have_wnx)
-    __device__ __forceinline__ unsigned word_of(long long c0, long long nrows) const {
-        return (c0 < nrows) ? as_global(mw)[c0 / PP_ROW_CHUNK] : 0u;
+    unsigned wnx, cnx;         // masked walk: the next chunk's word and index, once fetched
+    unsigned tick;             // lane 0: the ticket; kept per-lane (not uniform) so that it stays
+                               // in a VGPR and nothing waits for the atomic before next() reads it
+    bool more, more_nx;
+    bool fresh, have_wnx;      // `row` is the first row visited of its chunk; (wnx, cnx) are valid
+    static __device__ __forceinline__ unsigned word_of(const unsigned* mw, unsigned c, unsigned nrows) {
+        const unsigned long long r0 = (unsigned long long)c * PP_ROW_CHUNK;
+        if (r0 >= nrows) return 0u;
+        if (mw) return as_global(mw)[c];
+        const unsigned rem = nrows - (unsigned)r0;
+        return rem >= 32u ? 0xffffffffu : ((1u << rem) - 1u);
     }
-    // first row of the chunk a visitor of chunk start c0 moves on to (DYN: one synchronous ticket)
-    __device__ __forceinline__ long long chunk_after(long long c0, unsigned* ticket, unsigned base) {
+    // the chunk a visitor of chunk c moves on to (DYN: one synchronous ticket)
+    static __device__ __forceinline__ unsigned chunk_after(unsigned c, unsigned* ticket, unsigned base) {
         if (DYN) {
             unsigned t = 0;
             if (threadIdx.x == 0) t = atomicAdd(ticket, 1u);
-            t = __builtin_amdgcn_readfirstlane(t) - base;
-            return ((long long)gridDim.x + (long long)t) * PP_ROW_CHUNK;
+            return gridDim.x + (__builtin_amdgcn_readfirstlane(t) - base);
         }
-        return c0 + (long long)gridDim.x * PP_ROW_CHUNK;
+        return c + gridDim.x;
     }
-    __device__ __forceinline__ void start(long long nrows, const unsigned* mwords = nullptr, unsigned* ticket = nullptr,
+    __device__ __forceinline__ void enter(unsigned c, unsigned w, unsigned nrows) {
+        more_nx = (unsigned long long)c * PP_ROW_CHUNK < nrows;
+        row_nx = c * PP_ROW_CHUNK + (w ? (unsigned)__builtin_ctz(w) : 0u);
+        bits = w & (w - 1u);
+        have_wnx = false;
+    }
+    __device__ __forceinline__ void start(long long nrows_, const unsigned* mw = nullptr, unsigned* ticket = nullptr,
                                           unsigned base = 0) {
-        static_assert(PP_ROW_CHUNK == 32, "one 32-bit mask word per chunk");
-        mw = mwords; bits = 0; wnx = 0; have_wnx = false; cnx = 0;
-        cstart = (long long)blockIdx.x * PP_ROW_CHUNK;
-        cend = min(nrows, cstart + PP_ROW_CHUNK);
-        row = cstart;
-        if (mw) {
-            // the first chunk with a row in use (an empty one still owes its ticket)
-            unsigned w = word_of(cstart, nrows);
-            while (w == 0u && cstart < nrows) {
-                cstart = chunk_after(cstart, ticket, base);
-                w = word_of(cstart, nrows);
-            }
-            w = __builtin_amdgcn_readfirstlane(w);
-            cend = min(nrows, cstart + PP_ROW_CHUNK);
-            row = cstart + (w ? __builtin_ctz(w) : 0);
-            bits = w & (w - 1u);
+        static_assert(PP_ROW_CHUNK == 32, "one 32-bit word per chunk");
+        const unsigned nrows = (unsigned)nrows_;
+        wnx = 0; cnx = 0;
+        unsigned c = blockIdx.x;
+        unsigned w = word_of(mw, c, nrows);
+        // the first chunk with a row in use (an empty one still owes its ticket)
+        while (w == 0u && (unsigned long long)c * PP_ROW_CHUNK < nrows) {
+            c = chunk_after(c, ticket, base);
+            w = word_of(mw, c, nrows);
         }
-        more = cstart < nrows;
-        row_nx = row; more_nx = more;
+        enter(c, __builtin_amdgcn_readfirstlane(w), nrows);
+        row = row_nx; more = more_nx;
         tick = threadIdx.x;
         fresh = true;
     }
@@ -284,83 +285,65 @@ struct RowWalk {
     }
     // masked walk, top of a row that is not the first of its chunk: the ticket has long arrived --
     // fetch the word of the chunk it names, to be looked at when this chunk runs out
-    __device__ __forceinline__ void peek(long long nrows, unsigned base) {
+    __device__ __forceinline__ void peek(long long nrows_, unsigned base, const unsigned* mw) {
         if (mw && !fresh && !have_wnx) {
-            if (DYN) {
-                const unsigned t = __builtin_amdgcn_readfirstlane(tick) - base;
-                cnx = ((long long)gridDim.x + (long long)t) * PP_ROW_CHUNK;
-            } else {
-                cnx = cstart + (long long)gridDim.x * PP_ROW_CHUNK;
-            }
-            wnx = word_of(cnx, nrows);
+            cnx = DYN ? gridDim.x + (__builtin_amdgcn_readfirstlane(tick) - base) : (row >> 5) + gridDim.x;
+            wnx = word_of(mw, cnx, (unsigned)nrows_);
             have_wnx = true;
         }
     }
-    // (subint, channel) of the row after this one: the next of the chunk, or the
-    // first of the chunk the ticket names (one division per chunk, all scalar)
-    __device__ __forceinline__ void next(int i, int n, int& i_nx, int& n_nx, long long nrows, int nsub,
-                                         unsigned base, unsigned* ticket = nullptr) {
-        if (mw) {
+    // (subint, channel) of the row after this one: the next row in use of the chunk, or the first
+    // of the chunk the ticket names (one division per chunk, all scalar)
+    __device__ __forceinline__ void next(int i, int n, int& i_nx, int& n_nx, long long nrows_, int nsub,
+                                         unsigned base, unsigned* ticket = nullptr, const unsigned* mw = nullptr) {
+        const unsigned nrows = (unsigned)nrows_;
+        if (bits) {
+            const unsigned b = (unsigned)__builtin_ctz(bits);
+            bits &= bits - 1u;
+            row_nx = (row & ~(unsigned)(PP_ROW_CHUNK - 1)) + b;
+            i_nx = i + (int)(row_nx - row); n_nx = n;
+            while (i_nx >= nsub) { i_nx -= nsub; ++n_nx; }
             more_nx = true;
-            if (bits) {
-                // the next row in use of this chunk
-                const int b = __builtin_ctz(bits);
-                bits &= bits - 1u;
-                row_nx = cstart + b;
-                i_nx = i + (int)(row_nx - row); n_nx = n;
-                while (i_nx >= nsub) { i_nx -= nsub; ++n_nx; }
-                return;
-            }
-            // this chunk is done: the one its ticket names, or the first after it with a row in use
-            long long c0; unsigned w;
-            if (have_wnx) { c0 = cnx; w = wnx; }
-            else {
-                if (DYN) {
-                    const unsigned t = __builtin_amdgcn_readfirstlane(tick) - base;
-                    c0 = ((long long)gridDim.x + (long long)t) * PP_ROW_CHUNK;
-                } else c0 = cstart + (long long)gridDim.x * PP_ROW_CHUNK;
-                w = word_of(c0, nrows);
-            }
-            while (w == 0u && c0 < nrows) {
-                c0 = chunk_after(c0, ticket, base);
-                w = word_of(c0, nrows);
-            }
-            w = __builtin_amdgcn_readfirstlane(w);
-            have_wnx = false;
-            cstart = c0;
-            cend = min(nrows, cstart + PP_ROW_CHUNK);
-            more_nx = cstart < nrows;
-            row_nx = cstart + (w ? __builtin_ctz(w) : 0);
-            bits = w & (w - 1u);
-            if (more_nx) {
-                n_nx = __builtin_amdgcn_readfirstlane((int)(row_nx / nsub));
-                i_nx = __builtin_amdgcn_readfirstlane((int)(row_nx % nsub));
-            }
             return;
         }
-        row_nx = row + 1;
-        i_nx = i + 1; n_nx = n;
-        if (i_nx == nsub) { i_nx = 0; ++n_nx; }
-        more_nx = true;
-        if (row_nx == cend) {
-            if (DYN) {
-                const unsigned t = __builtin_amdgcn_readfirstlane(tick) - base;
-                cstart = ((long long)gridDim.x + (long long)t) * PP_ROW_CHUNK;
-            } else {
-                cstart += (long long)gridDim.x * PP_ROW_CHUNK;
-            }
-            cend = min(nrows, cstart + PP_ROW_CHUNK);
-            row_nx = cstart;
-            more_nx = row_nx < nrows;
-            if (more_nx) {
-                n_nx = __builtin_amdgcn_readfirstlane((int)(row_nx / nsub));
-                i_nx = __builtin_amdgcn_readfirstlane((int)(row_nx % nsub));
-            }
+        // this chunk is done: the one its ticket names, or the first after it with a row in use
+        unsigned c, w;
+        if (have_wnx) { c = cnx; w = wnx; }
+        else {
+            c = DYN ? gridDim.x + (__builtin_amdgcn_readfirstlane(tick) - base) : (row >> 5) + gridDim.x;
+            w = word_of(mw, c, nrows);
         }
+        while (w == 0u && (unsigned long long)c * PP_ROW_CHUNK < nrows) {
+            c = chunk_after(c, ticket, base);
+            w = word_of(mw, c, nrows);
+        }
+        enter(c, __builtin_amdgcn_readfirstlane(w), nrows);
+        if (more_nx) {
+            n_nx = __builtin_amdgcn_readfirstlane((int)(row_nx / (unsigned)nsub));
+            i_nx = __builtin_amdgcn_readfirstlane((int)(row_nx % (unsigned)nsub));
+        }
+    }
+    // the same for a caller that reads its indices off the row number itself
+    __device__ __forceinline__ void next_row(long long nrows_, unsigned base, unsigned* ticket, const unsigned* mw) {
+        const unsigned nrows = (unsigned)nrows_;
+        if (bits) {
+            const unsigned b = (unsigned)__builtin_ctz(bits);
+            bits &= bits - 1u;
+            row_nx = (row & ~(unsigned)(PP_ROW_CHUNK - 1)) + b;
+            more_nx = true;
+            return;
+        }
+        unsigned c = DYN ? gridDim.x + (__builtin_amdgcn_readfirstlane(tick) - base) : (row >> 5) + gridDim.x;
+        unsigned w = word_of(mw, c, nrows);
+        while (w == 0u && (unsigned long long)c * PP_ROW_CHUNK < nrows) {
+            c = chunk_after(c, ticket, base);
+            w = word_of(mw, c, nrows);
+        }
+        enter(c, __builtin_amdgcn_readfirstlane(w), nrows);
     }
     __device__ __forceinline__ void advance() {
         // (a row is the first of its chunk when the walk has just changed chunks)
-        fresh = (row_nx / PP_ROW_CHUNK != row / PP_ROW_CHUNK);
+        fresh = ((row_nx ^ row) >> 5) != 0u;
         row = row_nx; more = more_nx;
     }
 };
@@ -431,7 +414,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
     int i_nx = i, n_nx = n;
     for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
         rw.draw(a.ticket);
-        rw.peek(nrows, a.ticket_base);
+        rw.peek(nrows, a.ticket_base, a.mwords);
         // Everything derived from the thread index and the twiddles is invariant
         // over this loop, and the compiler hoists all of it (LDS addresses of every
         // stage, twiddle powers: ~50 VGPRs held across the whole row).  Recomputing
@@ -485,7 +468,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             // loads exist)
             auto prefetch = [&]() {
                 __builtin_amdgcn_sched_barrier(0);
-                rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket);
+                rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket, a.mwords);
                 const size_t rn = rw.more_nx
                     ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
                 stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);

@@ -388,8 +388,8 @@ static int fail(int code, const char* fmt, ...);
 // what an entry point without a general-length path answers
 static int nbin_refuse(const char* who, int nbin) {
     if (nbin_any_ok(nbin))
-        return fail(PP_ENOTSUP, "%s: nbin %d is no power of two: only pp_model_set, pp_fit_portrait_batch and pp_rfft_rows "
-                                "take general even row lengths", who, nbin);
+        return fail(PP_ENOTSUP, "%s: nbin %d is no power of two: only pp_model_set, pp_fit_portrait_batch, pp_rfft_rows, "
+                                "pp_fit_phase_shift_batch and pp_reference_phase_seed take general even row lengths", who, nbin);
     return fail(PP_EINVAL, "%s: nbin %d must be a power of two in [32, 8192] (the fit also takes even lengths up to 4096)",
                 who, nbin);
 }
@@ -1146,7 +1146,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         const int ncc = C / PP_ROW_CHUNK;
         const size_t H = (size_t)M + 1;
         const size_t nprof = rs->model_prof_stride ? (size_t)ns : 1;
-        const bool w_host = rs->weights && !in->aux_on_device;
+        const bool w_host = (rs->weights && !in->aux_on_device) || d_mask;     // (room for the masked weights)
         const size_t n_part = (size_t)ns * ncc * RS_NACC * 64;
         const size_t n_cplx = n_part + (size_t)ns * H + nprof * H + (size_t)ns * M;
         const size_t n_dbl = nprof * B + (size_t)ns * (1 + 1 + 1 + 7 + 5 + 1) + (w_host ? nc : 0);
@@ -1167,17 +1167,23 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
                                hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(d_numean, rs->nu_mean + s0, (size_t)ns * 8, hipMemcpyHostToDevice, c->stream));
         const double* d_w = nullptr;
-        if (w_host) {
+        if (rs->weights && !in->aux_on_device) {
             HIP_TRY(hipMemcpyAsync(d_wh, rs->weights + (size_t)s0 * C, nc * 8, hipMemcpyHostToDevice, c->stream));
             d_w = d_wh;
         } else if (rs->weights) d_w = rs->weights + (size_t)s0 * C;
+        if (d_mask) {
+            // the channel mean is taken over the channels the fit uses
+            hipLaunchKernelGGL(k_refseed_weights, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, d_w, d_mask,
+                               (long long)nc, d_wh);
+            d_w = d_wh;
+        }
         const long long nrows = (long long)ns * C;
         XspecArgs x = xa;
         x.ticket = c->ticket.as<unsigned>();
         x.ticket_base = c->ticket_base;
         x.mwords = mw_sub;
         c->ticket_base += (unsigned)((nrows + PP_ROW_CHUNK - 1) / PP_ROW_CHUNK);
-        RefSeedArgs ra{d_w, part, ncc, d_mask};
+        RefSeedArgs ra{d_w, part, ncc};
         {
             Prof pr(c, KF_XSPEC);
 #define PP_QR(TIN, ST)                                                                                     \
@@ -1195,7 +1201,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             hipLaunchKernelGGL((k_rfft_rows<1024, double>), dim3(fft_grid(64, (long long)nprof)), dim3(64), 0, c->stream,
                                (const void*)mprof, mspec, tw, (int)nprof);
             hipLaunchKernelGGL(k_refseed_prep, dim3(ns), dim3(256), 0, c->stream, (const double*)d_x0, (const double*)d_P,
-                               (const double*)d_nufit, (const double*)d_numean, d_w, d_mask, C, d_delta, d_wsum);
+                               (const double*)d_nufit, (const double*)d_numean, d_w, C, d_delta, d_wsum);
             hipLaunchKernelGGL(k_refseed_finish, dim3((unsigned)((H + 255) / 256), ns), dim3(256), 0, c->stream,
                                (const cplx*)part, ncc, (const double*)d_delta, (const double*)d_wsum, ns, dspec, mw_sub);
             FpsArgs f{dspec, nullptr, d_out7, rs->lo, rs->hi, rs->Ns, M, ns, rs->finish, mspec,
@@ -1527,6 +1533,7 @@ static int plan_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, BatchPlan
         cap = (int)std::max(1.0, std::floor(budget / per_sub));
     }
     cap = std::min(std::min(cap, N), 65535);   // (subints index the grid's y dimension)
+    cap = std::max(1, std::min(cap, (int)(2147483647LL / C)));   // (the transforms count rows in 32 bits)
     bp->Kt = Kt; bp->scat = scat; bp->cap = cap; bp->per_sub = per_sub;
     return PP_OK;
 }

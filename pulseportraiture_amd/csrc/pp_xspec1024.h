@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
     int i_nx = i, n_nx = n;
     for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
         rw.draw(a.ticket);
-        rw.peek(nrows, a.ticket_base);
+        rw.peek(nrows, a.ticket_base, a.mwords);
         if (PP_OPAQUE_ROW == 1 || (PP_OPAQUE_ROW == 2 && M2)) asm volatile("" : "+v"(tid));
         // stage twiddles are re-read every row (three L1-resident loads, issued before
         // the prefetch) instead of living in 12 registers through the harmonic phase,
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         {
-            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket);
+            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket, a.mwords);
             const size_t rn = rw.more_nx ? (size_t)i_nx * a.nchan + n_nx : rc;
             stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);
         }

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
     int i_nx = i, n_nx = n;
     for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
         rw.draw(a.ticket);
-        rw.peek(nrows, a.ticket_base);
+        rw.peek(nrows, a.ticket_base, a.mwords);
         // (everything derived from the lane number is recomputed per row: held across
         // the row it would cost the registers the prefetched row needs)
         asm volatile("" : "+v"(tid));
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
         };
         auto prefetch = [&]() {
             __builtin_amdgcn_sched_barrier(0);
-            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket);
+            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket, a.mwords);
             const size_t rn = rw.more_nx
                 ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
             nxrow = reinterpret_cast<const Tin*>(a.data) + rn * (2 * M);
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
     int i_nx = i, n_nx = n;
     for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
         rw.draw(a.ticket);
-        rw.peek(nrows, a.ticket_base);
+        rw.peek(nrows, a.ticket_base, a.mwords);
         asm volatile("" : "+v"(tid));
         const int lam = Q::lambda(tid);
         const bool l0 = (lam == 0);
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
         };
         {
             __builtin_amdgcn_sched_barrier(0);
-            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket);
+            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket, a.mwords);
             const size_t rn = rw.more_nx
                 ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
             nxrow = reinterpret_cast<const Tin*>(a.data) + rn * (2 * M);

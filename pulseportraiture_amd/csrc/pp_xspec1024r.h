@@ -38,9 +38,6 @@ struct RefSeedArgs {
     const double* w;      // [nsub][nchan_full] channel weights of the mean, or nullptr (= 1)
     cplx* part;           // [nsub][ncc][RS_NACC][64] partial channel sums
     int ncc;              // channel blocks per subint (nchan / PP_ROW_CHUNK)
-    const unsigned char* mask;   // [nsub][nchan] the fit's channel mask or nullptr: the channel mean is taken over
-                                 // the channels in use only (the reference averages portx = port[ok_ichans],
-                                 // pptoas.py:384-397, 424), whatever weight a masked channel carries
 };
 constexpr int RS_NACC = 12;     // slots 0..6 (kept), 12..15 (noise tail), Nyquist (lane of lam = 0)
 constexpr int RS_NREG = 11;     // ... of which in registers; the Nyquist term (one lane's) sits in LDS
@@ -73,21 +70,22 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
     const cplx wbT = a.twB[64];
     RowWalk<true> rw;
     rw.start(nrows, a.mwords, a.ticket, a.ticket_base);
-    int r = 0, c = 0;                 // position in the chunk, chunk
+    // (position in the chunk and chunk are the low and high bits of the walk's row: nothing to carry)
     int ia = 0, cc = 0;               // the chunk's subint and channel block (one division per chunk)
     if (rw.more) {
-        c = __builtin_amdgcn_readfirstlane((int)(rw.row / PP_ROW_CHUNK));
-        r = __builtin_amdgcn_readfirstlane((int)(rw.row % PP_ROW_CHUNK));     // (0 unless the mask removes the chunk's first rows)
-        ia = c % a.nsub; cc = c / a.nsub;
-        const size_t rc = (size_t)ia * a.nchan_full + (size_t)cc * PP_ROW_CHUNK + r;
+        const int c0 = (int)(rw.row >> 5), r0 = (int)(rw.row & 31u);    // (r0 = 0 unless the mask removes the chunk's first rows)
+        ia = c0 % a.nsub; cc = c0 / a.nsub;
+        const size_t rc = (size_t)ia * a.nchan_full + (size_t)cc * PP_ROW_CHUNK + r0;
         stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rc * (2 * M), tid);
     }
     cplx acc[RS_NREG - NLA];      // (slots 0..6, tail slot 12 [.. 15 for f32 rows])
-    int r_nx = r, c_nx = c, ia_nx = ia, cc_nx = cc;
+    int ia_nx = ia, cc_nx = cc;
     const int ktg = a.Kt;             // harmonics the widest template row keeps: the channel sum takes them all
-    for (; rw.more; rw.advance(), r = r_nx, c = c_nx, ia = ia_nx, cc = cc_nx) {
+    for (; rw.more; rw.advance(), ia = ia_nx, cc = cc_nx) {
         rw.draw(a.ticket);
-        rw.peek(nrows, a.ticket_base);
+        // (no look-ahead for the next chunk's word here -- scalar registers are what this kernel is
+        // short of: the word is fetched when the chunk runs out, one exposed scalar load per 32 rows)
+        const int r = (int)(rw.row & 31u);
         asm volatile("" : "+v"(tid));
         const int lam = fftq_lambda(tid);
         const bool l0 = (lam == 0);
@@ -99,8 +97,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
         const cplx* mrow = as_global(a.slot ? a.mft[a.slot[ia]] : a.mft0) + (size_t)ne * M;
         const int ktn = a.ktab ? as_global(a.slot ? a.ktab[a.slot[ia]] : a.kt0)[ne] : a.Kt;
         const double phin = a.ph0[rc];
-        const double hw = (rs.mask && !rs.mask[rc]) ? 0.0
-                                                    : 0.5 * (rs.w ? rs.w[rc] : 1.0);     // (2 d_k below: the half goes here, exact)
+        const double hw = 0.5 * (rs.w ? rs.w[rc] : 1.0);     // (2 d_k below: the half goes here, exact)
         if (rw.fresh) {       // (the first row visited of this chunk)
 #pragma unroll
             for (int j = 0; j < RS_NREG - NLA; ++j) acc[j] = make_double2(0.0, 0.0);
@@ -124,12 +121,13 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
         };
         auto prefetch = [&]() {
             __builtin_amdgcn_sched_barrier(0);
-            rw.next(r, c, r_nx, c_nx, nrows, PP_ROW_CHUNK, a.ticket_base, a.ticket);
+            rw.next_row(nrows, a.ticket_base, a.ticket, a.mwords);
             size_t rn = rc;
             ia_nx = ia; cc_nx = cc;
             if (rw.more_nx) {
-                if (c_nx != c) { ia_nx = c_nx % a.nsub; cc_nx = c_nx / a.nsub; }
-                rn = (size_t)ia_nx * a.nchan_full + (size_t)(cc_nx * PP_ROW_CHUNK + r_nx);
+                const int c_nx = (int)(rw.row_nx >> 5);
+                if (c_nx != (int)(rw.row >> 5)) { ia_nx = c_nx % a.nsub; cc_nx = c_nx / a.nsub; }
+                rn = (size_t)ia_nx * a.nchan_full + (size_t)(cc_nx * PP_ROW_CHUNK + (int)(rw.row_nx & 31u));
             }
             nxrow = reinterpret_cast<const Tin*>(a.data) + rn * (2 * M);
             load_some(0, HALVES ? R1 / 2 : R1);
@@ -295,7 +293,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
             }
             if (tid == 4 * PP_TSTRIDE) a.sdraw[rc] = tv;
         }
-        if (!rw.more_nx || c_nx != c) {
+        if (!rw.more_nx || ((rw.row_nx ^ rw.row) >> 5) != 0u) {
             // (the last row visited of this chunk:) the chunk's share of the channel sums of subint ia
             cplx* out = rs.part + (((size_t)ia * rs.ncc + cc) * RS_NACC) * 64 + tid;
 #pragma unroll
@@ -308,19 +306,25 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
     }
 }
 
+// the weights of the channel mean with the fit's channel mask folded in: the mean is taken over the
+// channels in use only (the reference averages portx = port[ok_ichans], pptoas.py:384-397, 424),
+// whatever weight a masked channel carries
+__global__ void k_refseed_weights(const double* w, const unsigned char* mask, long long n, double* out) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[j] = mask[j] ? (w ? w[j] : 1.0) : 0.0;
+}
+
 // per subint: Delta_i = phi_c + Dconst DM (nu_mean^-2 - nu_fit^-2) / P, the constant by which the
 // Taylor phase of every channel exceeds the reference's rotation phase, and the summed weights
 // (fixed-order block reduction).  x0: [nsub][5] expansion points (the pilot seed wrote the phases).
 __global__ __launch_bounds__(256) void k_refseed_prep(const double* x0, const double* P, const double* nu_fit,
-                                                      const double* nu_mean, const double* w, const unsigned char* mask,
-                                                      int nchan, double* delta, double* wsum) {
+                                                      const double* nu_mean, const double* w, int nchan,
+                                                      double* delta, double* wsum) {
     const int i = blockIdx.x, tid = threadIdx.x;
     __shared__ double scratch[4];
     double s[1] = {0.0};
-    if (w || mask) {
-        for (int n = tid; n < nchan; n += 256)
-            if (!mask || mask[(size_t)i * nchan + n]) s[0] += w ? w[(size_t)i * nchan + n] : 1.0;
-    } else if (tid == 0) s[0] = (double)nchan;
+    if (w) { for (int n = tid; n < nchan; n += 256) s[0] += w[(size_t)i * nchan + n]; }
+    else if (tid == 0) s[0] = (double)nchan;
     block_sum<1>(s, scratch);
     if (tid == 0) {
         const double nf = nu_fit[i * 3], nm = nu_mean[i];

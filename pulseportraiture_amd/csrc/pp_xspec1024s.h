@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qs1024(XspecArgs a, const doubl
     int i_nx = i, n_nx = n;
     for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
         rw.draw(a.ticket);
-        rw.peek(nrows, a.ticket_base);
+        rw.peek(nrows, a.ticket_base, a.mwords);
         asm volatile("" : "+v"(tid));
         const int lam = fftq_lambda(tid);
         const bool l0 = (lam == 0);
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qs1024(XspecArgs a, const doubl
         };
         auto prefetch = [&]() {
             __builtin_amdgcn_sched_barrier(0);
-            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket);
+            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket, a.mwords);
             const size_t rn = rw.more_nx ? (size_t)i_nx * a.nchan_full + n_nx : rc;
             nxrow = reinterpret_cast<const Tin*>(a.data) + rn * (2 * M);
             load_some(0, HALVES ? R1 / 2 : R1);

@@ -33,6 +33,11 @@ def _load(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
 
+# (case, subint) draws of test_randomised_shapes_and_flags_match_oracle whose raw miss is one of the
+# reference's own bistable exits -- each needs its row of tools/ref_exit_points.py as evidence
+MARGINAL_EXITS_RANDOMISED_SHAPES = set()
+
+
 def _note_marginal(test, key, raw, stall):
     """Record a raw miss that was accepted as one of SciPy's marginal exits (gpurun_out/, when present)."""
     d = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
@@ -1248,18 +1253,16 @@ def test_randomised_shapes_and_flags_match_oracle(eng):
                 Kg * (o.nu_GM ** -4 - rn["nu_refs"][i, 1] ** -4)
             raw = _dphi(phi_rn, o.phi)
             if raw >= PHI_BAR:
-                # A marginal exit: SciPy's last accepted step was worth about one ulp
-                # of f, so whether it is taken depends on the rounding of f itself (the
-                # oracle's own answer moves by as much when its channel sums are
-                # reordered).  The two answers are then neighbouring iterates, no
-                # farther apart than the reference's answer is from its own optimum.
-                dFT = np.fft.rfft(datas[i][ok], axis=-1); dFT[:, 0] = 0
-                mFT = np.fft.rfft(model[ok], axis=-1); mFT[:, 0] = 0
-                oargs = (dFT, mFT, errs[i][ok] * np.sqrt(nbin / 2.0), Ps[i], freqs[ok],
-                         o.nu_DM, o.nu_GM, o.nu_tau, flags, False)
-                stall = _oracle_newton_step(oargs, np.asarray(o.params), flags)
-                _note_marginal("randomised_shapes", (case, i), raw, stall[0])
-                assert raw < 2.0 * abs(stall[0]) + 1e-10, (case, i, "trust-ncg", raw, stall)
+                # SciPy's exit with gtol = -1 is a ratio test between an actual reduction of -1, 0 or +1
+                # ulp(f) and a predicted one of ~1 ulp: a fit can end on either of two neighbouring exit
+                # points, and which one is decided by the rounding of the last evaluation -- the TRUE
+                # reference moves between them when nothing but the order of its channels changes
+                # (profiles/r04_ref_exit_points.txt: 107 of the 116 device answers that are >= 1e-10 rot
+                # from the reference's natural-order answer ARE answers the reference gives under another
+                # channel order).  No draw of this test is such a case today: the list is empty, and a
+                # (case, subint) may only be added with that evidence (tools/ref_exit_points.py).
+                assert (case, i) in MARGINAL_EXITS_RANDOMISED_SHAPES, (case, i, "trust-ncg", raw)
+                _note_marginal("randomised_shapes", (case, i), raw, 0.0)
             assert abs(rn["params"][i, 1] - o.DM) < DM_BAR, (case, i, "trust-ncg")
             assert abs(r["params"][i, 1] - o.DM) < DM_BAR, (case, i)
             np.testing.assert_allclose(r["param_errs"][i, :3], np.asarray(o.param_errs)[:3],
@@ -2945,14 +2948,39 @@ def test_any_even_nbin_ragged_batch_matches_oracle(eng, nbin, C):
             assert np.abs(_dphi_arr(rs["params"][:, 0], rw["params"][:, 0])).max() < PHI_BAR
 
 
+@pytest.mark.parametrize("nbin", [1000, 100, 1536])
+def test_reference_guess_at_any_even_nbin(eng, nbin):
+    """fit_phase_shift and the reference's whole initial-guess block (rotation to nu_mean, weighted
+    channel mean, fit_phase_shift with SciPy's simplex finish; pptoas.py:421-457) at row lengths
+    without a tuned plan, against the oracle: what GetTOAs.get_TOAs' default flow needs for such data."""
+    from oracle import pptoas_oracle as orc
+    from tests.synth_host import make_inputs, model_portrait
+    C = 24
+    freqs, model = model_portrait(C, nbin)
+    inp = make_inputs(C, nbin, 5 * nbin, model=model, DM0=34.56789, sigma=0.05)
+    w = np.random.default_rng(nbin).uniform(0.5, 1.5, C)
+    w[[2, 11]] = 0.0
+    nu_mean = freqs[w > 0].mean()
+    rot = orc.rotate_data(inp["data"], 0.0, inp["DM0"], inp["P"], freqs, nu_mean)
+    rot_prof = np.average(rot, axis=0, weights=w)
+    mprof = model[w > 0].mean(axis=0)
+    o = orc.fit_phase_shift(rot_prof, mprof, Ns=100)
+    got = eng.fit_phase_shift_batch(rot_prof, mprof, Ns=100, finish='simplex')[0]
+    assert abs(got[0] - o.phase) < 1e-10 and abs(got[1] / o.phase_err - 1) < 1e-7 and abs(got[4] / o.snr - 1) < 1e-7
+    seed = eng.reference_phase_seed(inp["data"][None], freqs, inp["P"], w[None], mprof, DM=inp["DM0"], nu_DM=nu_mean,
+                                    Ns=100, finish='simplex')[0]
+    assert abs(seed[0] - o.phase) < 1e-10, (seed[0], o.phase)
+    np.testing.assert_allclose(seed[1:6], [o.phase_err, o.scale, o.scale_err, o.snr, o.red_chi2], rtol=1e-7)
+
+
 def test_entry_points_without_a_general_length_path_refuse_loudly(eng):
-    """fit_phase_shift, the rotations, ppalign's accumulation ... have tuned plans only: a row
-    length that is no power of two is answered with PP_ENOTSUP (EngineNotSupported) and a
+    """The rotations, ppalign's accumulation, the template synthesisers ... have tuned plans only: a
+    row length that is no power of two is answered with PP_ENOTSUP (EngineNotSupported) and a
     message that says which entry points do take it -- never a silent resampling."""
     from pulseportraiture_amd.engine import EngineError, EngineNotSupported
     x = np.random.default_rng(1).normal(size=(2, 3, 1000))
     with pytest.raises(EngineNotSupported, match="no power of two"):
-        eng.fit_phase_shift_batch(x[0, 0], x[0, 1])
+        eng.align_accumulate(x, np.linspace(1200., 1300., 3), 0.003, 0.0, 0.0, np.inf, np.ones((2, 3)))
     with pytest.raises(EngineNotSupported, match="no power of two"):
         eng.rotate_portraits(x, np.linspace(1200., 1300., 3), 0.003, phi=0.1)
     with pytest.raises(EngineError):
@@ -3031,3 +3059,43 @@ def test_enqueued_batches_equal_synchronous_fits(eng):
         for key in ("params", "chi2", "nfeval", "npass"):
             np.testing.assert_array_equal(s2[key], r2[key], err_msg=key)
     e2.close()
+
+
+@pytest.mark.parametrize("seed", ["reference", "device"])
+def test_get_TOAs_at_a_row_length_that_is_no_power_of_two(seed):
+    """GetTOAs.get_TOAs end to end on 1000-bin data (the reference's rfft takes any nbin): the
+    template from the .gmodel file, the reference's guess (a pass of its own at such lengths) or the
+    device seed, the fit, TOAs and DMs -- against fit_portrait_full of the oracle from the same
+    guesses, subint by subint."""
+    from oracle import pptoas_oracle as orc
+    from pulseportraiture_amd.pptoas import GetTOAs, MJD, data_from_arrays
+    from pulseportraiture_amd import gmodel
+    nsub, C, B = 3, 32, 1000
+    freqs1, model, P0 = gmodel.example_model(C, B)
+    rng = np.random.default_rng(12)
+    DM0 = 34.56789
+    sub = np.empty((nsub, 1, C, B))
+    inj = []
+    for i in range(nsub):
+        phi, dDM = rng.uniform(-0.5, 0.5), rng.normal(3e-4, 2e-4)
+        inj.append((phi, DM0 + dDM))
+        sub[i, 0] = orc.rotate_portrait_full(model, -phi, -(DM0 + dDM), 0.0, freqs1, np.inf, np.inf, P0) + \
+            rng.normal(0, 0.05, (C, B))
+    weights = np.ones((nsub, C)); weights[1, 5:9] = 0.0
+    d = data_from_arrays(sub, np.tile(freqs1, (nsub, 1)), np.full(nsub, P0), [MJD(58000 + i, 0.25) for i in range(nsub)],
+                         weights=weights, noise_stds=np.full((nsub, 1, C), 0.05), SNRs=np.ones((nsub, 1, C)),
+                         DM=DM0, doppler_factors=np.ones(nsub), backend_delay=0.0, bw=800.0, nu0=1500.0,
+                         subtimes=np.full(nsub, 60.0), source="J0000+0000", filename="fake.fits")
+    gt = GetTOAs(d, os.path.join(GOLDEN, "example.gmodel"), quiet=True)
+    gt.get_TOAs(quiet=True, bary=False, seed=seed)
+    for i in range(nsub):
+        ok = np.where(weights[i] > 0)[0]
+        x0 = [gt.phis[0][i], gt.DMs[0][i], 0.0, 0.0, 0.0]      # (start the oracle at the answer: its Newton step must vanish)
+        dFT = np.fft.rfft(sub[i, 0][ok], axis=-1); dFT[:, 0] = 0
+        mFT = np.fft.rfft(model[ok], axis=-1); mFT[:, 0] = 0
+        nu = gt.nu_refs[0][i][0]
+        args = (dFT, mFT, np.full(len(ok), 0.05) * np.sqrt(B / 2.0), P0, freqs1[ok], nu, nu, nu, [1, 1, 0, 0, 0], False)
+        step = _oracle_newton_step(args, np.asarray(x0), [1, 1, 0, 0, 0])
+        assert abs(step[0]) < PHI_BAR and abs(step[1]) < DM_BAR, (i, step)
+        assert abs(gt.DMs[0][i] - inj[i][1]) < 6 * gt.DM_errs[0][i]
+    assert len(gt.TOA_list) == nsub
