@@ -238,13 +238,17 @@ struct RowWalk {
     unsigned wnx, cnx;         // masked walk: the next chunk's word and index, once fetched
     unsigned tick;             // lane 0: the ticket; kept per-lane (not uniform) so that it stays
                                // in a VGPR and nothing waits for the atomic before next() reads it
-    bool more, more_nx;
-    bool fresh, have_wnx;      // `row` is the first row visited of its chunk; (wnx, cnx) are valid
+    // (32-bit flags, not bool: byte-sized members of this struct ended up in scratch memory, and a
+    // scratch load queues behind the prefetched row like every other vector-memory access)
+    unsigned more, more_nx;
+    unsigned fresh, have_wnx;  // `row` is the first row visited of its chunk; (wnx, cnx) are valid
     static __device__ __forceinline__ unsigned word_of(const unsigned* mw, unsigned c, unsigned nrows) {
-        const unsigned long long r0 = (unsigned long long)c * PP_ROW_CHUNK;
+        // (32-bit arithmetic throughout -- there is no scalar 64-bit ordered compare, and a flag made by
+        // the vector ALU lives in a vector register: c < 2^27 because nrows < 2^31 and the grid is small)
+        const unsigned r0 = c * PP_ROW_CHUNK;
         if (r0 >= nrows) return 0u;
         if (mw) return as_global(mw)[c];
-        const unsigned rem = nrows - (unsigned)r0;
+        const unsigned rem = nrows - r0;
         return rem >= 32u ? 0xffffffffu : ((1u << rem) - 1u);
     }
     // the chunk a visitor of chunk c moves on to (DYN: one synchronous ticket)
@@ -257,27 +261,26 @@ struct RowWalk {
         return c + gridDim.x;
     }
     __device__ __forceinline__ void enter(unsigned c, unsigned w, unsigned nrows) {
-        more_nx = (unsigned long long)c * PP_ROW_CHUNK < nrows;
+        more_nx = (c * PP_ROW_CHUNK < nrows) ? 1u : 0u;
         row_nx = c * PP_ROW_CHUNK + (w ? (unsigned)__builtin_ctz(w) : 0u);
         bits = w & (w - 1u);
-        have_wnx = false;
     }
     __device__ __forceinline__ void start(long long nrows_, const unsigned* mw = nullptr, unsigned* ticket = nullptr,
                                           unsigned base = 0) {
         static_assert(PP_ROW_CHUNK == 32, "one 32-bit word per chunk");
         const unsigned nrows = (unsigned)nrows_;
-        wnx = 0; cnx = 0;
+        wnx = 0; cnx = 0; have_wnx = 0u;
         unsigned c = blockIdx.x;
         unsigned w = word_of(mw, c, nrows);
         // the first chunk with a row in use (an empty one still owes its ticket)
-        while (w == 0u && (unsigned long long)c * PP_ROW_CHUNK < nrows) {
+        while (w == 0u && c * PP_ROW_CHUNK < nrows) {
             c = chunk_after(c, ticket, base);
             w = word_of(mw, c, nrows);
         }
         enter(c, __builtin_amdgcn_readfirstlane(w), nrows);
         row = row_nx; more = more_nx;
         tick = threadIdx.x;
-        fresh = true;
+        fresh = 1u;
     }
     // top of a row: draw the ticket of the chunk after this one
     __device__ __forceinline__ void draw(unsigned* ticket) {
@@ -289,7 +292,7 @@ struct RowWalk {
         if (mw && !fresh && !have_wnx) {
             cnx = DYN ? gridDim.x + (__builtin_amdgcn_readfirstlane(tick) - base) : (row >> 5) + gridDim.x;
             wnx = word_of(mw, cnx, (unsigned)nrows_);
-            have_wnx = true;
+            have_wnx = 1u;
         }
     }
     // (subint, channel) of the row after this one: the next row in use of the chunk, or the first
@@ -303,17 +306,20 @@ struct RowWalk {
             row_nx = (row & ~(unsigned)(PP_ROW_CHUNK - 1)) + b;
             i_nx = i + (int)(row_nx - row); n_nx = n;
             while (i_nx >= nsub) { i_nx -= nsub; ++n_nx; }
-            more_nx = true;
+            more_nx = 1u;
             return;
         }
         // this chunk is done: the one its ticket names, or the first after it with a row in use
         unsigned c, w;
-        if (have_wnx) { c = cnx; w = wnx; }
+        // (have_wnx is cleared HERE and not in enter(): two stores of constants to different members
+        // on joining paths are merged by the compiler into one store through a selected pointer, which
+        // keeps the whole walk in scratch memory)
+        if (have_wnx) { c = cnx; w = wnx; have_wnx = 0u; }
         else {
             c = DYN ? gridDim.x + (__builtin_amdgcn_readfirstlane(tick) - base) : (row >> 5) + gridDim.x;
             w = word_of(mw, c, nrows);
         }
-        while (w == 0u && (unsigned long long)c * PP_ROW_CHUNK < nrows) {
+        while (w == 0u && c * PP_ROW_CHUNK < nrows) {
             c = chunk_after(c, ticket, base);
             w = word_of(mw, c, nrows);
         }
@@ -330,12 +336,12 @@ struct RowWalk {
             const unsigned b = (unsigned)__builtin_ctz(bits);
             bits &= bits - 1u;
             row_nx = (row & ~(unsigned)(PP_ROW_CHUNK - 1)) + b;
-            more_nx = true;
+            more_nx = 1u;
             return;
         }
         unsigned c = DYN ? gridDim.x + (__builtin_amdgcn_readfirstlane(tick) - base) : (row >> 5) + gridDim.x;
         unsigned w = word_of(mw, c, nrows);
-        while (w == 0u && (unsigned long long)c * PP_ROW_CHUNK < nrows) {
+        while (w == 0u && c * PP_ROW_CHUNK < nrows) {
             c = chunk_after(c, ticket, base);
             w = word_of(mw, c, nrows);
         }
@@ -343,7 +349,7 @@ struct RowWalk {
     }
     __device__ __forceinline__ void advance() {
         // (a row is the first of its chunk when the walk has just changed chunks)
-        fresh = ((row_nx ^ row) >> 5) != 0u;
+        fresh = (((row_nx ^ row) >> 5) != 0u) ? 1u : 0u;
         row = row_nx; more = more_nx;
     }
 };
@@ -466,12 +472,14 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
             // under a branch makes the compiler drain the whole queue, vmcnt(0), before
             // every use of an earlier load, because on the path without it no younger
             // loads exist)
+            // (the row after this one is decided outside the lambda: see k_xspec_q1024)
+            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket, a.mwords);
+            const size_t rn = rw.more_nx
+                ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
+            const Tin* const nxrow = reinterpret_cast<const Tin*>(a.data) + rn * (2 * M);
             auto prefetch = [&]() {
                 __builtin_amdgcn_sched_barrier(0);
-                rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket, a.mwords);
-                const size_t rn = rw.more_nx
-                    ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
-                stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rn * (2 * M), tid);
+                stage_load_global<M, T, R1>(cur, nxrow, tid);
                 __builtin_amdgcn_sched_barrier(0);
             };
             fft_first_stage<M, M2>(lds, v, tw, tid, prefetch);

@@ -119,9 +119,9 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
                 if (k >= k0 && k < k1)
                     cur[0][k] = load_row_once<Raw>(gb + (size_t)(k * 64) * sizeof(Raw) + boff);
         };
-        auto prefetch = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-            rw.next_row(nrows, a.ticket_base, a.ticket, a.mwords);
+        // (the row after this one is decided here, outside the lambda: see k_xspec_q1024)
+        rw.next_row(nrows, a.ticket_base, a.ticket, a.mwords);
+        {
             size_t rn = rc;
             ia_nx = ia; cc_nx = cc;
             if (rw.more_nx) {
@@ -130,6 +130,10 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
                 rn = (size_t)ia_nx * a.nchan_full + (size_t)(cc_nx * PP_ROW_CHUNK + (int)(rw.row_nx & 31u));
             }
             nxrow = reinterpret_cast<const Tin*>(a.data) + rn * (2 * M);
+        }
+        const bool last_of_chunk = !rw.more_nx || ((rw.row_nx ^ rw.row) >> 5) != 0u;
+        auto prefetch = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
             load_some(0, HALVES ? R1 / 2 : R1);
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
             }
             if (tid == 4 * PP_TSTRIDE) a.sdraw[rc] = tv;
         }
-        if (!rw.more_nx || ((rw.row_nx ^ rw.row) >> 5) != 0u) {
+        if (last_of_chunk) {
             // (the last row visited of this chunk:) the chunk's share of the channel sums of subint ia
             cplx* out = rs.part + (((size_t)ia * rs.ncc + cc) * RS_NACC) * 64 + tid;
 #pragma unroll

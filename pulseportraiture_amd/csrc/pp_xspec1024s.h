@@ -75,11 +75,14 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qs1024(XspecArgs a, const doubl
                 if (k >= k0 && k < k1)
                     cur[0][k] = load_row_once<Raw>(gb + (size_t)(k * 64) * sizeof(Raw) + boff);
         };
-        auto prefetch = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket, a.mwords);
+        // (the row after this one is decided outside the lambda: see k_xspec_q1024)
+        rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket, a.mwords);
+        {
             const size_t rn = rw.more_nx ? (size_t)i_nx * a.nchan_full + n_nx : rc;
             nxrow = reinterpret_cast<const Tin*>(a.data) + rn * (2 * M);
+        }
+        auto prefetch = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
             load_some(0, HALVES ? R1 / 2 : R1);
             __builtin_amdgcn_sched_barrier(0);
         };
