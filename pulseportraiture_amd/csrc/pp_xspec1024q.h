@@ -127,14 +127,22 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
         // split into registers -- its flags went through scratch memory, whose loads queue behind the
         // prefetched row -- and at the top of a row everything older than this row's own data has landed,
         // the ticket of the chunk's first row included)
+#ifndef PP_NEXT_IN_LAMBDA
         rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket, a.mwords);
         {
             const size_t rn = rw.more_nx
                 ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
             nxrow = reinterpret_cast<const Tin*>(a.data) + rn * (2 * M);
         }
+#endif
         auto prefetch = [&]() {
             __builtin_amdgcn_sched_barrier(0);
+#ifdef PP_NEXT_IN_LAMBDA
+            rw.next(i, n, i_nx, n_nx, nrows, a.nsub, a.ticket_base, a.ticket, a.mwords);
+            const size_t rn = rw.more_nx
+                ? (size_t)sub_of(a.act, i_nx) * a.nchan_full + (a.coff + n_nx * a.cstep) : rc;
+            nxrow = reinterpret_cast<const Tin*>(a.data) + rn * (2 * M);
+#endif
             load_some(0, HALVES ? R1 / 2 : R1);
             __builtin_amdgcn_sched_barrier(0);
         };
