@@ -12,6 +12,7 @@ static int aux_chunk_cap(pp_ctx* c, double per_sub, int nsub) {
 
 extern "C" int pp_fit_phase_shift_batch(pp_ctx* c, const double* data, const double* model, const double* noise,
                                         int nprof, int nbin, double lo, double hi, int Ns, double* out7) {
+    if (int busy_ = ctx_busy(c, "pp_fit_phase_shift_batch")) return busy_;
     if (!c || !data || !model || !out7) return fail(PP_EINVAL, "pp_fit_phase_shift_batch: null argument");
     if (!nbin_any_ok(nbin)) return nbin_refuse("pp_fit_phase_shift_batch", nbin);
     const bool anyb = !nbin_ok(nbin);
@@ -82,6 +83,7 @@ extern "C" int pp_reference_phase_seed(pp_ctx* c, const void* src, int dtype, in
                                        int nbin, const double* freqs, int64_t freqs_stride, const double* P,
                                        const double* par3, double nu_DM, double nu_GM, const double* weights,
                                        const double* model_profs, double lo, double hi, int Ns, double* out7) {
+    if (int busy_ = ctx_busy(c, "pp_reference_phase_seed")) return busy_;
     if (!c || !src || !freqs || !P || !par3 || !weights || !model_profs || !out7)
         return fail(PP_EINVAL, "pp_reference_phase_seed: null argument");
     if (!nbin_any_ok(nbin)) return nbin_refuse("pp_reference_phase_seed", nbin);
@@ -191,6 +193,7 @@ extern "C" int pp_reference_phase_seed(pp_ctx* c, const void* src, int dtype, in
 extern "C" int pp_synth_portraits(pp_ctx* c, int slot, void* dst, int dtype, int nsub, const double* freqs,
                                   const double* P, const double* inj, const double* gains, double sigma,
                                   uint64_t seed, int64_t first_subint) {
+    if (int busy_ = ctx_busy(c, "pp_synth_portraits")) return busy_;
     if (!c || !dst || !freqs || !P || !inj) return fail(PP_EINVAL, "pp_synth_portraits: null argument");
     if (slot < 0 || slot >= PP_MAX_SLOTS || !c->slots[slot].set) return fail(PP_ESTATE, "pp_synth_portraits: slot %d not set", slot);
     if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_synth_portraits: dtype %d", dtype);
@@ -226,6 +229,7 @@ extern "C" int pp_synth_portraits(pp_ctx* c, int slot, void* dst, int dtype, int
 extern "C" int pp_rotate_portraits(pp_ctx* c, const void* src, void* dst, int dtype, int on_device, int nsub,
                                    int nchan, int nbin, const double* freqs, int64_t freqs_stride,
                                    const double* P, const double* par3, double nu_DM, double nu_GM) {
+    if (int busy_ = ctx_busy(c, "pp_rotate_portraits")) return busy_;
     if (!c || !src || !dst || !freqs || !P || !par3) return fail(PP_EINVAL, "pp_rotate_portraits: null argument");
     if (!nbin_ok(nbin)) return nbin_refuse("pp_rotate_portraits", nbin);
     if (nsub < 1 || nchan < 1) return fail(PP_EINVAL, "pp_rotate_portraits: bad shape");
@@ -285,6 +289,7 @@ extern "C" int pp_align_accumulate(pp_ctx* c, const void* src, int dtype, int on
                                    int nbin, const double* freqs, int64_t freqs_stride, const double* P,
                                    const double* par3, const double* weights, double* aligned,
                                    double* total_weights) {
+    if (int busy_ = ctx_busy(c, "pp_align_accumulate")) return busy_;
     if (!c || !src || !freqs || !P || !par3 || !weights || !aligned || !total_weights)
         return fail(PP_EINVAL, "pp_align_accumulate: null argument");
     if (!nbin_ok(nbin)) return nbin_refuse("pp_align_accumulate", nbin);
@@ -353,6 +358,7 @@ extern "C" int pp_channel_red_chi2(pp_ctx* c, const void* src, int dtype, int on
                                    int64_t freqs_stride, const double* P, const double* params5,
                                    const double* nu_refs3, const double* scales, const double* errs,
                                    double* red_chi2) {
+    if (int busy_ = ctx_busy(c, "pp_channel_red_chi2")) return busy_;
     if (!c || !src || !freqs || !P || !params5 || !nu_refs3 || !scales || !errs || !red_chi2)
         return fail(PP_EINVAL, "pp_channel_red_chi2: null argument");
     if (!nbin_ok(nbin)) return nbin_refuse("pp_channel_red_chi2", nbin);
@@ -454,6 +460,7 @@ static int gauss_generate(pp_ctx* c, int nchan, int nbin, const double* freqs, c
 extern "C" int pp_gaussian_portrait(pp_ctx* c, int nchan, int nbin, const double* freqs, const char* code,
                                     double nu_ref, double dc, double tau_rot, double alpha, int ngauss,
                                     const double* comps, double* portrait, int out_on_device) {
+    if (int busy_ = ctx_busy(c, "pp_gaussian_portrait")) return busy_;
     if (!c || !portrait) return fail(PP_EINVAL, "pp_gaussian_portrait: null argument");
     HIP_TRY(hipSetDevice(c->device));
     int rc;
@@ -472,6 +479,7 @@ extern "C" int pp_gaussian_portrait(pp_ctx* c, int nchan, int nbin, const double
 extern "C" int pp_model_set_gaussian(pp_ctx* c, int slot, int nchan, int nbin, const double* freqs,
                                      const char* code, double nu_ref, double dc, double tau_rot, double alpha,
                                      int ngauss, const double* comps) {
+    if (int busy_ = ctx_busy(c, "pp_model_set_gaussian")) return busy_;
     if (!c) return fail(PP_EINVAL, "pp_model_set_gaussian: null context");
     HIP_TRY(hipSetDevice(c->device));
     int rc;
@@ -514,6 +522,7 @@ static int spline_generate(pp_ctx* c, int nchan, int nbin, const double* freqs, 
 extern "C" int pp_spline_portrait(pp_ctx* c, int nchan, int nbin, const double* freqs, int ncomp,
                                   const double* basis, int nknots, const double* t, const double* coefs,
                                   int degree, double* portrait, int out_on_device) {
+    if (int busy_ = ctx_busy(c, "pp_spline_portrait")) return busy_;
     if (!c || !portrait) return fail(PP_EINVAL, "pp_spline_portrait: null argument");
     HIP_TRY(hipSetDevice(c->device));
     int rc;
@@ -532,6 +541,7 @@ extern "C" int pp_spline_portrait(pp_ctx* c, int nchan, int nbin, const double* 
 extern "C" int pp_model_set_spline(pp_ctx* c, int slot, int nchan, int nbin, const double* freqs, int ncomp,
                                    const double* basis, int nknots, const double* t, const double* coefs,
                                    int degree) {
+    if (int busy_ = ctx_busy(c, "pp_model_set_spline")) return busy_;
     if (!c) return fail(PP_EINVAL, "pp_model_set_spline: null context");
     if (!nbin_ok(nbin)) return nbin_refuse("pp_model_set_spline", nbin);
     HIP_TRY(hipSetDevice(c->device));
@@ -544,6 +554,7 @@ extern "C" int pp_model_set_spline(pp_ctx* c, int slot, int nchan, int nbin, con
 
 // ---- instrumental response applied to a resident template ---------------------
 extern "C" int pp_model_apply_response(pp_ctx* c, int slot, const double* rconst, const double* smear_wid) {
+    if (int busy_ = ctx_busy(c, "pp_model_apply_response")) return busy_;
     if (!c || slot < 0 || slot >= PP_MAX_SLOTS || !c->slots[slot].set)
         return fail(PP_ESTATE, "pp_model_apply_response: slot not set");
     if (!rconst && !smear_wid) return PP_OK;

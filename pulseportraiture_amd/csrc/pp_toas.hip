@@ -41,6 +41,9 @@ static int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+struct pp_ctx;
+static int ctx_busy(pp_ctx* c, const char* who);
+
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
@@ -197,6 +200,17 @@ static void resolve_spans(pp_ctx* c) {
         c->ev_pool.push_back(s.a); c->ev_pool.push_back(s.b);
     }
     c->spans.clear();
+}
+
+// a submitted (pp_fit_submit) or enqueued (pp_fit_enqueue) batch owns the context's work buffers, stream
+// and counters until it has been waited for / collected: every other entry point that uses them refuses
+static int ctx_busy(pp_ctx* c, const char* who) {
+    if (!c) return PP_OK;           // (the entry point reports the null context itself)
+    if (c->job_active && std::this_thread::get_id() != c->job.get_id())
+        return fail(PP_ESTATE, "%s: a submitted fit is pending on this context (pp_fit_wait first)", who);
+    if (!c->pending.empty())
+        return fail(PP_ESTATE, "%s: %zu enqueued batch(es) not collected yet (pp_fit_collect first)", who, c->pending.size());
+    return PP_OK;
 }
 
 extern "C" int pp_abi_version(void) { return PP_ABI_VERSION; }
@@ -530,6 +544,7 @@ static int model_publish(pp_ctx* c, int slot) {
 
 extern "C" int pp_model_set(pp_ctx* c, int slot, const void* portrait, int dtype, int on_device, int nchan,
                             int nbin) {
+    if (int busy_ = ctx_busy(c, "pp_model_set")) return busy_;
     if (!c || !portrait) return fail(PP_EINVAL, "pp_model_set: null argument");
     if (slot < 0 || slot >= PP_MAX_SLOTS) return fail(PP_EINVAL, "pp_model_set: slot %d", slot);
     if (!nbin_any_ok(nbin))
@@ -603,6 +618,7 @@ extern "C" int pp_model_nharm(pp_ctx* c, int slot) {
 // rFFT parity hook
 // --------------------------------------------------------------------------
 extern "C" int pp_rfft_rows(pp_ctx* c, const void* rows, int dtype, int nrows, int nbin, double* out) {
+    if (int busy_ = ctx_busy(c, "pp_rfft_rows")) return busy_;
     if (!c || !rows || !out) return fail(PP_EINVAL, "pp_rfft_rows: null argument");
     if (!nbin_any_ok(nbin) || nrows < 1) return fail(PP_EINVAL, "pp_rfft_rows: bad shape %d x %d", nrows, nbin);
     HIP_TRY(hipSetDevice(c->device));
