@@ -782,23 +782,26 @@ def cpu_baseline(pool, data64, model, freqs, P, x0, sigma, nu_fit, flags, log10_
             np.save(paths[-1], data64[i].astype(np.float64))
         jobs = [(paths[j % ndistinct], mpath, x0[j % ndistinct], P[j % ndistinct], freqs, nu_fit, errs,
                  flags, log10_tau) for j in range(njobs)]
-        # two rounds of the same jobs: the rate is the mean, the spread says how repeatable it is
+        # two rounds of the same jobs: the spread says how repeatable the rate is
         rounds = []
         for _ in range(2):
             t0 = time.perf_counter()
             pres = pool.map(_cpu_fit, jobs, chunksize=1)
             rounds.append(time.perf_counter() - t0)
-        dtp = float(np.mean(rounds))
+        # (the better round is the baseline: the first one also pays for cold page caches and whatever
+        # else the host was doing -- 63 s against 17 s on one box; both are listed)
+        dtp = float(min(rounds))
     for j, (phi, DM, _) in enumerate(pres):
         i = j % ndistinct
         dphi = max(dphi, abs(((phi - res["params"][i, 0]) + 0.5) % 1.0 - 0.5))
         dDM = max(dDM, abs(DM - res["params"][i, 1]))
     return {"value": round(njobs / dtp, 4), "unit": "fits/s", "cores": workers, "kind": "port",
             "workers": workers, "host_cpu_count": os.cpu_count(),
-            "sample": "2 rounds of %d fits (%d distinct subints of the timed batch, one per worker, "
+            "sample": "%d round(s) of %d fits (%d distinct subints of the timed batch, one per worker, "
                       "single-threaded NumPy/SciPy each), whole fit_portrait_full "
-                      "(oracle/pptoas_oracle.py), %.1f s and %.1f s wall; mean %.1f s per fit inside a worker"
-                      % (njobs, ndistinct, rounds[0], rounds[1], float(np.mean([p[2] for p in pres]))),
+                      "(oracle/pptoas_oracle.py), %s s wall; mean %.1f s per fit inside a worker"
+                      % (len(rounds), njobs, ndistinct, " and ".join("%.1f" % r for r in rounds),
+                         float(np.mean([p[2] for p in pres]))),
             "rounds_fits_per_s": [round(njobs / r, 4) for r in rounds],
             "one_core": {"value": round(n1 / dt1, 5), "unit": "fits/s", "cores": 1,
                          "sample": "%d subint(s), %.1f s" % (n1, dt1)},

@@ -181,6 +181,92 @@ __global__ __launch_bounds__(64) void k_model_from_harm(const cplx* hout, int M,
     if (tid == 0) { msum[n] = s; mmax[n] = mx; mdc[n] = h[0].x; }
 }
 
+// Fourier rotation of rows of any even length (k_rotate for general B; rotate_data pplib.py:2338-2426,
+// rotate_portrait_full pptoaslib.py:52-81): forward chirp-z transform, harmonics times
+// e^{2 pi i k phi_n} (the Nyquist harmonic keeps its real part, as irfft does), the packed
+// spectrum of the inverse, and the chirp-z transform once more (x = conj(DFT(conj Z)) / M).
+template <int L, typename Tio>
+__global__ __launch_bounds__(FftPlan<L>::T) void k_rotate_any(RotateArgs a, AnyArgs g) {
+    constexpr int T = FftPlan<L>::T, PL = FftPlan<L>::PADLOG;
+    __shared__ cplx lds[FftPlan<L>::LDS_ELEMS];
+    __shared__ cplx buf[L];
+    const int tid = threadIdx.x;
+    const int M = g.M;
+    const double invL = 1.0 / (double)L;
+    const long long nrows = (long long)a.nsub * a.nchan;
+    // one chirp-z transform of the M values in buf (zero-padded to L): DFT_M(buf)[k] -> buf[k]
+    auto czt = [&]() {
+        for (int j = tid; j < L; j += T) buf[j] = (j < M) ? cmul(buf[j], g.chirp[j]) : make_double2(0.0, 0.0);
+        __syncthreads();
+        fft_row<L, cplx>(lds, buf, g.twL, tid);
+        __syncthreads();
+        for (int k = tid; k < L; k += T) {
+            const cplx p = cmul(lds[lds_pad<PL>(k)], g.bft[k]);
+            buf[k] = make_double2(p.x, -p.y);
+        }
+        __syncthreads();
+        fft_row<L, cplx>(lds, buf, g.twL, tid);
+        __syncthreads();
+        for (int k = tid; k < M; k += T) {
+            const cplx c = lds[lds_pad<PL>(k)];
+            buf[k] = cmul(make_double2(c.x * invL, -c.y * invL), g.chirp[k]);
+        }
+        __syncthreads();
+    };
+    for (long long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int i = (int)(row / a.nchan), n = (int)(row % a.nchan);
+        const double nu = a.freqs[(size_t)i * a.freqs_stride + n], P = a.P[i];
+        const double a2 = 1.0 / (nu * nu);
+        const double phin = a.par[i * 3] + PP_DCONST * a.par[i * 3 + 1] * (a2 - a.inv_nuDM2) / P +
+                            PP_DCONST * PP_DCONST * a.par[i * 3 + 2] * (a2 * a2 - a.inv_nuGM4) / P;
+        const Tio* x = reinterpret_cast<const Tio*>(a.src) + (size_t)row * g.nbin;
+        for (int j = tid; j < M; j += T) buf[j] = make_double2((double)x[2 * j], (double)x[2 * j + 1]);
+        __syncthreads();
+        czt();
+        // harmonics d_k = E - i W_B^k O of the real transform from the packed one in buf
+        auto harm = [&](int k) -> cplx {
+            const cplx zk = buf[k];
+            cplx zc = buf[M - k];
+            zc.y = -zc.y;
+            const cplx E = make_double2(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
+            const cplx O = make_double2(0.5 * (zk.x - zc.x), 0.5 * (zk.y - zc.y));
+            const cplx wo = cmul(g.twB[k], O);
+            return make_double2(E.x + wo.y, E.y - wo.x);
+        };
+        const cplx z0 = buf[0];
+        const double y0 = z0.x + z0.y;
+        const double yM = (z0.x - z0.y) * unit_phasor((double)M, phin).x;
+        // rotated harmonics -> packed spectrum of the inverse, conjugated; parked in the (free) image
+        for (int k = tid; k < M; k += T) {
+            cplx yk, ym;
+            if (k == 0) { yk = make_double2(y0, 0.0); ym = make_double2(yM, 0.0); }
+            else {
+                yk = cmul(harm(k), unit_phasor((double)k, phin));
+                ym = cmul(harm(M - k), unit_phasor((double)(M - k), phin));
+            }
+            ym.y = -ym.y;
+            const cplx ev = make_double2(0.5 * (yk.x + ym.x), 0.5 * (yk.y + ym.y));
+            cplx od = make_double2(0.5 * (yk.x - ym.x), 0.5 * (yk.y - ym.y));
+            cplx w = g.twB[k];
+            w.y = -w.y;
+            od = cmul(od, w);
+            lds[k] = make_double2(ev.x - od.y, -(ev.y + od.x));   // conj(ev + i od)
+        }
+        __syncthreads();
+        for (int k = tid; k < M; k += T) buf[k] = lds[k];
+        __syncthreads();
+        czt();
+        Tio* out = reinterpret_cast<Tio*>(a.dst) + (size_t)row * g.nbin;
+        const double inv = 1.0 / (double)M;
+        for (int j = tid; j < M; j += T) {
+            const cplx r = buf[j];
+            out[2 * j] = (Tio)(r.x * inv);
+            out[2 * j + 1] = (Tio)(-r.y * inv);
+        }
+        __syncthreads();
+    }
+}
+
 // The reference's rot_prof from the harmonics k_any left in hout (general row lengths; pp_reference_phase_seed):
 // spec[i][k] = sum_n w_n d_nk e^{2 pi i k phi'_n} / sum_n w_n, phi'_n the rotation of rotate_data
 // (pplib.py:2338-2426).  hout rows are channel-major (row = n nsub + i).  One thread per harmonic,

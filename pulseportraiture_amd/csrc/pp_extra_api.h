@@ -231,7 +231,7 @@ extern "C" int pp_rotate_portraits(pp_ctx* c, const void* src, void* dst, int dt
                                    const double* P, const double* par3, double nu_DM, double nu_GM) {
     if (int busy_ = ctx_busy(c, "pp_rotate_portraits")) return busy_;
     if (!c || !src || !dst || !freqs || !P || !par3) return fail(PP_EINVAL, "pp_rotate_portraits: null argument");
-    if (!nbin_ok(nbin)) return nbin_refuse("pp_rotate_portraits", nbin);
+    if (!nbin_any_ok(nbin)) return nbin_refuse("pp_rotate_portraits", nbin);
     if (nsub < 1 || nchan < 1) return fail(PP_EINVAL, "pp_rotate_portraits: bad shape");
     if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_rotate_portraits: dtype %d", dtype);
     if (freqs_stride != 0 && freqs_stride != nchan) return fail(PP_EINVAL, "freqs_stride must be 0 or nchan");
@@ -269,7 +269,29 @@ extern "C" int pp_rotate_portraits(pp_ctx* c, const void* src, void* dst, int dt
     RotateArgs a{dsrc, ddst, c->freqs.as<double>(), (long long)freqs_stride, c->P.as<double>(), c->x0.as<double>(), tw,
                  std::isinf(nu_DM) ? 0.0 : 1.0 / (nu_DM * nu_DM),
                  std::isinf(nu_GM) ? 0.0 : 1.0 / (nu_GM * nu_GM * nu_GM * nu_GM), nsub, nchan};
-    {
+    if (!nbin_ok(nbin)) {
+        // a row length without a tuned plan: the chirp-z route, forward and back (pp_anybin.h)
+        Prof pr(c, KF_SYNTH);
+        pp_ctx::AnyPlan* pl = nullptr;
+        if ((rc = get_any_plan(c, nbin, &pl))) return rc;
+        const cplx* twL = nullptr;
+        if ((rc = get_twiddles(c, 2 * pl->L, &twL))) return rc;
+        AnyArgs g{nbin, M, ((M + 63) / 64) * 64, pl->chirp.as<cplx>(), pl->bft.as<cplx>(), twL, tw, 0, 0, nullptr, nullptr};
+        const int grid = (int)std::max(1LL, std::min((long long)nsub * nchan, 2048LL));
+#define PP_ROT_ANY(LL)                                                                                          \
+    do {                                                                                                        \
+        if (dtype == PP_F64) hipLaunchKernelGGL((k_rotate_any<LL, double>), dim3(grid), dim3(FftPlan<LL>::T), 0, c->stream, a, g); \
+        else hipLaunchKernelGGL((k_rotate_any<LL, float>), dim3(grid), dim3(FftPlan<LL>::T), 0, c->stream, a, g); \
+    } while (0)
+        switch (pl->L) {
+            case 64: PP_ROT_ANY(64); break;
+            case 256: PP_ROT_ANY(256); break;
+            case 1024: PP_ROT_ANY(1024); break;
+            case 4096: PP_ROT_ANY(4096); break;
+            default: return fail(PP_EINVAL, "no transform of %d points", pl->L);
+        }
+#undef PP_ROT_ANY
+    } else {
         Prof pr(c, KF_SYNTH);
         PP_DISPATCH_M(M, {
             const int T = FftPlan<MM>::T;

@@ -403,7 +403,7 @@ static int fail(int code, const char* fmt, ...);
 static int nbin_refuse(const char* who, int nbin) {
     if (nbin_any_ok(nbin))
         return fail(PP_ENOTSUP, "%s: nbin %d is no power of two: only pp_model_set, pp_fit_portrait_batch, pp_rfft_rows, "
-                                "pp_fit_phase_shift_batch and pp_reference_phase_seed take general even row lengths", who, nbin);
+                                "pp_fit_phase_shift_batch, pp_reference_phase_seed and pp_rotate_portraits take general even row lengths", who, nbin);
     return fail(PP_EINVAL, "%s: nbin %d must be a power of two in [32, 8192] (the fit also takes even lengths up to 4096)",
                 who, nbin);
 }

@@ -2982,7 +2982,8 @@ def test_entry_points_without_a_general_length_path_refuse_loudly(eng):
     with pytest.raises(EngineNotSupported, match="no power of two"):
         eng.align_accumulate(x, np.linspace(1200., 1300., 3), 0.003, 0.0, 0.0, np.inf, np.ones((2, 3)))
     with pytest.raises(EngineNotSupported, match="no power of two"):
-        eng.rotate_portraits(x, np.linspace(1200., 1300., 3), 0.003, phi=0.1)
+        eng.channel_red_chi2(x, np.linspace(1200., 1300., 3), 0.003, np.zeros((2, 5)), np.full((2, 3), 1250.),
+                             np.ones((2, 3)), np.ones((2, 3)))
     with pytest.raises(EngineError):
         eng.rfft_rows(np.zeros((1, 1001)))            # odd lengths: not even the reference's nbin = 2 (nharm - 1) holds
 
@@ -3099,3 +3100,23 @@ def test_get_TOAs_at_a_row_length_that_is_no_power_of_two(seed):
         assert abs(step[0]) < PHI_BAR and abs(step[1]) < DM_BAR, (i, step)
         assert abs(gt.DMs[0][i] - inj[i][1]) < 6 * gt.DM_errs[0][i]
     assert len(gt.TOA_list) == nsub
+
+
+@pytest.mark.parametrize("nbin", [1000, 100, 250, 3000])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_rotation_at_any_even_nbin_matches_oracle(eng, nbin, dtype):
+    """rotate_data / rotate_portrait_full (pplib.py:2338-2426, pptoaslib.py:52-81) at row lengths
+    without a tuned plan: the chirp-z route forward and back, against the oracle's NumPy rotation --
+    what a dedispersed (dmc) archive of such data needs before its fit."""
+    from oracle import pptoas_oracle as orc
+    rng = np.random.default_rng(nbin)
+    nsub, C = 2, 5
+    x = rng.normal(size=(nsub, C, nbin)).astype(dtype)
+    freqs = np.linspace(1200.0, 1700.0, C)
+    P = np.array([0.003, 0.0041])
+    phi, DM, GM = np.array([0.123, -0.31]), np.array([12.5, 3.0]), np.array([0.2, 0.0])
+    got = eng.rotate_portraits(x, freqs, P, phi=phi, DM=DM, GM=GM, nu_DM=1400.0, nu_GM=1400.0)
+    for i in range(nsub):
+        ref = orc.rotate_portrait_full(x[i].astype(np.float64), phi[i], DM[i], GM[i], freqs, 1400.0, 1400.0, P[i])
+        tol = 2e-13 if dtype == np.float64 else 3e-6
+        assert np.abs(got[i] - ref).max() < tol * max(1.0, np.abs(ref).max()), (i, np.abs(got[i] - ref).max())
