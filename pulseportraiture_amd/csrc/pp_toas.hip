@@ -217,6 +217,20 @@ extern "C" int pp_abi_version(void) { return PP_ABI_VERSION; }
 extern "C" const char* pp_last_error(void) { return g_err.c_str(); }
 
 static int ctx_init(pp_ctx* c) {
+    // PP_CU_EXCLUDE=n (experiments): the context's stream may not use the last n compute units
+    // (hipExtStreamCreateWithCUMask) and the persistent grids are sized for the rest -- measures what
+    // the transform loses when a few CUs are set aside for other work (profiles/README.md, round 4)
+    const char* ex = getenv("PP_CU_EXCLUDE");
+    const int nex = ex ? atoi(ex) : 0;
+    if (nex > 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int i = 0; i < ncu - nex; ++i) mask[i / 32] |= 1u << (i % 32);
+        HIP_TRY(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()));
+        c->ncu = ncu - nex;
+    } else
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipHostMalloc((void**)&c->nactive_h, sizeof(int) * 4, hipHostMallocDefault));
     HIP_TRY(hipEventCreate(&c->ev0));
