@@ -2886,7 +2886,7 @@ def test_headline_shape_with_the_benchs_guesses_and_masks(guess):
 # --------------------------------------------------------------------------
 # round 4: row lengths that are no power of two
 # --------------------------------------------------------------------------
-@pytest.mark.parametrize("nbin,C", [(1000, 37), (100, 12), (1536, 20), (3000, 9)])
+@pytest.mark.parametrize("nbin,C", [(1000, 37), (100, 12), (1536, 20), (3000, 9), (250, 8)])
 def test_any_even_nbin_ragged_batch_matches_oracle(eng, nbin, C):
     """A ragged batch at a row length without a tuned plan -- masks, per-channel noise, a
     non-dedispersed DM, every phase / DM / GM family and a scattering fit, noise given and
