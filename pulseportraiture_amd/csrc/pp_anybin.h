@@ -152,7 +152,7 @@ __global__ __launch_bounds__(FftPlan<L>::T) void k_any(XspecArgs a, AnyArgs g) {
             else if (g.mode >= 2) {
                 // Re(i^q z): +Re, -Im, -Re, +Im, ...
                 if (tid < PP_TSTRIDE)
-                    a.tay[rc * PP_TSTRIDE + tid] = (tid <= PP_TJ && ((tid & 3) == 1 || (tid & 3) == 2)) ? -v : v;
+                    a.tay[tay_idx(rc, tid)] = (tid <= PP_TJ && ((tid & 3) == 1 || (tid & 3) == 2)) ? -v : v;
             } else if (g.mode == 1 && tid < 3) {
                 a.csum0[rc * 3 + tid] = (tid == 0) ? v : (tid == 1 ? -PP_TWO_PI * v : -PP_TWO_PI * PP_TWO_PI * v);
             }

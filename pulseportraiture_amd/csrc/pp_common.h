@@ -210,6 +210,49 @@ __device__ inline void block_sum(double (&v)[NV], double* scratch) {
     }
 }
 
+// The same block-wide sums -- the same additions in the same order, so bitwise the same totals --
+// with the transposing wave reduction (17 exchanges per 16 values instead of 96) and ONE barrier:
+// `scratch` holds two buffers of (blockDim.x/64) * (NV + 1) doubles used alternately (`flip`, which
+// the caller keeps between calls, starts at 0): a wave can be at most one call ahead of the slowest
+// one, so the buffer it writes is never one still being read.  mx (optional): a value reduced by max.
+template <int NV, int C0>
+__device__ __forceinline__ void wave_totals_to(const double (&v)[NV], int lane, double* dst) {
+    constexpr int n = (NV - C0) < 16 ? (NV - C0) : 16;
+    double part[n];
+#pragma unroll
+    for (int j = 0; j < n; ++j) part[j] = v[C0 + j];
+    const double tot = wave_reduce16<n>(part, lane);
+    if ((lane & 3) == 0 && (lane >> 2) < n) dst[C0 + (lane >> 2)] = tot;
+    if constexpr (C0 + 16 < NV) wave_totals_to<NV, C0 + 16>(v, lane, dst);
+}
+#define PP_BSUM_DOUBLES(NW, NVMAX) (2 * (NW) * ((NVMAX) + 1))
+// NVMAX: the largest NV among the kernel's calls on this scratch (the two buffers are NW * (NVMAX + 1) doubles apart
+// whatever the call's own NV: buffers of different sizes would overlap the one a slow wave still reads)
+template <int NV, int NVMAX>
+__device__ __forceinline__ void block_sum_t(double (&v)[NV], double* scratch, int& flip, double* mx = nullptr) {
+    static_assert(NV <= NVMAX, "scratch sized for NVMAX values");
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    double* buf = scratch + flip * nw * (NVMAX + 1);
+    flip ^= 1;
+    wave_totals_to<NV, 0>(v, lane, buf + wid * (NV + 1));
+    if (mx) {
+        const double m = group_max<64>(*mx);
+        if (lane == 0) buf[wid * (NV + 1) + NV] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += buf[w * (NV + 1) + i];
+        v[i] = s;
+    }
+    if (mx) {
+        double m = buf[NV];
+        for (int w = 1; w < nw; ++w) m = fmax(m, buf[w * (NV + 1) + NV]);
+        *mx = m;
+    }
+}
+
 // ---- per-subint solver state (device resident) ---------------------------
 struct SubState {
     double x[5];       // accepted parameters (at the fit reference frequencies)
@@ -243,5 +286,12 @@ struct SubState {
 // A_0 .. A_PP_TJ (derivatives) + a rigorous remainder coefficient
 #define PP_TJ 10
 #define PP_TSTRIDE (PP_TJ + 2)
+// The Taylor rows in HBM: blocks of 64 rows, the coefficients in pairs -- [row / 64][pair 0..5][row % 64][2] -- so that
+// the solve, where lane l works on row r0 + l, reads 1 KB contiguous per load instruction (row-major rows 96 B
+// apart cost it 48 cache lines per instruction, six times over); the transform writes a row as six 16-byte pieces,
+// which consecutive rows of its chunk complete to whole lines in L2.  The buffer holds a multiple of 64 rows.
+__device__ __forceinline__ size_t tay_idx(size_t row, int q) {
+    return (row >> 6) * (size_t)(64 * PP_TSTRIDE) + (size_t)(q >> 1) * 128 + (row & 63) * 2 + (q & 1);
+}
 
 }  // namespace pp

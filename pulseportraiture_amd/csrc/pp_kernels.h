@@ -128,6 +128,7 @@ struct FitArgs {
     // phase), the iteration starts from xstart (the reference's own guess, known only after the pass)
     const double* xstart;     // [nsub][5] or nullptr (= start at the expansion point)
     int nfev_shadow;          // one-pass flow: SciPy's one-point cache compared on the absolute iterate fl(x + p)
+    int solve_cache;          // k_taylor_solve: channels whose weight / geometry / template power are kept in LDS (32 B each)
     int x_full;               // the channel subset (coff, cstep, nchan_x) is evaluated over a cross-spectrum stored for
                               // ALL channels: X rows are addressed by the true channel (k_eval_scat)
 };
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
                 // Re(i^q z): +Re, -Im, -Re, +Im, ...
                 // (x 1/2: the template values were used unhalved against 2 d_k)
                 tv *= 0.5;
-                a.tay[rc * PP_TSTRIDE + q] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
+                a.tay[tay_idx(rc, q)] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
             }
         }
         if (RIDE) {
@@ -1164,7 +1165,8 @@ __device__ inline bool chol_solve(const double* A, const double* b, double* x) {
 }
 
 // in-place Gauss-Jordan inverse with partial pivoting; false if singular
-__device__ inline bool mat_inverse(int n, double* A) {
+template <int n>
+__device__ inline bool mat_inverse(double* A) {
     double inv[25];
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) inv[i * n + j] = (i == j) ? 1.0 : 0.0;
@@ -1338,6 +1340,11 @@ __device__ inline bool chol_solve(int n, const double* A, const double* b, doubl
     PP_FOR_N(n, ok = chol_solve<N_>(A, b, x));
     return ok;
 }
+__device__ inline bool mat_inverse(int n, double* A) {
+    bool ok = false;
+    PP_FOR_N(n, ok = mat_inverse<N_>(A));
+    return ok;
+}
 __device__ inline double vdot(int n, const double* a, const double* b) {
     double v = 0.0;
     PP_FOR_N(n, v = vdot<N_>(a, b));
@@ -1363,6 +1370,63 @@ __device__ inline bool tr_scipy_accept(double f, double f_new, double pred, int 
     return rho > 0.15;
 }
 
+// The (phi, DM, GM) solvers' proposals on the fit subspace WITHOUT a dynamically indexed array (those
+// live in scratch memory: every access of the serial walk a round trip): ix[k] = position of the k-th
+// fitted parameter, N = their number (compile time, PP_FOR_N3); the proposal comes back scattered to
+// the three positions (0 where not fitted).  Same operations in the same order as the pointer versions.
+#define PP_FOR_N3(n_, EXPR)           \
+    switch (n_) {                     \
+        case 1: { constexpr int N_ = 1; EXPR; } break; \
+        case 2: { constexpr int N_ = 2; EXPR; } break; \
+        default: { constexpr int N_ = 3; EXPR; } break; \
+    }
+__device__ __forceinline__ double sel3(const double* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
+template <int N>
+__device__ __forceinline__ void gather_sub3(const double (&g)[3], const double (&H)[9], const int (&ix)[3], double (&gs)[N],
+                                            double (&Hs)[N * N]) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        gs[r] = sel3(g, ix[r]);
+        const int k = ix[r];
+        const double row[3] = {k == 0 ? H[0] : (k == 1 ? H[3] : H[6]), k == 0 ? H[1] : (k == 1 ? H[4] : H[7]),
+                               k == 0 ? H[2] : (k == 1 ? H[5] : H[8])};   // row ix[r] of H
+#pragma unroll
+        for (int c = 0; c < N; ++c) Hs[r * N + c] = sel3(row, ix[c]);
+    }
+}
+template <int N>
+__device__ __forceinline__ void scatter_sub3(const double (&p)[N], const int (&ix)[3], double (&p3)[3]) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        p3[j] = 0.0;
+#pragma unroll
+        for (int r = 0; r < N; ++r) if (ix[r] == j) p3[j] = p[r];
+    }
+}
+template <int N>
+__device__ __forceinline__ void tr_propose_scipy3(double f, const double (&g)[3], const double (&H)[9], const int (&ix)[3],
+                                                  double radius, double (&p3)[3], int& hits, double& pred) {
+    double gs[N], Hs[N * N], p[N];
+    gather_sub3<N>(g, H, ix, gs, Hs);
+    tr_cg_steihaug_scipy<N>(f, gs, Hs, radius, p, &hits);
+    pred = f - tr_model_value<N>(f, gs, Hs, p);
+    scatter_sub3<N>(p, ix, p3);
+}
+template <int N>
+__device__ __forceinline__ bool newton_propose3(const double (&g)[3], const double (&H)[9], const int (&ix)[3], double (&p3)[3],
+                                                double& pred) {
+    double gs[N], Hs[N * N], p[N], mg[N], Hp[N];
+    gather_sub3<N>(g, H, ix, gs, Hs);
+#pragma unroll
+    for (int r = 0; r < N; ++r) mg[r] = -gs[r];
+    if (!chol_solve<N>(Hs, mg, p)) return false;
+#pragma unroll
+    for (int r = 0; r < N; ++r) Hp[r] = vdot<N>(Hs + r * N, p);
+    pred = -(vdot<N>(gs, p) + 0.5 * vdot<N>(p, Hp));
+    scatter_sub3<N>(p, ix, p3);
+    return true;
+}
+
 // --------------------------------------------------------------------------
 // One pass over X that makes further passes unnecessary (no scattering): the
 // per-channel cross-correlation C_n(phi_n + d) = Re sum_k X_nk e^{2 pi i k (phi_n + d)}
@@ -1386,7 +1450,8 @@ __global__ __launch_bounds__(256) void k_eval_moments(FitArgs a) {
     const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
     const double* wts = a.wts + (size_t)i * a.nchan;
     const int* ktv = a.ktab ? as_global(a.ktab[a.slot ? a.slot[i] : 0]) : nullptr;
-    double* tay = a.tay + (size_t)i * a.nchan * PP_TSTRIDE;
+    double* tay = a.tay;
+    const size_t row0 = (size_t)i * a.nchan;
     const int n0 = chunk * a.cpc, n1 = min(n0 + a.cpc, a.nchan_x);
     const int src = ((tid & 63) & ~(LPC - 1)) | (LPC - 1);
     for (int nn = n0 + g; nn < n1; nn += 256 / LPC) {
@@ -1444,28 +1509,24 @@ __global__ __launch_bounds__(256) void k_eval_moments(FitArgs a) {
         for (int j = 0; j < PP_TSTRIDE; ++j) {
             double v = group_sum<LPC>(s[j]);
             if (j <= PP_TJ && ((j & 3) == 1 || (j & 3) == 2)) v = -v;
-            if (l == (j % LPC)) tay[(size_t)n * PP_TSTRIDE + j] = v;
+            if (l == (j % LPC)) tay[tay_idx(row0 + n, j)] = v;
         }
     }
 }
 
 // Horner evaluation of the shifted sums A0', A1', A2' from the Taylor model
 // (the channel's 12 doubles are fetched as six 16-byte loads: rows are 96 B apart)
-__device__ __forceinline__ void taylor_load(const double* tg, double (&t)[PP_TSTRIDE]) {
+__device__ __forceinline__ void taylor_load(const double* tay, size_t row, double (&t)[PP_TSTRIDE]) {
     static_assert(PP_TSTRIDE % 2 == 0, "rows of the Taylor model are read in pairs");
+    const double* tg = tay + tay_idx(row, 0);
 #pragma unroll
     for (int j = 0; j < PP_TSTRIDE / 2; ++j) {
-        const double2 v = reinterpret_cast<const double2*>(tg)[j];
+        const double2 v = *reinterpret_cast<const double2*>(tg + j * 128);
         t[2 * j] = v.x; t[2 * j + 1] = v.y;
     }
 }
 __device__ __forceinline__ void taylor_shift_reg(const double (&t)[PP_TSTRIDE], double d, double& A0, double& A1,
                                                  double& A2);
-__device__ __forceinline__ void taylor_shift(const double* tg, double d, double& A0, double& A1, double& A2) {
-    double t[PP_TSTRIDE];
-    taylor_load(tg, t);
-    taylor_shift_reg(t, d, A0, A1, A2);
-}
 __device__ __forceinline__ void taylor_shift_reg(const double (&t)[PP_TSTRIDE], double d, double& A0, double& A1,
                                                  double& A2) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -1480,95 +1541,153 @@ __device__ __forceinline__ void taylor_shift_reg(const double (&t)[PP_TSTRIDE], 
     A0 = a0; A1 = a1; A2 = a2;
 }
 
-// Solve on the Taylor model, one 256-thread block per subint.  method 0 walks
+// Solve on the Taylor model, one block of NT threads per subint.  method 0 walks
 // SciPy's trust-ncg iteration on the model (every evaluation is O(nchan), no pass
 // over the data), method 1 is plain Newton to the rounding of f.
-// CPT > 0: 512 threads, each keeps the Taylor rows of its CPT channels (nchan <= 512 CPT)
-// in registers, so the ~8 passes of the solve read them from HBM once; CPT = 0: 256
-// threads re-reading the rows on every pass (any nchan).
-#ifndef PP_TAYLOR_WAVES
-#define PP_TAYLOR_WAVES 2     // waves per SIMD the generic variant is compiled for (register cap 512 / n)
+// NT: the walk is a chain of ~20 serial decisions between evaluations of ~C/NT channels per thread --
+// a narrow band is solved by ONE wave per subint (no barrier, four times the subints in flight per CU),
+// a wide one by up to eight (8 channels per thread; the CU's eight waves then belong to ONE subint, and the
+// rows the subints in flight re-read on every evaluation -- 393 KB each at 4096 channels -- stay inside the
+// Infinity Cache).  (Rows held in registers over the evaluations: measured slower in round 3, profiles/README.md.)
+#define PP_SOLVE_CACHE_MAX 4096   // channels whose invariants k_taylor_solve can keep in LDS (32 B each: 512 per wave of the block)
+#ifndef PP_SOLVE_PF
+#define PP_SOLVE_PF 2         // Taylor rows a thread keeps on their way (24 registers each)
 #endif
-template <int CPT>
-__global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a) {
-    constexpr int NT = CPT ? 512 : 256, NWV = NT / 64;
+#ifndef PP_TAYLOR_WAVES
+#define PP_TAYLOR_WAVES 2     // waves per SIMD the kernel is compiled for (register cap 512 / n)
+#endif
+template <int NT>
+__global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a) {
+    constexpr int NWV = NT / 64;
     const int i = blockIdx.x, tid = threadIdx.x;
     SubState& st = a.st[i];
     if (st.done) return;                 // (second launch, after a re-expansion of the others)
-    __shared__ double scratch[NWV * 12];
-    __shared__ double shx[8];
+    __shared__ double scratch[PP_BSUM_DOUBLES(NWV, 10)];
+    int flip = 0;
     const double P = a.P[i];
     const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1];
     const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
     const double* wts = a.wts + (size_t)i * a.nchan;
     const double* msum = as_global(a.msum[a.slot ? a.slot[i] : 0]);
-    const double* tay = a.tay + (size_t)i * a.nchan * PP_TSTRIDE;
+    const double* tay = a.tay;
+    const size_t row0 = (size_t)i * a.nchan;
     const int* fl = a.flags;
-    int idx[3], nf = 0;
-    for (int j = 0; j < 3; ++j) if (fl[j]) idx[nf++] = j;
-    double treg[CPT ? CPT : 1][PP_TSTRIDE];
-    if constexpr (CPT > 0) {
+    int ix[3] = {0, 0, 0}, nf = 0;       // positions of the fitted parameters (statically indexed: no scratch)
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) {
-            const int n = tid + NT * q;
-            if (n < a.nchan) taylor_load(tay + (size_t)n * PP_TSTRIDE, treg[q]);
-            else {
-#pragma unroll
-                for (int j = 0; j < PP_TSTRIDE; ++j) treg[q][j] = 0.0;
-            }
+    for (int j = 0; j < 3; ++j)
+        if (fl[j]) {
+            if (nf == 0) ix[0] = j; else if (nf == 1) ix[1] = j; else ix[2] = j;
+            ++nf;
         }
+    // what an evaluation needs of a channel beside its Taylor row -- weight, phase geometry (five
+    // divisions), template power -- is the same in every evaluation of the solve: formed once, kept in
+    // LDS (dynamic: 32 B x a.solve_cache channels; channels beyond, if any, are formed again on every evaluation)
+    extern __shared__ double inv_lds[];
+    const int ncache = a.solve_cache;
+    double *inv_w = inv_lds, *inv_p1 = inv_lds + ncache, *inv_p2 = inv_lds + 2 * ncache, *inv_S = inv_lds + 3 * ncache;
+    {
+        const int nc = min(a.nchan, ncache);
+#pragma unroll 4
+        for (int n = tid; n < nc; n += NT) {
+            double p1, p2;
+            phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
+            inv_w[n] = wts[n]; inv_p1[n] = p1; inv_p2[n] = p2; inv_S[n] = msum[n];
+        }
+        __syncthreads();
     }
+    auto chan_inv = [&](int n, double& w, double& p1, double& p2, double& S0) {
+        if (n < ncache) { w = inv_w[n]; p1 = inv_p1[n]; p2 = inv_p2[n]; S0 = inv_S[n]; }
+        else { w = wts[n]; phase_geom(freqs[n], P, nuDM, nuGM, p1, p2); S0 = msum[n]; }
+    };
     // this thread's channels: body(n, row of the Taylor model)
     auto for_channels = [&](auto&& body) {
-        if constexpr (CPT > 0) {
+        // (the next row is on its way while this one is worked on: the loop is a chain of
+        // memory latencies otherwise, two waves per SIMD hide none of it)
+        // (PP_SOLVE_PF rows ahead: what bounds the evaluation is the bytes a CU keeps in flight)
+        double buf[PP_SOLVE_PF][PP_TSTRIDE];
 #pragma unroll
-            for (int q = 0; q < CPT; ++q) {
-                const int n = tid + NT * q;
-                if (n < a.nchan) body(n, treg[q]);
-            }
-        } else {
-            for (int n = tid; n < a.nchan; n += NT) {
-                double t[PP_TSTRIDE];
-                taylor_load(tay + (size_t)n * PP_TSTRIDE, t);
-                body(n, t);
+        for (int d = 0; d < PP_SOLVE_PF; ++d)
+            if (tid + d * NT < a.nchan) taylor_load(tay, row0 + tid + d * NT, buf[d]);
+        for (int n0 = tid; n0 < a.nchan; n0 += PP_SOLVE_PF * NT) {
+#pragma unroll
+            for (int d = 0; d < PP_SOLVE_PF; ++d) {
+                const int n = n0 + d * NT;
+                if (n < a.nchan) {
+                    double t[PP_TSTRIDE];
+#pragma unroll
+                    for (int j = 0; j < PP_TSTRIDE; ++j) t[j] = buf[d][j];
+                    if (n + PP_SOLVE_PF * NT < a.nchan) taylor_load(tay, row0 + n + PP_SOLVE_PF * NT, buf[d]);
+                    body(n, t);
+                }
             }
         }
     };
     // f, g, H of the model at displacement dx from x0 (identical in every thread);
     // returns the largest per-channel phase displacement
-    auto evalm = [&](const double* dx, double& f, double* g, double* H) -> double {
+#ifdef PP_SOLVE_CLOCKS
+    long long ck_loop = 0, ck_red = 0, ck_start = clock64(), ck_n = 0;
+#endif
+    // ... and at the expansion point itself (the first evaluation of the ordinary flow: d = 0 in every channel,
+    // where Horner's rule returns A0, A1, A2 = t[0], t[1], t[2] exactly) only the first two coefficient pairs
+    // of a row are read: 32 of its 96 bytes
+    auto for_channels_at_origin = [&](auto&& body) {
+        constexpr int U = 4;
+        for (int n0 = tid; n0 < a.nchan; n0 += U * NT) {
+            double2 h[U][2];
+#pragma unroll
+            for (int d = 0; d < U; ++d)
+                if (n0 + d * NT < a.nchan) {
+                    const double* tg = tay + tay_idx(row0 + n0 + d * NT, 0);
+                    h[d][0] = *reinterpret_cast<const double2*>(tg);
+                    h[d][1] = *reinterpret_cast<const double2*>(tg + 128);
+                }
+#pragma unroll
+            for (int d = 0; d < U; ++d)
+                if (n0 + d * NT < a.nchan) body(n0 + d * NT, h[d][0].x, h[d][0].y, h[d][1].x);
+        }
+    };
+    auto evalm = [&](const double* dx, double& f, double* g, double* H, bool at_origin = false) -> double {
+#ifdef PP_SOLVE_CLOCKS
+        const long long ck0 = clock64();
+#endif
         double acc[10];
 #pragma unroll
         for (int j = 0; j < 10; ++j) acc[j] = 0.0;
         double dmax = 0.0;
-        for_channels([&](int n, const double (&t)[PP_TSTRIDE]) {
-            const double w = wts[n];
-            if (w == 0.0) return;
-            double p1, p2;
-            phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
-            const double d = dx[0] + dx[1] * p1 + dx[2] * p2;
-            dmax = fmax(dmax, fabs(d));
-            double A0, A1, A2;
-            taylor_shift_reg(t, d, A0, A1, A2);
-            const double S0 = msum[n], r = A0 / S0;
+        auto add = [&](double w, double p1, double p2, double S0, double A0, double A1, double A2) {
+            const double r = A0 / S0;
             const double F = -w * A0 * r, Gp = -2.0 * w * r * A1;
             const double Lpp = -2.0 * w * (A1 * A1 / S0 + r * A2);
             acc[0] += F;
             acc[1] += Gp; acc[2] += Gp * p1; acc[3] += Gp * p2;
             acc[4] += Lpp; acc[5] += Lpp * p1; acc[6] += Lpp * p2;
             acc[7] += Lpp * p1 * p1; acc[8] += Lpp * p1 * p2; acc[9] += Lpp * p2 * p2;
-        });
-        block_sum<10>(acc, scratch);
-        dmax = group_max<64>(dmax);
-        __syncthreads();
-        if ((tid & 63) == 0) shx[tid >> 6] = dmax;
-        __syncthreads();
-        {
-            double m = shx[0];
-            for (int w_ = 1; w_ < NWV; ++w_) m = fmax(m, shx[w_]);
-            dmax = m;
-        }
-        __syncthreads();
+        };
+        if (at_origin)
+            for_channels_at_origin([&](int n, double A0, double A1, double A2) {
+                double w, p1, p2, S0;
+                chan_inv(n, w, p1, p2, S0);
+                if (w == 0.0) return;
+                add(w, p1, p2, S0, A0, A1, A2);
+            });
+        else
+            for_channels([&](int n, const double (&t)[PP_TSTRIDE]) {
+                double w, p1, p2, S0;
+                chan_inv(n, w, p1, p2, S0);
+                if (w == 0.0) return;
+                const double d = dx[0] + dx[1] * p1 + dx[2] * p2;
+                dmax = fmax(dmax, fabs(d));
+                double A0, A1, A2;
+                taylor_shift_reg(t, d, A0, A1, A2);
+                add(w, p1, p2, S0, A0, A1, A2);
+            });
+#ifdef PP_SOLVE_CLOCKS
+        const long long ck1 = clock64();
+#endif
+        block_sum_t<10, 10>(acc, scratch, flip, &dmax);
+#ifdef PP_SOLVE_CLOCKS
+        ck_loop += ck1 - ck0; ck_red += clock64() - ck1; ++ck_n;
+#endif
         f = acc[0];
         // (phi, DM, GM) block only: 3 + 9 numbers per thread instead of 5 + 25
         g[0] = fl[0] ? acc[1] : 0.0; g[1] = fl[1] ? acc[2] : 0.0; g[2] = fl[2] ? acc[3] : 0.0;
@@ -1579,12 +1698,6 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
             for (int c_ = 0; c_ < 3; ++c_) H[r_ * 3 + c_] = (fl[r_] && fl[c_]) ? hh[r_][c_] : 0.0;
         return dmax;
     };
-    auto subspace = [&](const double* g, const double* H, double* gs, double* Hs) {
-        for (int r_ = 0; r_ < nf; ++r_) {
-            gs[r_] = g[idx[r_]];
-            for (int c_ = 0; c_ < nf; ++c_) Hs[r_ * nf + c_] = H[idx[r_] * 3 + idx[c_]];
-        }
-    };
     double dx[3] = {0.0, 0.0, 0.0};      // accepted displacement from x0 in (phi, DM, GM)
     // (the reference-seed flow starts the iteration off centre: at the reference's own guess)
     const bool off_centre = (a.xstart != nullptr) && st.recentred == 0;
@@ -1594,7 +1707,7 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
     double f, g[3], H[9];
     bool ok = true;
     int it = 0, nfev = 1;                // objective evaluations as SciPy's nfev counts them
-    double dpath = evalm(dx, f, g, H);   // (0 at the expansion point)
+    double dpath = evalm(dx, f, g, H, !off_centre);   // (0 at the expansion point)
     if (tid == 0 && st.recentred == 0) {     // (objective hooks: at init_params only)
         st.f0 = f;
         for (int j = 0; j < 5; ++j) st.g0[j] = j < 3 ? g[j] : 0.0;
@@ -1620,13 +1733,12 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
         double f2 = f, g2[3] = {g[0], g[1], g[2]}, H2[9];
         for (int j = 0; j < 9; ++j) H2[j] = H[j];
         for (;;) {
-            double gs[3], Hs[9], p[3];
-            subspace(g, H, gs, Hs);
+            double p3[3], pred = 0.0;
             int hits = 0;
-            tr_cg_steihaug_scipy(nf, f, gs, Hs, radius, p, &hits);
-            const double pred = f - tr_model_value(nf, f, gs, Hs, p);
-            double xta[3] = {xa[0], xa[1], xa[2]}, xt[3] = {dx[0], dx[1], dx[2]};
-            for (int r_ = 0; r_ < nf; ++r_) { xta[idx[r_]] = xa[idx[r_]] + p[r_]; xt[idx[r_]] += p[r_]; }
+            PP_FOR_N3(nf, (tr_propose_scipy3<N_>(f, g, H, ix, radius, p3, hits, pred)));
+            double xta[3], xt[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { xta[j] = fl[j] ? xa[j] + p3[j] : xa[j]; xt[j] = fl[j] ? dx[j] + p3[j] : dx[j]; }
             // (nfev_shadow = 2: the model is evaluated AT the rounded point fl(x + p), as SciPy evaluates its
             // objective there; xta - x0 is exact, the two are neighbours)
             if (a.nfev_shadow >= 2)
@@ -1679,16 +1791,14 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
             if (it > 0) { dpath = fmax(dpath, evalm(dx, f, g, H)); ++nfev; }
             if (!isfinite(f)) { ok = false; break; }
             // Newton step on the fit subspace (every thread computes the same)
-            double gs[3], Hs[9], p[3], mg[3];
-            subspace(g, H, gs, Hs);
-            for (int r_ = 0; r_ < nf; ++r_) mg[r_] = -gs[r_];
-            if (!chol_solve(nf, Hs, mg, p)) { ok = false; break; }
-            double Hp[3];
-            for (int r_ = 0; r_ < nf; ++r_) Hp[r_] = vdot(nf, Hs + r_ * nf, p);
-            const double pred = -(vdot(nf, gs, p) + 0.5 * vdot(nf, p, Hp));
+            double p3[3], pred = 0.0;
+            bool solved = false;
+            PP_FOR_N3(nf, (solved = newton_propose3<N_>(g, H, ix, p3, pred)));
+            if (!solved) { ok = false; break; }
             if (f > fprev + 1e-9 * fabs(fprev)) { ok = false; break; }   // not descending: leave it to the trust region
             fprev = f;
-            for (int r_ = 0; r_ < nf; ++r_) dx[idx[r_]] += p[r_];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) if (fl[j]) dx[j] += p3[j];
             // converged to the rounding of f: that was the last step
             if (!(pred > 64.0 * 2.220446049250313e-16 * fabs(f))) break;
         }
@@ -1699,6 +1809,9 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
     // ---- certificate (truncation error of the gradient, in parameter units) and the
     // sums of the accepted point x0 + dx for the post-fit stage, in ONE pass over the
     // model (they go to the buffer that only becomes current if the certificate holds)
+#ifdef PP_SOLVE_CLOCKS
+    const long long ck_cert = clock64();
+#endif
     const int buf = 1 - st.cur;
     if (ok) {
         double* csum = a.csum + ((size_t)buf * a.nsub + i) * a.nchan * a.ncs;
@@ -1706,25 +1819,23 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
         double jf = 1.0;
         for (int j = 2; j <= PP_TJ; ++j) jf *= (double)j;   // PP_TJ!
         for_channels([&](int n, const double (&t)[PP_TSTRIDE]) {
-            const double w = wts[n];
-            double p1, p2;
-            phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
+            double w, p1, p2, S0;
+            chan_inv(n, w, p1, p2, S0);
             const double d = dx[0] + dx[1] * p1 + dx[2] * p2;
             double A0, A1, A2;
             taylor_shift_reg(t, d, A0, A1, A2);
             csum[(size_t)n * 3] = A0; csum[(size_t)n * 3 + 1] = A1; csum[(size_t)n * 3 + 2] = A2;
             if (w == 0.0) return;
-            ev[3] += -w * A0 * A0 / msum[n];
+            ev[3] += -w * A0 * A0 / S0;
             // remainder of A1's series (one derivative): Bn |d|^PP_TJ / PP_TJ!
             const double d2 = d * d, d4 = d2 * d2, d10 = d4 * d4 * d2;
             static_assert(PP_TJ == 10, "remainder power written for order 10");
             const double e1 = t[PP_TJ + 1] * d10 / jf;
-            const double r = fabs(t[0] / msum[n]) + 1e-300;
+            const double r = fabs(t[0] / S0) + 1e-300;
             const double ge = 2.0 * w * r * e1 * 1.5;   // + remainder through A0 (smaller by |d|/PP_TJ)
             ev[0] += ge; ev[1] += ge * fabs(p1); ev[2] += ge * fabs(p2);
         });
-        block_sum<4>(ev, scratch);
-        __syncthreads();
+        block_sum_t<4, 10>(ev, scratch, flip);
         // position error <= gradient error / curvature, per fitted parameter
         // (1e-11 pc cm^-3 of DM is worth ~1e-11 rot of phase at the band edge: two
         // decades inside the parity bars)
@@ -1760,6 +1871,13 @@ __global__ __launch_bounds__(CPT ? 512 : 256, CPT ? 1 : PP_TAYLOR_WAVES) void k_
             atomicSub(a.nactive, 1);
         }
     }
+#ifdef PP_SOLVE_CLOCKS
+    if (tid == 0 && (i % 200) == 0) {
+        const long long e = clock64();
+        printf("solve %d: total %lld loop %lld red %lld cert %lld evals %lld -> serial %lld\n", i, e - ck_start, ck_loop, ck_red,
+               e - ck_cert, ck_n, (e - ck_start) - ck_loop - ck_red - (e - ck_cert));
+    }
+#endif
     // Not ok.  The tentative answer x0 + dx is usually still far better than x0 (the
     // harmonics that carry the power are within the model's reach long after the
     // highest ones have left it): expand again about it -- one more pass over this
@@ -2084,10 +2202,15 @@ __device__ __forceinline__ double py_wrap_half(double x) {
     return x;
 }
 
-__global__ __launch_bounds__(256) void k_finalize(FitArgs a) {
+// CPT > 0 (phase / DM / GM fits, nchan <= NT CPT; NT threads): what the four passes read of a channel -- weight,
+// frequency, the three sums, template power, data power -- is fetched ONCE, into registers, with every
+// load in flight together; CPT = 0: any fit, any nchan, read pass by pass.  Same sums in the same order.
+template <int CPT, int NT>
+__global__ __launch_bounds__(NT) void k_finalize(FitArgs a) {
     const int i = blockIdx.x, tid = threadIdx.x;
     const SubState& s = a.st[i];
-    __shared__ double scratch[4 * 32];
+    __shared__ double scratch[PP_BSUM_DOUBLES(NT / 64, 31)];
+    int flip = 0;
     __shared__ double sh[64];
     const double P = a.P[i];
     const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
@@ -2103,22 +2226,62 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs a) {
     const double nfDM = a.nu_fit[i * 3], nfGM = a.nu_fit[i * 3 + 1], nftau = a.nu_fit[i * 3 + 2];
     double noDM = a.nu_out ? a.nu_out[i * 3] : NAN, noGM = a.nu_out ? a.nu_out[i * 3 + 1] : NAN,
            notau = a.nu_out ? a.nu_out[i * 3 + 2] : NAN;
-    auto load_cs = [&](int n, double* cs) {
-        if (a.ncs == 3) {
+    double rw[CPT ? CPT : 1], rf[CPT ? CPT : 1], rc0[CPT ? CPT : 1], rc1[CPT ? CPT : 1], rc2[CPT ? CPT : 1],
+           rS[CPT ? CPT : 1], rd[CPT ? CPT : 1];
+    if constexpr (CPT > 0) {
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int n = tid + NT * q;
+            const bool in = n < a.nchan;
+            rw[q] = in ? wts[n] : 0.0;
+            rf[q] = in ? freqs[n] : 0.0;
+            rc0[q] = in ? csum[(size_t)n * 3] : 0.0; rc1[q] = in ? csum[(size_t)n * 3 + 1] : 0.0;
+            rc2[q] = in ? csum[(size_t)n * 3 + 2] : 0.0;
+            rS[q] = in ? msum[n] : 0.0;
+            rd[q] = in ? a.sdraw[(size_t)i * a.nchan + n] : 0.0;
+        }
+    }
+    // body(n, q): channel n = tid + NT q of this thread
+    auto for_channels = [&](auto&& body) {
+        if constexpr (CPT > 0) {
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                const int n = tid + NT * q;
+                if (n < a.nchan) body(n, q);
+            }
+        } else {
+            for (int n = tid; n < a.nchan; n += NT) body(n, 0);
+        }
+    };
+    auto wt_of = [&](int n, int q) { if constexpr (CPT > 0) return rw[q]; else return wts[n]; };
+    auto nu_of = [&](int n, int q) { if constexpr (CPT > 0) return rf[q]; else return freqs[n]; };
+    auto load_cs = [&](int n, int q, double* cs) {
+        if constexpr (CPT > 0) {
+            cs[0] = rc0[q]; cs[1] = rc1[q]; cs[2] = rc2[q];
+            cs[3] = cs[4] = cs[5] = 0.0; cs[6] = rS[q]; cs[7] = cs[8] = 0.0;
+        } else if (a.ncs == 3) {
             cs[0] = csum[(size_t)n * 3]; cs[1] = csum[(size_t)n * 3 + 1]; cs[2] = csum[(size_t)n * 3 + 2];
             cs[3] = cs[4] = cs[5] = 0.0; cs[6] = msum[n]; cs[7] = cs[8] = 0.0;
         } else {
             for (int j = 0; j < PP_NCS; ++j) cs[j] = csum[(size_t)n * PP_NCS + j];
         }
     };
+#ifdef PP_SOLVE_CLOCKS
+    const long long fk0 = clock64();
+#endif
     // ---- pass 0: Sd, mean frequency, used channels -------------------------
     double v3[3] = {0.0, 0.0, 0.0};
-    for (int n = tid; n < a.nchan; n += 256) {
-        const double w = wts[n];
-        if (w != 0.0) { v3[0] += w * a.sdraw[(size_t)i * a.nchan + n]; v3[1] += freqs[n]; v3[2] += 1.0; }
-    }
-    block_sum<3>(v3, scratch);
+    for_channels([&](int n, int q) {
+        const double w = wt_of(n, q);
+        double sd;
+        if constexpr (CPT > 0) sd = rd[q]; else sd = (w != 0.0) ? a.sdraw[(size_t)i * a.nchan + n] : 0.0;
+        if (w != 0.0) { v3[0] += w * sd; v3[1] += nu_of(n, q); v3[2] += 1.0; }
+    });
+    block_sum_t<3, 31>(v3, scratch, flip);
     const double Sd = v3[0], nused = v3[2], fmean = v3[1] / v3[2];
+#ifdef PP_SOLVE_CLOCKS
+    const long long fk1 = clock64();
+#endif
     int pat = 0;
     for (int j = 0; j < 5; ++j) pat = pat * 2 + (fl[j] ? 1 : 0);
     if (pat == 0x1F) pat = 0x1B;  // [1,1,1,1,1] is approximated by [1,1,0,1,1] (:893-901)
@@ -2133,14 +2296,14 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs a) {
         // v[0..]: see per-pattern use below
         double v[20];
         for (int j = 0; j < 20; ++j) v[j] = 0.0;
-        for (int n = tid; n < a.nchan; n += 256) {
-            const double w = wts[n];
-            if (w == 0.0) continue;
+        for_channels([&](int n, int q) {
+            const double w = wt_of(n, q);
+            if (w == 0.0) return;
             double cs[PP_NCS];
-            load_cs(n, cs);
+            load_cs(n, q, cs);
             const Local L = local_terms(cs, w);
             ChanGeom cg;
-            const double nu = freqs[n];
+            const double nu = nu_of(n, q);
             chan_geom(nu, P, nfDM, nfGM, nftau, tau, alpha, a.log10_tau, scat_on, cg);
             const double a2 = 1.0 / (nu * nu), a4 = a2 * a2, lf = scat_on ? log(nu) : 0.0;
             const double h = L.Lpp;
@@ -2200,8 +2363,11 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs a) {
                 break; }
             default: break;
             }
-        }
-        block_sum<20>(v, scratch);
+        });
+#ifdef PP_SOLVE_CLOCKS
+        if (tid == 0 && (i % 200) == 0) printf("fin %d: zero-loop %lld\n", i, clock64() - fk1);
+#endif
+        block_sum_t<20, 31>(v, scratch, flip);
         switch (pat) {
         case 0x18: nzDM = 1.0 / sqrt(v[0] / v[1]); break;
         case 0x14: nzGM = pow(v[0] / v[1], -0.25); break;
@@ -2277,15 +2443,18 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs a) {
     // ---- covariance with the amplitude parameters at the output references --
     // A_ij (15 upper) + Schur correction sum_n U_i U_j/(2 S_n) (15) -> 30 sums,
     // then snr^2
+#ifdef PP_SOLVE_CLOCKS
+    const long long fk2 = clock64();
+#endif
     double m[31];
     for (int j = 0; j < 31; ++j) m[j] = 0.0;
-    for (int n = tid; n < a.nchan; n += 256) {
-        const double w = wts[n];
-        if (w == 0.0) continue;
+    for_channels([&](int n, int q) {
+        const double w = wt_of(n, q);
+        if (w == 0.0) return;
         double cs[PP_NCS];
-        load_cs(n, cs);
+        load_cs(n, q, cs);
         ChanGeom cg;
-        chan_geom(freqs[n], P, noDM, noGM, notau, tau_out, alpha, a.log10_tau, scat_on, cg);
+        chan_geom(nu_of(n, q), P, noDM, noGM, notau, tau_out, alpha, a.log10_tau, scat_on, cg);
         const double A0 = cs[0], A1 = cs[1], A2 = cs[2], T1 = cs[3], T2 = cs[4], A1T = cs[5];
         const double S0 = cs[6], S1 = cs[7], S2 = cs[8];
         const double r = A0 / S0;                     // scale a_n
@@ -2310,61 +2479,116 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs a) {
                 ++c;
             }
         m[30] += w * A0 * r;      // (a_n sqrt(S_n))^2 = w A0^2/S0
-    }
-    block_sum<31>(m, scratch);
-    int idx[5], nfit = 0;
-    for (int j = 0; j < 5; ++j) if (fl[j]) idx[nfit++] = j;
+    });
+#ifdef PP_SOLVE_CLOCKS
+    const long long fk3 = clock64();
+#endif
+    block_sum_t<31, 31>(m, scratch, flip);
+#ifdef PP_SOLVE_CLOCKS
+    const long long fk4 = clock64();
+#endif
+    // positions of the fitted parameters, and everything that works on the fit subspace -- the inverse, the
+    // per-channel scale errors, the covariance outputs -- with its dimension a compile-time number (PP_FOR_N):
+    // no dynamically indexed array (those live in scratch memory), same operations in the same order
+    int ix[5] = {0, 0, 0, 0, 0}, nfit = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+        if (fl[j]) {
+            if (nfit == 0) ix[0] = j; else if (nfit == 1) ix[1] = j; else if (nfit == 2) ix[2] = j;
+            else if (nfit == 3) ix[3] = j; else ix[4] = j;
+            ++nfit;
+        }
     // X = inv(Afit - U Cinv U^T)   (every thread computes the same small matrix)
-    double Xm[25], full[25];
+    double full[25];
     {
         int c = 0;
+#pragma unroll
         for (int ii = 0; ii < 5; ++ii)
+#pragma unroll
             for (int jj = ii; jj < 5; ++jj) {
                 const double vv = (fl[ii] && fl[jj]) ? (m[c] - m[15 + c]) : 0.0;
                 full[ii * 5 + jj] = vv; full[jj * 5 + ii] = vv;
                 ++c;
             }
-        for (int r = 0; r < nfit; ++r)
-            for (int c2 = 0; c2 < nfit; ++c2) Xm[r * nfit + c2] = full[idx[r] * 5 + idx[c2]];
     }
-    const bool inv_ok = mat_inverse(nfit, Xm);
-    // ---- per-channel outputs -------------------------------------------------
-    for (int n = tid; n < a.nchan; n += 256) {
-        const double w = wts[n];
-        double sc = 0.0, se = 0.0, sn = 0.0;
-        if (w != 0.0) {
-            double cs[PP_NCS];
-            load_cs(n, cs);
-            ChanGeom cg;
-            chan_geom(freqs[n], P, noDM, noGM, notau, tau_out, alpha, a.log10_tau, scat_on, cg);
-            const double r = cs[0] / cs[6];
-            const double up = -2.0 * w * cs[1], ut = -2.0 * w * (cs[3] - r * cs[7]);
-            const double U[5] = {up, up * cg.p1, up * cg.p2, ut * cg.q1, ut * cg.q2};
-            const double cinv = 1.0 / (2.0 * w * cs[6]);
-            double uXu = 0.0;
-            for (int r1 = 0; r1 < nfit; ++r1)
-                for (int c1 = 0; c1 < nfit; ++c1) uXu += U[idx[r1]] * Xm[r1 * nfit + c1] * U[idx[c1]];
-            sc = r;
-            se = sqrt(2.0 * (cinv + cinv * cinv * uXu));
-            sn = r * sqrt(w * cs[6]);
+    auto sel5 = [](const double* v, int k) { return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : k == 3 ? v[3] : v[4]; };
+#ifdef PP_SOLVE_CLOCKS
+    long long fk5 = 0;
+#endif
+    auto on_subspace = [&](auto NC) {
+        constexpr int N = decltype(NC)::value;
+        double Xs[N * N];
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            const int k = ix[r];
+            double row[5];
+#pragma unroll
+            for (int jj = 0; jj < 5; ++jj)
+                row[jj] = k == 0 ? full[jj] : k == 1 ? full[5 + jj] : k == 2 ? full[10 + jj] : k == 3 ? full[15 + jj] : full[20 + jj];
+#pragma unroll
+            for (int c2 = 0; c2 < N; ++c2) Xs[r * N + c2] = sel5(row, ix[c2]);
         }
-        if (a.o_scales) a.o_scales[(size_t)i * a.nchan + n] = sc;
-        if (a.o_scale_errs) a.o_scale_errs[(size_t)i * a.nchan + n] = se;
-        if (a.o_csnr) a.o_csnr[(size_t)i * a.nchan + n] = sn;
-    }
+        const bool inv_ok = mat_inverse<N>(Xs);
+#ifdef PP_SOLVE_CLOCKS
+        fk5 = clock64();
+#endif
+        // ---- per-channel outputs -------------------------------------------------
+        for_channels([&](int n, int q) {
+            const double w = wt_of(n, q);
+            double sc = 0.0, se = 0.0, sn = 0.0;
+            if (w != 0.0) {
+                double cs[PP_NCS];
+                load_cs(n, q, cs);
+                ChanGeom cg;
+                chan_geom(nu_of(n, q), P, noDM, noGM, notau, tau_out, alpha, a.log10_tau, scat_on, cg);
+                const double r = cs[0] / cs[6];
+                const double up = -2.0 * w * cs[1], ut = -2.0 * w * (cs[3] - r * cs[7]);
+                const double U[5] = {up, up * cg.p1, up * cg.p2, ut * cg.q1, ut * cg.q2};
+                double Us[N];
+#pragma unroll
+                for (int r1 = 0; r1 < N; ++r1) Us[r1] = sel5(U, ix[r1]);
+                const double cinv = 1.0 / (2.0 * w * cs[6]);
+                double uXu = 0.0;
+#pragma unroll
+                for (int r1 = 0; r1 < N; ++r1)
+#pragma unroll
+                    for (int c1 = 0; c1 < N; ++c1) uXu += Us[r1] * Xs[r1 * N + c1] * Us[c1];
+                sc = r;
+                se = sqrt(2.0 * (cinv + cinv * cinv * uXu));
+                sn = r * sqrt(w * cs[6]);
+            }
+            if (a.o_scales) a.o_scales[(size_t)i * a.nchan + n] = sc;
+            if (a.o_scale_errs) a.o_scale_errs[(size_t)i * a.nchan + n] = se;
+            if (a.o_csnr) a.o_csnr[(size_t)i * a.nchan + n] = sn;
+        });
+        if (tid == 0) {
+            double* oe = a.o_errs + (size_t)i * 5;
+            double* oc = a.o_cov + (size_t)i * 25;
+            for (int j = 0; j < 5; ++j) oe[j] = 0.0;
+            for (int j = 0; j < 25; ++j) oc[j] = 0.0;
+#pragma unroll
+            for (int r = 0; r < N; ++r) {
+                if (r >= nfit) break;         // (nfit = 0 lands in the N = 5 instance)
+#pragma unroll
+                for (int c = 0; c < N; ++c) if (c < nfit) oc[ix[r] * 5 + ix[c]] = inv_ok ? 2.0 * Xs[r * N + c] : NAN;
+                oe[ix[r]] = inv_ok ? sqrt(2.0 * Xs[r * N + r]) : NAN;
+            }
+        }
+    };
+    // (the register-cached variants serve fits without scattering: at most phi, DM, GM)
+    if constexpr (CPT > 0) { PP_FOR_N3(nfit, on_subspace(std::integral_constant<int, N_>{})); }
+    else { PP_FOR_N(nfit, on_subspace(std::integral_constant<int, N_>{})); }
+#ifdef PP_SOLVE_CLOCKS
+    if (tid == 0 && (i % 200) == 0)
+        printf("fin %d: pass0 %lld zero %lld covloop %lld covred %lld inv %lld chan %lld\n", i, fk1 - fk0, fk2 - fk1, fk3 - fk2,
+               fk4 - fk3, fk5 - fk4, clock64() - fk5);
+#endif
     if (tid == 0) {
         double* op = a.o_params + (size_t)i * 5;
         op[0] = phi_out; op[1] = DM; op[2] = GM;
         op[3] = a.log10_tau ? log10(tau_out) : tau_out;
         op[4] = alpha;
-        double* oe = a.o_errs + (size_t)i * 5;
-        double* oc = a.o_cov + (size_t)i * 25;
-        for (int j = 0; j < 5; ++j) oe[j] = 0.0;
-        for (int j = 0; j < 25; ++j) oc[j] = 0.0;
-        for (int r = 0; r < nfit; ++r) {
-            for (int c = 0; c < nfit; ++c) oc[idx[r] * 5 + idx[c]] = inv_ok ? 2.0 * Xm[r * nfit + c] : NAN;
-            oe[idx[r]] = inv_ok ? sqrt(2.0 * Xm[r * nfit + r]) : NAN;
-        }
+        const double* oe = a.o_errs + (size_t)i * 5;      // (written above, by this thread)
         a.o_nu[(size_t)i * 3] = noDM; a.o_nu[(size_t)i * 3 + 1] = noGM; a.o_nu[(size_t)i * 3 + 2] = notau;
         const double chi2 = Sd + s.f;
         const double dof = nused * a.nbin - (nfit + nused);

@@ -139,6 +139,11 @@ struct pp_ctx {
     int seed_ndm = 1;           // DM trials of the coarse (phi, DM) seed grid (1 = phase only, at the guessed DM)
     double seed_dm_step = 0.0;  // their spacing [pc cm^-3]
     double max_work_bytes = 96e9;
+    bool solve_lds_attr = false;
+    int solve_cache = -1;       // k_taylor_solve: channels whose weight / geometry / template power stay in LDS (-1: all, up to 4096)
+    int solve_threads = 0;      // k_taylor_solve: threads per subint (0: by band width; 64 / 128 / 256 / 512 for A/B)
+    int finalize_regs = 1;      // post-fit stage with the channel's numbers held in registers (fits without scattering,
+                                // <= 4096 channels); 0: the pass-by-pass kernel (A/B)
     int eager_flush = 1;        // poke the stream once the transform is queued (hipStreamQuery), so that the GPU starts
                                 // while the host is still queueing the rest of the batch
     int coarse_newton = 1;      // Newton solver, scattering fits: iterate on every 16th channel first
@@ -336,6 +341,8 @@ static bool option_ref(pp_ctx* c, const std::string& n, OptRef* out) {
         {"seed_dm_step", 'd', &c->seed_dm_step, 0}, {"skip_masked", 'i', &c->skip_masked, INT32_MIN},
         {"nfev_shadow", 'i', &c->nfev_shadow, INT32_MIN}, {"coarse_newton", 'i', &c->coarse_newton, INT32_MIN},
         {"eager_flush", 'i', &c->eager_flush, INT32_MIN},
+        {"finalize_regs", 'i', &c->finalize_regs, INT32_MIN}, {"solve_cache", 'i', &c->solve_cache, -1},
+        {"solve_threads", 'i', &c->solve_threads, 0},
     };
     for (const OptRef& o : tab)
         if (n == o.name) { *out = o; return true; }
@@ -935,7 +942,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     if ((rc = c->state.reserve((size_t)ns * sizeof(SubState)))) return rc;
     if ((rc = c->csum.reserve(2 * nc * ncs * 8))) return rc;
     if ((rc = c->partial.reserve((size_t)ns * nchunk * PP_NACC * 8))) return rc;
-    if (taylor) if ((rc = c->tay.reserve(nc * PP_TSTRIDE * 8))) return rc;
+    if (taylor) if ((rc = c->tay.reserve(((nc + 63) / 64) * 64 * PP_TSTRIDE * 8))) return rc;   // (whole blocks of 64 rows: tay_idx)
     // (SciPy's trust-ncg spends ~8 of its ~15 evaluations inside the model's range;
     // the Newton iteration only 2-3 of 6, less than the model pass costs)
     const bool smodel = scat && c->max_iter > 0 && (c->scat_model >= 2 || (c->scat_model == 1 && in->method == PP_METHOD_TRUST_NCG));
@@ -977,7 +984,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         // contents become NaNs that surface as failed certificates / non-finite results
         // (bit mask: 1 tay, 2 sdraw, 4 noise, 8 wts, 16 csum, 32 ph0, 64 X, 128 mdl)
         const int pz = c->debug_poison;
-        if ((pz & 1) && taylor) HIP_TRY(hipMemsetAsync(c->tay.p, 0xFF, nc * PP_TSTRIDE * 8, c->stream));
+        if ((pz & 1) && taylor) HIP_TRY(hipMemsetAsync(c->tay.p, 0xFF, ((nc + 63) / 64) * 64 * PP_TSTRIDE * 8, c->stream));
         if (pz & 2) HIP_TRY(hipMemsetAsync(c->sdraw.p, 0xFF, nc * 8, c->stream));
         if (pz & 4) HIP_TRY(hipMemsetAsync(c->noise.p, 0xFF, nc * 8, c->stream));
         if (pz & 8) HIP_TRY(hipMemsetAsync(c->wts.p, 0xFF, nc * 8, c->stream));
@@ -1049,6 +1056,22 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.x0w = d_x0;
     fa.x_f32 = xf32 ? 1 : 0;
     fa.nfev_shadow = c->nfev_shadow;
+    // (a band of up to 512 channels: one wave per subint; up to 1024: two; wider: four -- eight measured slower at 4096)
+    const int solve_nt = c->solve_threads > 0 ? c->solve_threads : (C <= 512 ? 64 : C <= 1024 ? 128 : 256);
+    // (LDS: 32 B per cached channel, 512 channels per wave of the block keep the CU's eight waves within 128 KB)
+    fa.solve_cache = std::min(C, c->solve_cache >= 0 ? c->solve_cache : std::min(PP_SOLVE_CACHE_MAX, solve_nt * 8));
+    auto launch_taylor_solve = [&]() {
+        const size_t lds = (size_t)fa.solve_cache * 32;
+        if (lds > 48 * 1024 && !c->solve_lds_attr) {     // (dynamic LDS beyond the default cap: said once)
+            (void)hipFuncSetAttribute((const void*)k_taylor_solve<256>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
+            (void)hipFuncSetAttribute((const void*)k_taylor_solve<512>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
+            c->solve_lds_attr = true;
+        }
+        if (solve_nt == 64) hipLaunchKernelGGL(k_taylor_solve<64>, dim3(ns), dim3(64), lds, c->stream, fa);
+        else if (solve_nt == 128) hipLaunchKernelGGL(k_taylor_solve<128>, dim3(ns), dim3(128), lds, c->stream, fa);
+        else if (solve_nt == 512) hipLaunchKernelGGL(k_taylor_solve<512>, dim3(ns), dim3(512), lds, c->stream, fa);
+        else hipLaunchKernelGGL(k_taylor_solve<256>, dim3(ns), dim3(256), lds, c->stream, fa);
+    };
 
     auto run_xspec = [&](const XspecArgs& x, int mode) -> int {
         Prof pr(c, KF_XSPEC);
@@ -1310,7 +1333,16 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         ff.act = nullptr; ff.nact = ns;
         {
             Prof pr(c, KF_FINAL);
-            hipLaunchKernelGGL(k_finalize, dim3(ns), dim3(256), 0, c->stream, ff);
+            // (phase / DM / GM fits of up to 4096 channels: the channel's numbers held in registers over the passes)
+            // (its passes are separated by block-wide sums and a serial stretch: as few waves per subint as hold
+            // the band at 8 channels per thread)
+            const int fnt = (ff.ncs != 3 || C > 4096 || !c->finalize_regs) ? 0
+                            : c->finalize_regs > 1 ? c->finalize_regs : C <= 512 ? 64 : C <= 1024 ? 128 : C <= 2048 ? 256 : 512;
+            if (fnt == 64 && C <= 512) hipLaunchKernelGGL((k_finalize<8, 64>), dim3(ns), dim3(64), 0, c->stream, ff);
+            else if (fnt == 128 && C <= 1024) hipLaunchKernelGGL((k_finalize<8, 128>), dim3(ns), dim3(128), 0, c->stream, ff);
+            else if (fnt == 256 && C <= 2048) hipLaunchKernelGGL((k_finalize<8, 256>), dim3(ns), dim3(256), 0, c->stream, ff);
+            else if (fnt == 512) hipLaunchKernelGGL((k_finalize<8, 512>), dim3(ns), dim3(512), 0, c->stream, ff);
+            else hipLaunchKernelGGL((k_finalize<0, 256>), dim3(ns), dim3(256), 0, c->stream, ff);
         }
         HIP_TRY(hipGetLastError());
 #define PP_D2H(dst, buf, off, bytes) \
@@ -1341,7 +1373,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         {
             Prof pr(c, KF_TAYLOR);
             // (rows of the Taylor model in registers where the channel count allows)
-            hipLaunchKernelGGL(k_taylor_solve<0>, dim3(ns), dim3(256), 0, c->stream, fa);
+            launch_taylor_solve();
         }
         HIP_TRY(hipGetLastError());
         // The solve certifies nearly every subint of nearly every batch: the post-fit stage is
@@ -1378,7 +1410,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             if ((rc = run_xspec(xl, xmode))) return rc;
             {
                 Prof pr(c, KF_TAYLOR);
-                hipLaunchKernelGGL(k_taylor_solve<0>, dim3(ns), dim3(256), 0, c->stream, fa);
+                launch_taylor_solve();
             }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(c->nactive_h, fa.nactive, sizeof(int), hipMemcpyDeviceToHost, c->stream));

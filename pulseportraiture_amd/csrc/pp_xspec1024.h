@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
             if ((tid & 3) == 0) {
                 const int q = wave_reduce16_index(tid);
                 if (q < PP_TSTRIDE)   // Re(i^q z): +Re, -Im, -Re, +Im, ...
-                    a.tay[rc * PP_TSTRIDE + q] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
+                    a.tay[tay_idx(rc, q)] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
             }
         }
         if (tid == 0) {

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
             if (q < PP_TSTRIDE) {
                 // Re(i^q z): +Re, -Im, -Re, +Im, ...   (x 1/2: unhalved template against 2 d_k)
                 tv *= 0.5;
-                a.tay[rc * PP_TSTRIDE + q] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
+                a.tay[tay_idx(rc, q)] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
             }
         }
         if (tid == 4 * PP_TSTRIDE) a.sdraw[rc] = tv;
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
             const int q = wave_reduce16_index(tid);
             if (q < PP_TSTRIDE) {
                 tv *= 0.5;
-                a.tay[rc * PP_TSTRIDE + q] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
+                a.tay[tay_idx(rc, q)] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
             }
         }
         if (tid == 4 * PP_TSTRIDE) a.sdraw[rc] = tv;

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
                 const int q = wave_reduce16_index(tid);
                 if (q < PP_TSTRIDE) {
                     tv *= 0.5;
-                    a.tay[rc * PP_TSTRIDE + q] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
+                    a.tay[tay_idx(rc, q)] = (q <= PP_TJ && ((q & 3) == 1 || (q & 3) == 2)) ? -tv : tv;
                 }
             }
             if (tid == 4 * PP_TSTRIDE) a.sdraw[rc] = tv;
