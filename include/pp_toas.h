@@ -151,6 +151,14 @@ void* pp_stream(pp_ctx* ctx);
  *                  (pptoas.py:384-397); 0 = every row is transformed and masked ones get weight 0
  *   "eager_flush"  1 (default) = the stream is queried once the transform has been queued, which makes the
  *                  runtime hand what is queued to the GPU at once instead of with the next blocking call
+ *   "solve_threads"  one-pass flow: threads per subint of the solve on the Taylor model (0 = default: 64 for a
+ *                  band of up to 512 channels, 128 up to 1024, 256 beyond; 64 / 128 / 256 / 512 force it).  The
+ *                  channel sums are taken in a different order for each: results agree to rounding, not bitwise
+ *   "solve_cache"  ... channels whose weight, phase geometry and template power that solve keeps in LDS
+ *                  (-1 = default: all, up to 8 per thread; 0 = formed again on every evaluation)
+ *   "finalize_regs"  post-fit stage of fits without scattering: 1 (default) = each thread holds its (up to 8)
+ *                  channels' numbers in registers over the stage's passes, 64 ... 512 threads per subint by band
+ *                  width; 0 = the pass-by-pass kernel every other fit uses; 64 / 128 / 256 / 512 force a width
  *   "coarse_newton"  1 (default) = scattering fits with PP_METHOD_NEWTON first iterate on every 16th channel
  *                  (each evaluation reads a sixteenth of the stored cross-spectrum) and start the
  *                  full-channel iteration from that answer -- the optimum does not depend on the path --;

@@ -1141,9 +1141,12 @@ __global__ __launch_bounds__(256) void k_eval_fast(FitArgs a) {
 template <int n>
 __device__ inline bool chol_solve(const double* A, const double* b, double* x) {
     double Lm[25];
+    #pragma unroll
     for (int i = 0; i < n; ++i)
+        #pragma unroll
         for (int j = 0; j <= i; ++j) {
             double s = A[i * n + j];
+            #pragma unroll
             for (int k = 0; k < j; ++k) s -= Lm[i * n + k] * Lm[j * n + k];
             if (i == j) {
                 if (!(s > 0.0)) return false;
@@ -1151,13 +1154,17 @@ __device__ inline bool chol_solve(const double* A, const double* b, double* x) {
             } else Lm[i * n + j] = s / Lm[j * n + j];
         }
     double y[5];
+    #pragma unroll
     for (int i = 0; i < n; ++i) {
         double s = b[i];
+        #pragma unroll
         for (int k = 0; k < i; ++k) s -= Lm[i * n + k] * y[k];
         y[i] = s / Lm[i * n + i];
     }
+    #pragma unroll
     for (int i = n - 1; i >= 0; --i) {
         double s = y[i];
+        #pragma unroll
         for (int k = i + 1; k < n; ++k) s -= Lm[k * n + i] * x[k];
         x[i] = s / Lm[i * n + i];
     }
@@ -1168,28 +1175,41 @@ __device__ inline bool chol_solve(const double* A, const double* b, double* x) {
 template <int n>
 __device__ inline bool mat_inverse(double* A) {
     double inv[25];
+    #pragma unroll
     for (int i = 0; i < n; ++i)
+        #pragma unroll
         for (int j = 0; j < n; ++j) inv[i * n + j] = (i == j) ? 1.0 : 0.0;
+    #pragma unroll
     for (int c = 0; c < n; ++c) {
         int piv = c;
         double best = fabs(A[c * n + c]);
+        #pragma unroll
         for (int r = c + 1; r < n; ++r)
             if (fabs(A[r * n + c]) > best) { best = fabs(A[r * n + c]); piv = r; }
         if (!(best > 0.0) || !isfinite(best)) return false;
-        if (piv != c)
-            for (int j = 0; j < n; ++j) {
-                double t = A[c * n + j]; A[c * n + j] = A[piv * n + j]; A[piv * n + j] = t;
-                t = inv[c * n + j]; inv[c * n + j] = inv[piv * n + j]; inv[piv * n + j] = t;
+        // (rows c and piv change places; written over the candidate rows so that every index is a constant)
+        #pragma unroll
+        for (int r = c + 1; r < n; ++r)
+            if (piv == r) {
+                #pragma unroll
+                for (int j = 0; j < n; ++j) {
+                    double t = A[c * n + j]; A[c * n + j] = A[r * n + j]; A[r * n + j] = t;
+                    t = inv[c * n + j]; inv[c * n + j] = inv[r * n + j]; inv[r * n + j] = t;
+                }
             }
         const double d = 1.0 / A[c * n + c];
+        #pragma unroll
         for (int j = 0; j < n; ++j) { A[c * n + j] *= d; inv[c * n + j] *= d; }
+        #pragma unroll
         for (int r = 0; r < n; ++r)
             if (r != c) {
                 const double f = A[r * n + c];
                 if (f != 0.0)
+                    #pragma unroll
                     for (int j = 0; j < n; ++j) { A[r * n + j] -= f * A[c * n + j]; inv[r * n + j] -= f * inv[c * n + j]; }
             }
     }
+    #pragma unroll
     for (int j = 0; j < n * n; ++j) A[j] = inv[j];
     return true;
 }
@@ -1197,6 +1217,7 @@ __device__ inline bool mat_inverse(double* A) {
 template <int n>
 __device__ inline double vdot(const double* a, const double* b) {
     double s = 0.0;
+    #pragma unroll
     for (int i = 0; i < n; ++i) s += a[i] * b[i];
     return s;
 }
@@ -1209,15 +1230,18 @@ __device__ inline void tr_subproblem(const double* g, const double* H, double ra
                                      int* hits) {
     *hits = 0;
     double mg[5];
+    #pragma unroll
     for (int i = 0; i < n; ++i) mg[i] = -g[i];
     if (chol_solve<n>(H, mg, p)) {
         if (sqrt(vdot<n>(p, p)) < radius) return;
     }
     double z[5] = {0, 0, 0, 0, 0}, r[5], d[5], Bd[5];
+    #pragma unroll
     for (int i = 0; i < n; ++i) { r[i] = g[i]; d[i] = -g[i]; }
     const double gnorm = sqrt(vdot<n>(g, g));
     const double tol = 1e-14 * gnorm;
     for (int it = 0; it < 4 * n + 4; ++it) {
+        #pragma unroll
         for (int i = 0; i < n; ++i) Bd[i] = vdot<n>(H + i * n, d);
         const double dBd = vdot<n>(d, Bd);
         const double dd = vdot<n>(d, d), zd = vdot<n>(z, d), zz = vdot<n>(z, z);
@@ -1226,30 +1250,40 @@ __device__ inline void tr_subproblem(const double* g, const double* H, double ra
         const double ta = (-zd - disc) / dd, tb = (-zd + disc) / dd;
         if (dBd <= 0.0) {
             double pa[5], pb[5], Hp[5];
+            #pragma unroll
             for (int i = 0; i < n; ++i) { pa[i] = z[i] + ta * d[i]; pb[i] = z[i] + tb * d[i]; }
+            #pragma unroll
             for (int i = 0; i < n; ++i) Hp[i] = vdot<n>(H + i * n, pa);
             const double ma = vdot<n>(g, pa) + 0.5 * vdot<n>(pa, Hp);
+            #pragma unroll
             for (int i = 0; i < n; ++i) Hp[i] = vdot<n>(H + i * n, pb);
             const double mb = vdot<n>(g, pb) + 0.5 * vdot<n>(pb, Hp);
+            #pragma unroll
             for (int i = 0; i < n; ++i) p[i] = (ma < mb) ? pa[i] : pb[i];
             *hits = 1;
             return;
         }
         const double rr = vdot<n>(r, r), al = rr / dBd;
         double zn[5];
+        #pragma unroll
         for (int i = 0; i < n; ++i) zn[i] = z[i] + al * d[i];
         if (sqrt(vdot<n>(zn, zn)) >= radius) {
+            #pragma unroll
             for (int i = 0; i < n; ++i) p[i] = z[i] + tb * d[i];
             *hits = 1;
             return;
         }
         double rn2 = 0.0;
+        #pragma unroll
         for (int i = 0; i < n; ++i) { r[i] += al * Bd[i]; rn2 += r[i] * r[i]; }
+        #pragma unroll
         for (int i = 0; i < n; ++i) z[i] = zn[i];
         if (sqrt(rn2) <= tol) break;
         const double be = rn2 / rr;
+        #pragma unroll
         for (int i = 0; i < n; ++i) d[i] = -r[i] + be * d[i];
     }
+    #pragma unroll
     for (int i = 0; i < n; ++i) p[i] = z[i];
 }
 
@@ -1267,6 +1301,7 @@ __device__ inline void tr_subproblem(const double* g, const double* H, double ra
 template <int n>
 __device__ inline double tr_model_value(double f, const double* g, const double* H, const double* p) {
     double Hp[5];
+    #pragma unroll
     for (int i = 0; i < n; ++i) Hp[i] = vdot<n>(H + i * n, p);
     return f + vdot<n>(g, p) + 0.5 * vdot<n>(p, Hp);
 }
@@ -1285,44 +1320,55 @@ template <int n>
 __device__ inline void tr_cg_steihaug_scipy(double f, const double* g, const double* H, double radius,
                                             double* p, int* hits) {
     *hits = 0;
+    #pragma unroll
     for (int i = 0; i < n; ++i) p[i] = 0.0;
     const double gmag = sqrt(vdot<n>(g, g));
     const double tol = fmin(0.5, sqrt(gmag)) * gmag;
     if (gmag < tol) return;
     double z[5] = {0, 0, 0, 0, 0}, r[5], d[5], Bd[5];
+    #pragma unroll
     for (int i = 0; i < n; ++i) { r[i] = g[i]; d[i] = -g[i]; }
     for (int it = 0; it < 64; ++it) {
+        #pragma unroll
         for (int i = 0; i < n; ++i) Bd[i] = vdot<n>(H + i * n, d);
         const double dBd = vdot<n>(d, Bd);
         if (dBd <= 0.0) {
             double ta, tb, pa[5], pb[5];
             tr_boundaries<n>(z, d, radius, &ta, &tb);
+            #pragma unroll
             for (int i = 0; i < n; ++i) { pa[i] = z[i] + ta * d[i]; pb[i] = z[i] + tb * d[i]; }
             const bool first = tr_model_value<n>(f, g, H, pa) < tr_model_value<n>(f, g, H, pb);
+            #pragma unroll
             for (int i = 0; i < n; ++i) p[i] = first ? pa[i] : pb[i];
             *hits = 1;
             return;
         }
         const double rsq = vdot<n>(r, r), alpha = rsq / dBd;
         double zn[5];
+        #pragma unroll
         for (int i = 0; i < n; ++i) zn[i] = z[i] + alpha * d[i];
         if (sqrt(vdot<n>(zn, zn)) >= radius) {
             double ta, tb;
             tr_boundaries<n>(z, d, radius, &ta, &tb);
+            #pragma unroll
             for (int i = 0; i < n; ++i) p[i] = z[i] + tb * d[i];
             *hits = 1;
             return;
         }
         double rn[5];
+        #pragma unroll
         for (int i = 0; i < n; ++i) rn[i] = r[i] + alpha * Bd[i];
         const double rnsq = vdot<n>(rn, rn);
         if (sqrt(rnsq) < tol || !(rnsq == rnsq)) {
+            #pragma unroll
             for (int i = 0; i < n; ++i) p[i] = zn[i];
             return;
         }
         const double beta = rnsq / rsq;
+        #pragma unroll
         for (int i = 0; i < n; ++i) { d[i] = -rn[i] + beta * d[i]; z[i] = zn[i]; r[i] = rn[i]; }
     }
+    #pragma unroll
     for (int i = 0; i < n; ++i) p[i] = z[i];
 }
 
@@ -1380,18 +1426,18 @@ __device__ inline bool tr_scipy_accept(double f, double f_new, double pred, int 
         case 2: { constexpr int N_ = 2; EXPR; } break; \
         default: { constexpr int N_ = 3; EXPR; } break; \
     }
-__device__ __forceinline__ double sel3(const double* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
+// (values, not addresses: given an array the compiler turns the selection into an indexed load from a scratch copy)
+__device__ __forceinline__ double sel3(double v0, double v1, double v2, int k) { return k == 0 ? v0 : (k == 1 ? v1 : v2); }
 template <int N>
 __device__ __forceinline__ void gather_sub3(const double (&g)[3], const double (&H)[9], const int (&ix)[3], double (&gs)[N],
                                             double (&Hs)[N * N]) {
 #pragma unroll
     for (int r = 0; r < N; ++r) {
-        gs[r] = sel3(g, ix[r]);
         const int k = ix[r];
-        const double row[3] = {k == 0 ? H[0] : (k == 1 ? H[3] : H[6]), k == 0 ? H[1] : (k == 1 ? H[4] : H[7]),
-                               k == 0 ? H[2] : (k == 1 ? H[5] : H[8])};   // row ix[r] of H
+        gs[r] = sel3(g[0], g[1], g[2], k);
+        const double r0 = sel3(H[0], H[3], H[6], k), r1 = sel3(H[1], H[4], H[7], k), r2 = sel3(H[2], H[5], H[8], k);   // row ix[r] of H
 #pragma unroll
-        for (int c = 0; c < N; ++c) Hs[r * N + c] = sel3(row, ix[c]);
+        for (int c = 0; c < N; ++c) Hs[r * N + c] = sel3(r0, r1, r2, ix[c]);
     }
 }
 template <int N>
@@ -1654,10 +1700,13 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
 #pragma unroll
         for (int j = 0; j < 10; ++j) acc[j] = 0.0;
         double dmax = 0.0;
+        // (a channel out of the fit adds zeros instead of branching around the work: the two channels a thread
+        // has in hand then interleave -- with one wave per SIMD a dependent chain costs its full latency)
         auto add = [&](double w, double p1, double p2, double S0, double A0, double A1, double A2) {
+            const bool in = (w != 0.0);
             const double r = A0 / S0;
-            const double F = -w * A0 * r, Gp = -2.0 * w * r * A1;
-            const double Lpp = -2.0 * w * (A1 * A1 / S0 + r * A2);
+            const double F = in ? -w * A0 * r : 0.0, Gp = in ? -2.0 * w * r * A1 : 0.0;
+            const double Lpp = in ? -2.0 * w * (A1 * A1 / S0 + r * A2) : 0.0;
             acc[0] += F;
             acc[1] += Gp; acc[2] += Gp * p1; acc[3] += Gp * p2;
             acc[4] += Lpp; acc[5] += Lpp * p1; acc[6] += Lpp * p2;
@@ -1667,16 +1716,14 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
             for_channels_at_origin([&](int n, double A0, double A1, double A2) {
                 double w, p1, p2, S0;
                 chan_inv(n, w, p1, p2, S0);
-                if (w == 0.0) return;
                 add(w, p1, p2, S0, A0, A1, A2);
             });
         else
             for_channels([&](int n, const double (&t)[PP_TSTRIDE]) {
                 double w, p1, p2, S0;
                 chan_inv(n, w, p1, p2, S0);
-                if (w == 0.0) return;
                 const double d = dx[0] + dx[1] * p1 + dx[2] * p2;
-                dmax = fmax(dmax, fabs(d));
+                dmax = fmax(dmax, (w != 0.0) ? fabs(d) : 0.0);
                 double A0, A1, A2;
                 taylor_shift_reg(t, d, A0, A1, A2);
                 add(w, p1, p2, S0, A0, A1, A2);
@@ -1702,6 +1749,7 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
     // (the reference-seed flow starts the iteration off centre: at the reference's own guess)
     const bool off_centre = (a.xstart != nullptr) && st.recentred == 0;
     if (off_centre)
+#pragma unroll
         for (int j = 0; j < 3; ++j) dx[j] = fl[j] ? a.xstart[i * 5 + j] - st.xe[j] : 0.0;
     const double dx0[3] = {dx[0], dx[1], dx[2]};
     double f, g[3], H[9];
@@ -1710,8 +1758,11 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
     double dpath = evalm(dx, f, g, H, !off_centre);   // (0 at the expansion point)
     if (tid == 0 && st.recentred == 0) {     // (objective hooks: at init_params only)
         st.f0 = f;
+#pragma unroll
         for (int j = 0; j < 5; ++j) st.g0[j] = j < 3 ? g[j] : 0.0;
+#pragma unroll
         for (int r_ = 0; r_ < 5; ++r_)
+#pragma unroll
             for (int c_ = 0; c_ < 5; ++c_) st.H0[r_ * 5 + c_] = (r_ < 3 && c_ < 3) ? H[r_ * 3 + c_] : 0.0;
     }
     if (!isfinite(f)) ok = false;
@@ -1729,8 +1780,10 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
         // displacement: half an ulp of DM is worth ~1e-15 rot, the same size as the rounding of the
         // reference's own phases at these DMs.)
         double xa[3], xla[3], xld[3] = {dx0[0], dx0[1], dx0[2]};
+#pragma unroll
         for (int j = 0; j < 3; ++j) { xa[j] = off_centre ? (fl[j] ? a.xstart[i * 5 + j] : st.xe[j]) : st.xe[j]; xla[j] = xa[j]; }
         double f2 = f, g2[3] = {g[0], g[1], g[2]}, H2[9];
+#pragma unroll
         for (int j = 0; j < 9; ++j) H2[j] = H[j];
         for (;;) {
             double p3[3], pred = 0.0;
@@ -1742,6 +1795,7 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
             // (nfev_shadow = 2: the model is evaluated AT the rounded point fl(x + p), as SciPy evaluates its
             // objective there; xta - x0 is exact, the two are neighbours)
             if (a.nfev_shadow >= 2)
+#pragma unroll
                 for (int j = 0; j < 3; ++j) xt[j] = xta[j] - st.xe[j];
             // (otherwise the comparison is made on the displacements, which resolve 1e-21 -- the closing
             // proposal is then always a new point and is counted.  Which rule lands on the reference's count
@@ -1761,10 +1815,12 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
             }
             if (!cached) {
                 dpath = fmax(dpath, evalm(xt, f2, g2, H2));
+#pragma unroll
                 for (int j = 0; j < 3; ++j) { xla[j] = xta[j]; xld[j] = xt[j]; }
                 ++nfev;
             }
             bool finite = isfinite(f2);
+#pragma unroll
             for (int j = 0; j < 3; ++j) finite = finite && isfinite(g2[j]);
 #if defined(PP_TAYLOR_TRACE) && PP_TAYLOR_TRACE >= 3
             if (tid == 0)
@@ -1772,9 +1828,12 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
                        f - f2, pred, (f - f2) / pred, radius, hits, (int)cached);
 #endif
             if (tr_scipy_accept(f, f2, pred, hits, finite, &radius)) {
+#pragma unroll
                 for (int j = 0; j < 3; ++j) { dx[j] = xt[j]; xa[j] = xta[j]; }
                 f = f2;
+#pragma unroll
                 for (int j = 0; j < 3; ++j) g[j] = g2[j];
+#pragma unroll
                 for (int j = 0; j < 9; ++j) H[j] = H2[j];
             }
             ++it;
@@ -1840,6 +1899,7 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
         // (1e-11 pc cm^-3 of DM is worth ~1e-11 rot of phase at the band edge: two
         // decades inside the parity bars)
         const double tol[3] = {1e-13, 1e-11, 1e-8};   // turns, pc cm^-3, GM units
+#pragma unroll
         for (int j = 0; j < 3; ++j)
             if (fl[j]) {
                 const double hjj = fabs(H[j * 3 + j]);
@@ -1861,11 +1921,15 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
             ok = false;
         }
         if (ok && tid == 0) {
+#pragma unroll
             for (int j = 0; j < 3; ++j) st.x[j] = st.xe[j] + dx[j];
             st.x[3] = st.xe[3]; st.x[4] = st.xe[4];
             st.f = ev[3];
+#pragma unroll
             for (int j = 0; j < 5; ++j) st.g[j] = j < 3 ? g[j] : 0.0;
+#pragma unroll
             for (int r_ = 0; r_ < 5; ++r_)
+#pragma unroll
                 for (int c_ = 0; c_ < 5; ++c_) st.H[r_ * 5 + c_] = (r_ < 3 && c_ < 3) ? H[r_ * 3 + c_] : 0.0;
             st.cur = buf; st.nfev += nfev; st.npass = 1 + st.recentred; st.iter = it; st.status = PP_RC_STALL; st.done = 1; st.fresh = 0;
             atomicSub(a.nactive, 1);
@@ -1889,17 +1953,21 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
         // (only from inside the model's nominal range: farther out the tentative answer may
         // belong to another maximum of the correlation altogether)
         bool fin = isfinite(dpath) && dpath < 0.02;
+#pragma unroll
         for (int j = 0; j < 3; ++j) fin = fin && isfinite(dx[j]);
         if (off_centre) {
             // reference-seed flow: the model about the pilot's phase did not carry the walk from
             // the reference's guess -- expand again about that guess itself (one more pass over
             // this subint's rows), which is the ordinary one-pass flow from there on: the walk
             // restarts at its own expansion point, whatever the fit family
+#pragma unroll
             for (int j = 0; j < 5; ++j) { st.xe[j] = a.xstart[i * 5 + j]; st.x[j] = st.xe[j]; a.x0w[i * 5 + j] = st.xe[j]; }
             st.recentred = 1;
         } else if (st.recentred < a.recentre && fin) {
             st.nfev += nfev;             // (the evaluations of the first expansion stay counted)
+#pragma unroll
             for (int j = 0; j < 3; ++j) st.xe[j] += dx[j];
+#pragma unroll
             for (int j = 0; j < 5; ++j) { st.x[j] = st.xe[j]; a.x0w[i * 5 + j] = st.xe[j]; }
             st.recentred += 1;
         } else { st.recentred = a.recentre + 1; st.nfev = 0; }   // (no further expansion: the evaluation
@@ -2511,7 +2579,10 @@ __global__ __launch_bounds__(NT) void k_finalize(FitArgs a) {
                 ++c;
             }
     }
-    auto sel5 = [](const double* v, int k) { return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : k == 3 ? v[3] : v[4]; };
+    // (values, not addresses: given an array the compiler turns the selection into an indexed load from a scratch copy)
+    auto sel5 = [](double v0, double v1, double v2, double v3, double v4, int k) {
+        return k == 0 ? v0 : k == 1 ? v1 : k == 2 ? v2 : k == 3 ? v3 : v4;
+    };
 #ifdef PP_SOLVE_CLOCKS
     long long fk5 = 0;
 #endif
@@ -2523,10 +2594,9 @@ __global__ __launch_bounds__(NT) void k_finalize(FitArgs a) {
             const int k = ix[r];
             double row[5];
 #pragma unroll
-            for (int jj = 0; jj < 5; ++jj)
-                row[jj] = k == 0 ? full[jj] : k == 1 ? full[5 + jj] : k == 2 ? full[10 + jj] : k == 3 ? full[15 + jj] : full[20 + jj];
+            for (int jj = 0; jj < 5; ++jj) row[jj] = sel5(full[jj], full[5 + jj], full[10 + jj], full[15 + jj], full[20 + jj], k);
 #pragma unroll
-            for (int c2 = 0; c2 < N; ++c2) Xs[r * N + c2] = sel5(row, ix[c2]);
+            for (int c2 = 0; c2 < N; ++c2) Xs[r * N + c2] = sel5(row[0], row[1], row[2], row[3], row[4], ix[c2]);
         }
         const bool inv_ok = mat_inverse<N>(Xs);
 #ifdef PP_SOLVE_CLOCKS
@@ -2546,7 +2616,7 @@ __global__ __launch_bounds__(NT) void k_finalize(FitArgs a) {
                 const double U[5] = {up, up * cg.p1, up * cg.p2, ut * cg.q1, ut * cg.q2};
                 double Us[N];
 #pragma unroll
-                for (int r1 = 0; r1 < N; ++r1) Us[r1] = sel5(U, ix[r1]);
+                for (int r1 = 0; r1 < N; ++r1) Us[r1] = sel5(U[0], U[1], U[2], U[3], U[4], ix[r1]);
                 const double cinv = 1.0 / (2.0 * w * cs[6]);
                 double uXu = 0.0;
 #pragma unroll
