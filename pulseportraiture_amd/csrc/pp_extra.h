@@ -826,6 +826,9 @@ __device__ inline int block_argmin256(double v, int j, double* shv, int* shj) {
     return j;
 }
 
+#define PP_FPS_LDS 2048       // harmonics of a profile pair's cross-spectrum k_fps keeps in LDS (16 B each)
+__device__ __forceinline__ void fps_fit(const FpsArgs& a, int i, int tid, int M, const cplx* X, const double (&v)[3], double sig,
+                                        double* scratch, double* shv, int* shj);
 __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
     const int i = blockIdx.x, tid = threadIdx.x, M = a.M;
     __shared__ double scratch[4 * 4];
@@ -833,12 +836,17 @@ __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
     __shared__ int shj[4];
     const cplx* d = a.specm ? a.spec + (size_t)i * (M + 1) : a.spec + (size_t)(2 * i) * (M + 1);
     const cplx* m = a.specm ? a.specm + (size_t)i * a.mstride : a.spec + (size_t)(2 * i + 1) * (M + 1);
-    cplx* X = xwork + (size_t)i * M;
+    // the cross-spectrum every grid point and every simplex vertex walks: in LDS when it fits (each of the Ns grid
+    // threads reads all M harmonics one after the other -- from global memory that is M dependent round trips,
+    // ~0.5 ms of the kernel's 0.7 at M = 1024), else in the work buffer
+    __shared__ cplx Xs[PP_FPS_LDS];
+    const bool in_lds = (M <= PP_FPS_LDS);
+    cplx* X = in_lds ? Xs : xwork + (size_t)i * M;
     const int H = M + 1, kc = (int)(0.75 * H);
     double v[3] = {0.0, 0.0, 0.0};   // sum |d|^2, sum |m|^2, tail of |d|^2
     for (int k = 1 + tid; k <= M; k += 256) {
         const cplx dk = d[k], mk = m[k];
-        X[k - 1] = cmulc(dk, mk);
+        if (in_lds) Xs[k - 1] = cmulc(dk, mk); else X[k - 1] = cmulc(dk, mk);
         const double pd = cnorm(dk);
         v[0] += pd; v[1] += cnorm(mk);
         if (k >= kc) v[2] += pd;
@@ -848,6 +856,14 @@ __global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
     const double B = 2.0 * M;
     double sig = a.noise ? a.noise[i] : NAN;
     if (!(sig >= 0.0)) sig = sqrt(v[2] / B / (double)(H - kc));   // get_noise_PS
+    if (in_lds) fps_fit(a, i, tid, M, (const cplx*)Xs, v, sig, scratch, shv, shj);
+    else fps_fit(a, i, tid, M, (const cplx*)X, v, sig, scratch, shv, shj);
+}
+
+// the fit proper, on the cross-spectrum X (LDS or global: inlined into both call sites)
+__device__ __forceinline__ void fps_fit(const FpsArgs& a, int i, int tid, int M, const cplx* X, const double (&v)[3], double sig,
+                                        double* scratch, double* shv, int* shj) {
+    const double B = 2.0 * M;
     const double err2 = sig * sig * (0.5 * B);
     const double dd = v[0] / err2, pp_ = v[1] / err2;
     // brute grid, both ends included (scipy.optimize.brute with complex(Ns))
@@ -1095,7 +1111,9 @@ __global__ __launch_bounds__(256) void k_seed_fit(FitArgs a, const cplx* ypart, 
     __shared__ double scratch[4 * 4];
     __shared__ double shv[4];
     __shared__ int shj[4];
-    cplx* Y = ywork + (size_t)jx * K;
+    // (the correlation's spectrum in LDS when it fits, as in k_fps: every grid thread walks all of it)
+    __shared__ cplx Ys[PP_FPS_LDS];
+    cplx* Y = (K <= PP_FPS_LDS) ? Ys : ywork + (size_t)jx * K;
     // scattering kernel of the guessed tau at the fit reference frequency
     const double taup = xbase[i * 5 + 3];
     const double tau = a.scat ? (a.log10_tau ? pow(10.0, taup) : taup) : 0.0;
