@@ -1063,6 +1063,8 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     auto launch_taylor_solve = [&]() {
         const size_t lds = (size_t)fa.solve_cache * 32;
         if (lds > 48 * 1024 && !c->solve_lds_attr) {     // (dynamic LDS beyond the default cap: said once)
+            (void)hipFuncSetAttribute((const void*)k_taylor_solve<64>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
+            (void)hipFuncSetAttribute((const void*)k_taylor_solve<128>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
             (void)hipFuncSetAttribute((const void*)k_taylor_solve<256>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
             (void)hipFuncSetAttribute((const void*)k_taylor_solve<512>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
             c->solve_lds_attr = true;

@@ -3062,6 +3062,52 @@ def test_enqueued_batches_equal_synchronous_fits(eng):
     e2.close()
 
 
+@pytest.mark.parametrize("C,flags", [(40, [1, 1, 0, 0, 0]), (600, [1, 1, 1, 0, 0]), (1100, [1, 0, 0, 0, 0]), (2300, [1, 1, 0, 0, 0])])
+def test_solve_and_postfit_widths_agree(eng, C, flags):
+    """The solve on the Taylor model and the post-fit stage pick their threads per subint from the band
+    width (one wave up to 512 channels ... four / eight beyond) and keep a channel's invariants in LDS /
+    registers; every width and the plain variants (invariants formed again per evaluation, the
+    pass-by-pass post-fit kernel) sum the channels in their own order and must agree to rounding --
+    parameters to 1e-13 rot, the walk's `nfeval` identical but for a marginal closing step, errors /
+    chi2 / scales to 1e-10 -- with masked channels and both solvers."""
+    nsub, B = 12, 256
+    data, freqs, P, x0, kw = _medium_batch(eng, nsub, C=C, B=B, seed=C)
+    rng = np.random.default_rng(C)
+    mask = (rng.random((nsub, C)) > 0.1).astype(np.uint8)
+    kw = dict(kw, fit_flags=flags, chan_mask=mask)
+    keys = ("solve_threads", "solve_cache", "finalize_regs")
+    saved = {k: eng.get_option(k) for k in keys}
+    try:
+        for method in ("trust-ncg", "newton"):
+            ref = eng.fit_batch(data, freqs, P, x0, method=method, **kw)
+            assert (ref["return_code"] == 2).all() and (ref["npass"] == 1).all()
+            variants = [dict(solve_threads=256, finalize_regs=0), dict(solve_cache=0), dict(solve_threads=64, finalize_regs=512),
+                        dict(solve_threads=128, solve_cache=100, finalize_regs=256), dict(solve_threads=512)]
+            for v in variants:
+                for k in keys:
+                    eng.set_option(k, v.get(k, saved[k]))
+                r = eng.fit_batch(data, freqs, P, x0, method=method, **kw)
+                # (a GM fit's optimum is ill-conditioned in (phi, DM, GM) at the fit frequencies: rounding moves it ~1e-12)
+                moved = np.abs(_dphi_arr(r["params"][:, 0], ref["params"][:, 0])) > (1e-11 if flags[2] else 1e-13)
+                # (SciPy's walk ends on a +-1 ulp(f) decision: another summation order can stop it one closing
+                # step away, ~1e-10 rot -- up to 4e-9 for GM fits, where a third of the exits are that marginal)
+                allowed = 0 if method == "newton" else (4 if flags[2] else 1)
+                assert moved.sum() <= allowed, (v, method, int(moved.sum()))
+                assert np.abs(_dphi_arr(r["params"][:, 0], ref["params"][:, 0])).max() < (1e-8 if flags[2] else PHI_BAR)
+                same = ~moved
+                np.testing.assert_array_equal(r["nfeval"][same], ref["nfeval"][same], err_msg=str(v))
+                np.testing.assert_allclose(r["params"][same, 1:3], ref["params"][same, 1:3], rtol=0,
+                                           atol=(1e-9 if flags[2] else 1e-12), err_msg=str(v))
+                for key in ("param_errs", "chi2", "red_chi2", "snr", "nu_refs"):
+                    np.testing.assert_allclose(r[key][same], ref[key][same], rtol=1e-10, err_msg=key + str(v))
+                for key in ("scales", "scale_errs", "channel_snrs"):
+                    np.testing.assert_allclose(r[key][same], ref[key][same], rtol=1e-10, atol=1e-14, err_msg=key + str(v))
+                assert (r["scales"][mask == 0] == 0).all()
+    finally:
+        for k in keys:
+            eng.set_option(k, saved[k])
+
+
 @pytest.mark.parametrize("seed", ["reference", "device"])
 def test_get_TOAs_at_a_row_length_that_is_no_power_of_two(seed):
     """GetTOAs.get_TOAs end to end on 1000-bin data (the reference's rfft takes any nbin): the
