@@ -800,6 +800,13 @@ static void unpack_stage(const void* o_host, pp_fit_out* out, int s0, int ns) {
     memcpy(out->return_code + s0, hi + ns, (size_t)ns * 4);
     if (out->npass) memcpy(out->npass + s0, hi + 2 * (size_t)ns, (size_t)ns * 4);
 }
+// the reference-seed flow's phase guesses ride in the same pinned block, behind the packed outputs (a copy
+// straight into the caller's pageable array would make the enqueueing call wait for the whole batch)
+static size_t stage_seed_offset(int ns) { return (((size_t)ns * 340 + 8) + 7) & ~(size_t)7; }
+static void unpack_seed_phases(const void* o_host, const pp_fit_in* in, int s0, int ns) {
+    if (in->ref_seed && in->ref_seed->seed_phase)
+        memcpy(in->ref_seed->seed_phase + s0, reinterpret_cast<const char*>(o_host) + stage_seed_offset(ns), (size_t)ns * 8);
+}
 // subints the post-fit stage found unfinished (as k_finalize saw it)
 static int unfinished_in_stage(const void* o_host, int ns) {
     return reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(o_host) + (size_t)ns * 41)[3 * (size_t)ns];
@@ -961,12 +968,13 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // per-subint scalar outputs: blocks of one allocation (params 5, errs 5, nu 3,
     // cov 25, chi2, red_chi2, snr doubles; nfeval, return_code, npass ints) = 340 B / subint
     const size_t o_bytes = (size_t)ns * 340 + 8;       // (+ the count of unfinished subints)
+    const size_t o_stage = stage_seed_offset(ns) + (size_t)ns * 8;   // (+ the reference-seed flow's phase guesses)
     if ((rc = c->o_pack.reserve(o_bytes))) return rc;
-    if (sg.o_cap < o_bytes) {
+    if (sg.o_cap < o_stage) {
         if (sg.o_host) (void)hipHostFree(sg.o_host);
         sg.o_host = nullptr; sg.o_cap = 0;
-        HIP_TRY(hipHostMalloc(&sg.o_host, o_bytes, hipHostMallocDefault));
-        sg.o_cap = o_bytes;
+        HIP_TRY(hipHostMalloc(&sg.o_host, o_stage, hipHostMallocDefault));
+        sg.o_cap = o_stage;
     }
     double* const o_base = c->o_pack.as<double>();
     if ((rc = c->o_f0.reserve((size_t)ns * 8))) return rc;
@@ -1172,8 +1180,10 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         fp.X = c->X.as<cplx>(); fp.nchan_x = Cp; fp.cstep = cstep;
         chunking(Cp, ns, fp.nchunk, fp.cpc);
         if ((rc = run_seed(fp, c->seedq.as<double>()))) return rc;
+        // (reference-seed flow: the pilot's phase is only the expansion point of the Taylor model, which the
+        // certificate guards -- a weak pilot costs its subint a second expansion, not the batch a host round trip)
         int nweak = 0;
-        if ((rc = list_active(c->seedq.as<double>(), c->seed_min_snr, &nweak))) return rc;
+        if (!refseed) if ((rc = list_active(c->seedq.as<double>(), c->seed_min_snr, &nweak))) return rc;
         if (nweak > 0) {
             // not convincing on a subset: seed these from all their channels
             if ((rc = store_x_for_list(nweak))) return rc;
@@ -1356,7 +1366,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             PP_D2H(out->channel_snrs, c->o_csnr, (size_t)s0 * C * 8, nc * 8);
         }
         if (d_seedph && rs->seed_phase)
-            HIP_TRY(hipMemcpyAsync(rs->seed_phase + s0, d_seedph, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync((char*)sg.o_host + stage_seed_offset(ns), d_seedph, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
         PP_D2H(out->obj_f, c->o_f0, (size_t)s0 * 8, (size_t)ns * 8);
         PP_D2H(out->obj_grad, c->o_g0, (size_t)s0 * 40, (size_t)ns * 40);
         PP_D2H(out->obj_hess, c->o_H0, (size_t)s0 * 200, (size_t)ns * 200);
@@ -1364,7 +1374,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         if (wait) HIP_TRY(hipStreamSynchronize(c->stream));
         return PP_OK;
     };
-    auto unpack_outputs = [&]() { unpack_stage(sg.o_host, out, s0, ns); };
+    auto unpack_outputs = [&]() { unpack_stage(sg.o_host, out, s0, ns); if (d_seedph) unpack_seed_phases(sg.o_host, in, s0, ns); };
     auto unfinished = [&]() -> int { return unfinished_in_stage(sg.o_host, ns); };
     bool all_done = false;
     if (taylor) {
@@ -1382,7 +1392,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         // launched straight behind it and the count of unfinished subints comes back with the
         // outputs -- one host round trip per batch instead of two.  (When some are left, what
         // the post-fit stage wrote for them is overwritten below.)
-        if (deferred && !pilot && !seed_full && !refseed) {
+        if (deferred && !seed_full && (!pilot || refseed)) {
             // nothing left for the host to decide before the outputs are on their way: pp_fit_collect
             // looks at the count of unfinished subints (and fits the batch again, synchronously, in the
             // rare case that some are left -- their guesses were poor)
@@ -1700,6 +1710,7 @@ extern "C" int pp_fit_collect(pp_ctx* c) {
     const int ns = d.in.nsub;
     if (unfinished_in_stage(sg.o_host, ns) <= 0) {
         unpack_stage(sg.o_host, &d.out, 0, ns);
+        unpack_seed_phases(sg.o_host, &d.in, 0, ns);
         if (d.out.duration) {
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, sg.t0, sg.done));

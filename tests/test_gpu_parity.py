@@ -1903,6 +1903,14 @@ def test_reference_seed_formed_inside_the_single_pass(dtype, flags):
     one2 = e.fit_batch(data, freqs, P, xb, ref_seed=rs2, **kw2)
     np.testing.assert_array_equal(one2["seed_phase"], one["seed_phase"])
     np.testing.assert_array_equal(one2["params"], one["params"])
+    # ... and enqueued two deep (the flow has no host decision in its middle: the weak-pilot check is the
+    # certificate's job here, the phase guesses ride in the pinned staging block): bitwise the same
+    e.enqueue(data, freqs, P, xb, ref_seed=rs, **kw)
+    e.enqueue(data, freqs, P, xb, ref_seed=rs2, **kw2)
+    for _ in range(2):
+        q = e.collect()
+        for key in ("seed_phase", "params", "param_errs", "chi2", "nfeval", "npass", "scales"):
+            np.testing.assert_array_equal(q[key], one[key], err_msg=key)
     # shapes without a single-pass path say so and do nothing
     xg = xb.copy(); xg[:, 2] = 1e-5                       # (a GM guess: the rotation is no longer the DM's alone)
     with pytest.raises(EngineNotSupported):
