@@ -363,7 +363,7 @@ int pp_fit_wait(pp_ctx* ctx);
  * order keeps batch k's solve and post-fit stage ahead of batch k + 1's transform, on one set of
  * device work buffers.  Batches whose flow needs a host decision in its middle (scattering fits,
  * device seeds, sub-batching) simply run to their end inside pp_fit_enqueue; the one-pass flow, with
- * the caller's guesses or with pp_seed_ref (phase / DM / GM fits), is deferred whole; a one-pass
+ * the caller's guesses or with the reference's own (pp_seed_ref; phase / DM / GM fits), is deferred whole; a one-pass
  * batch in which some subint fails its certificate (poor guesses) is fitted again by the general
  * flow inside pp_fit_collect.  Every buffer the argument blocks point to (pp_seed_ref included) must
  * stay valid and untouched until the batch has been collected; no other fit call may be made on the
