@@ -159,6 +159,9 @@ void* pp_stream(pp_ctx* ctx);
  *   "finalize_regs"  post-fit stage of fits without scattering: 1 (default) = each thread holds its (up to 8)
  *                  channels' numbers in registers over the stage's passes, 64 ... 512 threads per subint by band
  *                  width; 0 = the pass-by-pass kernel every other fit uses; 64 / 128 / 256 / 512 force a width
+ *   "copy_kernels"  1 (default) = the packed block of small inputs and the packed per-subint outputs cross PCIe by a
+ *                  kernel that reads / writes the pinned staging block directly; 0 = by hipMemcpyAsync (a copy
+ *                  command between two kernels hands the stream to the copy engine and back: ~0.05 ms per batch)
  *   "coarse_newton"  1 (default) = scattering fits with PP_METHOD_NEWTON first iterate on every 16th channel
  *                  (each evaluation reads a sixteenth of the stored cross-spectrum) and start the
  *                  full-channel iteration from that answer -- the optimum does not depend on the path --;

@@ -81,6 +81,13 @@ struct ModelSlot {
     DevBuf mft, msum, mmax, mdc, kt, msq;
 };
 
+// the small input block and the packed outputs cross PCIe by a kernel that reads / writes the pinned staging
+// block directly (option copy_kernels): a copy command between two kernels of a stream costs the stream a hand-over
+// to the copy engine and back, ~15 us each -- a tenth of a 512 x 1024 step
+__global__ void k_copy_words(unsigned long long* dst, const unsigned long long* src, size_t n) {
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) dst[j] = src[j];
+}
+static int staged_copy(pp_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 enum KernelFamily { KF_MODEL = 0, KF_XSPEC, KF_PREP, KF_SEED, KF_ACCUM, KF_EVAL, KF_TAYLOR, KF_STEP, KF_FINAL, KF_SYNTH, KF_FPS, KF_SCATMODEL, KF_COUNT };
 static const char* kFamilyNames[KF_COUNT] = {"model_fft", "xspec", "prep", "seed", "accum", "eval", "taylor_solve", "step", "finalize",
                                             "synth", "fit_phase_shift", "scat_model"};
@@ -142,6 +149,7 @@ struct pp_ctx {
     bool solve_lds_attr = false;
     int solve_cache = -1;       // k_taylor_solve: channels whose weight / geometry / template power stay in LDS (-1: all, up to 4096)
     int solve_threads = 0;      // k_taylor_solve: threads per subint (0: by band width; 64 / 128 / 256 / 512 for A/B)
+    int copy_kernels = 1;       // the staged input / output blocks are moved by a kernel instead of a copy command
     int finalize_regs = 1;      // post-fit stage with the channel's numbers held in registers (fits without scattering,
                                 // <= 4096 channels); 0: the pass-by-pass kernel (A/B)
     int eager_flush = 1;        // poke the stream once the transform is queued (hipStreamQuery), so that the GPU starts
@@ -342,7 +350,7 @@ static bool option_ref(pp_ctx* c, const std::string& n, OptRef* out) {
         {"nfev_shadow", 'i', &c->nfev_shadow, INT32_MIN}, {"coarse_newton", 'i', &c->coarse_newton, INT32_MIN},
         {"eager_flush", 'i', &c->eager_flush, INT32_MIN},
         {"finalize_regs", 'i', &c->finalize_regs, INT32_MIN}, {"solve_cache", 'i', &c->solve_cache, -1},
-        {"solve_threads", 'i', &c->solve_threads, 0},
+        {"solve_threads", 'i', &c->solve_threads, 0}, {"copy_kernels", 'i', &c->copy_kernels, INT32_MIN},
     };
     for (const OptRef& o : tab)
         if (n == o.name) { *out = o; return true; }
@@ -417,6 +425,16 @@ static int get_twiddles(pp_ctx* c, int nbin, const cplx** out) {
 // row lengths with a tuned plan (every entry point), and every row length the fit itself takes:
 // the reference's numpy.fft.rfft accepts any (pptoaslib.py:976-979); even lengths up to 4096 that
 // are no power of two go through pp_anybin.h
+static int staged_copy(pp_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    if (c->copy_kernels && bytes % 8 == 0 && bytes <= ((size_t)64 << 20)) {
+        const size_t n = bytes / 8;
+        const unsigned nb = (unsigned)std::min<size_t>((n + 255) / 256, 256);
+        hipLaunchKernelGGL(k_copy_words, dim3(nb ? nb : 1), dim3(256), 0, c->stream, (unsigned long long*)dst,
+                           (const unsigned long long*)src, n);
+        return hipGetLastError() == hipSuccess ? PP_OK : PP_EHIP;
+    }
+    return hipMemcpyAsync(dst, src, bytes, kind, c->stream) == hipSuccess ? PP_OK : PP_EHIP;
+}
 static bool nbin_ok(int nbin) { return nbin >= 32 && nbin <= 8192 && (nbin & (nbin - 1)) == 0; }
 static bool nbin_any_ok(int nbin) { return nbin_ok(nbin) || (nbin >= 8 && nbin <= 4096 && nbin % 2 == 0); }
 static int fail(int code, const char* fmt, ...);
@@ -844,7 +862,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // copies cost more than the solve of a 512 x 1024 batch): freqs | P | x0 | nu_fit | nu_out | slot
     const size_t nfreq = in->freqs_stride ? nc : (size_t)C;
     const size_t in_doubles = nfreq + (size_t)ns * (1 + 5 + 3 + 3);
-    const size_t in_bytes = in_doubles * 8 + (size_t)ns * 4;
+    const size_t in_bytes = (in_doubles * 8 + (size_t)ns * 4 + 7) & ~(size_t)7;      // (whole 8-byte words: staged_copy)
     if ((rc = c->inpack.reserve(in_bytes))) return rc;
     if (sg.in_cap < in_bytes) {
         if (sg.in_host) (void)hipHostFree(sg.in_host);
@@ -870,7 +888,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         memcpy(h, nufit_h.data() + (size_t)s0 * 3, (size_t)ns * 24); h += (size_t)ns * 3;
         memcpy(h, nuout_h.data() + (size_t)s0 * 3, (size_t)ns * 24); h += (size_t)ns * 3;
         if (in->model_slot) memcpy(h, in->model_slot + s0, (size_t)ns * 4);
-        HIP_TRY(hipMemcpyAsync(c->inpack.p, sg.in_host, in_bytes, hipMemcpyHostToDevice, c->stream));
+        if ((rc = staged_copy(c, c->inpack.p, sg.in_host, in_bytes, hipMemcpyHostToDevice))) return fail(rc, "input block copy failed");
     }
     const double* d_errs = nullptr;
     const unsigned char* d_mask = nullptr;
@@ -967,7 +985,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     if ((rc = c->act.reserve((size_t)ns * 4))) return rc;
     // per-subint scalar outputs: blocks of one allocation (params 5, errs 5, nu 3,
     // cov 25, chi2, red_chi2, snr doubles; nfeval, return_code, npass ints) = 340 B / subint
-    const size_t o_bytes = (size_t)ns * 340 + 8;       // (+ the count of unfinished subints)
+    const size_t o_bytes = ((size_t)ns * 340 + 8 + 7) & ~(size_t)7;       // (+ the count of unfinished subints; whole words)
     const size_t o_stage = stage_seed_offset(ns) + (size_t)ns * 8;   // (+ the reference-seed flow's phase guesses)
     if ((rc = c->o_pack.reserve(o_bytes))) return rc;
     if (sg.o_cap < o_stage) {
@@ -1359,7 +1377,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         HIP_TRY(hipGetLastError());
 #define PP_D2H(dst, buf, off, bytes) \
     if (dst) HIP_TRY(hipMemcpyAsync((char*)(dst) + (off), (buf).p, (bytes), hipMemcpyDeviceToHost, c->stream))
-        HIP_TRY(hipMemcpyAsync(sg.o_host, c->o_pack.p, o_bytes, hipMemcpyDeviceToHost, c->stream));
+        if ((rc = staged_copy(c, sg.o_host, c->o_pack.p, o_bytes, hipMemcpyDeviceToHost))) return fail(rc, "output block copy failed");
         if (!chan_dev) {
             PP_D2H(out->scales, c->o_scales, (size_t)s0 * C * 8, nc * 8);
             PP_D2H(out->scale_errs, c->o_serrs, (size_t)s0 * C * 8, nc * 8);
