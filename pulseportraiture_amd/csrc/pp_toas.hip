@@ -163,7 +163,6 @@ struct pp_ctx {
     struct Span { int fam; hipEvent_t a, b; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> ev_pool;       // recycled profiling events
-    std::vector<double> kx_host;           // reference-seed flow: host side of the start points
     double known_ok_bytes = 0.0;           // largest work-memory demand a batch has already been granted
     double fam_sec[KF_COUNT] = {0};
     long long fam_n[KF_COUNT] = {0};
@@ -872,7 +871,10 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // the small inputs travel in ONE copy from a pinned staging block (seven separate pageable
     // copies cost more than the solve of a 512 x 1024 batch): freqs | P | x0 | nu_fit | nu_out | slot
     const size_t nfreq = in->freqs_stride ? nc : (size_t)C;
-    const size_t in_doubles = nfreq + (size_t)ns * (1 + 5 + 3 + 3);
+    // (reference-seed flow: + the model profile(s), nu_mean and the start points' host-formed part)
+    const size_t rs_nprof = refseed ? (rs->model_prof_stride ? (size_t)ns : 1) : 0;
+    const size_t rs_doubles = refseed ? rs_nprof * B + (size_t)ns * (1 + 5) : 0;
+    const size_t in_doubles = nfreq + (size_t)ns * (1 + 5 + 3 + 3) + rs_doubles;
     const size_t in_bytes = (in_doubles * 8 + (size_t)ns * 4 + 7) & ~(size_t)7;      // (whole 8-byte words: staged_copy)
     if ((rc = c->inpack.reserve(in_bytes))) return rc;
     if (sg.in_cap < in_bytes) {
@@ -886,7 +888,10 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     double* const d_x0 = d_P + ns;
     double* const d_nufit = d_x0 + (size_t)ns * 5;
     double* const d_nuout = d_nufit + (size_t)ns * 3;
-    int* const d_slot = reinterpret_cast<int*>(d_nuout + (size_t)ns * 3);
+    double* const d_rs_mprof = d_nuout + (size_t)ns * 3;
+    double* const d_rs_numean = d_rs_mprof + rs_nprof * B;
+    double* const d_rs_xs = d_rs_numean + (refseed ? ns : 0);
+    int* const d_slot = reinterpret_cast<int*>(d_nuout + (size_t)ns * 3 + rs_doubles);
     {
         double* h = reinterpret_cast<double*>(sg.in_host);
         memcpy(h, in->freqs + (in->freqs_stride ? (size_t)s0 * C : 0), nfreq * 8); h += nfreq;
@@ -898,6 +903,21 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         h += (size_t)ns * 5;
         memcpy(h, nufit_h.data() + (size_t)s0 * 3, (size_t)ns * 24); h += (size_t)ns * 3;
         memcpy(h, nuout_h.data() + (size_t)s0 * 3, (size_t)ns * 24); h += (size_t)ns * 3;
+        if (refseed) {
+            memcpy(h, rs->model_profs + (rs->model_prof_stride ? (size_t)s0 * B : 0), rs_nprof * B * 8); h += rs_nprof * B;
+            memcpy(h, rs->nu_mean + s0, (size_t)ns * 8); h += ns;
+            // phase_transform(phi, DM, nu_mean, nu_fit, P, mod=True) (pplib.py:2592-2616): the term it adds
+            // depends on the inputs alone -- formed here in NumPy's order of operations with libm's pow, as the
+            // reference forms it -- so the device only adds it to its fit_phase_shift result and wraps: no
+            // host round trip between the pass and the iteration.  The other parameters start as given.
+            for (int i = 0; i < ns; ++i) {
+                const double* x0i = in->init_params + (size_t)(s0 + i) * 5;
+                const double P = in->P[s0 + i], nu1 = rs->nu_mean[s0 + i], nu2 = nufit_h[(size_t)(s0 + i) * 3];
+                h[(size_t)i * 5] = PP_DCONST * x0i[1] * pow(P, -1.0) * (pow(nu2, -2.0) - pow(nu1, -2.0));
+                for (int j = 1; j < 5; ++j) h[(size_t)i * 5 + j] = x0i[j];
+            }
+            h += (size_t)ns * 5;
+        }
         if (in->model_slot) memcpy(h, in->model_slot + s0, (size_t)ns * 4);
         if ((rc = staged_copy(c, c->inpack.p, sg.in_host, in_bytes, hipMemcpyHostToDevice))) return fail(rc, "input block copy failed");
     }
@@ -998,7 +1018,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // cov 25, chi2, red_chi2, snr doubles; nfeval, return_code, npass ints) = 340 B / subint
     const size_t o_bytes = ((size_t)ns * 340 + 8 + 7) & ~(size_t)7;       // (+ the count of unfinished subints; whole words)
     const size_t o_stage = stage_seed_offset(ns) + (size_t)ns * 8;   // (+ the reference-seed flow's phase guesses)
-    if ((rc = c->o_pack.reserve(o_bytes))) return rc;
+    if ((rc = c->o_pack.reserve(o_stage))) return rc;      // (the phase guesses of the reference-seed flow behind the pack)
     if (sg.o_cap < o_stage) {
         if (sg.o_host) (void)hipHostFree(sg.o_host);
         sg.o_host = nullptr; sg.o_cap = 0;
@@ -1243,23 +1263,22 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         const bool w_host = (rs->weights && !in->aux_on_device) || d_mask;     // (room for the masked weights)
         const size_t n_part = (size_t)ns * ncc * RS_NACC * 64;
         const size_t n_cplx = n_part + (size_t)ns * H + nprof * H + (size_t)ns * M;
-        const size_t n_dbl = nprof * B + (size_t)ns * (1 + 1 + 1 + 7 + 5 + 1) + (w_host ? nc : 0);
+        const size_t n_dbl = (size_t)ns * (1 + 1 + 7) + (w_host ? nc : 0);
         if ((rc = c->refbuf.reserve(n_cplx * sizeof(cplx) + n_dbl * 8))) return rc;
         cplx* part = c->refbuf.as<cplx>();
         cplx* dspec = part + n_part;
         cplx* mspec = dspec + (size_t)ns * H;
         cplx* xwork = mspec + nprof * H;
-        double* mprof = reinterpret_cast<double*>(xwork + (size_t)ns * M);
-        double* d_numean = mprof + nprof * B;
-        double* d_delta = d_numean + ns;
+        // (the model profile(s), nu_mean and the host-formed part of the start points came with the batch's one
+        // input block: no copy command of their own)
+        double* mprof = d_rs_mprof;
+        double* d_numean = d_rs_numean;
+        double* d_xs = d_rs_xs;
+        double* d_delta = reinterpret_cast<double*>(xwork + (size_t)ns * M);
         double* d_wsum = d_delta + ns;
         double* d_out7 = d_wsum + ns;
-        double* d_xs = d_out7 + (size_t)ns * 7;
-        double* d_sph = d_xs + (size_t)ns * 5;
-        double* d_wh = d_sph + ns;
-        HIP_TRY(hipMemcpyAsync(mprof, rs->model_profs + (rs->model_prof_stride ? (size_t)s0 * B : 0), nprof * B * 8,
-                               hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_numean, rs->nu_mean + s0, (size_t)ns * 8, hipMemcpyHostToDevice, c->stream));
+        double* d_sph = reinterpret_cast<double*>(reinterpret_cast<char*>(c->o_pack.p) + stage_seed_offset(ns));   // (leaves with the outputs)
+        double* d_wh = d_out7 + (size_t)ns * 7;
         const double* d_w = nullptr;
         if (rs->weights && !in->aux_on_device) {
             HIP_TRY(hipMemcpyAsync(d_wh, rs->weights + (size_t)s0 * C, nc * 8, hipMemcpyHostToDevice, c->stream));
@@ -1303,21 +1322,6 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             hipLaunchKernelGGL(k_fps, dim3(ns), dim3(256), 0, c->stream, f, xwork);
         }
         HIP_TRY(hipGetLastError());
-        // phase_transform(phi, DM, nu_mean, nu_fit, P, mod=True) (pplib.py:2592-2616): the term it adds
-        // depends on the inputs alone -- formed here in NumPy's order of operations with libm's pow, as the
-        // reference forms it -- so the device only adds it to its fit_phase_shift result and wraps: no
-        // host round trip between the pass and the iteration.  The other parameters start as given.
-        {
-            std::vector<double>& kx = c->kx_host;       // (outlives the copy queued below)
-            kx.resize((size_t)ns * 5);
-            for (int i = 0; i < ns; ++i) {
-                const double* x0i = in->init_params + (size_t)(s0 + i) * 5;
-                const double P = in->P[s0 + i], nu1 = rs->nu_mean[s0 + i], nu2 = nufit_h[(size_t)(s0 + i) * 3];
-                kx[(size_t)i * 5] = PP_DCONST * x0i[1] * pow(P, -1.0) * (pow(nu2, -2.0) - pow(nu1, -2.0));
-                for (int j = 1; j < 5; ++j) kx[(size_t)i * 5 + j] = x0i[j];
-            }
-            HIP_TRY(hipMemcpyAsync(d_xs, kx.data(), kx.size() * 8, hipMemcpyHostToDevice, c->stream));
-        }
         hipLaunchKernelGGL(k_refseed_start, dim3((ns + 63) / 64), dim3(64), 0, c->stream, (const double*)d_out7, ns, d_xs, d_sph);
         HIP_TRY(hipGetLastError());
         d_seedph = d_sph;
@@ -1388,14 +1392,12 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         HIP_TRY(hipGetLastError());
 #define PP_D2H(dst, buf, off, bytes) \
     if (dst) HIP_TRY(hipMemcpyAsync((char*)(dst) + (off), (buf).p, (bytes), hipMemcpyDeviceToHost, c->stream))
-        if ((rc = staged_copy(c, sg.o_host, c->o_pack.p, o_bytes, hipMemcpyDeviceToHost))) return fail(rc, "output block copy failed");
+        if ((rc = staged_copy(c, sg.o_host, c->o_pack.p, d_seedph ? o_stage : o_bytes, hipMemcpyDeviceToHost))) return fail(rc, "output block copy failed");
         if (!chan_dev) {
             PP_D2H(out->scales, c->o_scales, (size_t)s0 * C * 8, nc * 8);
             PP_D2H(out->scale_errs, c->o_serrs, (size_t)s0 * C * 8, nc * 8);
             PP_D2H(out->channel_snrs, c->o_csnr, (size_t)s0 * C * 8, nc * 8);
         }
-        if (d_seedph && rs->seed_phase)
-            HIP_TRY(hipMemcpyAsync((char*)sg.o_host + stage_seed_offset(ns), d_seedph, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
         PP_D2H(out->obj_f, c->o_f0, (size_t)s0 * 8, (size_t)ns * 8);
         PP_D2H(out->obj_grad, c->o_g0, (size_t)s0 * 40, (size_t)ns * 40);
         PP_D2H(out->obj_hess, c->o_H0, (size_t)s0 * 200, (size_t)ns * 200);
