@@ -20,6 +20,7 @@ process) and the CPU baseline (1 core and a one-worker-per-core pool).
                           device-generated sub-batches of --nsub
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -438,11 +439,18 @@ def main():
         def run(nsteps, out):
             res = None
             if piped:
+                trace = [] if os.environ.get("PP_BENCH_STEP_TIMES") else None
                 for k in range(nsteps):
+                    t_a = time.perf_counter()
                     batch.enqueue(records=None if out is None else out[k], method=method)
+                    t_b = time.perf_counter()
                     if k > 0:
                         res = eng.collect()
+                    if trace is not None:
+                        trace.append((1e3 * (t_b - t_a), 1e3 * (time.perf_counter() - t_b), torch.cuda.memory_reserved() / 2 ** 20))
                 res = eng.collect()
+                if trace:
+                    print("step times (enqueue, collect ms; torch MiB reserved): " + " ".join("%.2f/%.2f/%.0f" % t for t in trace), file=sys.stderr)
             else:
                 for k in range(nsteps):
                     res = batch.fit(records=None if out is None else out[k], method=method)
@@ -456,12 +464,19 @@ def main():
             run(3, None)
         eng.set_option("profile", 1)
         eng.kernel_times(reset=True)
+        # (the interpreter's cyclic garbage collector is held off over the timed steps, as timeit does: with torch
+        # and NumPy loaded a full collection takes 30-40 ms and used to land in one timed step or another)
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         fence()
         t0 = time.perf_counter()
         res = run(steps, recs)
         gathered = ppdist.gather_records(recs.view(-1, ppdist.RECORD_WIDTH))   # one RCCL gather
         fence()
         elapsed = time.perf_counter() - t0
+        if gc_was_on:
+            gc.enable()
         eng.set_option("profile", 0)
         if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -687,6 +702,8 @@ def strong_scaling(args, make_batch, sync, fence, device, rank, world, use_dist)
     recs = torch.zeros((hi - lo, ppdist.RECORD_WIDTH), dtype=torch.float64, device=device)
     batch = make_batch(args.workload, nsub, lo)
     batch.fit()                                  # warm-up (untimed)
+    gc.collect()
+    gc.disable()                                 # (a full collection takes 30-40 ms with torch loaded: not inside a timed fit)
     fit_s, done = 0.0, 0
     worst = 0.0
     sub_batches = []
@@ -708,6 +725,7 @@ def strong_scaling(args, make_batch, sync, fence, device, rank, world, use_dist)
     gathered = ppdist.gather_records(recs, counts=counts)
     fence()
     gather_s = time.perf_counter() - t0
+    gc.enable()
     total_s = fit_s + gather_s
     if use_dist:
         t = torch.tensor([total_s, worst], dtype=torch.float64,

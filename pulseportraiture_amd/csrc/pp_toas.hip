@@ -118,7 +118,7 @@ struct pp_ctx {
     Stage stage[2];
     int cur_stage = 0;
     // pp_fit_enqueue / pp_fit_collect: batches queued on the stream and not yet collected (oldest first)
-    struct Deferred { pp_fit_in in; pp_fit_out out; int stage; bool queued; int rc; std::string err; };
+    struct Deferred { pp_fit_in in; pp_fit_out out; int stage; bool queued; int rc; std::string err; size_t span_end = 0; };
     std::deque<Deferred> pending;
     DevBuf o_pack;   // per-subint scalar outputs, one allocation -> one D2H copy
     DevBuf o_params, o_errs, o_nu, o_cov, o_chi2, o_rchi2, o_snr, o_nfev, o_rc, o_scales, o_serrs, o_csnr,
@@ -204,8 +204,12 @@ struct Prof {
     }
 };
 
-static void resolve_spans(pp_ctx* c) {
-    for (auto& s : c->spans) {
+// (upto: the first `upto` spans only -- those of a collected batch while later batches are still queued, so that
+// a long pipelined run recycles its events instead of creating two per kernel span of every batch)
+static void resolve_spans(pp_ctx* c, size_t upto = (size_t)-1) {
+    upto = std::min(upto, c->spans.size());
+    for (size_t q = 0; q < upto; ++q) {
+        auto& s = c->spans[q];
         float ms = 0.f;
         if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
             c->fam_sec[s.fam] += 1e-3 * ms;
@@ -213,7 +217,9 @@ static void resolve_spans(pp_ctx* c) {
         }
         c->ev_pool.push_back(s.a); c->ev_pool.push_back(s.b);
     }
-    c->spans.clear();
+    c->spans.erase(c->spans.begin(), c->spans.begin() + upto);
+    // (batches still queued keep counting from the new front)
+    for (auto& q : c->pending) q.span_end = q.span_end > upto ? q.span_end - upto : 0;
 }
 
 // a submitted (pp_fit_submit) or enqueued (pp_fit_enqueue) batch owns the context's work buffers, stream
@@ -1705,6 +1711,7 @@ extern "C" int pp_fit_enqueue(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out) {
         c->known_ok_bytes = std::max(c->known_ok_bytes, bp.per_sub * in->nsub);
         HIP_TRY(hipEventRecord(sg.done, c->stream));
         d.queued = deferred;
+        d.span_end = c->spans.size();
         if (!deferred) {
             // (a flow with host decisions in its middle: it has run to its end)
             HIP_TRY(hipEventSynchronize(sg.done));
@@ -1714,6 +1721,7 @@ extern "C" int pp_fit_enqueue(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out) {
                 out->duration[0] = 1e-3 * ms;
             }
             if (c->profile) resolve_spans(c);
+            d.span_end = 0;
         }
     } else {
         // (more than the work-memory budget holds at once: sub-batches, synchronously -- only with
@@ -1748,7 +1756,7 @@ extern "C" int pp_fit_collect(pp_ctx* c) {
             HIP_TRY(hipEventElapsedTime(&ms, sg.t0, sg.done));
             d.out.duration[0] = 1e-3 * ms;
         }
-        if (c->profile && c->pending.empty()) resolve_spans(c);
+        if (c->profile) resolve_spans(c, d.span_end);
         return PP_OK;
     }
     // some subints left the one-pass flow (poor guesses): the batch is fitted again, synchronously, by
