@@ -286,12 +286,24 @@ struct SubState {
 // A_0 .. A_PP_TJ (derivatives) + a rigorous remainder coefficient
 #define PP_TJ 10
 #define PP_TSTRIDE (PP_TJ + 2)
-// The Taylor rows in HBM: blocks of 64 rows, the coefficients in pairs -- [row / 64][pair 0..5][row % 64][2] -- so that
-// the solve, where lane l works on row r0 + l, reads 1 KB contiguous per load instruction (row-major rows 96 B
-// apart cost it 48 cache lines per instruction, six times over); the transform writes a row as six 16-byte pieces,
-// which consecutive rows of its chunk complete to whole lines in L2.  The buffer holds a multiple of 64 rows.
+// The Taylor rows in HBM.  Row-major (default): 12 doubles per row, 96 B apart -- the transform writes a row as one
+// 96-byte piece.  PP_TAY_BLOCKED = 1: blocks of 64 rows with the coefficients in pairs, [row / 64][pair 0..5][row % 64][2],
+// so that the solve, where lane l works on row r0 + l, reads 1 KB contiguous per load instruction and its evaluation at
+// the expansion point only two of the six pairs.  Measured (profiles/README.md, round 4): the solve at 4096 channels is
+// bound by the bytes it re-reads, not by how it touches the lines (0.44 against 0.45-0.46 ms), while the transform pays
+// 6 more VALU instructions per row for the addresses and writes six pieces instead of one: +1 % of 14.4 ms.  Kept as a
+// build option; the buffer holds a multiple of 64 rows either way.
+#ifndef PP_TAY_BLOCKED
+#define PP_TAY_BLOCKED 0
+#endif
+#if PP_TAY_BLOCKED
+#define PP_TAY_PAIR_STRIDE 128     // doubles between the coefficient pairs of a row
 __device__ __forceinline__ size_t tay_idx(size_t row, int q) {
     return (row >> 6) * (size_t)(64 * PP_TSTRIDE) + (size_t)(q >> 1) * 128 + (row & 63) * 2 + (q & 1);
 }
+#else
+#define PP_TAY_PAIR_STRIDE 2
+__device__ __forceinline__ size_t tay_idx(size_t row, int q) { return row * PP_TSTRIDE + (size_t)q; }
+#endif
 
 }  // namespace pp

@@ -1567,7 +1567,7 @@ __device__ __forceinline__ void taylor_load(const double* tay, size_t row, doubl
     const double* tg = tay + tay_idx(row, 0);
 #pragma unroll
     for (int j = 0; j < PP_TSTRIDE / 2; ++j) {
-        const double2 v = *reinterpret_cast<const double2*>(tg + j * 128);
+        const double2 v = *reinterpret_cast<const double2*>(tg + j * PP_TAY_PAIR_STRIDE);
         t[2 * j] = v.x; t[2 * j + 1] = v.y;
     }
 }
@@ -1675,7 +1675,7 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
 #endif
     // ... and at the expansion point itself (the first evaluation of the ordinary flow: d = 0 in every channel,
     // where Horner's rule returns A0, A1, A2 = t[0], t[1], t[2] exactly) only the first two coefficient pairs
-    // of a row are read: 32 of its 96 bytes
+    // of a row are read: 32 of its 96 bytes (which saves HBM traffic with the blocked row layout only)
     auto for_channels_at_origin = [&](auto&& body) {
         constexpr int U = 4;
         for (int n0 = tid; n0 < a.nchan; n0 += U * NT) {
@@ -1685,7 +1685,7 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
                 if (n0 + d * NT < a.nchan) {
                     const double* tg = tay + tay_idx(row0 + n0 + d * NT, 0);
                     h[d][0] = *reinterpret_cast<const double2*>(tg);
-                    h[d][1] = *reinterpret_cast<const double2*>(tg + 128);
+                    h[d][1] = *reinterpret_cast<const double2*>(tg + PP_TAY_PAIR_STRIDE);
                 }
 #pragma unroll
             for (int d = 0; d < U; ++d)
