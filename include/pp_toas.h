@@ -154,6 +154,9 @@ void* pp_stream(pp_ctx* ctx);
  *   "solve_threads"  one-pass flow: threads per subint of the solve on the Taylor model (0 = default: 64 for a
  *                  band of up to 512 channels, 128 up to 1024, 256 beyond; 64 / 128 / 256 / 512 force it).  The
  *                  channel sums are taken in a different order for each: results agree to rounding, not bitwise
+ *   "solve_prefetch"  that solve at more than 2048 channels: 0 (default) = each Taylor row fetched when its turn comes
+ *                  (the batch's rows exceed the Infinity Cache there: the less a CU keeps in flight, the less it evicts),
+ *                  1 = rows prefetched two ahead as for narrower bands
  *   "solve_cache"  ... channels whose weight, phase geometry and template power that solve keeps in LDS
  *                  (-1 = default: all, up to 8 per thread; 0 = formed again on every evaluation)
  *   "finalize_regs"  post-fit stage of fits without scattering: 1 (default) = each thread holds its (up to 8)

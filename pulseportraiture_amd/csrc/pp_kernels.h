@@ -1602,7 +1602,7 @@ __device__ __forceinline__ void taylor_shift_reg(const double (&t)[PP_TSTRIDE], 
 #ifndef PP_TAYLOR_WAVES
 #define PP_TAYLOR_WAVES 2     // waves per SIMD the kernel is compiled for (register cap 512 / n)
 #endif
-template <int NT>
+template <int NT, int PF = PP_SOLVE_PF>
 __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a) {
     constexpr int NWV = NT / 64;
     const int i = blockIdx.x, tid = threadIdx.x;
@@ -1649,21 +1649,32 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
     auto for_channels = [&](auto&& body) {
         // (the next row is on its way while this one is worked on: the loop is a chain of
         // memory latencies otherwise, two waves per SIMD hide none of it)
-        // (PP_SOLVE_PF rows ahead: what bounds the evaluation is the bytes a CU keeps in flight)
-        double buf[PP_SOLVE_PF][PP_TSTRIDE];
+        // (PF rows ahead.  Narrow bands -- the subints' rows together fit the Infinity Cache, the evaluation is a chain of
+        // latencies: two ahead.  4096 channels -- 403 MB of rows per 1024 subints, re-read by every evaluation: the more
+        // a CU keeps in flight, the more of the others' rows it pushes out; PF = 0, each row fetched when its turn
+        // comes, measured fastest there: 0.45 ms against 0.47 / 0.48 / 0.485 for 1 / 2 / 3 ahead)
+        if constexpr (PF == 0) {
+            for (int n = tid; n < a.nchan; n += NT) {
+                double t[PP_TSTRIDE];
+                taylor_load(tay, row0 + n, t);
+                body(n, t);
+            }
+        } else {
+            double buf[PF ? PF : 1][PP_TSTRIDE];
 #pragma unroll
-        for (int d = 0; d < PP_SOLVE_PF; ++d)
-            if (tid + d * NT < a.nchan) taylor_load(tay, row0 + tid + d * NT, buf[d]);
-        for (int n0 = tid; n0 < a.nchan; n0 += PP_SOLVE_PF * NT) {
+            for (int d = 0; d < PF; ++d)
+                if (tid + d * NT < a.nchan) taylor_load(tay, row0 + tid + d * NT, buf[d]);
+            for (int n0 = tid; n0 < a.nchan; n0 += PF * NT) {
 #pragma unroll
-            for (int d = 0; d < PP_SOLVE_PF; ++d) {
-                const int n = n0 + d * NT;
-                if (n < a.nchan) {
-                    double t[PP_TSTRIDE];
+                for (int d = 0; d < PF; ++d) {
+                    const int n = n0 + d * NT;
+                    if (n < a.nchan) {
+                        double t[PP_TSTRIDE];
 #pragma unroll
-                    for (int j = 0; j < PP_TSTRIDE; ++j) t[j] = buf[d][j];
-                    if (n + PP_SOLVE_PF * NT < a.nchan) taylor_load(tay, row0 + n + PP_SOLVE_PF * NT, buf[d]);
-                    body(n, t);
+                        for (int j = 0; j < PP_TSTRIDE; ++j) t[j] = buf[d][j];
+                        if (n + PF * NT < a.nchan) taylor_load(tay, row0 + n + PF * NT, buf[d]);
+                        body(n, t);
+                    }
                 }
             }
         }

@@ -150,6 +150,7 @@ struct pp_ctx {
     double max_work_bytes = 96e9;
     bool solve_lds_attr = false;
     int solve_cache = -1;       // k_taylor_solve: channels whose weight / geometry / template power stay in LDS (-1: all, up to 4096)
+    int solve_prefetch = 0;     // k_taylor_solve at more than 2048 channels: 0 = rows fetched in turn (default), 1 = prefetched as for narrow bands
     int solve_threads = 0;      // k_taylor_solve: threads per subint (0: by band width; 64 / 128 / 256 / 512 for A/B)
     int copy_kernels = 1;       // the staged input / output blocks are moved by a kernel instead of a copy command
     int finalize_regs = 1;      // post-fit stage with the channel's numbers held in registers (fits without scattering,
@@ -358,6 +359,7 @@ static bool option_ref(pp_ctx* c, const std::string& n, OptRef* out) {
         {"eager_flush", 'i', &c->eager_flush, INT32_MIN},
         {"finalize_regs", 'i', &c->finalize_regs, INT32_MIN}, {"solve_cache", 'i', &c->solve_cache, -1},
         {"solve_threads", 'i', &c->solve_threads, 0}, {"copy_kernels", 'i', &c->copy_kernels, INT32_MIN},
+        {"solve_prefetch", 'i', &c->solve_prefetch, INT32_MIN},
     };
     for (const OptRef& o : tab)
         if (n == o.name) { *out = o; return true; }
@@ -1129,12 +1131,14 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             (void)hipFuncSetAttribute((const void*)k_taylor_solve<64>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
             (void)hipFuncSetAttribute((const void*)k_taylor_solve<128>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
             (void)hipFuncSetAttribute((const void*)k_taylor_solve<256>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
+            (void)hipFuncSetAttribute((const void*)k_taylor_solve<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
             (void)hipFuncSetAttribute((const void*)k_taylor_solve<512>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
             c->solve_lds_attr = true;
         }
         if (solve_nt == 64) hipLaunchKernelGGL(k_taylor_solve<64>, dim3(ns), dim3(64), lds, c->stream, fa);
         else if (solve_nt == 128) hipLaunchKernelGGL(k_taylor_solve<128>, dim3(ns), dim3(128), lds, c->stream, fa);
         else if (solve_nt == 512) hipLaunchKernelGGL(k_taylor_solve<512>, dim3(ns), dim3(512), lds, c->stream, fa);
+        else if (C > 2048 && c->solve_prefetch <= 0) hipLaunchKernelGGL((k_taylor_solve<256, 0>), dim3(ns), dim3(256), lds, c->stream, fa);
         else hipLaunchKernelGGL(k_taylor_solve<256>, dim3(ns), dim3(256), lds, c->stream, fa);
     };
 
