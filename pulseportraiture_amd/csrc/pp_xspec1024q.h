@@ -20,6 +20,9 @@
 // elements and reads contiguously; the partner map sends every aligned group of eight
 // lanes to eight lanes with distinct low three bits.
 #pragma once
+#ifndef PP_TAIL_M_LDS
+#define PP_TAIL_M_LDS 1
+#endif
 #include "pp_fftq.h"
 
 namespace pp {
@@ -44,7 +47,12 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
     static_assert(PP_TJ == 10, "power ladder written for order 10");
     constexpr int WRED = PP_WRED_DOUBLES(NRED) / 2;   // in cplx
     constexpr int LDSN = WRED > FFTQ_LDS_ELEMS ? WRED : FFTQ_LDS_ELEMS;
-    __shared__ cplx lds[LDSN];
+    // TAIL, f64 rows: the template values of the last NML slots live in LDS beside the image instead of in registers
+    // (with them held the kernel spilled one of them + three dwords to scratch, and the scratch reload in the middle
+    // of the row queues behind the prefetched half row: vector memory returns in order)
+    constexpr int NML = (PP_TAIL_M_LDS && TAIL && sizeof(Tin) == 8) ? 2 : 0;
+    __shared__ cplx lds[LDSN + 64 * NML];
+    cplx* const ldsm = lds + LDSN + threadIdx.x;
     int tid = threadIdx.x;
     const long long nrows = (long long)a.nsub * a.nchan;
     Raw cur[PER1][R1];
@@ -99,7 +107,10 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
         const int ktn = a.ktab ? as_global(a.slot ? a.ktab[a.slot[ia]] : a.kt0)[ne] : a.Kt;
         if (mrow != mheld) {
 #pragma unroll
-            for (int j = 0; j < NSL; ++j) mv2[j] = mrow[kb + 64 * j - 1];   // k <= 448: inside the row
+            for (int j = 0; j < NSL; ++j) {
+                const cplx mval = mrow[kb + 64 * j - 1];   // k <= 448: inside the row
+                if (j < NSL - NML) mv2[j] = mval; else ldsm[64 * (j - (NSL - NML))] = mval;
+            }
             mheld = mrow;
         }
         const double phin = a.ph0[rc];
@@ -209,7 +220,8 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
                 const cplx O = make_double2(zk.x - zc.x, zk.y - zc.y);
                 const cplx wo = cmul(wb, O);
                 // 2 d_k = E - i W^k O
-                const cplx x = cmulc(make_double2(E.x + wo.y, E.y - wo.x), mv2[j]);
+                const cplx mj = (j < NSL - NML) ? mv2[j < NSL - NML ? j : 0] : ldsm[64 * (j - (NSL - NML))];
+                const cplx x = cmulc(make_double2(E.x + wo.y, E.y - wo.x), mj);
                 const cplx z = cmul(x, e);
                 const double kap = j == 0 ? kap0 : kap0 + kconst<true>(PP_TWO_PI * (double)(64 * j));
                 // kappa^2, ^4 .. ^10 once per harmonic; every sum is then one FMA
