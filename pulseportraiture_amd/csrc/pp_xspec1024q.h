@@ -23,6 +23,9 @@
 #ifndef PP_TAIL_M_LDS
 #define PP_TAIL_M_LDS 1
 #endif
+#ifndef PP_MAIN_M_LDS
+#define PP_MAIN_M_LDS 0     // (the noise-given kernel does not spill: measured, no gain)
+#endif
 #include "pp_fftq.h"
 
 namespace pp {
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
     // TAIL, f64 rows: the template values of the last NML slots live in LDS beside the image instead of in registers
     // (with them held the kernel spilled one of them + three dwords to scratch, and the scratch reload in the middle
     // of the row queues behind the prefetched half row: vector memory returns in order)
-    constexpr int NML = (PP_TAIL_M_LDS && TAIL && sizeof(Tin) == 8) ? 2 : 0;
+    constexpr int NML = ((PP_TAIL_M_LDS && TAIL) || (PP_MAIN_M_LDS && !TAIL)) && sizeof(Tin) == 8 ? 2 : 0;
     __shared__ cplx lds[LDSN + 64 * NML];
     cplx* const ldsm = lds + LDSN + threadIdx.x;
     int tid = threadIdx.x;
