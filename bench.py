@@ -432,6 +432,13 @@ def main():
         waits for the host between steps.  One stream: kernels do not overlap, the per-kernel
         HIP-event times stay exact; every step is still a whole fit of the whole batch."""
         recs = torch.zeros((steps, batch.nsub, ppdist.RECORD_WIDTH), dtype=torch.float64, device=device)
+        # (the interpreter's cyclic garbage collector is held off over the timed steps, as timeit does: with torch
+        # and NumPy loaded a full collection takes 30-40 ms and used to land in one timed step or another.  Collected
+        # HERE, before the warm-up steps: a device left idle for those 40 ms starts the timed region at a ramping
+        # clock, 1-3 ms longer for its first step -- profiles/r04_strong_gap.txt)
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         for _ in range(warmup):
             batch.fit(method=method)
         piped = args.pipeline > 1 and batch.can_pipeline()
@@ -464,11 +471,6 @@ def main():
             run(3, None)
         eng.set_option("profile", 1)
         eng.kernel_times(reset=True)
-        # (the interpreter's cyclic garbage collector is held off over the timed steps, as timeit does: with torch
-        # and NumPy loaded a full collection takes 30-40 ms and used to land in one timed step or another)
-        gc.collect()
-        gc_was_on = gc.isenabled()
-        gc.disable()
         fence()
         t0 = time.perf_counter()
         res = run(steps, recs)
