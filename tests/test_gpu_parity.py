@@ -3116,6 +3116,35 @@ def test_solve_and_postfit_widths_agree(eng, C, flags):
             eng.set_option(k, saved[k])
 
 
+def test_transport_and_prefetch_options_change_nothing(eng):
+    """`copy_kernels` (the staged input / output blocks moved by a kernel on the pinned block, or by copy
+    commands) and `solve_prefetch` (a wide band's Taylor rows fetched in turn or ahead) only change HOW
+    bytes move: every output is bitwise the same, synchronous and enqueued, odd batch sizes (the staged
+    blocks are padded to whole words) and the reference-seed flow (its phase guesses ride in the output
+    block) included."""
+    keys = ("copy_kernels", "solve_prefetch")
+    saved = {k: eng.get_option(k) for k in keys}
+    try:
+        for nsub, C, B in ((7, 2304, 256), (5, 256, 2048)):
+            data, freqs, P, x0, kw = _medium_batch(eng, nsub, C=C, B=B, seed=nsub)
+            model_prof = None
+            outs = []
+            for ck, pf in ((1, 0), (0, 0), (1, 1), (0, 1)):
+                eng.set_option("copy_kernels", ck); eng.set_option("solve_prefetch", pf)
+                r = eng.fit_batch(data, freqs, P, x0, **kw)
+                eng.enqueue(data, freqs, P, x0, **kw)
+                q = eng.collect()
+                outs.append((r, q))
+            for r, q in outs:
+                for key in ("params", "param_errs", "nu_refs", "cov", "chi2", "red_chi2", "snr", "nfeval", "npass", "return_code",
+                            "scales", "scale_errs", "channel_snrs"):
+                    np.testing.assert_array_equal(r[key], outs[0][0][key], err_msg=key)
+                    np.testing.assert_array_equal(q[key], outs[0][0][key], err_msg=key)
+    finally:
+        for k in keys:
+            eng.set_option(k, saved[k])
+
+
 @pytest.mark.parametrize("seed", ["reference", "device"])
 def test_get_TOAs_at_a_row_length_that_is_no_power_of_two(seed):
     """GetTOAs.get_TOAs end to end on 1000-bin data (the reference's rfft takes any nbin): the
