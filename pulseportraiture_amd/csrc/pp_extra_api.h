@@ -121,13 +121,11 @@ extern "C" int pp_reference_phase_seed(pp_ctx* c, const void* src, int dtype, in
     if ((rc = upload(c, c->x0, par3, (size_t)nsub * 24))) return rc;
     if ((rc = upload(c, c->wts, weights, (size_t)nsub * nchan * 8))) return rc;
     if ((rc = upload(c, c->errs, model_profs, (size_t)nsub * nbin * 8))) return rc;
-#ifndef PP_ROTMEAN_WGS
-#define PP_ROTMEAN_WGS 8192
-#endif
-    // runs of channels per subint: enough workgroups to fill the device
-    int nrun = std::max(1, std::min(nchan / 16 > 0 ? nchan / 16 : 1, (PP_ROTMEAN_WGS + nsub - 1) / nsub));
-    const int cpr = (nchan + nrun - 1) / nrun;
-    nrun = (nchan + cpr - 1) / cpr;
+    // runs of channels per subint: one partial spectrum per run, the runs added in a fixed order.  The run
+    // length is a function of the band alone (an eighth of it, 16 ... 256 channels), never of the number of
+    // subints in the call: the reference's guess for a subint does not depend on its neighbours (pptoas.py:421-457)
+    const int cpr = std::max(16, std::min(256, (((nchan + 7) / 8) + 15) / 16 * 16));
+    int nrun = (nchan + cpr - 1) / cpr;
     const size_t H = (size_t)M + 1;
     // (general row lengths: the harmonics of every row are written out first -- nrun = nchan slots of H)
     if (anyb) nrun = nchan;

@@ -87,7 +87,7 @@ struct ModelSlot {
 __global__ void k_copy_words(unsigned long long* dst, const unsigned long long* src, size_t n) {
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) dst[j] = src[j];
 }
-static int staged_copy(pp_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+static int staged_copy(pp_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st = nullptr);
 __global__ void k_publish_int(int* host_dst, const int* dev_src) { *host_dst = *dev_src; }
 static int publish_int(pp_ctx* c, int* host_dst, const int* dev_src);
 enum KernelFamily { KF_MODEL = 0, KF_XSPEC, KF_PREP, KF_SEED, KF_ACCUM, KF_EVAL, KF_TAYLOR, KF_STEP, KF_FINAL, KF_SYNTH, KF_FPS, KF_SCATMODEL, KF_COUNT };
@@ -110,7 +110,30 @@ struct pp_ctx {
     int ncu = 0;                            // compute units of the device
     DevBuf mwords;   // rows in use of a masked batch, one word per chunk (k_mask_words), both row orders
     DevBuf refbuf;   // reference-seed flow: partial channel sums, spectra, profiles, start points
-    DevBuf inpack;   // per-batch small inputs (freqs, P, x0, nu_fit, nu_out, slot): one H2D copy
+    // Device work buffers of a batch's SOLVE and POST-FIT stage, two sets: a deferred batch (pp_fit_enqueue) runs those
+    // stages on a second stream (`stream2`) while the next batch's transform already runs on `stream` -- the next batch
+    // writes the other set.  (inpack: the per-batch small inputs -- freqs, P, x0, nu_fit, nu_out, slot -- one H2D copy.)
+    // Buffers only the transform stage touches (data, X, errs, mask, the pilot's seed buffers) stay single:
+    // transforms are serialised on `stream`.  Synchronous flows use one set and one stream.
+    struct WorkSet {
+        DevBuf inpack, sdraw, noise, wts, state, csum, partial, tay, mdl, ph0, misc, act, o_pack, o_f0, o_g0, o_H0,
+            o_scales, o_serrs, o_csnr, refbuf,
+            mwords;      // rows in use of a masked batch, one word per chunk (k_mask_words), both row orders: the reference-seed
+                         // flow's finish reads them in the solve stage
+        hipEvent_t xdone = nullptr;      // the batch's transform stage has been queued up to here
+        void release() {
+            DevBuf* b[] = {&inpack, &sdraw, &noise, &wts, &state, &csum, &partial, &tay, &mdl, &ph0, &misc, &act, &o_pack,
+                           &o_f0, &o_g0, &o_H0, &o_scales, &o_serrs, &o_csnr, &refbuf, &mwords};
+            for (DevBuf* q : b) q->release();
+            if (xdone) (void)hipEventDestroy(xdone);
+            xdone = nullptr;
+        }
+    };
+    WorkSet work[2];
+    hipStream_t stream2 = nullptr;   // solve + post-fit stage of deferred batches (higher priority than `stream`)
+    hipStream_t last_post = nullptr; // the stream the last fit_chunk queued its post-fit stage on
+    int overlap_post = 1;            // deferred batches: 1 = solve / post-fit stage on stream2, beside the next transform
+    DevBuf inpack;   // (aux entry points)
     // pinned host staging of the small inputs / the packed outputs of a batch: two sets, so that a
     // deferred batch (pp_fit_enqueue) keeps its own while the next one is being queued
     struct Stage { void* in_host = nullptr; size_t in_cap = 0; void* o_host = nullptr; size_t o_cap = 0;
@@ -190,16 +213,16 @@ static hipEvent_t prof_event(pp_ctx* c) {
 }
 
 struct Prof {
-    pp_ctx* c; int fam; hipEvent_t a = nullptr, b = nullptr;
-    Prof(pp_ctx* c_, int fam_) : c(c_), fam(fam_) {
+    pp_ctx* c; int fam; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    Prof(pp_ctx* c_, int fam_, hipStream_t st_ = nullptr) : c(c_), fam(fam_), st(st_ ? st_ : c_->stream) {
         if (c->profile) {
             a = prof_event(c); b = prof_event(c);
-            (void)hipEventRecord(a, c->stream);
+            (void)hipEventRecord(a, st);
         }
     }
     ~Prof() {
         if (c->profile) {
-            (void)hipEventRecord(b, c->stream);
+            (void)hipEventRecord(b, st);
             c->spans.push_back({fam, a, b});
         }
     }
@@ -253,6 +276,17 @@ static int ctx_init(pp_ctx* c) {
         c->ncu = ncu - nex;
     } else
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        // the stream of the solve / post-fit stage of deferred batches: OLDER work, dispatched first where the
+        // two streams compete (numerically lower = higher priority)
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        }
+        for (auto& w : c->work) HIP_TRY(hipEventCreateWithFlags(&w.xdone, hipEventDisableTiming));
+    }
     HIP_TRY(hipHostMalloc((void**)&c->nactive_h, sizeof(int) * 4, hipHostMallocDefault));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
@@ -299,7 +333,9 @@ extern "C" int pp_destroy(pp_ctx* c) {
     if (c->job_active) { c->job.join(); c->job_active = false; }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     resolve_spans(c);
+    for (auto& w : c->work) w.release();
     for (auto& kv : c->twiddles) kv.second.release();
     for (auto& kv : c->anyplans) { kv.second.chirp.release(); kv.second.bft.release(); }
     for (auto& s : c->slots) { s.mft.release(); s.msum.release(); s.mmax.release(); s.mdc.release(); s.kt.release(); s.msq.release(); }
@@ -325,6 +361,7 @@ extern "C" int pp_destroy(pp_ctx* c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto& e : c->evq) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
     return PP_OK;
 }
@@ -332,6 +369,7 @@ extern "C" int pp_destroy(pp_ctx* c) {
 extern "C" int pp_synchronize(pp_ctx* c) {
     if (!c) return fail(PP_EINVAL, "null context");
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream2));
     return PP_OK;
 }
 
@@ -359,7 +397,7 @@ static bool option_ref(pp_ctx* c, const std::string& n, OptRef* out) {
         {"eager_flush", 'i', &c->eager_flush, INT32_MIN},
         {"finalize_regs", 'i', &c->finalize_regs, INT32_MIN}, {"solve_cache", 'i', &c->solve_cache, -1},
         {"solve_threads", 'i', &c->solve_threads, 0}, {"copy_kernels", 'i', &c->copy_kernels, INT32_MIN},
-        {"solve_prefetch", 'i', &c->solve_prefetch, INT32_MIN},
+        {"solve_prefetch", 'i', &c->solve_prefetch, INT32_MIN}, {"overlap_post", 'i', &c->overlap_post, INT32_MIN},
     };
     for (const OptRef& o : tab)
         if (n == o.name) { *out = o; return true; }
@@ -386,6 +424,7 @@ extern "C" int pp_get_option(pp_ctx* c, const char* name, double* value) {
 extern "C" int pp_kernel_times(pp_ctx* c, int cap, const char** names, double* seconds, int64_t* launches) {
     if (!c) return fail(PP_EINVAL, "null context");
     (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream2);
     resolve_spans(c);
     int n = std::min(cap, (int)KF_COUNT);
     for (int i = 0; i < n; ++i) {
@@ -399,6 +438,7 @@ extern "C" int pp_kernel_times(pp_ctx* c, int cap, const char** names, double* s
 extern "C" int pp_kernel_times_reset(pp_ctx* c) {
     if (!c) return fail(PP_EINVAL, "null context");
     (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream2);
     resolve_spans(c);
     for (int i = 0; i < KF_COUNT; ++i) { c->fam_sec[i] = 0; c->fam_n[i] = 0; }
     return PP_OK;
@@ -434,15 +474,16 @@ static int get_twiddles(pp_ctx* c, int nbin, const cplx** out) {
 // row lengths with a tuned plan (every entry point), and every row length the fit itself takes:
 // the reference's numpy.fft.rfft accepts any (pptoaslib.py:976-979); even lengths up to 4096 that
 // are no power of two go through pp_anybin.h
-static int staged_copy(pp_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+static int staged_copy(pp_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+    if (!st) st = c->stream;
     if (c->copy_kernels && bytes % 8 == 0 && bytes <= ((size_t)64 << 20)) {
         const size_t n = bytes / 8;
         const unsigned nb = (unsigned)std::min<size_t>((n + 255) / 256, 256);
-        hipLaunchKernelGGL(k_copy_words, dim3(nb ? nb : 1), dim3(256), 0, c->stream, (unsigned long long*)dst,
+        hipLaunchKernelGGL(k_copy_words, dim3(nb ? nb : 1), dim3(256), 0, st, (unsigned long long*)dst,
                            (const unsigned long long*)src, n);
         return hipGetLastError() == hipSuccess ? PP_OK : PP_EHIP;
     }
-    return hipMemcpyAsync(dst, src, bytes, kind, c->stream) == hipSuccess ? PP_OK : PP_EHIP;
+    return hipMemcpyAsync(dst, src, bytes, kind, st) == hipSuccess ? PP_OK : PP_EHIP;
 }
 // one int of device state into the pinned word the host looks at an iteration later (the lagged check of the
 // evaluation loop: the count of unfinished subints); where the host waits at once a copy command measured faster
@@ -854,6 +895,7 @@ static int unfinished_in_stage(const void* o_host, int ns) {
 static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, int ns, int Kt, bool scat,
                      const std::vector<double>& nufit_h, const std::vector<double>& nuout_h, bool* deferred = nullptr) {
     pp_ctx::Stage& sg = c->stage[c->cur_stage];
+    pp_ctx::WorkSet& W = c->work[c->cur_stage];
     const pp_seed_ref* rs = in->ref_seed;        // (applicability was checked by the caller)
     const bool refseed = (rs != nullptr);
     const int seed_ns = refseed ? rs->Ns : in->seed_ns;
@@ -884,14 +926,14 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     const size_t rs_doubles = refseed ? rs_nprof * B + (size_t)ns * (1 + 5) : 0;
     const size_t in_doubles = nfreq + (size_t)ns * (1 + 5 + 3 + 3) + rs_doubles;
     const size_t in_bytes = (in_doubles * 8 + (size_t)ns * 4 + 7) & ~(size_t)7;      // (whole 8-byte words: staged_copy)
-    if ((rc = c->inpack.reserve(in_bytes))) return rc;
+    if ((rc = W.inpack.reserve(in_bytes))) return rc;
     if (sg.in_cap < in_bytes) {
         if (sg.in_host) (void)hipHostFree(sg.in_host);
         sg.in_host = nullptr; sg.in_cap = 0;
         HIP_TRY(hipHostMalloc(&sg.in_host, in_bytes, hipHostMallocDefault));
         sg.in_cap = in_bytes;
     }
-    double* const d_freqs = c->inpack.as<double>();
+    double* const d_freqs = W.inpack.as<double>();
     double* const d_P = d_freqs + nfreq;
     double* const d_x0 = d_P + ns;
     double* const d_nufit = d_x0 + (size_t)ns * 5;
@@ -927,7 +969,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             h += (size_t)ns * 5;
         }
         if (in->model_slot) memcpy(h, in->model_slot + s0, (size_t)ns * 4);
-        if ((rc = staged_copy(c, c->inpack.p, sg.in_host, in_bytes, hipMemcpyHostToDevice))) return fail(rc, "input block copy failed");
+        if ((rc = staged_copy(c, W.inpack.p, sg.in_host, in_bytes, hipMemcpyHostToDevice))) return fail(rc, "input block copy failed");
     }
     const double* d_errs = nullptr;
     const unsigned char* d_mask = nullptr;
@@ -943,9 +985,9 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     const unsigned* mw_sub = nullptr;
     if (d_mask && c->skip_masked) {
         const size_t nw_main = (nc + 31) / 32 + 1, nw_sub = (C % 32 == 0) ? nc / 32 : 0;
-        if ((rc = c->mwords.reserve((nw_main + nw_sub) * sizeof(unsigned)))) return rc;
-        HIP_TRY(hipMemsetAsync(c->mwords.p, 0, (nw_main + nw_sub) * sizeof(unsigned), c->stream));
-        unsigned* wm = c->mwords.as<unsigned>();
+        if ((rc = W.mwords.reserve((nw_main + nw_sub) * sizeof(unsigned)))) return rc;
+        HIP_TRY(hipMemsetAsync(W.mwords.p, 0, (nw_main + nw_sub) * sizeof(unsigned), c->stream));
+        unsigned* wm = W.mwords.as<unsigned>();
         unsigned* ws = nw_sub ? wm + nw_main : nullptr;
         hipLaunchKernelGGL(k_mask_words, dim3((unsigned)((C + 255) / 256), (unsigned)((ns + 31) / 32)), dim3(256), 0, c->stream,
                            d_mask, ns, C, wm, ws);
@@ -977,7 +1019,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     constexpr int kCoarseStep = 16;
     const bool coarse = scat && in->method == PP_METHOD_NEWTON && !seeded && !refseed && c->max_iter > 0 &&
                         c->coarse_newton && C / kCoarseStep >= 32 && !(c->x_f32 > 0);
-    const bool fuse_scat = scat && !seeded && !coarse && c->max_iter > 0 && c->one_exchange && c->fuse_scat && M == 1024 &&
+    const bool fuse_scat = scat && !seeded && !coarse && c->max_iter > 0 && c->one_exchange && c->fuse_scat && !anyb && B == 2048 &&
                            2 * Kt < M && !(c->x_f32 > 0) && in->errs != nullptr;
     const bool fuse = (!scat && !taylor && !seeded) || fuse_scat;   // first evaluation folded into the transform
     // k_xspec mode: 2/3 = Taylor model only, no cross-spectrum stored;
@@ -985,32 +1027,45 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     const bool xmom = taylor && c->moments_in_xspec && !seed_full;
     const int xmode = xmom ? (2 * Kt < M ? 2 : 3) : (fuse ? 1 : 0);
     const bool xstore = (xmode < 2);
+    // a batch of the one-pass flow without a host decision in its middle may be left queued (pp_fit_enqueue); its
+    // solve and post-fit stage then go to the context's second stream, behind an event of the transform, so that
+    // they run BESIDE the next batch's transform (queued on `stream` right behind this one's) instead of in front of
+    // it: the solve re-reads the Taylor rows at the HBM roofline with the SIMDs idle, the transform is bound by
+    // instruction issue with bandwidth to spare -- and the persistent transform draws its rows by ticket, so its
+    // workgroups may start as the solve's retire
+    const bool defer_ok = deferred && taylor && !seed_full && (!pilot || refseed);
+    const hipStream_t sp = (defer_ok && c->overlap_post && c->stream2) ? c->stream2 : c->stream;
+    c->last_post = sp;
     const int ncs = scat ? PP_NCS : 3;
-    auto chunking = [&](int nch, int nsu, int& nchunk_, int& cpc_) {
-        nchunk_ = std::min(std::max(1, nch / 64), std::max(1, (4096 + nsu - 1) / nsu));
-        cpc_ = (nch + nchunk_ - 1) / nchunk_;
-        cpc_ = ((cpc_ + 15) / 16) * 16;
+    // Channel chunks of the kernels that sum over channels (evaluators, seed, moments).  The run length is a
+    // function of the BAND alone -- never of how many subints share the launch -- so that the partial sums of a
+    // subint are formed and added in one order whatever else is in the batch: a subint's answer is a function of
+    // that subint alone, as in the reference's loop (pptoas.py:344-489).  (Until round 4 the number of chunks
+    // grew as the batch shrank, to fill the chip with a single subint: the rounding of f then depended on the
+    // batch, and through SciPy's 1-ulp exit tests so did ~1e-9 rot of some answers.)
+    auto chunking = [&](int nch, int& nchunk_, int& cpc_) {
+        cpc_ = nch >= PP_CHUNK_CHANNELS ? PP_CHUNK_CHANNELS : ((nch + 15) / 16) * 16;
         nchunk_ = (nch + cpc_ - 1) / cpc_;
     };
     int nchunk, cpc;
-    chunking(C, ns, nchunk, cpc);
+    chunking(C, nchunk, cpc);
     // pitch of the stored cross-spectrum's rows: Kt harmonics + an optional pad (option x_pad, elements).
     // Kt x 16 B is a multiple of 1 KB and the evaluators stream 32 rows per workgroup at the same
     // pace, which looked like a recipe for memory-channel camping: measured, pads of 8 / 16 / 48
     // elements change nothing (profiles/README.md, round 3) -- the default stays 0
     const size_t Xs = (size_t)Kt + (size_t)std::max(0, c->x_pad);
     if (xstore) if ((rc = c->X.reserve(nc * Xs * sizeof(cplx)))) return rc;
-    if ((rc = c->sdraw.reserve(nc * 8))) return rc;
-    if ((rc = c->noise.reserve(nc * 8))) return rc;
-    if ((rc = c->wts.reserve(nc * 8))) return rc;
-    if ((rc = c->state.reserve((size_t)ns * sizeof(SubState)))) return rc;
-    if ((rc = c->csum.reserve(2 * nc * ncs * 8))) return rc;
-    if ((rc = c->partial.reserve((size_t)ns * nchunk * PP_NACC * 8))) return rc;
-    if (taylor) if ((rc = c->tay.reserve(((nc + 63) / 64) * 64 * PP_TSTRIDE * 8))) return rc;   // (whole blocks of 64 rows: tay_idx)
+    if ((rc = W.sdraw.reserve(nc * 8))) return rc;
+    if ((rc = W.noise.reserve(nc * 8))) return rc;
+    if ((rc = W.wts.reserve(nc * 8))) return rc;
+    if ((rc = W.state.reserve((size_t)ns * sizeof(SubState)))) return rc;
+    if ((rc = W.csum.reserve(2 * nc * ncs * 8))) return rc;
+    if ((rc = W.partial.reserve((size_t)ns * nchunk * PP_NACC * 8))) return rc;
+    if (taylor) if ((rc = W.tay.reserve(((nc + 63) / 64) * 64 * PP_TSTRIDE * 8))) return rc;   // (whole blocks of 64 rows: tay_idx)
     // (SciPy's trust-ncg spends ~8 of its ~15 evaluations inside the model's range;
     // the Newton iteration only 2-3 of 6, less than the model pass costs)
     const bool smodel = scat && c->max_iter > 0 && (c->scat_model >= 2 || (c->scat_model == 1 && in->method == PP_METHOD_TRUST_NCG));
-    if (smodel) if ((rc = c->mdl.reserve(nc * PP_MROW * 8))) return rc;
+    if (smodel) if ((rc = W.mdl.reserve(nc * PP_MROW * 8))) return rc;
     // Option x_f32 (off by default): the stored cross-spectrum of a scattering fit kept as float
     // pairs, half the bytes of every evaluation pass.  Measured on configs[3] with the Newton
     // solver (profiles/README.md, round 3, with the first evaluator, which was not HBM-bound: the
@@ -1019,29 +1074,29 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // moves f by ~1e-6 of itself; the optimum by ~1e-11 rot).  Kept for experiments.
     const bool xf32 = scat && !seeded && !smodel && c->max_iter > 0 && c->x_f32 > 0;
     const bool want_ph0 = xmode != 0 || fuse_scat || refseed;
-    if (want_ph0) if ((rc = c->ph0.reserve(nc * 8 * (fuse_scat ? 2 : 1)))) return rc;
-    if ((rc = c->misc.reserve(256))) return rc;
-    if ((rc = c->act.reserve((size_t)ns * 4))) return rc;
+    if (want_ph0) if ((rc = W.ph0.reserve(nc * 8 * (fuse_scat ? 2 : 1)))) return rc;
+    if ((rc = W.misc.reserve(256))) return rc;
+    if ((rc = W.act.reserve((size_t)ns * 4))) return rc;
     // per-subint scalar outputs: blocks of one allocation (params 5, errs 5, nu 3,
     // cov 25, chi2, red_chi2, snr doubles; nfeval, return_code, npass ints) = 340 B / subint
     const size_t o_bytes = ((size_t)ns * 340 + 8 + 7) & ~(size_t)7;       // (+ the count of unfinished subints; whole words)
     const size_t o_stage = stage_seed_offset(ns) + (size_t)ns * 8;   // (+ the reference-seed flow's phase guesses)
-    if ((rc = c->o_pack.reserve(o_stage))) return rc;      // (the phase guesses of the reference-seed flow behind the pack)
+    if ((rc = W.o_pack.reserve(o_stage))) return rc;      // (the phase guesses of the reference-seed flow behind the pack)
     if (sg.o_cap < o_stage) {
         if (sg.o_host) (void)hipHostFree(sg.o_host);
         sg.o_host = nullptr; sg.o_cap = 0;
         HIP_TRY(hipHostMalloc(&sg.o_host, o_stage, hipHostMallocDefault));
         sg.o_cap = o_stage;
     }
-    double* const o_base = c->o_pack.as<double>();
-    if ((rc = c->o_f0.reserve((size_t)ns * 8))) return rc;
-    if ((rc = c->o_g0.reserve((size_t)ns * 40))) return rc;
-    if ((rc = c->o_H0.reserve((size_t)ns * 200))) return rc;
+    double* const o_base = W.o_pack.as<double>();
+    if ((rc = W.o_f0.reserve((size_t)ns * 8))) return rc;
+    if ((rc = W.o_g0.reserve((size_t)ns * 40))) return rc;
+    if ((rc = W.o_H0.reserve((size_t)ns * 200))) return rc;
     const bool chan_dev = out->chan_on_device != 0;
     if (!chan_dev) {
-        if (out->scales) if ((rc = c->o_scales.reserve(nc * 8))) return rc;
-        if (out->scale_errs) if ((rc = c->o_serrs.reserve(nc * 8))) return rc;
-        if (out->channel_snrs) if ((rc = c->o_csnr.reserve(nc * 8))) return rc;
+        if (out->scales) if ((rc = W.o_scales.reserve(nc * 8))) return rc;
+        if (out->scale_errs) if ((rc = W.o_serrs.reserve(nc * 8))) return rc;
+        if (out->channel_snrs) if ((rc = W.o_csnr.reserve(nc * 8))) return rc;
     }
 
     if (c->debug_poison) {
@@ -1049,14 +1104,14 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         // contents become NaNs that surface as failed certificates / non-finite results
         // (bit mask: 1 tay, 2 sdraw, 4 noise, 8 wts, 16 csum, 32 ph0, 64 X, 128 mdl)
         const int pz = c->debug_poison;
-        if ((pz & 1) && taylor) HIP_TRY(hipMemsetAsync(c->tay.p, 0xFF, ((nc + 63) / 64) * 64 * PP_TSTRIDE * 8, c->stream));
-        if (pz & 2) HIP_TRY(hipMemsetAsync(c->sdraw.p, 0xFF, nc * 8, c->stream));
-        if (pz & 4) HIP_TRY(hipMemsetAsync(c->noise.p, 0xFF, nc * 8, c->stream));
-        if (pz & 8) HIP_TRY(hipMemsetAsync(c->wts.p, 0xFF, nc * 8, c->stream));
-        if (pz & 16) HIP_TRY(hipMemsetAsync(c->csum.p, 0xFF, 2 * nc * ncs * 8, c->stream));
-        if ((pz & 32) && want_ph0) HIP_TRY(hipMemsetAsync(c->ph0.p, 0xFF, nc * 8, c->stream));
+        if ((pz & 1) && taylor) HIP_TRY(hipMemsetAsync(W.tay.p, 0xFF, ((nc + 63) / 64) * 64 * PP_TSTRIDE * 8, c->stream));
+        if (pz & 2) HIP_TRY(hipMemsetAsync(W.sdraw.p, 0xFF, nc * 8, c->stream));
+        if (pz & 4) HIP_TRY(hipMemsetAsync(W.noise.p, 0xFF, nc * 8, c->stream));
+        if (pz & 8) HIP_TRY(hipMemsetAsync(W.wts.p, 0xFF, nc * 8, c->stream));
+        if (pz & 16) HIP_TRY(hipMemsetAsync(W.csum.p, 0xFF, 2 * nc * ncs * 8, c->stream));
+        if ((pz & 32) && want_ph0) HIP_TRY(hipMemsetAsync(W.ph0.p, 0xFF, nc * 8, c->stream));
         if ((pz & 64) && xstore) HIP_TRY(hipMemsetAsync(c->X.p, 0xFF, nc * Xs * sizeof(cplx), c->stream));
-        if ((pz & 128) && smodel) HIP_TRY(hipMemsetAsync(c->mdl.p, 0xFF, nc * PP_MROW * 8, c->stream));
+        if ((pz & 128) && smodel) HIP_TRY(hipMemsetAsync(W.mdl.p, 0xFF, nc * PP_MROW * 8, c->stream));
     }
     // ---- argument blocks ----
     const bool tail = (in->errs == nullptr);
@@ -1067,13 +1122,13 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     xa.ktab = (const int* const*)c->kt_table.p;
     xa.kt0 = c->slots[0].kt.as<int>();
     xa.slot = in->model_slot ? d_slot : nullptr;
-    xa.X = c->X.as<cplx>(); xa.sdraw = c->sdraw.as<double>(); xa.noise = c->noise.as<double>();
+    xa.X = c->X.as<cplx>(); xa.sdraw = W.sdraw.as<double>(); xa.noise = W.noise.as<double>();
     xa.twB = tw; xa.nsub = ns; xa.nchan = C; xa.Kt = Kt; xa.Xs = (int)Xs;
     xa.x0 = d_x0; xa.P = d_P; xa.nu_fit = d_nufit;
     xa.freqs = d_freqs; xa.freqs_stride = in->freqs_stride ? C : 0;
-    xa.csum0 = c->csum.as<double>();
-    xa.tay = c->tay.as<double>();
-    xa.ph0 = c->ph0.as<double>();
+    xa.csum0 = W.csum.as<double>();
+    xa.tay = W.tay.as<double>();
+    xa.ph0 = W.ph0.as<double>();
     xa.act = nullptr; xa.cstep = 1; xa.coff = 0; xa.nchan_full = C;
     xa.x_f32 = xf32 ? 1 : 0;
     FitArgs fa;
@@ -1090,13 +1145,13 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.ktab = (const int* const*)c->kt_table.p;
     fa.slot = in->model_slot ? d_slot : nullptr;
     fa.freqs = d_freqs; fa.freqs_stride = in->freqs_stride ? C : 0;
-    fa.wts = c->wts.as<double>(); fa.sdraw = c->sdraw.as<double>();
+    fa.wts = W.wts.as<double>(); fa.sdraw = W.sdraw.as<double>();
     fa.P = d_P; fa.nu_fit = d_nufit; fa.nu_out = d_nuout;
-    fa.x0 = d_x0; fa.st = c->state.as<SubState>();
-    fa.csum = c->csum.as<double>(); fa.ncs = ncs;
-    fa.tay = c->tay.as<double>();
-    fa.partial = c->partial.as<double>(); fa.nchunk = nchunk; fa.cpc = cpc;
-    fa.nactive = c->misc.as<int>();
+    fa.x0 = d_x0; fa.st = W.state.as<SubState>();
+    fa.csum = W.csum.as<double>(); fa.ncs = ncs;
+    fa.tay = W.tay.as<double>();
+    fa.partial = W.partial.as<double>(); fa.nchunk = nchunk; fa.cpc = cpc;
+    fa.nactive = W.misc.as<int>();
     fa.o_params = o_base; fa.o_errs = o_base + (size_t)ns * 5; fa.o_nu = o_base + (size_t)ns * 10;
     fa.o_cov = o_base + (size_t)ns * 13; fa.o_chi2 = o_base + (size_t)ns * 38; fa.o_rchi2 = o_base + (size_t)ns * 39;
     fa.o_snr = o_base + (size_t)ns * 40;
@@ -1106,14 +1161,14 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         fa.o_scale_errs = out->scale_errs ? out->scale_errs + (size_t)s0 * C : nullptr;
         fa.o_csnr = out->channel_snrs ? out->channel_snrs + (size_t)s0 * C : nullptr;
     } else {
-        fa.o_scales = out->scales ? c->o_scales.as<double>() : nullptr;
-        fa.o_scale_errs = out->scale_errs ? c->o_serrs.as<double>() : nullptr;
-        fa.o_csnr = out->channel_snrs ? c->o_csnr.as<double>() : nullptr;
+        fa.o_scales = out->scales ? W.o_scales.as<double>() : nullptr;
+        fa.o_scale_errs = out->scale_errs ? W.o_serrs.as<double>() : nullptr;
+        fa.o_csnr = out->channel_snrs ? W.o_csnr.as<double>() : nullptr;
     }
-    fa.o_f0 = c->o_f0.as<double>(); fa.o_g0 = c->o_g0.as<double>(); fa.o_H0 = c->o_H0.as<double>();
+    fa.o_f0 = W.o_f0.as<double>(); fa.o_g0 = W.o_g0.as<double>(); fa.o_H0 = W.o_H0.as<double>();
     fa.o_rec = out->records_dev ? out->records_dev + (size_t)s0 * PP_RECORD_WIDTH : nullptr;
     fa.act = nullptr; fa.nact = ns; fa.nchan_x = C; fa.cstep = 1; fa.coff = 0;
-    fa.mdl = c->mdl.as<double>(); fa.use_model = smodel ? 1 : 0; fa.model_tol = c->scat_model_tol; fa.model_bet = c->scat_model_bet;
+    fa.mdl = W.mdl.as<double>(); fa.use_model = smodel ? 1 : 0; fa.model_tol = c->scat_model_tol; fa.model_bet = c->scat_model_bet;
     // (a GM fit walked the SciPy way ends where its path ends: it keeps the exact path; the
     // Newton solver converges to the optimum from anywhere)
     fa.recentre = (taylor && xmom && (!in->fit_flags[2] || in->method == PP_METHOD_NEWTON))
@@ -1135,11 +1190,11 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             (void)hipFuncSetAttribute((const void*)k_taylor_solve<512>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
             c->solve_lds_attr = true;
         }
-        if (solve_nt == 64) hipLaunchKernelGGL(k_taylor_solve<64>, dim3(ns), dim3(64), lds, c->stream, fa);
-        else if (solve_nt == 128) hipLaunchKernelGGL(k_taylor_solve<128>, dim3(ns), dim3(128), lds, c->stream, fa);
-        else if (solve_nt == 512) hipLaunchKernelGGL(k_taylor_solve<512>, dim3(ns), dim3(512), lds, c->stream, fa);
-        else if (C > 2048 && c->solve_prefetch <= 0) hipLaunchKernelGGL((k_taylor_solve<256, 0>), dim3(ns), dim3(256), lds, c->stream, fa);
-        else hipLaunchKernelGGL(k_taylor_solve<256>, dim3(ns), dim3(256), lds, c->stream, fa);
+        if (solve_nt == 64) hipLaunchKernelGGL(k_taylor_solve<64>, dim3(ns), dim3(64), lds, sp, fa);
+        else if (solve_nt == 128) hipLaunchKernelGGL(k_taylor_solve<128>, dim3(ns), dim3(128), lds, sp, fa);
+        else if (solve_nt == 512) hipLaunchKernelGGL(k_taylor_solve<512>, dim3(ns), dim3(512), lds, sp, fa);
+        else if (C > 2048 && c->solve_prefetch <= 0) hipLaunchKernelGGL((k_taylor_solve<256, 0>), dim3(ns), dim3(256), lds, sp, fa);
+        else hipLaunchKernelGGL(k_taylor_solve<256>, dim3(ns), dim3(256), lds, sp, fa);
     };
 
     auto run_xspec = [&](const XspecArgs& x, int mode) -> int {
@@ -1155,7 +1210,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     auto run_prep = [&]() -> int {
         Prof pr(c, KF_PREP);
         hipLaunchKernelGGL(k_prep, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, ns, C, B,
-                           d_errs, c->noise.as<double>(), d_mask, c->wts.as<double>());
+                           d_errs, W.noise.as<double>(), d_mask, W.wts.as<double>());
         HIP_TRY(hipGetLastError());
         return PP_OK;
     };
@@ -1202,12 +1257,12 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         HIP_TRY(hipGetLastError());
         return PP_OK;
     };
-    // list the subints that need more work into c->act; returns their number
+    // list the subints that need more work into W.act; returns their number
     auto list_active = [&](const double* seedq, double qmin, int* count) -> int {
-        hipLaunchKernelGGL(k_list_active, dim3(1), dim3(256), 0, c->stream, (const SubState*)c->state.p, seedq, qmin,
-                           ns, c->act.as<int>(), c->misc.as<int>() + 1);
+        hipLaunchKernelGGL(k_list_active, dim3(1), dim3(256), 0, c->stream, (const SubState*)W.state.p, seedq, qmin,
+                           ns, W.act.as<int>(), W.misc.as<int>() + 1);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(c->nactive_h + 1, c->misc.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->nactive_h + 1, W.misc.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         *count = c->nactive_h[1];
         return PP_OK;
@@ -1217,12 +1272,12 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     auto store_x_for_list = [&](int count) -> int {
         if ((rc = c->X.reserve((size_t)count * C * Xs * sizeof(cplx)))) return rc;
         XspecArgs xl = xa;
-        xl.X = c->X.as<cplx>(); xl.act = c->act.as<int>(); xl.nsub = count;
+        xl.X = c->X.as<cplx>(); xl.act = W.act.as<int>(); xl.nsub = count;
         if ((rc = run_xspec(xl, 0))) return rc;
-        fa.X = c->X.as<cplx>(); fa.act = c->act.as<int>(); fa.nact = count;
-        chunking(C, count, fa.nchunk, fa.cpc);
-        if ((rc = c->partial.reserve((size_t)ns * fa.nchunk * PP_NACC * 8))) return rc;
-        fa.partial = c->partial.as<double>();
+        fa.X = c->X.as<cplx>(); fa.act = W.act.as<int>(); fa.nact = count;
+        chunking(C, fa.nchunk, fa.cpc);
+        if ((rc = W.partial.reserve((size_t)ns * fa.nchunk * PP_NACC * 8))) return rc;
+        fa.partial = W.partial.as<double>();
         return PP_OK;
     };
 
@@ -1237,7 +1292,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         if ((rc = run_prep())) return rc;      // (rows not transformed yet have no measured noise: unused here)
         FitArgs fp = fa;
         fp.X = c->X.as<cplx>(); fp.nchan_x = Cp; fp.cstep = cstep;
-        chunking(Cp, ns, fp.nchunk, fp.cpc);
+        chunking(Cp, fp.nchunk, fp.cpc);
         if ((rc = run_seed(fp, c->seedq.as<double>()))) return rc;
         // (reference-seed flow: the pilot's phase is only the expansion point of the Taylor model, which the
         // certificate guards -- a weak pilot costs its subint a second expansion, not the batch a host round trip)
@@ -1259,13 +1314,23 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     {
         Prof pr(c, KF_PREP);
         hipLaunchKernelGGL(k_setup, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, fa,
-                           wts_early ? d_errs : (const double*)nullptr, d_mask, c->wts.as<double>(),
-                           want_ph0 ? c->ph0.as<double>() : (double*)nullptr,
-                           fuse_scat ? c->ph0.as<double>() + nc : (double*)nullptr, seed_full ? 0 : 1);
+                           wts_early ? d_errs : (const double*)nullptr, d_mask, W.wts.as<double>(),
+                           want_ph0 ? W.ph0.as<double>() : (double*)nullptr,
+                           fuse_scat ? W.ph0.as<double>() + nc : (double*)nullptr, seed_full ? 0 : 1);
     }
     // ---- reference-seed flow: Taylor model about the pilot's phase + the rotated channel sums in
     // one pass, then the reference's fit_phase_shift on the channel mean, then the start points
     double* d_seedph = nullptr;      // [ns] the phase guesses the reference-seed flow formed (fetched with the outputs)
+    // hand-over from the transform stage (on `stream`) to the solve / post-fit stage (on `sp`), once per batch
+    bool chained = false;
+    auto chain_post = [&]() -> int {
+        if (sp == c->stream || chained) return PP_OK;
+        HIP_TRY(hipEventRecord(W.xdone, c->stream));
+        HIP_TRY(hipStreamWaitEvent(sp, W.xdone, 0));
+        if (c->eager_flush) (void)hipStreamQuery(c->stream);
+        chained = true;
+        return PP_OK;
+    };
     auto run_refseed_pass = [&]() -> int {
         const int ncc = C / PP_ROW_CHUNK;
         const size_t H = (size_t)M + 1;
@@ -1274,8 +1339,8 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         const size_t n_part = (size_t)ns * ncc * RS_NACC * 64;
         const size_t n_cplx = n_part + (size_t)ns * H + nprof * H + (size_t)ns * M;
         const size_t n_dbl = (size_t)ns * (1 + 1 + 7) + (w_host ? nc : 0);
-        if ((rc = c->refbuf.reserve(n_cplx * sizeof(cplx) + n_dbl * 8))) return rc;
-        cplx* part = c->refbuf.as<cplx>();
+        if ((rc = W.refbuf.reserve(n_cplx * sizeof(cplx) + n_dbl * 8))) return rc;
+        cplx* part = W.refbuf.as<cplx>();
         cplx* dspec = part + n_part;
         cplx* mspec = dspec + (size_t)ns * H;
         cplx* xwork = mspec + nprof * H;
@@ -1287,7 +1352,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         double* d_delta = reinterpret_cast<double*>(xwork + (size_t)ns * M);
         double* d_wsum = d_delta + ns;
         double* d_out7 = d_wsum + ns;
-        double* d_sph = reinterpret_cast<double*>(reinterpret_cast<char*>(c->o_pack.p) + stage_seed_offset(ns));   // (leaves with the outputs)
+        double* d_sph = reinterpret_cast<double*>(reinterpret_cast<char*>(W.o_pack.p) + stage_seed_offset(ns));   // (leaves with the outputs)
         double* d_wh = d_out7 + (size_t)ns * 7;
         const double* d_w = nullptr;
         if (rs->weights && !in->aux_on_device) {
@@ -1319,20 +1384,24 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
 #undef PP_QR
         }
         HIP_TRY(hipGetLastError());
+        // (what follows the pass -- the channel mean's spectrum, the reference's fit_phase_shift, the start points --
+        // belongs to the solve stage: beside the next batch's transform when the batch is deferred.  The mask words
+        // the finish reads are the transform stage's buffer: a deferred batch has its own copy)
+        if ((rc = chain_post())) return rc;
         {
-            Prof pr(c, KF_FPS);
-            hipLaunchKernelGGL((k_rfft_rows<1024, double>), dim3(fft_grid(64, (long long)nprof)), dim3(64), 0, c->stream,
+            Prof pr(c, KF_FPS, sp);
+            hipLaunchKernelGGL((k_rfft_rows<1024, double>), dim3(fft_grid(64, (long long)nprof)), dim3(64), 0, sp,
                                (const void*)mprof, mspec, tw, (int)nprof);
-            hipLaunchKernelGGL(k_refseed_prep, dim3(ns), dim3(256), 0, c->stream, (const double*)d_x0, (const double*)d_P,
+            hipLaunchKernelGGL(k_refseed_prep, dim3(ns), dim3(256), 0, sp, (const double*)d_x0, (const double*)d_P,
                                (const double*)d_nufit, (const double*)d_numean, d_w, C, d_delta, d_wsum);
-            hipLaunchKernelGGL(k_refseed_finish, dim3((unsigned)((H + 255) / 256), ns), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(k_refseed_finish, dim3((unsigned)((H + 255) / 256), ns), dim3(256), 0, sp,
                                (const cplx*)part, ncc, (const double*)d_delta, (const double*)d_wsum, ns, dspec, mw_sub);
             FpsArgs f{dspec, nullptr, d_out7, rs->lo, rs->hi, rs->Ns, M, ns, rs->finish, mspec,
                       rs->model_prof_stride ? (int)H : 0};
-            hipLaunchKernelGGL(k_fps, dim3(ns), dim3(256), 0, c->stream, f, xwork);
+            hipLaunchKernelGGL(k_fps, dim3(ns), dim3(256), 0, sp, f, xwork);
         }
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_refseed_start, dim3((ns + 63) / 64), dim3(64), 0, c->stream, (const double*)d_out7, ns, d_xs, d_sph);
+        hipLaunchKernelGGL(k_refseed_start, dim3((ns + 63) / 64), dim3(64), 0, sp, (const double*)d_out7, ns, d_xs, d_sph);
         HIP_TRY(hipGetLastError());
         d_seedph = d_sph;
         if (scat) {
@@ -1366,11 +1435,11 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             if (in->data_dtype == PP_F64) {
                 const dim3 grid(resident_grid(c, k_xspec_qs1024<double>, 64, nrows, fft_grid(64, nrows)));
                 hipLaunchKernelGGL((k_xspec_qs1024<double>), grid, dim3(64), 0, c->stream, x,
-                                   (const double*)(c->ph0.as<double>() + nc), c->csum.as<double>());
+                                   (const double*)(W.ph0.as<double>() + nc), W.csum.as<double>());
             } else {
                 const dim3 grid(resident_grid(c, k_xspec_qs1024<float>, 64, nrows, fft_grid(64, nrows)));
                 hipLaunchKernelGGL((k_xspec_qs1024<float>), grid, dim3(64), 0, c->stream, x,
-                                   (const double*)(c->ph0.as<double>() + nc), c->csum.as<double>());
+                                   (const double*)(W.ph0.as<double>() + nc), W.csum.as<double>());
             }
         }
         if (!wts_early) if ((rc = run_prep())) return rc;
@@ -1387,32 +1456,33 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         FitArgs ff = fa;
         ff.act = nullptr; ff.nact = ns;
         {
-            Prof pr(c, KF_FINAL);
+            Prof pr(c, KF_FINAL, sp);
             // (phase / DM / GM fits of up to 4096 channels: the channel's numbers held in registers over the passes)
             // (its passes are separated by block-wide sums and a serial stretch: as few waves per subint as hold
             // the band at 8 channels per thread)
             const int fnt = (ff.ncs != 3 || C > 4096 || !c->finalize_regs) ? 0
                             : c->finalize_regs > 1 ? c->finalize_regs : C <= 512 ? 64 : C <= 1024 ? 128 : C <= 2048 ? 256 : 512;
-            if (fnt == 64 && C <= 512) hipLaunchKernelGGL((k_finalize<8, 64>), dim3(ns), dim3(64), 0, c->stream, ff);
-            else if (fnt == 128 && C <= 1024) hipLaunchKernelGGL((k_finalize<8, 128>), dim3(ns), dim3(128), 0, c->stream, ff);
-            else if (fnt == 256 && C <= 2048) hipLaunchKernelGGL((k_finalize<8, 256>), dim3(ns), dim3(256), 0, c->stream, ff);
-            else if (fnt == 512) hipLaunchKernelGGL((k_finalize<8, 512>), dim3(ns), dim3(512), 0, c->stream, ff);
-            else hipLaunchKernelGGL((k_finalize<0, 256>), dim3(ns), dim3(256), 0, c->stream, ff);
+            if (fnt == 64 && C <= 512) hipLaunchKernelGGL((k_finalize<8, 64>), dim3(ns), dim3(64), 0, sp, ff);
+            else if (fnt == 128 && C <= 1024) hipLaunchKernelGGL((k_finalize<8, 128>), dim3(ns), dim3(128), 0, sp, ff);
+            else if (fnt == 256 && C <= 2048) hipLaunchKernelGGL((k_finalize<8, 256>), dim3(ns), dim3(256), 0, sp, ff);
+            else if (fnt == 512) hipLaunchKernelGGL((k_finalize<8, 512>), dim3(ns), dim3(512), 0, sp, ff);
+            else hipLaunchKernelGGL((k_finalize<0, 256>), dim3(ns), dim3(256), 0, sp, ff);
         }
         HIP_TRY(hipGetLastError());
 #define PP_D2H(dst, buf, off, bytes) \
-    if (dst) HIP_TRY(hipMemcpyAsync((char*)(dst) + (off), (buf).p, (bytes), hipMemcpyDeviceToHost, c->stream))
-        if ((rc = staged_copy(c, sg.o_host, c->o_pack.p, d_seedph ? o_stage : o_bytes, hipMemcpyDeviceToHost))) return fail(rc, "output block copy failed");
+    if (dst) HIP_TRY(hipMemcpyAsync((char*)(dst) + (off), (buf).p, (bytes), hipMemcpyDeviceToHost, sp))
+        if ((rc = staged_copy(c, sg.o_host, W.o_pack.p, d_seedph ? o_stage : o_bytes, hipMemcpyDeviceToHost, sp))) return fail(rc, "output block copy failed");
         if (!chan_dev) {
-            PP_D2H(out->scales, c->o_scales, (size_t)s0 * C * 8, nc * 8);
-            PP_D2H(out->scale_errs, c->o_serrs, (size_t)s0 * C * 8, nc * 8);
-            PP_D2H(out->channel_snrs, c->o_csnr, (size_t)s0 * C * 8, nc * 8);
+            PP_D2H(out->scales, W.o_scales, (size_t)s0 * C * 8, nc * 8);
+            PP_D2H(out->scale_errs, W.o_serrs, (size_t)s0 * C * 8, nc * 8);
+            PP_D2H(out->channel_snrs, W.o_csnr, (size_t)s0 * C * 8, nc * 8);
         }
-        PP_D2H(out->obj_f, c->o_f0, (size_t)s0 * 8, (size_t)ns * 8);
-        PP_D2H(out->obj_grad, c->o_g0, (size_t)s0 * 40, (size_t)ns * 40);
-        PP_D2H(out->obj_hess, c->o_H0, (size_t)s0 * 200, (size_t)ns * 200);
+        PP_D2H(out->obj_f, W.o_f0, (size_t)s0 * 8, (size_t)ns * 8);
+        PP_D2H(out->obj_grad, W.o_g0, (size_t)s0 * 40, (size_t)ns * 40);
+        PP_D2H(out->obj_hess, W.o_H0, (size_t)s0 * 200, (size_t)ns * 200);
 #undef PP_D2H
-        if (wait) HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->eager_flush && sp != c->stream) (void)hipStreamQuery(sp);
+        if (wait) HIP_TRY(hipStreamSynchronize(sp));
         return PP_OK;
     };
     auto unpack_outputs = [&]() { unpack_stage(sg.o_host, out, s0, ns); if (d_seedph) unpack_seed_phases(sg.o_host, in, s0, ns); };
@@ -1423,8 +1493,9 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             Prof pr(c, KF_EVAL);
             hipLaunchKernelGGL(k_eval_moments, dim3(ns, nchunk), dim3(256), 0, c->stream, fa);
         }
+        if ((rc = chain_post())) return rc;
         {
-            Prof pr(c, KF_TAYLOR);
+            Prof pr(c, KF_TAYLOR, sp);
             // (rows of the Taylor model in registers where the channel count allows)
             launch_taylor_solve();
         }
@@ -1433,7 +1504,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         // launched straight behind it and the count of unfinished subints comes back with the
         // outputs -- one host round trip per batch instead of two.  (When some are left, what
         // the post-fit stage wrote for them is overwritten below.)
-        if (deferred && !seed_full && (!pilot || refseed)) {
+        if (defer_ok) {
             // nothing left for the host to decide before the outputs are on their way: pp_fit_collect
             // looks at the count of unfinished subints (and fits the batch again, synchronously, in the
             // rare case that some are left -- their guesses were poor)
@@ -1456,10 +1527,10 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             {
                 Prof pr(c, KF_PREP);
                 hipLaunchKernelGGL(k_phase0, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, ns, C,
-                                   xa.x0, xa.P, xa.nu_fit, xa.freqs, xa.freqs_stride, c->ph0.as<double>());
+                                   xa.x0, xa.P, xa.nu_fit, xa.freqs, xa.freqs_stride, W.ph0.as<double>());
             }
             XspecArgs xl = xa;
-            xl.act = c->act.as<int>(); xl.nsub = nleft;
+            xl.act = W.act.as<int>(); xl.nsub = nleft;
             if ((rc = run_xspec(xl, xmode))) return rc;
             {
                 Prof pr(c, KF_TAYLOR);
@@ -1482,7 +1553,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         FitArgs fs = fa;
         fs.cstep = kCoarseStep; fs.coff = 0; fs.nchan_x = (C + kCoarseStep - 1) / kCoarseStep; fs.x_full = 1;
         fs.use_model = 0;
-        chunking(fs.nchan_x, ns, fs.nchunk, fs.cpc);
+        chunking(fs.nchan_x, fs.nchunk, fs.cpc);
         // (a fixed number of iterations, no host check: subints that are done cost their kernels nothing)
         for (int it = 0; it < std::min(12, c->max_iter + 1); ++it) {
             { Prof pr(c, KF_EVAL);
@@ -1713,7 +1784,8 @@ extern "C" int pp_fit_enqueue(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out) {
         rc = fit_chunk(c, in, out, 0, in->nsub, bp.Kt, bp.scat, bp.nufit, bp.nuout, &deferred);
         if (rc) return rc;
         c->known_ok_bytes = std::max(c->known_ok_bytes, bp.per_sub * in->nsub);
-        HIP_TRY(hipEventRecord(sg.done, c->stream));
+        // (a deferred batch ends on the stream of its post-fit stage, which waited for its transform)
+        HIP_TRY(hipEventRecord(sg.done, (deferred && c->last_post) ? c->last_post : c->stream));
         d.queued = deferred;
         d.span_end = c->spans.size();
         if (!deferred) {

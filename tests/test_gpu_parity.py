@@ -2192,6 +2192,22 @@ def test_tnc_bounds_are_honoured():
     # other methods drop the bounds (pptoaslib.py:995-997)
     same = fit_portrait_full(*args, bounds=bnds, log10_tau=False, method='Newton-CG')
     assert same.DM == free.DM
+    # default reference frequencies (nu_fits = [None] * 3, the signature's default, pptoaslib.py:928-932): the
+    # active-set iteration resolves them ONCE, before its loop -- the constrained fit and its refits must all
+    # work at the same nu_fit (round-4 ADVICE: they did not)
+    dargs = (g["data"], g["model"], g["init_params"], float(g["P"]), g["freqs"])
+    dkw = dict(errs=g["errs"], fit_flags=[1, 1, 0, 0, 0], log10_tau=False)
+    free_d = fit_portrait_full(*dargs, method='Newton-CG', **dkw)
+    cap_d = free_d.DM - 3.0 * free_d.DM_err
+    bnds_d = [(None, None), (None, cap_d), (None, None), (None, None), (None, None)]
+    r_d = fit_portrait_full(*dargs, bounds=bnds_d, method='TNC', **dkw)
+    o_d = orc.fit_portrait_full(*dargs, bounds=bnds_d, method='TNC', **dkw)
+    assert r_d.DM == cap_d and abs(o_d.DM - cap_d) < 1e-12
+    assert _dphi(r_d.phi, o_d.phi) < 1e-7, (r_d.phi, o_d.phi)
+    np.testing.assert_allclose(r_d.chi2, o_d.chi2, rtol=1e-9)
+    np.testing.assert_allclose([r_d.nu_DM, r_d.nu_GM, r_d.nu_tau], [o_d.nu_DM, o_d.nu_GM, o_d.nu_tau], rtol=1e-6)
+    wide_d = fit_portrait_full(*dargs, bounds=[(-1.0, 1.0), (0.0, 100.0)] + [(None, None)] * 3, method='TNC', **dkw)
+    assert _dphi(wide_d.phi, free_d.phi) < 1e-12 and abs(wide_d.DM - free_d.DM) < 1e-12
 
 
 def test_coarse_phase_dm_grid_recovers_a_poor_dm_guess(eng):
@@ -2894,7 +2910,11 @@ def test_headline_shape_with_the_benchs_guesses_and_masks(guess):
 # --------------------------------------------------------------------------
 # round 4: row lengths that are no power of two
 # --------------------------------------------------------------------------
-@pytest.mark.parametrize("nbin,C", [(1000, 37), (100, 12), (1536, 20), (3000, 9), (250, 8)])
+@pytest.mark.parametrize("nbin,C", [(1000, 37), (100, 12), (1536, 20), (3000, 9), (250, 8),
+                                    # nbin 1922 ... 2046 pads its spectrum rows to 1024 harmonics, the pitch of a
+                                    # 2048-bin row: the scattering fit must NOT take the 2048-bin transform's fused
+                                    # first evaluation there (round-4 ADVICE: it did, with a wrong row stride)
+                                    (2000, 10), (2046, 6), (1922, 5)])
 def test_any_even_nbin_ragged_batch_matches_oracle(eng, nbin, C):
     """A ragged batch at a row length without a tuned plan -- masks, per-channel noise, a
     non-dedispersed DM, every phase / DM / GM family and a scattering fit, noise given and

@@ -166,14 +166,12 @@ def test_rccl_backend_with_one_rank():
     out = torch.zeros((220, ppdist.RECORD_WIDTH), dtype=torch.float64, device=dev)
     b.fit(records=out)
     mine = out.cpu().numpy()
-    # (chi2 = S_d + f is a difference of two numbers ~1e3 times its size: the child formed its guesses
-    # in batches of 256, this process in one of 220 -- last-bit differences of the guess show there; and
-    # SciPy's walk ends on a +-1 ulp(f) decision that such a difference can flip: a subint or two of the
-    # 220 may stop one closing step apart, ~1e-9 rot, which is the reference's own reproducibility)
+    # (the child formed its guesses in batches of 256, this process in one of 220: since round 5 the channel
+    # runs of pp_reference_phase_seed depend on the band alone, so the guesses -- and with them every output --
+    # are the same bits whatever the batch; until round 4 up to 4 of the 220 rows moved by ~1e-9 rot)
     tail = rec[1280:]
     moved = (np.abs(mine[:, :13] - tail[:, :13]) > 1e-13 * np.abs(tail[:, :13]) + 1e-15).any(axis=1)
-    assert moved.sum() <= 4, int(moved.sum())
-    np.testing.assert_allclose(mine[moved, :2], tail[moved, :2], rtol=0, atol=5e-9)
-    np.testing.assert_array_equal(mine[~moved, 16:], tail[~moved, 16:])
-    np.testing.assert_allclose(mine[:, 13:16], tail[:, 13:16], rtol=1e-9)
+    assert moved.sum() == 0, int(moved.sum())
+    np.testing.assert_array_equal(mine[:, 16:], tail[:, 16:])
+    np.testing.assert_allclose(mine[:, 13:16], tail[:, 13:16], rtol=1e-11)
     b.free(); eng.close()

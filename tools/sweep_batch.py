@@ -20,7 +20,8 @@ worst = {}
 nfit = 0
 for b in range(nb):
     flags, scat = FLAGS[b % len(FLAGS)]
-    C = int(rng.integers(8, 40)); nbin = int(2 ** rng.integers(*LOG2NBIN)); N = int(rng.integers(5, 14))
+    # (bands up to 512 channels: at 128 channels and more the channel sums are formed in several chunks)
+    C = int(rng.integers(8, 40)) if rng.random() < 0.5 else int(rng.integers(64, 513)); nbin = int(2 ** rng.integers(*LOG2NBIN)); N = int(rng.integers(5, 14))
     l10 = bool(rng.random() < 0.6) if scat else False
     freqs, model = model_portrait(C, nbin)
     eng.set_model(model)
