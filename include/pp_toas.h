@@ -165,6 +165,11 @@ void* pp_stream(pp_ctx* ctx);
  *   "copy_kernels"  1 (default) = the packed block of small inputs and the packed per-subint outputs cross PCIe by a
  *                  kernel that reads / writes the pinned staging block directly; 0 = by hipMemcpyAsync (a copy
  *                  command between two kernels hands the stream to the copy engine and back: ~0.05 ms per batch)
+ *   "overlap_post"  pp_fit_enqueue: 1 = the solve and post-fit stage of a deferred batch are queued on a second,
+ *                  higher-priority stream of the context behind an event of its transform, with a work-buffer set
+ *                  of their own, so that they may run beside the NEXT batch's transform; 0 (default) = one stream.
+ *                  Same results either way.  Measured neutral (profiles/r05_overlap_ab.txt): the persistent transform
+ *                  holds every wave slot, the two kernels alternate instead of co-residing
  *   "coarse_newton"  1 (default) = scattering fits with PP_METHOD_NEWTON first iterate on every 16th channel
  *                  (each evaluation reads a sixteenth of the stored cross-spectrum) and start the
  *                  full-channel iteration from that answer -- the optimum does not depend on the path --;

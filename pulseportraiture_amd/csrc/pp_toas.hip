@@ -132,7 +132,16 @@ struct pp_ctx {
     WorkSet work[2];
     hipStream_t stream2 = nullptr;   // solve + post-fit stage of deferred batches (higher priority than `stream`)
     hipStream_t last_post = nullptr; // the stream the last fit_chunk queued its post-fit stage on
-    int overlap_post = 1;            // deferred batches: 1 = solve / post-fit stage on stream2, beside the next transform
+    int overlap_post = 0;            // deferred batches: 1 = solve / post-fit stage on stream2, beside the next transform.
+                                     // Measured (profiles/r05_overlap_ab.txt, three alternations on one box): no gain --
+                                     // headline 67.8-68.0 k fits/s either way, configs[1] 735-754 k either way, configs[2]
+                                     // -0.5 ... -2.8 %.  The persistent transform of the next batch holds every wave slot
+                                     // (two waves of 250 VGPRs per SIMD) before the solve's workgroups (four waves + 64 KB
+                                     // of LDS on one CU) are dispatched, stream priority notwithstanding: the solve's event
+                                     // span grows from 0.46 to 12-14 ms, i.e. it runs when that transform's workgroups
+                                     // retire.  And a wave slot given to the solve is one the transform does not have:
+                                     // with registers as the binding resource the two do not co-reside, they alternate.
+                                     // Kept as an option: the work-set / two-stream plumbing is what a fused tail would use.
     DevBuf inpack;   // (aux entry points)
     // pinned host staging of the small inputs / the packed outputs of a batch: two sets, so that a
     // deferred batch (pp_fit_enqueue) keeps its own while the next one is being queued

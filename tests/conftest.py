@@ -16,7 +16,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # initialised the GPU must not start other programs on this pool) -- it runs beside the
 # first tests and is collected by the last one
 BENCH_CHILD = {}
-BENCH_CHILD_ARGS = ["--total-nsub", "2500", "--nsub", "1024", "--no-cpu-baseline"]
+# (--group 2: two resident sub-batches of 68.7 GB -- the children and the tests share one GPU)
+BENCH_CHILD_ARGS = ["--total-nsub", "2500", "--nsub", "1024", "--group", "2", "--no-cpu-baseline"]
 
 
 def pytest_configure(config):
@@ -26,7 +27,7 @@ def pytest_configure(config):
 def pytest_collection_finish(session):
     # only when a test that collects a child is going to run
     want = ("test_strong_scaling_bench_in_a_child_process", "test_two_ranks_sharing_the_gpu",
-            "test_rccl_backend_with_one_rank")
+            "test_rccl_backend_with_one_rank", "test_rccl_backend_with_two_ranks")
     if not any(w in it.nodeid for it in session.items for w in want) or os.environ.get("PP_NO_BENCH_CHILD"):
         return
     try:
@@ -85,9 +86,30 @@ def pytest_collection_finish(session):
             BENCH_CHILD["rccl_" + tag] = dict(proc=p1, out=o, err=e, records=r1)
 
 
+    # ... and, on a node with two GPUs or more, the real thing: TWO ranks, one GPU each, over the "nccl" backend
+    # (RCCL over xGMI).  The one-GPU boxes of this pool skip it (tests/test_gpu_zz_bench.py).
+    if any("test_rccl_backend_with_two_ranks" in it.nodeid for it in session.items) and torch.cuda.device_count() >= 2:
+        import socket
+        for tag, extra in (("weak", ["--nsub", "256", "--steps", "2", "--no-other-workloads"]),
+                           ("strong", ["--total-nsub", "1500", "--nsub", "256"])):
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            o = open(os.path.join(tmp, "lineN2_%s.json" % tag), "w")
+            e = open(os.path.join(tmp, "stderrN2_%s.txt" % tag), "w")
+            r1 = os.path.join(tmp, "recordsN2_%s.npy" % tag)
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                   "--gpus", "2", "--no-cpu-baseline"] + extra
+            if tag == "strong":
+                cmd += ["--dump-records", r1]
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+            env.pop("PP_BENCH_SHARE_GPU", None)
+            p1 = subprocess.Popen(cmd, stdout=o, stderr=e, cwd=ROOT, env=env)
+            BENCH_CHILD["rccl2_" + tag] = dict(proc=p1, out=o, err=e, records=r1)
+
+
 def pytest_sessionfinish(session, exitstatus):
     procs = [BENCH_CHILD.get("proc")] + [v.get("proc") for k, v in BENCH_CHILD.items()
-                                         if k.startswith("two_") or k.startswith("rccl_")]
+                                         if k.startswith("two_") or k.startswith("rccl_") or k.startswith("rccl2_")]
     for proc in procs:
         if proc is not None and proc.poll() is None:
             proc.kill()

@@ -164,7 +164,10 @@ def _worker_strong(rank, world, port, total, nsub, q):
         while g < hi:
             want.append((g, min(nsub, hi - g)))
             g += nsub
-        assert made[0].calls == want, (made[0].calls, want)
+        # (the shard is worked through in groups of up to three resident sub-batches: the calls of all of them)
+        assert len(made) <= 3
+        calls = sorted(c for m in made for c in m.calls)
+        assert calls == want, (calls, want)
         q.put((rank, line))
         dist.barrier()
     finally:

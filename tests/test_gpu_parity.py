@@ -3165,6 +3165,42 @@ def test_transport_and_prefetch_options_change_nothing(eng):
             eng.set_option(k, saved[k])
 
 
+def test_post_fit_stage_on_its_own_stream_changes_nothing(eng):
+    """Option `overlap_post`: the solve and post-fit stage of an enqueued batch on the context's second stream,
+    with a work-buffer set of their own, behind an event of the transform -- so that they MAY run beside the
+    next batch's transform.  Three batches two deep (plain, masked + measured noise, the reference's seed
+    inside the pass): bitwise what the one-stream flow and the synchronous call return, in order."""
+    nsub = 9
+    data, freqs, P, x0, kw = _medium_batch(eng, nsub, C=256, B=2048, seed=5)
+    rng = np.random.default_rng(5)
+    mask = (rng.random((nsub, 256)) > 0.2).astype(np.uint8)
+    from tests.synth_host import model_portrait
+    _, model = model_portrait(256, 2048)
+    nu_mean = np.full(nsub, freqs.mean())
+    rs = dict(weights=None, model_profs=model.mean(axis=0), nu_mean=nu_mean, Ns=100, finish='simplex')
+    kw_m = dict(kw, chan_mask=mask); kw_m["errs"] = None
+    jobs = [(x0, kw), (x0, kw_m), (x0, dict(kw, ref_seed=rs)), (x0, dict(kw, method='newton', fit_flags=[1, 1, 1, 0, 0]))]
+    sync = [eng.fit_batch(data, freqs, P, x, **k) for x, k in jobs]
+    keys = ("params", "param_errs", "nu_refs", "cov", "chi2", "red_chi2", "snr", "nfeval", "npass", "return_code",
+            "scales", "scale_errs", "channel_snrs")
+    try:
+        for ov in (1, 0, 1):
+            eng.set_option("overlap_post", ov)
+            got = []
+            for j, (x, k) in enumerate(jobs * 2):
+                eng.enqueue(data, freqs, P, x, **k)
+                if j > 0:
+                    got.append(eng.collect())
+            got.append(eng.collect())
+            for a, b in zip(sync * 2, got):
+                for key in keys:
+                    np.testing.assert_array_equal(a[key], b[key], err_msg="overlap_post=%d %s" % (ov, key))
+                if "seed_phase" in a:
+                    np.testing.assert_array_equal(a["seed_phase"], b["seed_phase"])
+    finally:
+        eng.set_option("overlap_post", 0)
+
+
 @pytest.mark.parametrize("seed", ["reference", "device"])
 def test_get_TOAs_at_a_row_length_that_is_no_power_of_two(seed):
     """GetTOAs.get_TOAs end to end on 1000-bin data (the reference's rfft takes any nbin): the

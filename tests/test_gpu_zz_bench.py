@@ -35,7 +35,9 @@ def test_strong_scaling_bench_in_a_child_process():
     assert cfg["total_nsub"] == total and cfg["fits_per_rank"] == [total] and cfg["sub_batch"] == nsub
     assert cfg["sub_batches_rank0"] == [1024, 1024, 452]              # (the ragged last sub-batch)
     assert line["gathered_records"]["rows"] == total
-    assert line["value"] > 1e4 and line["max_abs_dDM_over_err"] < 6.0
+    # (the rate is no measurement here: five bench children and the test process share the box's one GPU)
+    assert line["value"] > 1e3 and line["max_abs_dDM_over_err"] < 6.0
+    assert cfg["resident_sub_batches"] == 2 and cfg["steps_in_flight"] == 2
     rec = np.load(BENCH_CHILD["records"])
     assert rec.shape == (total, ppdist.RECORD_WIDTH)
     np.testing.assert_allclose(rec.sum(axis=0), line["gathered_records"]["column_sums"], rtol=1e-12)
@@ -51,9 +53,10 @@ def test_strong_scaling_bench_in_a_child_process():
         out = torch.zeros((n, ppdist.RECORD_WIDTH), dtype=torch.float64, device=dev)
         r = b.fit(records=out)
         mine = out.cpu().numpy()
-        np.testing.assert_array_equal(mine[:, 16:], rec[first:first + n, 16:])         # nfeval, return_code
-        np.testing.assert_allclose(mine[:, :16], rec[first:first + n, :16], rtol=1e-13, atol=1e-15)
-        np.testing.assert_allclose(r["params"], rec[first:first + n, :5], rtol=1e-13, atol=1e-15)
+        # (bit for bit: the child fitted these subints in sub-batches of 1024 / 452, this process in batches of
+        # 48 / 452 -- a subint's answer does not depend on the batch)
+        np.testing.assert_array_equal(mine, rec[first:first + n])
+        np.testing.assert_array_equal(r["params"], rec[first:first + n, :5])
         b.free()
     eng.close()
 
@@ -98,8 +101,7 @@ def test_two_ranks_sharing_the_gpu():
     out = torch.zeros((total, ppdist.RECORD_WIDTH), dtype=torch.float64, device=dev)
     b.fit(records=out)
     mine = out.cpu().numpy()
-    np.testing.assert_array_equal(mine[:, 16:], rec[:, 16:])            # nfeval, return_code: rank 0's and rank 1's
-    np.testing.assert_allclose(mine[:, :16], rec[:, :16], rtol=1e-13, atol=1e-15)
+    np.testing.assert_array_equal(mine, rec)            # rank 0's and rank 1's, bit for bit (sub-batches 256 + 44 there, 600 here)
     b.free(); eng.close()
     w = lines["weak"]
     assert w["scaling"] == "weak" and w["n_gpus"] == 2 and w["steps"] == 2
@@ -175,3 +177,55 @@ def test_rccl_backend_with_one_rank():
     np.testing.assert_array_equal(mine[:, 16:], tail[:, 16:])
     np.testing.assert_allclose(mine[:, 13:16], tail[:, 13:16], rtol=1e-11)
     b.free(); eng.close()
+
+
+@pytest.mark.timeout(900)
+def test_rccl_backend_with_two_ranks():
+    """N = 2 for real -- one rank per GPU over the "nccl" backend (RCCL over xGMI) -- on a node that has two
+    GPUs; the one-GPU boxes of this pool skip it.  Weak mode (256 subints per rank and step): rows and
+    bookkeeping.  configs[4]'s strong mode (1500 subints in shards of 750, sub-batches 256 + 256 + 238):
+    every gathered record against fits made directly in this process -- bit for bit, since a subint's
+    answer does not depend on how shards and sub-batches fall (tests/test_gpu_y_batch_independence.py)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (this box has %d)" % torch.cuda.device_count())
+    from tests.conftest import BENCH_CHILD
+    import bench
+    from pulseportraiture_amd import dist as ppdist
+    from pulseportraiture_amd.engine import Engine
+    if os.environ.get("PP_NO_BENCH_CHILD"):
+        pytest.skip("PP_NO_BENCH_CHILD")
+    lines = {}
+    for tag in ("weak", "strong"):
+        ch = BENCH_CHILD.get("rccl2_" + tag)
+        assert ch is not None, "conftest did not start the two-rank RCCL bench"
+        rc = ch["proc"].wait(timeout=800)
+        ch["out"].close(); ch["err"].close()
+        text = open(os.path.join(BENCH_CHILD["tmp"], "lineN2_%s.json" % tag)).read().strip()
+        err = open(os.path.join(BENCH_CHILD["tmp"], "stderrN2_%s.txt" % tag)).read()
+        assert rc == 0 and text, err[-3000:]
+        out_lines = [ln for ln in text.splitlines() if ln.strip()]
+        assert len(out_lines) == 1, out_lines[:5]
+        lines[tag] = json.loads(out_lines[0])
+    w = lines["weak"]
+    assert w["scaling"] == "weak" and w["n_gpus"] == 2 and w["steps"] == 2
+    assert w["gathered_records"]["rows"] == 2 * 2 * 256 and "2 rank(s)" in w["config"]["parallelism"]
+    assert abs(w["value"] - 2 * 256 * 2 / (w["ms_per_step"] * 2e-3)) < 5e-3 * w["value"]
+    s = lines["strong"]
+    total = 1500
+    assert s["scaling"] == "strong" and s["n_gpus"] == 2
+    assert s["config"]["fits_per_rank"] == [750, 750] and s["config"]["sub_batches_rank0"] == [256, 256, 238]
+    rec = np.load(BENCH_CHILD["rccl2_strong"]["records"])
+    assert rec.shape == (total, ppdist.RECORD_WIDTH) and (rec[:, 17] == 2).all()
+    np.testing.assert_allclose(rec.sum(axis=0), s["gathered_records"]["column_sums"], rtol=1e-12)
+    ns = argparse.Namespace(seed=20260101, dm0=34.56789, dm_offset=[3e-4, 2e-4], sigma=0.05,
+                            truth_guesses=False, measured_noise=False, method="trust-ncg")
+    eng = Engine(0)
+    dev = torch.device("cuda", 0)
+    for first, n in ((0, 300), (750, 256), (1262, 238)):       # rank 0's start, rank 1's first and last sub-batch
+        b = bench.Batch(eng, ns, dev, s["config"]["workload"], n, "f64", first)
+        out = torch.zeros((n, ppdist.RECORD_WIDTH), dtype=torch.float64, device=dev)
+        b.fit(records=out)
+        np.testing.assert_array_equal(out.cpu().numpy(), rec[first:first + n])
+        b.free()
+    eng.close()
