@@ -267,6 +267,219 @@ __global__ __launch_bounds__(FftPlan<L>::T) void k_rotate_any(RotateArgs a, AnyA
     }
 }
 
+// --------------------------------------------------------------------------
+// Round 5: the auxiliary entry points at any even row length (ppalign's accumulation, the per-channel
+// chi^2 of the zap proposals, the template synthesisers' scattering filter, the synthetic generator).
+// All of them work on HARMONICS: k_any (mode -1) leaves the harmonics 0..M of every row in
+// hout[row][M + 1], a small kernel does the entry point's arithmetic per harmonic, and k_irfft_any
+// brings rows of harmonics back to the time domain by the chirp-z route.
+// --------------------------------------------------------------------------
+// one chirp-z transform of the M values in buf (zero-padded to L): DFT_M(buf)[k] -> buf[k]
+template <int L>
+__device__ __forceinline__ void czt_any(cplx* buf, cplx* lds, const AnyArgs& g, int tid) {
+    constexpr int T = FftPlan<L>::T, PL = FftPlan<L>::PADLOG;
+    const int M = g.M;
+    const double invL = 1.0 / (double)L;
+    for (int j = tid; j < L; j += T) buf[j] = (j < M) ? cmul(buf[j], g.chirp[j]) : make_double2(0.0, 0.0);
+    __syncthreads();
+    fft_row<L, cplx>(lds, buf, g.twL, tid);
+    __syncthreads();
+    for (int k = tid; k < L; k += T) {
+        const cplx p = cmul(lds[lds_pad<PL>(k)], g.bft[k]);
+        buf[k] = make_double2(p.x, -p.y);
+    }
+    __syncthreads();
+    fft_row<L, cplx>(lds, buf, g.twL, tid);
+    __syncthreads();
+    for (int k = tid; k < M; k += T) {
+        const cplx c = lds[lds_pad<PL>(k)];
+        buf[k] = cmul(make_double2(c.x * invL, -c.y * invL), g.chirp[k]);
+    }
+    __syncthreads();
+}
+
+// conj of the packed spectrum of the inverse real transform: slot k of the M complex values whose
+// DFT (conjugated, / M) is the row; yk = harmonic k, ym = harmonic M - k (k = 0: DC and Nyquist, both real)
+__device__ __forceinline__ cplx irfft_pack(cplx yk, cplx ym, cplx wk) {
+    ym.y = -ym.y;
+    const cplx ev = make_double2(0.5 * (yk.x + ym.x), 0.5 * (yk.y + ym.y));
+    cplx od = make_double2(0.5 * (yk.x - ym.x), 0.5 * (yk.y - ym.y));
+    wk.y = -wk.y;
+    od = cmul(od, wk);
+    return make_double2(ev.x - od.y, -(ev.y + od.x));   // conj(ev + i od)
+}
+
+// numpy.fft.irfft of rows of harmonics h[row][M + 1] (the imaginary parts of h_0 and h_M are ignored, as
+// irfft ignores them): out[row][nbin]
+template <int L>
+__global__ __launch_bounds__(FftPlan<L>::T) void k_irfft_any(const cplx* harm, AnyArgs g, long long nrows, double* out) {
+    constexpr int T = FftPlan<L>::T;
+    __shared__ cplx lds[FftPlan<L>::LDS_ELEMS];
+    __shared__ cplx buf[L];
+    const int tid = threadIdx.x;
+    const int M = g.M;
+    for (long long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const cplx* h = harm + (size_t)row * (M + 1);
+        for (int k = tid; k < M; k += T) {
+            const cplx yk = (k == 0) ? make_double2(h[0].x, 0.0) : h[k];
+            const cplx ym = (k == 0) ? make_double2(h[M].x, 0.0) : h[M - k];
+            buf[k] = irfft_pack(yk, ym, g.twB[k]);
+        }
+        __syncthreads();
+        czt_any<L>(buf, lds, g, tid);
+        double* o = out + (size_t)row * g.nbin;
+        const double inv = 1.0 / (double)M;
+        for (int j = tid; j < M; j += T) {
+            const cplx r = buf[j];
+            o[2 * j] = r.x * inv;
+            o[2 * j + 1] = -r.y * inv;
+        }
+        __syncthreads();
+    }
+}
+
+// k_synth for general row lengths: dst = gain irfft(m_k e^{2 pi i k phi_n}) + sigma N(0, 1) from the slot's
+// spectrum (rows pitched to Mp)
+template <int L, typename Tout>
+__global__ __launch_bounds__(FftPlan<L>::T) void k_synth_any(SynthArgs a, AnyArgs g) {
+    constexpr int T = FftPlan<L>::T;
+    __shared__ cplx lds[FftPlan<L>::LDS_ELEMS];
+    __shared__ cplx buf[L];
+    const int tid = threadIdx.x;
+    const int M = g.M;
+    const long long nrows = (long long)a.nsub * a.nchan;
+    for (long long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int i = (int)(row / a.nchan), n = (int)(row % a.nchan);
+        const double nu = a.freqs[n], P = a.P[i];
+        const double a2 = 1.0 / (nu * nu);
+        const double phin = -(a.inj[i * 3] + PP_DCONST * a.inj[i * 3 + 1] * a2 / P +
+                              PP_DCONST * PP_DCONST * a.inj[i * 3 + 2] * a2 * a2 / P);
+        const cplx* mrow = a.mft + (size_t)n * g.Mp;
+        const double yM = cmul(mrow[M - 1], unit_phasor((double)M, phin)).x;   // Nyquist: real part
+        for (int k = tid; k < M; k += T) {
+            cplx yk, ym;
+            if (k == 0) { yk = make_double2(a.mdc[n], 0.0); ym = make_double2(yM, 0.0); }
+            else {
+                yk = cmul(mrow[k - 1], unit_phasor((double)k, phin));
+                ym = cmul(mrow[M - k - 1], unit_phasor((double)(M - k), phin));
+            }
+            buf[k] = irfft_pack(yk, ym, g.twB[k]);
+        }
+        __syncthreads();
+        czt_any<L>(buf, lds, g, tid);
+        Tout* out = reinterpret_cast<Tout*>(a.dst) + (size_t)row * g.nbin;
+        const double inv = (a.gain ? a.gain[row] : 1.0) / (double)M;
+        for (int j = tid; j < M; j += T) {
+            const cplx r = buf[j];
+            double z0, z1;
+            normal_pair(a.seed, a.first_subint + i, n, j, z0, z1);
+            out[2 * j] = (Tout)(r.x * inv + a.sigma * z0);
+            out[2 * j + 1] = (Tout)(-r.y * inv + a.sigma * z1);
+        }
+        __syncthreads();
+    }
+}
+
+// ppalign's accumulation (ppalign.py:199-206; k_align_accum for general row lengths): spec[n][k] (+)= sum_i w_in
+// d_ink e^{2 pi i k phi_in} over the ns subints of this chunk, in index order; hout is k_any's, channel-major
+// (row = n ns + i); the DC harmonic is unchanged, the Nyquist harmonic keeps its real part (irfft)
+__global__ __launch_bounds__(256) void k_align_harm(const cplx* hout, AlignArgs a, int s0, int ns, int M, cplx* spec,
+                                                    double* totw, int first) {
+    const int n = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > M) return;
+    const int H = M + 1;
+    cplx acc = first ? make_double2(0.0, 0.0) : spec[(size_t)n * H + k];
+    double wsum = first ? 0.0 : totw[n];
+    for (int ii = 0; ii < ns; ++ii) {
+        const int i = s0 + ii;
+        const double w = a.w[(size_t)i * a.nchan + n];
+        if (w == 0.0 || w != w) continue;
+        const double nu = a.freqs[(size_t)i * a.freqs_stride + n], P = a.P[i];
+        const double phase = a.par[i * 3], DM = a.par[i * 3 + 1], nuref = a.par[i * 3 + 2];
+        // reference order of operations (pplib.py:2419-2424)
+        const double D = PP_DCONST * DM / P;
+        const double iref = (nuref == INFINITY) ? 0.0 : 1.0 / (nuref * nuref);
+        const double phin = (DM == 0.0) ? phase : phase + D * (1.0 / (nu * nu) - iref);
+        const cplx d = hout[((size_t)n * ns + ii) * H + k];
+        cplx y;
+        if (k == 0) y = make_double2(d.x, 0.0);
+        else {
+            const cplx e = unit_phasor((double)k, phin);
+            y = (k == M) ? make_double2(d.x * e.x, 0.0) : cmul(d, e);
+        }
+        acc.x = fma(w, y.x, acc.x);
+        acc.y = fma(w, y.y, acc.y);
+        wsum += w;
+    }
+    spec[(size_t)n * H + k] = acc;
+    if (k == 0) totw[n] = wsum;
+}
+
+// per-channel reduced chi^2 (k_chan_chi2 for general row lengths) from k_any's harmonics of the data rows,
+// channel-major (row = n ns + i); the slot's spectrum rows are pitched to Mp
+__global__ __launch_bounds__(256) void k_chan_chi2_harm(const cplx* hout, ChanChi2Args a, int s0, int ns, int M, int Mp) {
+    __shared__ double scratch[4];
+    const int tid = threadIdx.x;
+    const int H = M + 1;
+    const long long nrows = (long long)ns * a.nchan;
+    for (long long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int ii = (int)(row / a.nchan), n = (int)(row % a.nchan), i = s0 + ii;
+        const double nu = a.freqs[(size_t)i * a.freqs_stride + n], P = a.P[i];
+        const double* pr = a.par + (size_t)i * 5;
+        const double nuDM = a.nuref[i * 3], nuGM = a.nuref[i * 3 + 1], nutau = a.nuref[i * 3 + 2];
+        const double a2 = 1.0 / (nu * nu);
+        const double iDM = (nuDM == INFINITY) ? 0.0 : 1.0 / (nuDM * nuDM);
+        const double iGM = (nuGM == INFINITY) ? 0.0 : 1.0 / (nuGM * nuGM * nuGM * nuGM);
+        const double phin = pr[0] + PP_DCONST * pr[1] * (a2 - iDM) / P +
+                            PP_DCONST * PP_DCONST * pr[2] * (a2 * a2 - iGM) / P;
+        const double taun = (pr[3] != 0.0) ? pr[3] * pow(nu / nutau, pr[4]) : 0.0;
+        const int sl = a.slot ? a.slot[i] : 0;
+        const cplx* mrow = as_global(a.mft[sl]) + (size_t)n * Mp;
+        const double m0 = as_global(a.mdc[sl])[n];
+        const double sc = a.scales[(size_t)i * a.nchan + n], sg = a.errs[(size_t)i * a.nchan + n];
+        const cplx* h = hout + ((size_t)n * ns + ii) * H;
+        double sum = 0.0;
+        for (int k = tid; k <= M; k += 256) {
+            double wgt = 2.0;
+            cplx d, m;
+            if (k == 0) { d = make_double2(h[0].x, 0.0); m = make_double2(m0, 0.0); wgt = 1.0; }
+            else {
+                d = (k == M) ? make_double2(h[M].x, 0.0) : h[k];
+                d = cmul(d, unit_phasor((double)k, phin));
+                m = mrow[k - 1];
+                if (taun != 0.0) {
+                    const double x = PP_TWO_PI * (double)k * taun, den = 1.0 / (1.0 + x * x);
+                    m = cmul(m, make_double2(den, -x * den));
+                }
+            }
+            cplx r = make_double2(d.x - sc * m.x, d.y - sc * m.y);
+            if (k == M) { r.y = 0.0; wgt = 1.0; }     // irfft drops the imaginary part at Nyquist
+            sum = fma(wgt, cnorm(r), sum);
+        }
+        sum = group_sum<64>(sum);
+        if ((tid & 63) == 0) scratch[tid >> 6] = sum;
+        __syncthreads();
+        if (tid == 0) {
+            const double tot = ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+            a.out[(size_t)i * a.nchan + n] = tot / (2.0 * M) / (sg * sg) / (double)(2 * M - 2);
+        }
+        __syncthreads();
+    }
+}
+
+// the scattering filter of a Gaussian-component template at general row lengths: h_nk <- h_nk / (1 + 2 pi i k tau_n),
+// tau_n = tau_ref (nu_n / nu_ref)^alpha; DC unchanged, Nyquist Re(d_M B_M) with d_M real (k_gauss_portrait)
+__global__ __launch_bounds__(256) void k_scatter_harm(cplx* harm, const double* freqs, double nu_ref, double tau_ref,
+                                                      double alpha, int M) {
+    const int n = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > M || k == 0) return;
+    const double taun = tau_ref * pow(freqs[n] / nu_ref, alpha);
+    cplx* h = harm + (size_t)n * (M + 1);
+    const double xk = PP_TWO_PI * (double)k * taun, dk = 1.0 / (1.0 + xk * xk);
+    if (k == M) h[M] = make_double2(h[M].x * dk, 0.0);
+    else h[k] = cmul(h[k], make_double2(dk, -xk * dk));
+}
+
 // The reference's rot_prof from the harmonics k_any left in hout (general row lengths; pp_reference_phase_seed):
 // spec[i][k] = sum_n w_n d_nk e^{2 pi i k phi'_n} / sum_n w_n, phi'_n the rotation of rotate_data
 // (pplib.py:2338-2426).  hout rows are channel-major (row = n nsub + i).  One thread per harmonic,

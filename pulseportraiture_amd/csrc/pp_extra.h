@@ -426,6 +426,57 @@ __device__ __forceinline__ double gauss_val(double x, const GaussComp& g) {
     return (fabs(z) < 20.0) ? exp(-0.5 * mul_rn(z, z)) / g.norm : 0.0;
 }
 
+// the evolved components of channel frequency nu on a row of B bins (threads tid, tid + T, ... of the workgroup)
+__device__ __forceinline__ void gauss_components(const GaussArgs& a, double nu, int B, GaussComp* gc, int tid, int T) {
+    for (int c = tid; c < a.ngauss; c += T) {
+        const double* p = a.comps + c * 6;
+        const double loc = gauss_evolve(nu, a.nu_ref, p[0], p[1], a.code_loc);
+        const double wid = gauss_evolve(nu, a.nu_ref, p[2], p[3], a.code_wid);
+        GaussComp g;
+        g.amp = gauss_evolve(nu, a.nu_ref, p[4], p[5], a.code_amp);
+        g.on = wid > 0.0;
+        g.sigma = (g.on ? wid : 1.0) / (2.0 * sqrt(2.0 * log(2.0)));
+        g.mean = loc - floor(loc);                 // loc % 1.0
+        g.norm = g.sigma * sqrt(2.0 * PP_TWO_PI * 0.5);   // sigma sqrt(2 pi)
+        // peak bin = argmax of the sampled profile (first maximum): the bin
+        // centre nearest to the mean, searched among its neighbours
+        const int j0 = min(B - 1, max(0, (int)floor(g.mean * (double)B)));
+        int jb = -1; double vb = -1.0;
+        for (int dj = -1; dj <= 1; ++dj) {
+            const int j = (j0 + dj + B) % B;
+            const double v = gauss_val(gauss_bin_centre(j, B), g);
+            if (v > vb || (v == vb && j < jb)) { vb = v; jb = j; }
+        }
+        const double zpk = (gauss_wrap(gauss_bin_centre(jb, B), g.mean) - loc) / g.sigma;
+        g.fact = (vb > 0.0) ? exp(-0.5 * mul_rn(zpk, zpk)) / vb : 0.0;
+        gc[c] = g;
+    }
+}
+// the value of the (unscattered) template row at bin j of B
+__device__ __forceinline__ double gauss_row_value(const GaussArgs& a, const GaussComp* gc, int j, int B) {
+    const double x = gauss_bin_centre(j, B);
+    double sum = 0.0;
+    for (int c = 0; c < a.ngauss; ++c) {
+        const GaussComp g = gc[c];
+        if (g.on) sum = add_rn(sum, mul_rn(g.amp, mul_rn(g.fact, gauss_val(x, g))));
+    }
+    return add_rn(a.dc, sum);
+}
+
+// the unscattered rows at ANY row length B (round 5: general even nbin; the scattering filter then goes through
+// the harmonics -- k_any, k_scatter_harm, k_irfft_any of pp_anybin.h)
+__global__ __launch_bounds__(256) void k_gauss_rows(GaussArgs a, int B) {
+    __shared__ GaussComp gc[PP_MAX_GAUSS];
+    const int tid = threadIdx.x;
+    for (int n = blockIdx.x; n < a.nchan; n += gridDim.x) {
+        gauss_components(a, a.freqs[n], B, gc, tid, 256);
+        __syncthreads();
+        double* out = a.out + (size_t)n * B;
+        for (int j = tid; j < B; j += 256) out[j] = gauss_row_value(a, gc, j, B);
+        __syncthreads();
+    }
+}
+
 template <int M>
 __global__ __launch_bounds__(FftPlan<M>::T) void k_gauss_portrait(GaussArgs a) {
     constexpr int T = FftPlan<M>::T, B = 2 * M;
@@ -436,39 +487,9 @@ __global__ __launch_bounds__(FftPlan<M>::T) void k_gauss_portrait(GaussArgs a) {
     const int tid = threadIdx.x;
     for (int n = blockIdx.x; n < a.nchan; n += gridDim.x) {
         const double nu = a.freqs[n];
-        for (int c = tid; c < a.ngauss; c += T) {
-            const double* p = a.comps + c * 6;
-            const double loc = gauss_evolve(nu, a.nu_ref, p[0], p[1], a.code_loc);
-            const double wid = gauss_evolve(nu, a.nu_ref, p[2], p[3], a.code_wid);
-            GaussComp g;
-            g.amp = gauss_evolve(nu, a.nu_ref, p[4], p[5], a.code_amp);
-            g.on = wid > 0.0;
-            g.sigma = (g.on ? wid : 1.0) / (2.0 * sqrt(2.0 * log(2.0)));
-            g.mean = loc - floor(loc);                 // loc % 1.0
-            g.norm = g.sigma * sqrt(2.0 * PP_TWO_PI * 0.5);   // sigma sqrt(2 pi)
-            // peak bin = argmax of the sampled profile (first maximum): the bin
-            // centre nearest to the mean, searched among its neighbours
-            const int j0 = min(B - 1, max(0, (int)floor(g.mean * (double)B)));
-            int jb = -1; double vb = -1.0;
-            for (int dj = -1; dj <= 1; ++dj) {
-                const int j = (j0 + dj + B) % B;
-                const double v = gauss_val(gauss_bin_centre(j, B), g);
-                if (v > vb || (v == vb && j < jb)) { vb = v; jb = j; }
-            }
-            const double zpk = (gauss_wrap(gauss_bin_centre(jb, B), g.mean) - loc) / g.sigma;
-            g.fact = (vb > 0.0) ? exp(-0.5 * mul_rn(zpk, zpk)) / vb : 0.0;
-            gc[c] = g;
-        }
+        gauss_components(a, nu, B, gc, tid, T);
         __syncthreads();
-        for (int j = tid; j < B; j += T) {
-            const double x = gauss_bin_centre(j, B);
-            double sum = 0.0;
-            for (int c = 0; c < a.ngauss; ++c) {
-                const GaussComp g = gc[c];
-                if (g.on) sum = add_rn(sum, mul_rn(g.amp, mul_rn(g.fact, gauss_val(x, g))));
-            }
-            reinterpret_cast<double*>(zin)[j] = add_rn(a.dc, sum);
-        }
+        for (int j = tid; j < B; j += T) reinterpret_cast<double*>(zin)[j] = gauss_row_value(a, gc, j, B);
         __syncthreads();
         double* out = a.out + (size_t)n * B;
         const double taun = (a.tau_ref != 0.0) ? a.tau_ref * pow(nu / a.nu_ref, a.alpha) : 0.0;
@@ -583,9 +604,11 @@ __global__ __launch_bounds__(256) void k_spline_portrait(SplineArgs a) {
 // and wid_n the dispersive smearing of channel n in rotations (0 = none).  Re-forms
 // |m_nk|^2, its sum and maximum per channel, and the DC term.
 // --------------------------------------------------------------------------
+// (Mp: pitch of the slot's spectrum rows -- M, or M rounded up to 64 with zeros beyond M for row lengths that are
+// no power of two; rconst has M + 1 entries)
 __global__ __launch_bounds__(256) void k_model_response(cplx* mft, double* msq, double* msum, double* mmax,
                                                         double* mdc, const cplx* rconst, const double* wid,
-                                                        int nchan, int M) {
+                                                        int nchan, int M, int Mp) {
     __shared__ double scratch[8];
     const int n = blockIdx.x, tid = threadIdx.x;
     const double wn = wid ? wid[n] : 0.0;
@@ -598,10 +621,10 @@ __global__ __launch_bounds__(256) void k_model_response(cplx* mft, double* msq, 
             const double sc = sin(y) / y;
             r.x *= sc; r.y *= sc;
         }
-        const cplx m = cmul(mft[(size_t)n * M + (k - 1)], r);
-        mft[(size_t)n * M + (k - 1)] = m;
+        const cplx m = cmul(mft[(size_t)n * Mp + (k - 1)], r);
+        mft[(size_t)n * Mp + (k - 1)] = m;
         const double p = cnorm(m);
-        msq[(size_t)n * M + (k - 1)] = p;
+        msq[(size_t)n * Mp + (k - 1)] = p;
         s += p;
         mx = fmax(mx, p);
     }

@@ -188,6 +188,45 @@ extern "C" int pp_reference_phase_seed(pp_ctx* c, const void* src, int dtype, in
     return PP_OK;
 }
 
+// ---- general row lengths (pp_anybin.h): harmonics out, harmonics back ---------------------
+// the Bluestein tables of a row length as the kernels take them
+static int any_args(pp_ctx* c, int nbin, AnyArgs* g, int* L) {
+    pp_ctx::AnyPlan* pl = nullptr;
+    int rc;
+    if ((rc = get_any_plan(c, nbin, &pl))) return rc;
+    const cplx *twL = nullptr, *twB = nullptr;
+    if ((rc = get_twiddles(c, 2 * pl->L, &twL))) return rc;
+    if ((rc = get_twiddles(c, nbin, &twB))) return rc;
+    const int M = nbin / 2;
+    *g = AnyArgs{nbin, M, ((M + 63) / 64) * 64, pl->chirp.as<cplx>(), pl->bft.as<cplx>(), twL, twB, 0, 0, nullptr, nullptr};
+    *L = pl->L;
+    return PP_OK;
+}
+// harmonics 0..M of nrows_sub x nrows_chan rows of `rows` (row-major [nsub][nchan][nbin]) into hout, CHANNEL-major
+// (hout row = n nsub + i), by k_any
+static int harmonics_any(pp_ctx* c, const void* rows, int dtype, int nsub, int nchan, int nbin, cplx* hout) {
+    XspecArgs xa;
+    memset(&xa, 0, sizeof xa);
+    xa.data = rows; xa.nsub = nsub; xa.nchan = nchan; xa.nchan_full = nchan; xa.cstep = 1;
+    return launch_any(c, xa, nbin, ((nbin / 2 + 63) / 64) * 64, dtype, -1, false, hout, nullptr);
+}
+// numpy.fft.irfft of nrows rows of M + 1 harmonics -> out[nrows][nbin] (device pointers)
+static int irfft_any(pp_ctx* c, int nbin, const cplx* harm, long long nrows, double* out) {
+    AnyArgs g;
+    int L = 0, rc;
+    if ((rc = any_args(c, nbin, &g, &L))) return rc;
+    const int grid = (int)std::max(1LL, std::min(nrows, 2048LL));
+    switch (L) {
+        case 64: hipLaunchKernelGGL((k_irfft_any<64>), dim3(grid), dim3(FftPlan<64>::T), 0, c->stream, harm, g, nrows, out); break;
+        case 256: hipLaunchKernelGGL((k_irfft_any<256>), dim3(grid), dim3(FftPlan<256>::T), 0, c->stream, harm, g, nrows, out); break;
+        case 1024: hipLaunchKernelGGL((k_irfft_any<1024>), dim3(grid), dim3(FftPlan<1024>::T), 0, c->stream, harm, g, nrows, out); break;
+        case 4096: hipLaunchKernelGGL((k_irfft_any<4096>), dim3(grid), dim3(FftPlan<4096>::T), 0, c->stream, harm, g, nrows, out); break;
+        default: return fail(PP_EINVAL, "no transform of %d points", L);
+    }
+    HIP_TRY(hipGetLastError());
+    return PP_OK;
+}
+
 extern "C" int pp_synth_portraits(pp_ctx* c, int slot, void* dst, int dtype, int nsub, const double* freqs,
                                   const double* P, const double* inj, const double* gains, double sigma,
                                   uint64_t seed, int64_t first_subint) {
@@ -196,7 +235,6 @@ extern "C" int pp_synth_portraits(pp_ctx* c, int slot, void* dst, int dtype, int
     if (slot < 0 || slot >= PP_MAX_SLOTS || !c->slots[slot].set) return fail(PP_ESTATE, "pp_synth_portraits: slot %d not set", slot);
     if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_synth_portraits: dtype %d", dtype);
     if (nsub < 1) return fail(PP_EINVAL, "pp_synth_portraits: nsub %d", nsub);
-    if (!nbin_ok(c->slots[slot].nbin)) return nbin_refuse("pp_synth_portraits", c->slots[slot].nbin);
     HIP_TRY(hipSetDevice(c->device));
     ModelSlot& s = c->slots[slot];
     const int C = s.nchan, B = s.nbin, M = B / 2;
@@ -210,7 +248,27 @@ extern "C" int pp_synth_portraits(pp_ctx* c, int slot, void* dst, int dtype, int
     SynthArgs a{s.mft.as<cplx>(), s.mdc.as<double>(), dst, c->freqs.as<double>(), c->P.as<double>(),
                 c->x0.as<double>(), tw, sigma, seed, first_subint, nsub, C,
                 gains ? c->errs.as<double>() : (const double*)nullptr};
-    {
+    if (!nbin_ok(B)) {
+        // a row length without a tuned plan: the rotated template's harmonics back by the chirp-z route
+        Prof pr(c, KF_SYNTH);
+        AnyArgs g;
+        int L = 0;
+        if ((rc = any_args(c, B, &g, &L))) return rc;
+        const int grid = (int)std::max(1LL, std::min((long long)nsub * C, 2048LL));
+#define PP_SYN_ANY(LL)                                                                                          \
+    do {                                                                                                        \
+        if (dtype == PP_F64) hipLaunchKernelGGL((k_synth_any<LL, double>), dim3(grid), dim3(FftPlan<LL>::T), 0, c->stream, a, g); \
+        else hipLaunchKernelGGL((k_synth_any<LL, float>), dim3(grid), dim3(FftPlan<LL>::T), 0, c->stream, a, g); \
+    } while (0)
+        switch (L) {
+            case 64: PP_SYN_ANY(64); break;
+            case 256: PP_SYN_ANY(256); break;
+            case 1024: PP_SYN_ANY(1024); break;
+            case 4096: PP_SYN_ANY(4096); break;
+            default: return fail(PP_EINVAL, "no transform of %d points", L);
+        }
+#undef PP_SYN_ANY
+    } else {
         Prof pr(c, KF_SYNTH);
         PP_DISPATCH_M(M, {
             const int T = FftPlan<MM>::T;
@@ -312,7 +370,7 @@ extern "C" int pp_align_accumulate(pp_ctx* c, const void* src, int dtype, int on
     if (int busy_ = ctx_busy(c, "pp_align_accumulate")) return busy_;
     if (!c || !src || !freqs || !P || !par3 || !weights || !aligned || !total_weights)
         return fail(PP_EINVAL, "pp_align_accumulate: null argument");
-    if (!nbin_ok(nbin)) return nbin_refuse("pp_align_accumulate", nbin);
+    if (!nbin_any_ok(nbin)) return nbin_refuse("pp_align_accumulate", nbin);
     if (nsub < 1 || nchan < 1) return fail(PP_EINVAL, "pp_align_accumulate: bad shape");
     if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_align_accumulate: dtype %d", dtype);
     if (freqs_stride != 0 && freqs_stride != nchan) return fail(PP_EINVAL, "freqs_stride must be 0 or nchan");
@@ -357,7 +415,25 @@ extern "C" int pp_align_accumulate(pp_ctx* c, const void* src, int dtype, int on
     if ((rc = get_twiddles(c, nbin, &tw))) return rc;
     AlignArgs a{dsrc, c->freqs.as<double>(), (long long)freqs_stride, c->P.as<double>(), c->x0.as<double>(),
                 c->wts.as<double>(), tw, c->X.as<double>(), c->sdraw.as<double>(), nsub, nchan};
-    {
+    if (!nbin_ok(nbin)) {
+        // a row length without a tuned plan (pp_anybin.h): harmonics of every row by the chirp-z route, the weighted,
+        // rotated sum per (channel, harmonic) over the subints in index order, ONE inverse transform per channel.
+        // Subints go through in chunks whose harmonics fit a 2 GB scratch buffer.
+        Prof pr(c, KF_SYNTH);
+        const size_t H = (size_t)M + 1;
+        const int cs = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsub, ((size_t)2 << 30) / ((size_t)nchan * H * sizeof(cplx))));
+        if ((rc = c->seedbuf.reserve(((size_t)cs * nchan * H + (size_t)nchan * H) * sizeof(cplx)))) return rc;
+        cplx* hout = c->seedbuf.as<cplx>();
+        cplx* spec = hout + (size_t)cs * nchan * H;
+        for (int s0 = 0; s0 < nsub; s0 += cs) {
+            const int ns = std::min(cs, nsub - s0);
+            if ((rc = harmonics_any(c, (const char*)dsrc + (size_t)s0 * nchan * nbin * esz, dtype, ns, nchan, nbin, hout))) return rc;
+            hipLaunchKernelGGL(k_align_harm, dim3((unsigned)((H + 255) / 256), nchan), dim3(256), 0, c->stream,
+                               (const cplx*)hout, a, s0, ns, M, spec, c->sdraw.as<double>(), s0 == 0 ? 1 : 0);
+            HIP_TRY(hipGetLastError());
+        }
+        if ((rc = irfft_any(c, nbin, spec, nchan, c->X.as<double>()))) return rc;
+    } else {
         Prof pr(c, KF_SYNTH);
         PP_DISPATCH_M(M, {
             const int T = FftPlan<MM>::T;
@@ -381,7 +457,7 @@ extern "C" int pp_channel_red_chi2(pp_ctx* c, const void* src, int dtype, int on
     if (int busy_ = ctx_busy(c, "pp_channel_red_chi2")) return busy_;
     if (!c || !src || !freqs || !P || !params5 || !nu_refs3 || !scales || !errs || !red_chi2)
         return fail(PP_EINVAL, "pp_channel_red_chi2: null argument");
-    if (!nbin_ok(nbin)) return nbin_refuse("pp_channel_red_chi2", nbin);
+    if (!nbin_any_ok(nbin)) return nbin_refuse("pp_channel_red_chi2", nbin);
     if (nsub < 1 || nchan < 1) return fail(PP_EINVAL, "pp_channel_red_chi2: bad shape");
     if (dtype != PP_F64 && dtype != PP_F32) return fail(PP_EINVAL, "pp_channel_red_chi2: dtype %d", dtype);
     if (freqs_stride != 0 && freqs_stride != nchan) return fail(PP_EINVAL, "freqs_stride must be 0 or nchan");
@@ -433,7 +509,23 @@ extern "C" int pp_channel_red_chi2(pp_ctx* c, const void* src, int dtype, int on
                    model_slot ? c->slot.as<int>() : nullptr, c->freqs.as<double>(), (long long)freqs_stride,
                    c->P.as<double>(), c->x0.as<double>(), c->nufit.as<double>(), c->wts.as<double>(),
                    c->errs.as<double>(), tw, c->sdraw.as<double>(), nsub, nchan};
-    {
+    if (!nbin_ok(nbin)) {
+        // a row length without a tuned plan: the data rows' harmonics by the chirp-z route, then Parseval on the
+        // residual spectrum exactly as k_chan_chi2 forms it (the slot's spectrum rows are pitched to Mp)
+        Prof pr(c, KF_FINAL);
+        const size_t H = (size_t)M + 1;
+        const int Mp = c->slots[model_slot ? model_slot[0] : 0].Mp;
+        const int cs = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsub, ((size_t)2 << 30) / ((size_t)nchan * H * sizeof(cplx))));
+        if ((rc = c->seedbuf.reserve((size_t)cs * nchan * H * sizeof(cplx)))) return rc;
+        cplx* hout = c->seedbuf.as<cplx>();
+        for (int s0 = 0; s0 < nsub; s0 += cs) {
+            const int ns = std::min(cs, nsub - s0);
+            if ((rc = harmonics_any(c, (const char*)dsrc + (size_t)s0 * nchan * nbin * esz, dtype, ns, nchan, nbin, hout))) return rc;
+            const int grid = (int)std::max(1LL, std::min((long long)ns * nchan, 4096LL));
+            hipLaunchKernelGGL(k_chan_chi2_harm, dim3(grid), dim3(256), 0, c->stream, (const cplx*)hout, a, s0, ns, M, Mp);
+            HIP_TRY(hipGetLastError());
+        }
+    } else {
         Prof pr(c, KF_FINAL);
         PP_DISPATCH_M(M, {
             const int T = FftPlan<MM>::T;
@@ -453,7 +545,7 @@ static int gauss_generate(pp_ctx* c, int nchan, int nbin, const double* freqs, c
                           double dc, double tau_rot, double alpha, int ngauss, const double* comps,
                           double* dev_out) {
     if (!freqs || !code || !comps) return fail(PP_EINVAL, "gaussian portrait: null argument");
-    if (!nbin_ok(nbin)) return nbin_refuse("gaussian portrait", nbin);
+    if (!nbin_any_ok(nbin)) return nbin_refuse("gaussian portrait", nbin);
     if (nchan < 1) return fail(PP_EINVAL, "gaussian portrait: bad shape");
     if (ngauss < 1 || ngauss > PP_MAX_GAUSS) return fail(PP_EINVAL, "gaussian portrait: 1..%d components", PP_MAX_GAUSS);
     for (int j = 0; j < 3; ++j)
@@ -466,6 +558,24 @@ static int gauss_generate(pp_ctx* c, int nchan, int nbin, const double* freqs, c
     GaussArgs a{c->freqs.as<double>(), c->misc.as<double>(), tw, dev_out, nu_ref, dc, tau_rot, alpha, nchan, ngauss,
                 code[0] - '0', code[1] - '0', code[2] - '0'};
     const int M = nbin / 2;
+    if (!nbin_ok(nbin)) {
+        // a row length without a tuned plan: the rows need no transform; a scattered model's filter
+        // 1 / (1 + 2 pi i k tau_n) goes through the harmonics (chirp-z route there and back)
+        Prof pr(c, KF_MODEL);
+        hipLaunchKernelGGL(k_gauss_rows, dim3(nchan), dim3(256), 0, c->stream, a, nbin);
+        HIP_TRY(hipGetLastError());
+        if (tau_rot != 0.0) {
+            const size_t H = (size_t)M + 1;
+            if ((rc = c->seedbuf.reserve((size_t)nchan * H * sizeof(cplx)))) return rc;
+            cplx* harm = c->seedbuf.as<cplx>();
+            if ((rc = harmonics_any(c, dev_out, PP_F64, 1, nchan, nbin, harm))) return rc;
+            hipLaunchKernelGGL(k_scatter_harm, dim3((unsigned)((H + 255) / 256), nchan), dim3(256), 0, c->stream, harm,
+                               (const double*)c->freqs.as<double>(), nu_ref, tau_rot, alpha, M);
+            HIP_TRY(hipGetLastError());
+            if ((rc = irfft_any(c, nbin, harm, nchan, dev_out))) return rc;
+        }
+        return PP_OK;
+    }
     {
         Prof pr(c, KF_MODEL);
         PP_DISPATCH_M(M, {
@@ -503,11 +613,13 @@ extern "C" int pp_model_set_gaussian(pp_ctx* c, int slot, int nchan, int nbin, c
     if (!c) return fail(PP_EINVAL, "pp_model_set_gaussian: null context");
     HIP_TRY(hipSetDevice(c->device));
     int rc;
-    if ((rc = c->X.reserve((size_t)nchan * nbin * 8))) return rc;     // scratch for the portrait
+    // scratch for the portrait (general row lengths: pp_model_set leaves the rows' harmonics in c->X)
+    DevBuf& scratch = nbin_ok(nbin) ? c->X : c->data;
+    if ((rc = scratch.reserve((size_t)nchan * nbin * 8))) return rc;
     if ((rc = gauss_generate(c, nchan, nbin, freqs, code, nu_ref, dc, tau_rot, alpha, ngauss, comps,
-                             c->X.as<double>())))
+                             scratch.as<double>())))
         return rc;
-    return pp_model_set(c, slot, c->X.p, PP_F64, 1, nchan, nbin);
+    return pp_model_set(c, slot, scratch.p, PP_F64, 1, nchan, nbin);
 }
 
 // ---- spline (PCA + B-spline) templates on the device --------------------------
@@ -563,13 +675,14 @@ extern "C" int pp_model_set_spline(pp_ctx* c, int slot, int nchan, int nbin, con
                                    int degree) {
     if (int busy_ = ctx_busy(c, "pp_model_set_spline")) return busy_;
     if (!c) return fail(PP_EINVAL, "pp_model_set_spline: null context");
-    if (!nbin_ok(nbin)) return nbin_refuse("pp_model_set_spline", nbin);
+    if (!nbin_any_ok(nbin)) return nbin_refuse("pp_model_set_spline", nbin);
     HIP_TRY(hipSetDevice(c->device));
     int rc;
-    if ((rc = c->X.reserve((size_t)nchan * nbin * 8))) return rc;     // scratch for the portrait
-    if ((rc = spline_generate(c, nchan, nbin, freqs, ncomp, basis, nknots, t, coefs, degree, c->X.as<double>())))
+    DevBuf& scratch = nbin_ok(nbin) ? c->X : c->data;      // (as pp_model_set_gaussian)
+    if ((rc = scratch.reserve((size_t)nchan * nbin * 8))) return rc;
+    if ((rc = spline_generate(c, nchan, nbin, freqs, ncomp, basis, nknots, t, coefs, degree, scratch.as<double>())))
         return rc;
-    return pp_model_set(c, slot, c->X.p, PP_F64, 1, nchan, nbin);
+    return pp_model_set(c, slot, scratch.p, PP_F64, 1, nchan, nbin);
 }
 
 // ---- instrumental response applied to a resident template ---------------------
@@ -578,7 +691,6 @@ extern "C" int pp_model_apply_response(pp_ctx* c, int slot, const double* rconst
     if (!c || slot < 0 || slot >= PP_MAX_SLOTS || !c->slots[slot].set)
         return fail(PP_ESTATE, "pp_model_apply_response: slot not set");
     if (!rconst && !smear_wid) return PP_OK;
-    if (!nbin_ok(c->slots[slot].nbin)) return nbin_refuse("pp_model_apply_response", c->slots[slot].nbin);
     HIP_TRY(hipSetDevice(c->device));
     ModelSlot& s = c->slots[slot];
     const int M = s.nbin / 2;
@@ -597,7 +709,7 @@ extern "C" int pp_model_apply_response(pp_ctx* c, int slot, const double* rconst
         Prof pr(c, KF_MODEL);
         hipLaunchKernelGGL(k_model_response, dim3(s.nchan), dim3(256), 0, c->stream, s.mft.as<cplx>(),
                            s.msq.as<double>(), s.msum.as<double>(), s.mmax.as<double>(), s.mdc.as<double>(), drc,
-                           dwid, s.nchan, M);
+                           dwid, s.nchan, M, s.Mp);
     }
     HIP_TRY(hipGetLastError());
     return model_publish(c, slot);

@@ -196,7 +196,10 @@ struct pp_ctx {
     struct Span { int fam; hipEvent_t a, b; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> ev_pool;       // recycled profiling events
-    double known_ok_bytes = 0.0;           // largest work-memory demand a batch has already been granted
+    std::map<int, double> known_ok;        // largest work-memory demand a batch of each FLOW has already been granted
+                                           // (key: scattering | host data | dtype | reference seed | device seed --
+                                           // flows hold different buffer sets, and free memory may have shrunk)
+    int max_lds_bytes = 0;                 // LDS a workgroup of this device may use (sharedMemPerBlock)
     double fam_sec[KF_COUNT] = {0};
     long long fam_n[KF_COUNT] = {0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -506,13 +509,10 @@ static int publish_int(pp_ctx* c, int* host_dst, const int* dev_src) {
 static bool nbin_ok(int nbin) { return nbin >= 32 && nbin <= 8192 && (nbin & (nbin - 1)) == 0; }
 static bool nbin_any_ok(int nbin) { return nbin_ok(nbin) || (nbin >= 8 && nbin <= 4096 && nbin % 2 == 0); }
 static int fail(int code, const char* fmt, ...);
-// what an entry point without a general-length path answers
+// what an entry point answers for a row length nobody takes (round 5: every entry point takes the general even
+// lengths the fit takes)
 static int nbin_refuse(const char* who, int nbin) {
-    if (nbin_any_ok(nbin))
-        return fail(PP_ENOTSUP, "%s: nbin %d is no power of two: only pp_model_set, pp_fit_portrait_batch, pp_rfft_rows, "
-                                "pp_fit_phase_shift_batch, pp_reference_phase_seed and pp_rotate_portraits take general even row lengths", who, nbin);
-    return fail(PP_EINVAL, "%s: nbin %d must be a power of two in [32, 8192] (the fit also takes even lengths up to 4096)",
-                who, nbin);
+    return fail(PP_EINVAL, "%s: nbin %d must be a power of two in [32, 8192] or an even number in [8, 4096]", who, nbin);
 }
 
 // Bluestein tables of a row length B = 2 M that is no power of two
@@ -1189,16 +1189,33 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     const int solve_nt = c->solve_threads > 0 ? c->solve_threads : (C <= 512 ? 64 : C <= 1024 ? 128 : 256);
     // (LDS: 32 B per cached channel, 512 channels per wave of the block keep the CU's eight waves within 128 KB)
     fa.solve_cache = std::min(C, c->solve_cache >= 0 ? c->solve_cache : std::min(PP_SOLVE_CACHE_MAX, solve_nt * 8));
+    {
+        // what the device grants a workgroup (160 KB on gfx950; 64 KB on older parts) less the kernel's static scratch
+        // bounds the cache: a smaller cache only means more channels' invariants formed again per evaluation
+        if (!c->max_lds_bytes) {
+            hipDeviceProp_t prop;
+            c->max_lds_bytes = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.sharedMemPerBlock > 0)
+                                   ? (int)std::min<size_t>(prop.sharedMemPerBlock, (size_t)1 << 30) : 64 * 1024;
+        }
+        const int room = std::max(0, c->max_lds_bytes - 16 * 1024) / 32;
+        fa.solve_cache = std::min(fa.solve_cache, room);
+    }
     auto launch_taylor_solve = [&]() {
-        const size_t lds = (size_t)fa.solve_cache * 32;
+        size_t lds = (size_t)fa.solve_cache * 32;
         if (lds > 48 * 1024 && !c->solve_lds_attr) {     // (dynamic LDS beyond the default cap: said once)
-            (void)hipFuncSetAttribute((const void*)k_taylor_solve<64>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
-            (void)hipFuncSetAttribute((const void*)k_taylor_solve<128>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
-            (void)hipFuncSetAttribute((const void*)k_taylor_solve<256>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
-            (void)hipFuncSetAttribute((const void*)k_taylor_solve<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
-            (void)hipFuncSetAttribute((const void*)k_taylor_solve<512>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32);
+            const void* fns[5] = {(const void*)k_taylor_solve<64>, (const void*)k_taylor_solve<128>, (const void*)k_taylor_solve<256>,
+                                  (const void*)k_taylor_solve<256, 0>, (const void*)k_taylor_solve<512>};
+            bool ok = true;
+            for (const void* fn : fns)
+                ok = (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32) == hipSuccess) && ok;
+            if (!ok) {
+                // the runtime refuses that much dynamic LDS: the solve runs without the cache
+                (void)hipGetLastError();
+                c->solve_cache = 0;
+            }
             c->solve_lds_attr = true;
         }
+        if (lds > 48 * 1024 && c->solve_cache == 0) { fa.solve_cache = 0; lds = 0; }
         if (solve_nt == 64) hipLaunchKernelGGL(k_taylor_solve<64>, dim3(ns), dim3(64), lds, sp, fa);
         else if (solve_nt == 128) hipLaunchKernelGGL(k_taylor_solve<128>, dim3(ns), dim3(128), lds, sp, fa);
         else if (solve_nt == 512) hipLaunchKernelGGL(k_taylor_solve<512>, dim3(ns), dim3(512), lds, sp, fa);
@@ -1632,7 +1649,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
 // what a batch needs before its first sub-batch: validation, the models it uses, whether the scattering
 // path is needed, default reference frequencies, the sub-batch size the work-memory budget allows
 struct BatchPlan {
-    int Kt = 0, cap = 0;
+    int Kt = 0, cap = 0, flow_key = 0;
     bool scat = false;
     double per_sub = 0.0;
     std::vector<double> nufit, nuout;
@@ -1723,7 +1740,11 @@ static int plan_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, BatchPlan
     // (a batch no larger than one that already ran under this budget needs no look at the free
     // memory: hipMemGetInfo costs as much as the post-fit stage of a 512 x 1024 batch)
     int cap = N;
-    if (per_sub * N > std::min(c->max_work_bytes, c->known_ok_bytes)) {
+    const int flow_key = (scat ? 1 : 0) | (in->data_on_device ? 2 : 0) | (in->data_dtype == PP_F64 ? 4 : 0) |
+                         (in->ref_seed ? 8 : 0) | (in->seed_ns > 0 ? 16 : 0) | (in->method == PP_METHOD_NEWTON ? 32 : 0);
+    bp->flow_key = flow_key;
+    const auto known = c->known_ok.find(flow_key);
+    if (per_sub * N > std::min(c->max_work_bytes, known == c->known_ok.end() ? 0.0 : known->second)) {
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         const double budget = std::min(c->max_work_bytes, 0.85 * ((double)free_b + (double)c->X.cap + (double)c->data.cap + (double)c->csum.cap));
         cap = (int)std::max(1.0, std::floor(budget / per_sub));
@@ -1743,7 +1764,7 @@ static int run_batch_sync(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, const
         int rc = fit_chunk(c, in, out, s0, ns, bp.Kt, bp.scat, bp.nufit, bp.nuout);
         if (rc) return rc;
     }
-    c->known_ok_bytes = std::max(c->known_ok_bytes, bp.per_sub * std::min(bp.cap, N));
+    c->known_ok[bp.flow_key] = std::max(c->known_ok[bp.flow_key], bp.per_sub * std::min(bp.cap, N));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     if (out->duration) {
@@ -1792,7 +1813,7 @@ extern "C" int pp_fit_enqueue(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out) {
         bool deferred = false;
         rc = fit_chunk(c, in, out, 0, in->nsub, bp.Kt, bp.scat, bp.nufit, bp.nuout, &deferred);
         if (rc) return rc;
-        c->known_ok_bytes = std::max(c->known_ok_bytes, bp.per_sub * in->nsub);
+        c->known_ok[bp.flow_key] = std::max(c->known_ok[bp.flow_key], bp.per_sub * in->nsub);
         // (a deferred batch ends on the stream of its post-fit stage, which waited for its transform)
         HIP_TRY(hipEventRecord(sg.done, (deferred && c->last_post) ? c->last_post : c->stream));
         d.queued = deferred;

@@ -405,8 +405,17 @@ class Engine(object):
         """Complete the oldest enqueued batch; returns what fit_batch returns."""
         if not getattr(self, "_queue", None):
             raise EngineError("nothing enqueued")
-        res, keep = self._queue.pop(0)
-        _check(self._lib.pp_fit_collect(self._ctx), "pp_fit_collect")
+        # the entry (result arrays + keep-alive references of everything the argument blocks point to) leaves the
+        # queue only once the C call is through with it; if that call fails, the Python queue is brought back in
+        # step with the library's (pp_fit_pending): the failed batch is gone there, younger ones may still be queued
+        res, keep = self._queue[0]
+        try:
+            _check(self._lib.pp_fit_collect(self._ctx), "pp_fit_collect")
+        finally:
+            left = self._lib.pp_fit_pending(self._ctx)
+            left = left if left >= 0 else 0
+            while len(self._queue) > left:
+                self._queue.pop(0)
         del keep
         res["duration"] = float(res["duration"][0])
         return res

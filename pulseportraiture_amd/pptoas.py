@@ -312,12 +312,6 @@ class GetTOAs(object):
         Gaussian-component models are synthesised on the device, spline models are
         evaluated on the host and uploaded."""
         mdl = self._gmodel()
-        if nbin & (nbin - 1):
-            # a row length that is no power of two: the device synthesisers have tuned plans only; the
-            # portrait is built on the host (as the reference builds it, pptoas.py:352-379) and the
-            # engine transforms it by its general-length path
-            eng.set_model(self._model_for(freqs_row, nbin, P, unscattered), slot=slot)
-            return
         if mdl is None:
             # spline (.spl) template: B-spline curve x eigenvectors evaluated on the
             # device straight into the slot (no host portrait)

@@ -3001,19 +3001,152 @@ def test_reference_guess_at_any_even_nbin(eng, nbin):
     np.testing.assert_allclose(seed[1:6], [o.phase_err, o.scale, o.scale_err, o.snr, o.red_chi2], rtol=1e-7)
 
 
-def test_entry_points_without_a_general_length_path_refuse_loudly(eng):
-    """The rotations, ppalign's accumulation, the template synthesisers ... have tuned plans only: a
-    row length that is no power of two is answered with PP_ENOTSUP (EngineNotSupported) and a
-    message that says which entry points do take it -- never a silent resampling."""
-    from pulseportraiture_amd.engine import EngineError, EngineNotSupported
-    x = np.random.default_rng(1).normal(size=(2, 3, 1000))
-    with pytest.raises(EngineNotSupported, match="no power of two"):
-        eng.align_accumulate(x, np.linspace(1200., 1300., 3), 0.003, 0.0, 0.0, np.inf, np.ones((2, 3)))
-    with pytest.raises(EngineNotSupported, match="no power of two"):
-        eng.channel_red_chi2(x, np.linspace(1200., 1300., 3), 0.003, np.zeros((2, 5)), np.full((2, 3), 1250.),
-                             np.ones((2, 3)), np.ones((2, 3)))
+def test_no_entry_point_refuses_a_general_even_length(eng):
+    """Round 5: every entry point takes the row lengths the fit takes (the reference's numpy.fft takes any
+    nbin).  Only what the reference's own arithmetic cannot do is refused: odd lengths (nbin = 2 (nharm - 1)
+    does not hold) -- loudly, with EngineError."""
+    from pulseportraiture_amd.engine import EngineError
     with pytest.raises(EngineError):
-        eng.rfft_rows(np.zeros((1, 1001)))            # odd lengths: not even the reference's nbin = 2 (nharm - 1) holds
+        eng.rfft_rows(np.zeros((1, 1001)))
+    x = np.random.default_rng(1).normal(size=(2, 3, 1001))
+    with pytest.raises(EngineError, match="nbin"):
+        eng.align_accumulate(x, np.linspace(1200., 1300., 3), 0.003, 0.0, 0.0, np.inf, np.ones((2, 3)))
+
+
+@pytest.mark.parametrize("nbin,dtype", [(1000, np.float64), (100, np.float64), (1536, np.float32), (3000, np.float64), (250, np.float32)])
+def test_align_accumulate_at_any_even_nbin_matches_oracle(eng, nbin, dtype):
+    """ppalign's accumulation (ppalign.py:199-206) at row lengths without a tuned plan: the rows' harmonics by the
+    chirp-z route, the weighted rotated sum per (channel, harmonic), one inverse per channel -- against the oracle's
+    loop of rotate_data, as test_align_accumulate_matches_oracle does for powers of two."""
+    from oracle import pptoas_oracle as orc
+    from tests.synth_host import model_portrait
+    C_, nsub = 12, 5
+    freqs, model = model_portrait(C_, nbin)
+    rng = np.random.default_rng(nbin)
+    ports = np.stack([model * rng.uniform(0.5, 2.0) + 0.1 * rng.standard_normal(model.shape)
+                      for _ in range(nsub)]).astype(dtype)
+    Ps = rng.uniform(0.002, 0.005, nsub)
+    phases = rng.uniform(-0.5, 0.5, nsub)
+    DMs = np.array([0.0, 3e-3, -2e-3, 15.0, 1e-4])
+    nu_refs = np.array([1400.0, np.inf, 1234.5, 1500.0, 1100.0])
+    w = rng.uniform(0.5, 3.0, (nsub, C_))
+    w[1, 3] = 0.0
+    w[2, :] = 0.0
+    w[4, 7:] = 0.0
+    al, tw = eng.align_accumulate(ports, freqs, Ps, phases, DMs, nu_refs, w)
+    oal, otw = orc.align_accumulate(ports.astype(np.float64), freqs, Ps, phases, DMs, nu_refs, w)
+    np.testing.assert_allclose(tw, otw, rtol=1e-15)
+    np.testing.assert_allclose(al, oal, rtol=0, atol=5e-10 * np.abs(oal).max())
+    ok = [0, 1, 2, 4]   # without the large-DM subint the agreement is at rounding level
+    al2, _ = eng.align_accumulate(ports[ok], freqs, Ps[ok], phases[ok], DMs[ok], nu_refs[ok], w[ok])
+    oal2, _ = orc.align_accumulate(ports[ok].astype(np.float64), freqs, Ps[ok], phases[ok], DMs[ok],
+                                   nu_refs[ok], w[ok])
+    np.testing.assert_allclose(al2, oal2, rtol=0, atol=2e-12 * np.abs(oal2).max())
+
+
+@pytest.mark.parametrize("name", ["fpf_48x1000_phiDM", "fpf_48x1000_scat", "fpf_40x100_phiDMGM", "fpf_24x1536_phiDMtau"])
+def test_channel_red_chi2_at_any_even_nbin_matches_oracle(eng, name):
+    """The per-channel reduced chi^2 of the zap proposals (pptoas.py:1239-1245) at row lengths without a tuned
+    plan, from the TRUE reference's fit results at nbin = 1000 / 100 / 1536 (tests/golden/make_golden_nbin.py), and
+    with a scattering time switched on (the template filtered in the same kernel)."""
+    from oracle import pptoas_oracle as orc
+    g = _load(name)
+    eng.set_model(g["model"])
+    for tau, alpha in ((0.0, 0.0), (2e-3, -4.0)):
+        params = np.array([float(g["out_phi"]), float(g["out_DM"]), float(g["out_GM"]), tau, alpha])
+        nu_refs = np.array([float(g["out_nu_DM"]), float(g["out_nu_GM"]), float(g["freqs"].mean())])
+        got = eng.channel_red_chi2(np.stack([g["data"], g["data"][::-1] * 1.0]), g["freqs"], float(g["P"]),
+                                   np.stack([params, params]), np.stack([nu_refs, nu_refs]),
+                                   np.stack([g["out_scales"], g["out_scales"]]), np.stack([g["errs"], g["errs"]]))
+        want = orc.channel_red_chi2s(g["data"], g["model"], params[0], params[1], params[2], tau, alpha, g["freqs"],
+                                     nu_refs, float(g["P"]), g["out_scales"], g["errs"])
+        np.testing.assert_allclose(got[0], want, rtol=1e-9)
+        want1 = orc.channel_red_chi2s(g["data"][::-1], g["model"], params[0], params[1], params[2], tau, alpha, g["freqs"],
+                                      nu_refs, float(g["P"]), g["out_scales"], g["errs"])
+        np.testing.assert_allclose(got[1], want1, rtol=1e-9)
+        if tau == 0.0:
+            assert 0.5 < np.median(want) < 2.0
+
+
+@pytest.mark.parametrize("nbin", [1000, 100, 1536, 3000])
+def test_device_templates_at_any_even_nbin(eng, nbin):
+    """The template synthesisers and the instrumental response at row lengths without a tuned plan: .gmodel
+    portraits (plain and scattered: the filter goes through the harmonics and back) against the host construction
+    the reference's read_model is pinned to, .spl portraits against gen_spline_portrait, the slots they load and
+    the response multiplied into such a slot against an uploaded host portrait -- same fit either way; and the
+    synthetic generator against its host restatement."""
+    import torch
+    from oracle import pptoas_oracle as orc
+    from pulseportraiture_amd import gmodel, splmodel
+    from pulseportraiture_amd.pptoaslib import instrumental_response_device_args
+    from tests.synth_host import device_recipe_host
+    freqs = np.linspace(1100.0, 1900.0, 20)
+    text = """MODEL test
+CODE 011
+FREQ 1500.0
+DC 0.01 0
+TAU 2.5e-5 0
+ALPHA -3.7 0
+COMP01 0.02 0 -1e-5 0 0.03 0 2e-6 0 3.0 0 -5e-4 0
+COMP02 0.97 0 2e-5 0 0.012 0 -1e-6 0 1.5 0 1e-3 0
+COMP03 0.50 0 0.0 0 0.2 0 1e-5 0 0.4 0 0.0 0
+"""
+    m2 = gmodel.parse_gmodel(text)
+    P = 0.004
+    for Pm in (P, None):
+        mm = dict(m2)
+        if Pm is None:
+            mm["params"] = m2["params"].copy()
+            mm["params"][1] = 0.0
+        want = gmodel.gaussian_portrait(mm, freqs, nbin, Pm)
+        got = eng.gaussian_portrait(mm, freqs, nbin, Pm)
+        np.testing.assert_allclose(got, want, rtol=0, atol=(2e-14 if Pm is None else 5e-13) * np.abs(want).max())
+    # the slot: synthesised on the device == uploaded from the host, with an instrumental response on top
+    port = gmodel.gaussian_portrait(m2, freqs, nbin, P)
+    rng = np.random.default_rng(nbin)
+    data = orc.rotate_portrait_full(port, -0.123, -2e-4, 0.0, freqs, np.inf, np.inf, P) * 1.3 + rng.normal(0, 0.02, port.shape)
+    kw = dict(errs=np.full(len(freqs), 0.02), nu_fits=[[1500.0] * 3], fit_flags=[1, 1, 0, 0, 0], method="newton")
+    wids, types, DM = [0.011, 0.004], ["rect", "gauss"], 30.0
+    rconst, smear = instrumental_response_device_args(nbin, freqs, DM, P, wids, types)
+    resp = orc.instrumental_response_port_FT(nbin, freqs, DM, P, wids, types)
+    smeared = np.fft.irfft(resp * np.fft.rfft(port, axis=-1), n=nbin, axis=-1)
+    x0 = [0.12, 0.0, 0, 0, 0]
+    eng.set_model(port)
+    a = eng.fit_batch(data[None], freqs, P, x0, **kw)
+    eng.set_model_gaussian(m2, freqs, nbin, P)
+    b = eng.fit_batch(data[None], freqs, P, x0, **kw)
+    assert _dphi(a["params"][0, 0], b["params"][0, 0]) < 1e-12 and abs(a["params"][0, 0] - 0.123) < 1e-3
+    np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-10)
+    eng.apply_response(0, rconst, smear)
+    c1 = eng.fit_batch(data[None], freqs, P, x0, **kw)
+    eng.set_model(smeared)
+    c2 = eng.fit_batch(data[None], freqs, P, x0, **kw)
+    assert _dphi(c1["params"][0, 0], c2["params"][0, 0]) < 1e-11
+    np.testing.assert_allclose(c1["chi2"], c2["chi2"], rtol=1e-10)
+    np.testing.assert_allclose(c1["scales"], c2["scales"], rtol=1e-9)
+    # .spl templates
+    name, src, dfile, mean_prof, eigvec, tck = splmodel.read_spline_model(os.path.join(GOLDEN, "example.spl"), quiet=True)
+    fs = np.linspace(1150.0, 1850.0, 9)
+    got = eng.spline_portrait(mean_prof, eigvec, tck, fs, nbin=nbin)
+    want = splmodel.gen_spline_portrait(mean_prof, fs, eigvec, tck, nbin=nbin)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-13 * np.abs(want).max())
+    d2 = want * 0.9 + rng.normal(0, 0.02, want.shape)
+    kw2 = dict(errs=np.full(len(fs), 0.02), nu_fits=[[1500.0] * 3], fit_flags=[1, 1, 0, 0, 0], method="newton")
+    eng.set_model(want)
+    a = eng.fit_batch(d2[None], fs, 0.003, [0.0] * 5, **kw2)
+    eng.set_model_spline(mean_prof, eigvec, tck, fs, nbin)
+    b = eng.fit_batch(d2[None], fs, 0.003, [0.0] * 5, **kw2)
+    assert abs(a["params"][0, 0] - b["params"][0, 0]) < 1e-12
+    np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-10)
+    # the synthetic generator (Philox noise keyed on the global subint index) against its host restatement
+    eng.set_model(port)
+    Ps = np.full(3, P)
+    inj = np.array([[0.2, 1e-3, 0.0], [-0.4, 30.0, 0.1], [0.0, 0.0, 0.0]])
+    dst = torch.empty((3, len(freqs), nbin), dtype=torch.float64, device="cuda:0")
+    eng.synth_portraits(dst, freqs, Ps, inj, 0.05, seed=20260101, first_subint=7)
+    host = device_recipe_host(port, freqs, Ps, inj, 0.05, 20260101, 7)
+    np.testing.assert_allclose(dst.cpu().numpy(), host, rtol=0, atol=2e-9 * np.abs(port).max())
+    np.testing.assert_allclose(dst[2].cpu().numpy(), host[2], rtol=0, atol=1e-12 * np.abs(port).max())
 
 
 @pytest.mark.parametrize("flags,l10", [([1, 1, 0, 1, 1], True), ([1, 1, 0, 1, 0], False), ([1, 1, 1, 1, 1], True)])
