@@ -20,7 +20,12 @@
  *     context.  One context per (host thread, GPU); calls on one context are
  *     serialised by the caller.
  *   - portraits are C-contiguous [nsub][nchan][nbin]; nbin is a power of two
- *     in [32, 8192].
+ *     in [32, 8192] (tuned plans) or any even number in [8, 4096] (every entry
+ *     point, by the chirp-z route: the reference's numpy.fft takes every nbin).
+ *   - a subint's outputs are a function of that subint's inputs alone: whatever
+ *     else is in the batch, however it is cut into sub-batches, shards or ranks,
+ *     the same bits come back (the reference fits subints in a plain loop,
+ *     pptoas.py:344-489).
  */
 #ifndef PP_TOAS_H
 #define PP_TOAS_H

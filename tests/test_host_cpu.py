@@ -172,3 +172,49 @@ def test_get_TOAs_flag_order_is_the_reference_insertion_order():
              "'flux_ref_freq'", "'par_angle'"]
     pos = [src.index("toa_flags[%s]" % k) for k in order]
     assert pos == sorted(pos), [k for k, a, b in zip(order[1:], pos, pos[1:]) if b < a]
+
+
+def test_scale_run_checker(tmp_path):
+    """tools/check_scale.py (the table tools/run_scale.sh writes on a multi-GPU node): accepts runs whose
+    strong-scaling records are the same bits for every N, flags a run whose records differ or whose rows /
+    return codes are off."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    total, nsub, steps = 40, 8, 2
+    rng = np.random.default_rng(0)
+    rec = rng.normal(size=(total, 18))
+    rec[:, 17] = 2.0
+
+    def write(n, mode, records=None, rows=None, rc=2):
+        line = {"metric": "subint_fits_per_sec", "value": 1000.0 * n, "ms_per_step": 1.0, "n_gpus": n, "scaling": mode,
+                "steps": steps}
+        if mode == "weak":
+            line["config"] = {"nsub_per_gpu_per_step": nsub}
+            line["gathered_records"] = {"rows": rows if rows is not None else n * nsub * steps}
+            line["convergence"] = {"return_codes": {str(rc): n * nsub}}
+        else:
+            base, extra = divmod(total, n)
+            line["config"] = {"total_nsub": total, "fits_per_rank": [base + (1 if r < extra else 0) for r in range(n)]}
+            line["gathered_records"] = {"rows": total, "return_code_sum": float(records[:, 17].sum())}
+            line["max_abs_dDM_over_err"] = 3.0
+            np.save(tmp_path / ("records_strong_n%d.npy" % n), records)
+        (tmp_path / ("%s_n%d.json" % (mode, n))).write_text("some banner\n" + json.dumps(line) + "\n")
+
+    for n in (1, 2):
+        write(n, "weak")
+        write(n, "strong", rec)
+    cmd = [sys.executable, os.path.join(root, "tools", "check_scale.py"), str(tmp_path), "1", "2"]
+    ok = subprocess.run(cmd, capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stdout + ok.stderr
+    assert "bit for bit" in ok.stdout and ok.stdout.count("OK") == 4
+    moved = rec.copy()
+    moved[7, 0] += 1e-12
+    write(2, "strong", moved)
+    bad = subprocess.run(cmd, capture_output=True, text=True)
+    assert bad.returncode == 1 and "differ from the N = 1 job in 1 rows" in bad.stdout
+    write(2, "strong", rec)
+    write(2, "weak", rows=5)
+    bad = subprocess.run(cmd, capture_output=True, text=True)
+    assert bad.returncode == 1 and "FAIL" in bad.stdout
