@@ -161,6 +161,7 @@ struct pp_ctx {
     int max_iter = 64;
     int profile = 0;
     int check_every = 1;
+    int check_from = 2;         // evaluation loop: the first iteration after which the host looks at the count of unfinished subints
     int use_taylor = 1;
     int moments_in_xspec = 1;   // fold the Taylor moments into k_xspec (mode 2) when it applies
     int scat_model = 1;         // scattering fits: closing iterations on the per-channel model (pp_scatmodel.h)
@@ -176,6 +177,7 @@ struct pp_ctx {
     int paired_split = 1;       // 2048-bin rows: last FFT stage + split in registers (k_xspec_p1024)
     int one_exchange = 1;       // 2048-bin rows, mode 2, noise given: one-exchange FFT (k_xspec_q1024)
     int seed_chan_stride = 16;  // device phase seed: pilot pass over every n-th channel (1 = all channels)
+    int refseed_stride = 0;     // reference-seed flow: its pilot's channel stride on wide bands (0 = 64; >= 32 pilot channels kept)
     double seed_min_snr = 8.0;  // pilot seeds below this peak significance are redone from all channels
     int seed_ndm = 1;           // DM trials of the coarse (phi, DM) seed grid (1 = phase only, at the guessed DM)
     double seed_dm_step = 0.0;  // their spacing [pc cm^-3]
@@ -394,7 +396,7 @@ struct OptRef { const char* name; char kind; void* p; int imin; };
 static bool option_ref(pp_ctx* c, const std::string& n, OptRef* out) {
     const OptRef tab[] = {
         {"harm_eps", 'd', &c->harm_eps, 0}, {"max_iter", 'i', &c->max_iter, INT32_MIN},
-        {"profile", 'i', &c->profile, INT32_MIN}, {"check_every", 'i', &c->check_every, 1},
+        {"profile", 'i', &c->profile, INT32_MIN}, {"check_every", 'i', &c->check_every, 1}, {"check_from", 'i', &c->check_from, 2},
         {"lagged_check", 'i', &c->lagged_check, INT32_MIN}, {"max_work_bytes", 'd', &c->max_work_bytes, 0},
         {"taylor", 'i', &c->use_taylor, INT32_MIN}, {"moments_in_xspec", 'i', &c->moments_in_xspec, INT32_MIN},
         {"paired_split", 'i', &c->paired_split, INT32_MIN}, {"one_exchange", 'i', &c->one_exchange, INT32_MIN},
@@ -410,6 +412,7 @@ static bool option_ref(pp_ctx* c, const std::string& n, OptRef* out) {
         {"finalize_regs", 'i', &c->finalize_regs, INT32_MIN}, {"solve_cache", 'i', &c->solve_cache, -1},
         {"solve_threads", 'i', &c->solve_threads, 0}, {"copy_kernels", 'i', &c->copy_kernels, INT32_MIN},
         {"solve_prefetch", 'i', &c->solve_prefetch, INT32_MIN}, {"overlap_post", 'i', &c->overlap_post, INT32_MIN},
+        {"refseed_stride", 'i', &c->refseed_stride, 0},
     };
     for (const OptRef& o : tab)
         if (n == o.name) { *out = o; return true; }
@@ -1016,7 +1019,8 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     // fits store the whole cross-spectrum anyway and seed from it.
     // (reference-seed flow: the pilot only supplies the expansion point of the Taylor model, which the
     // certificate guards -- wide bands take every 64th channel, a quarter of the pilot's rows)
-    const int cstep = (refseed && C / 64 >= 32) ? std::max(64, c->seed_chan_stride) : std::max(1, c->seed_chan_stride);
+    const int rstride = c->refseed_stride > 0 ? c->refseed_stride : 64;
+    const int cstep = (refseed && C / rstride >= 32) ? std::max(rstride, c->seed_chan_stride) : std::max(1, c->seed_chan_stride);
     const bool pilot = seeded && taylor && c->moments_in_xspec && cstep > 1 && C / cstep >= 16;
     const bool seed_full = seeded && !pilot;
     // scattering fits of 2048-bin rows (template cut 2 Kt < M): the transform built on the
@@ -1628,13 +1632,13 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
                 if (c->nactive_h[2 + pending] <= 0) break;
                 pending = -1;
             }
-            if (it >= 2 && ((it - 2) % c->check_every) == 0) {
+            if (it >= c->check_from && ((it - c->check_from) % c->check_every) == 0) {
                 const int slot = it & 1;
                 if ((rc = publish_int(c, c->nactive_h + 2 + slot, fa.nactive))) return fail(rc, "count copy failed");
                 HIP_TRY(hipEventRecord(c->evq[slot], c->stream));
                 pending = slot;
             }
-        } else if (it >= 2 && ((it - 2) % c->check_every) == 0) {
+        } else if (it >= c->check_from && ((it - c->check_from) % c->check_every) == 0) {
             // (a copy command here: followed at once by a wait, it measured faster than the publishing kernel)
             HIP_TRY(hipMemcpyAsync(c->nactive_h, fa.nactive, sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
