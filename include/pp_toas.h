@@ -170,6 +170,10 @@ void* pp_stream(pp_ctx* ctx);
  *   "copy_kernels"  1 (default) = the packed block of small inputs and the packed per-subint outputs cross PCIe by a
  *                  kernel that reads / writes the pinned staging block directly; 0 = by hipMemcpyAsync (a copy
  *                  command between two kernels hands the stream to the copy engine and back: ~0.05 ms per batch)
+ *   "check_from"   evaluation loop: the first iteration after which the host looks at the count of unfinished subints
+ *                  (default 2; trust-ncg scattering fits with the closing model: 5 at least -- none is done before)
+ *   "refseed_stride"  pp_seed_ref: channel stride of the pilot pass on wide bands (0 = default 64; at least 32 pilot
+ *                  channels are kept).  128 measured +0.4 % at 4096 channels: not taken, a thinner pilot is a weaker one
  *   "overlap_post"  pp_fit_enqueue: 1 = the solve and post-fit stage of a deferred batch are queued on a second,
  *                  higher-priority stream of the context behind an event of its transform, with a work-buffer set
  *                  of their own, so that they may run beside the NEXT batch's transform; 0 (default) = one stream.
