@@ -28,6 +28,15 @@
 #endif
 #include "pp_fftq.h"
 
+// The harmonics a lane works on come in slots of 64 (k = kb + 64 j) and a channel's template keeps a PREFIX of them
+// (kt_n is a multiple of 64, wave-uniform).  Round 5: the slot loop ends with the last kept slot instead of walking
+// the dropped ones for their two recurrences (split twiddle W^k and phasor e^{i kappa phi}: 8 f64 instructions a
+// slot) and their partner read from LDS: the example template keeps 4.5 of 7 (of 8 at 1024 bins) slots on average.
+// Same sums, same bits.
+#ifndef PP_SLOT_EARLY_EXIT
+#define PP_SLOT_EARLY_EXIT 1
+#endif
+
 namespace pp {
 
 // Where the next row's loads are queued (measured choices, profiles/README.md): f64 rows in two
@@ -213,8 +222,9 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
         cplx zc_nx = pc[64 * 6];
 #pragma unroll
         for (int j = 0; j < NSL; ++j) {
+            if (PP_SLOT_EARLY_EXIT && j > 0 && !(64 * j < ktu)) break;     // (kept slots are a prefix)
             cplx zc = zc_nx;
-            if (j + 1 < NSL) zc_nx = pc[64 * (5 - j)];
+            if (j + 1 < NSL && (!PP_SLOT_EARLY_EXIT || 64 * (j + 1) < ktu)) zc_nx = pc[64 * (5 - j)];
             // the template cut is a multiple of 64: a slot is kept or dropped as a whole
             if (j == 0 || 64 * j < ktu) {
                 const cplx zk = csel(l0, v[j + 1], v[j]);
@@ -259,8 +269,10 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
                     tm[11] = fma(p10 * kap, ax, tm[11]);
                 }
             }
-            wb = cmul(wb, wbT);
-            e = cmul(e, wst);
+            if (!PP_SLOT_EARLY_EXIT || (j + 1 < NSL && 64 * (j + 1) < ktu)) {
+                wb = cmul(wb, wbT);
+                e = cmul(e, wst);
+            }
         }
         // ---- the 12 sums and S_d: one reduction through LDS ----
         double tr[NRED];
@@ -399,8 +411,13 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
         cplx zc_nx = pc[64 * (NSL - 1)];
 #pragma unroll
         for (int j = 0; j < NSL; ++j) {
+            // (noise given: the kept slots are a prefix and nothing beyond them is needed.  The loop may only END once
+            // the second half of the next row's loads has been queued, at slot NSL / 2 -- a copy of those loads at
+            // every earlier exit cost the kernel its register allocation: 54 / 123 spilled VGPRs --; before that a
+            // dropped slot just skips its body, its recurrences and its partner read)
+            if (PP_SLOT_EARLY_EXIT && !TAIL && j > NSL / 2 && !(64 * j < ktu)) break;
             cplx zc = zc_nx;
-            if (j + 1 < NSL) zc_nx = pc[64 * (NSL - 2 - j)];
+            if (j + 1 < NSL && (!PP_SLOT_EARLY_EXIT || TAIL || 64 * (j + 1) < ktu)) zc_nx = pc[64 * (NSL - 2 - j)];
             if (j == NSL / 2) {
                 __builtin_amdgcn_sched_barrier(0);
                 load_some(R1 / 2, R1);
@@ -456,8 +473,10 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
                 }
               }
             }
-            wb = cmul(wb, wbT);
-            e = cmul(e, wst);
+            if (!PP_SLOT_EARLY_EXIT || TAIL || (j + 1 < NSL && 64 * (j + 1) < ktu)) {
+                wb = cmul(wb, wbT);
+                e = cmul(e, wst);
+            }
         }
         double tr[NRED];
 #pragma unroll

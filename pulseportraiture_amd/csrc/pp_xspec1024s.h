@@ -109,8 +109,9 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qs1024(XspecArgs a, const doubl
         cplx zc_nx = pc[64 * 6];
 #pragma unroll
         for (int j = 0; j < NSL; ++j) {
+            if (PP_SLOT_EARLY_EXIT && j > 0 && !(64 * j < ktu)) break;     // (kept slots are a prefix: pp_xspec1024q.h)
             cplx zc = zc_nx;
-            if (j + 1 < NSL) zc_nx = pc[64 * (5 - j)];
+            if (j + 1 < NSL && (!PP_SLOT_EARLY_EXIT || 64 * (j + 1) < ktu)) zc_nx = pc[64 * (5 - j)];
             if (j == 0 || 64 * j < ktu) {
                 const cplx zk = csel(l0, v[j + 1], v[j]);
                 zc.y = -zc.y;
@@ -141,8 +142,10 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qs1024(XspecArgs a, const doubl
                 S1 = fma(kap * u * D2, Mk, S1);
                 S2 = fma(k2 * D2 * fma(4.0 * u * u, D, -1.0), Mk, S2);
             }
-            wb = cmul(wb, wbT);
-            e = cmul(e, wst);
+            if (!PP_SLOT_EARLY_EXIT || (j + 1 < NSL && 64 * (j + 1) < ktu)) {
+                wb = cmul(wb, wbT);
+                e = cmul(e, wst);
+            }
         }
         double tr[NRED] = {s0, -s1, -s2, -q1, -2.0 * q2, -a1t, S0, -2.0 * S1, 2.0 * S2, sd};
         lds_sync<T>();
