@@ -36,6 +36,11 @@
 #ifndef PP_SLOT_EARLY_EXIT
 #define PP_SLOT_EARLY_EXIT 1
 #endif
+#ifndef PP_SLOT_PUBLISH_KEPT
+#define PP_SLOT_PUBLISH_KEPT 0     // k_xspec_q1024: 1 = only the kept slots' partner registers are published to LDS (2.5 fewer
+                                   // ds_write_b128 of 65 LDS instructions a row).  Measured neutral to -0.5 %
+                                   // (profiles/r05_publish_kept_ab.txt): the scalar jump costs what the stores save
+#endif
 
 namespace pp {
 
@@ -174,8 +179,19 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
         // ---- partners through LDS: registers 9..15 out, seven values back ----
         {
             cplx* pub = lds + tid;
-#pragma unroll
-            for (int s = 0; s < NSL; ++s) pub[64 * s] = v[9 + s];
+            // (slot j reads the partner's register 15 - j = published piece 6 - j: only the pieces of the KEPT slots
+            // are published -- one scalar jump into the run of stores)
+            const int nk = PP_SLOT_PUBLISH_KEPT ? max(1, min(NSL, __builtin_amdgcn_readfirstlane(ktn) >> 6)) : NSL;
+            switch (NSL - nk) {
+                case 0: pub[64 * 0] = v[9];  [[fallthrough]];
+                case 1: pub[64 * 1] = v[10]; [[fallthrough]];
+                case 2: pub[64 * 2] = v[11]; [[fallthrough]];
+                case 3: pub[64 * 3] = v[12]; [[fallthrough]];
+                case 4: pub[64 * 4] = v[13]; [[fallthrough]];
+                case 5: pub[64 * 5] = v[14]; [[fallthrough]];
+                default: pub[64 * 6] = v[15];
+            }
+            static_assert(NSL == 7, "the run of stores above is written for seven slots");
             if (TAIL) {
 #pragma unroll
                 for (int r = 0; r < 5; ++r) pub[64 * (NSL + r)] = v[r];
