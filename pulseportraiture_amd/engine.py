@@ -115,6 +115,10 @@ class Engine(object):
             # what no kernel of the batch wrote shows up in the results (a poor man's
             # sanitizer; run the GPU tests once with PP_DEBUG_POISON=255)
             self.set_option("debug_poison", int(os.environ["PP_DEBUG_POISON"]))
+        if os.environ.get("PP_OVERLAP_POST"):
+            # (run the GPU suite once with the solve / post-fit stage of enqueued batches on the context's second
+            # stream: PP_OVERLAP_POST=1)
+            self.set_option("overlap_post", int(os.environ["PP_OVERLAP_POST"]))
         self._digests = {}      # slot -> content digest of the resident template
 
     def close(self):
