@@ -789,7 +789,11 @@ static int resident_grid(pp_ctx* c, K kernel, int T, long long nrows, int fallba
         c->ncu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
                      ? prop.multiProcessorCount : 256;
     }
-    const long long g = per_cu > 0 ? (long long)per_cu * c->ncu : (long long)fallback;
+    long long g = per_cu > 0 ? (long long)per_cu * c->ncu : (long long)fallback;
+    // PP_GRID_SCALE=f (experiments): the persistent grids at a fraction f of their residency -- what the transform
+    // loses when wave slots are left free for other work (profiles/README.md, round 5)
+    static const double scale = [] { const char* e = getenv("PP_GRID_SCALE"); return e ? atof(e) : 1.0; }();
+    if (scale > 0.0 && scale != 1.0) g = std::max(1LL, (long long)std::llround((double)g * scale));
     return (int)std::max(1LL, std::min(nrows, g));
 }
 
