@@ -1602,13 +1602,60 @@ __device__ __forceinline__ void taylor_shift_reg(const double (&t)[PP_TSTRIDE], 
 #ifndef PP_TAYLOR_WAVES
 #define PP_TAYLOR_WAVES 2     // waves per SIMD the kernel is compiled for (register cap 512 / n)
 #endif
-template <int NT, int PF = PP_SOLVE_PF>
-__global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a) {
-    constexpr int NWV = NT / 64;
-    const int i = blockIdx.x, tid = threadIdx.x;
+// The body serves two kernels.  NVW = 1: NT real threads, one subint per workgroup (k_taylor_solve).  NVW = NT / 64:
+// ONE real wave walks the NT / 64 waves of that kernel in turn -- lane l plays threads l, l + 64, ... -- and forms
+// every block-wide sum from the same per-wave totals in the same order (vblock_sum): bitwise the results of the
+// NT-thread kernel from a workgroup of 64 threads (k_taylor_solve_v; what a transform wave could run between rows).
+// `tid`: the real thread (0 .. NT / NVW - 1).  scratch: PP_BSUM_DOUBLES(NT / 64, 10) doubles of LDS; inv_lds:
+// 4 a.solve_cache doubles of LDS.
+template <int NV, int NVMAX, int NT, int NVW, typename F>
+__device__ __forceinline__ void vblock_sum(double (&out)[NV], double* scratch, int& flip, double* mx, int tid, F&& accumulate) {
+    static_assert(NV <= NVMAX, "scratch sized for NVMAX values");
+    constexpr int NWV = NT / 64, RT = NT / NVW;      // virtual waves, real threads
+    const int lane = tid & 63, rw = tid >> 6;
+    double* buf = scratch + flip * NWV * (NVMAX + 1);
+    flip ^= 1;
+    // (`out` is the accumulator of the wave in hand, as block_sum_t's argument was: no second set of NV registers)
+    auto one_wave = [&](const int vw) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) out[j] = 0.0;
+        double m = 0.0;
+        accumulate(lane + 64 * vw, out, m);
+        wave_totals_to<NV, 0>(out, lane, buf + vw * (NV + 1));
+        if (mx) {
+            m = group_max<64>(m);
+            if (lane == 0) buf[vw * (NV + 1) + NV] = m;
+        }
+    };
+    if constexpr (NVW == 1) one_wave(rw);
+    else {
+#pragma unroll 1
+        for (int k = 0; k < NVW; ++k) one_wave(rw + (RT / 64) * k);   // the virtual wave this real wave plays now
+    }
+    __syncthreads();
+    // (the waves' totals are added one wave at a time, as block_sum_t's run-time loop does: with the wave loop
+    // unrolled too, 8 x 31 LDS reads are in flight at once and the post-fit kernels spill hundreds of registers)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) out[i] = 0.0;
+#pragma unroll 1
+    for (int w = 0; w < NWV; ++w) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) out[i] += buf[w * (NV + 1) + i];
+    }
+    if (mx) {
+        double m = buf[NV];
+#pragma unroll 1
+        for (int w = 1; w < NWV; ++w) m = fmax(m, buf[w * (NV + 1) + NV]);
+        *mx = m;
+    }
+}
+
+template <int NT, int PF, int NVW>
+__device__ __forceinline__ void taylor_solve_body(const FitArgs& a, const int i, const int tid, double* scratch, double* inv_lds) {
+    constexpr int RT = NT / NVW;         // real threads
+    static_assert(NT % 64 == 0 && RT % 64 == 0 && NT % RT == 0, "whole waves");
     SubState& st = a.st[i];
     if (st.done) return;                 // (second launch, after a re-expansion of the others)
-    __shared__ double scratch[PP_BSUM_DOUBLES(NWV, 10)];
     int flip = 0;
     const double P = a.P[i];
     const double nuDM = a.nu_fit[i * 3], nuGM = a.nu_fit[i * 3 + 1];
@@ -1628,13 +1675,12 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
     // what an evaluation needs of a channel beside its Taylor row -- weight, phase geometry (five
     // divisions), template power -- is the same in every evaluation of the solve: formed once, kept in
     // LDS (dynamic: 32 B x a.solve_cache channels; channels beyond, if any, are formed again on every evaluation)
-    extern __shared__ double inv_lds[];
     const int ncache = a.solve_cache;
     double *inv_w = inv_lds, *inv_p1 = inv_lds + ncache, *inv_p2 = inv_lds + 2 * ncache, *inv_S = inv_lds + 3 * ncache;
     {
         const int nc = min(a.nchan, ncache);
 #pragma unroll 4
-        for (int n = tid; n < nc; n += NT) {
+        for (int n = tid; n < nc; n += RT) {
             double p1, p2;
             phase_geom(freqs[n], P, nuDM, nuGM, p1, p2);
             inv_w[n] = wts[n]; inv_p1[n] = p1; inv_p2[n] = p2; inv_S[n] = msum[n];
@@ -1645,8 +1691,8 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
         if (n < ncache) { w = inv_w[n]; p1 = inv_p1[n]; p2 = inv_p2[n]; S0 = inv_S[n]; }
         else { w = wts[n]; phase_geom(freqs[n], P, nuDM, nuGM, p1, p2); S0 = msum[n]; }
     };
-    // this thread's channels: body(n, row of the Taylor model)
-    auto for_channels = [&](auto&& body) {
+    // the channels of (virtual) thread vt: body(n, row of the Taylor model)
+    auto for_channels = [&](const int vt, auto&& body) {
         // (the next row is on its way while this one is worked on: the loop is a chain of
         // memory latencies otherwise, two waves per SIMD hide none of it)
         // (PF rows ahead.  Narrow bands -- the subints' rows together fit the Infinity Cache, the evaluation is a chain of
@@ -1654,7 +1700,7 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
         // a CU keeps in flight, the more of the others' rows it pushes out; PF = 0, each row fetched when its turn
         // comes, measured fastest there: 0.45 ms against 0.47 / 0.48 / 0.485 for 1 / 2 / 3 ahead)
         if constexpr (PF == 0) {
-            for (int n = tid; n < a.nchan; n += NT) {
+            for (int n = vt; n < a.nchan; n += NT) {
                 double t[PP_TSTRIDE];
                 taylor_load(tay, row0 + n, t);
                 body(n, t);
@@ -1663,8 +1709,8 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
             double buf[PF ? PF : 1][PP_TSTRIDE];
 #pragma unroll
             for (int d = 0; d < PF; ++d)
-                if (tid + d * NT < a.nchan) taylor_load(tay, row0 + tid + d * NT, buf[d]);
-            for (int n0 = tid; n0 < a.nchan; n0 += PF * NT) {
+                if (vt + d * NT < a.nchan) taylor_load(tay, row0 + vt + d * NT, buf[d]);
+            for (int n0 = vt; n0 < a.nchan; n0 += PF * NT) {
 #pragma unroll
                 for (int d = 0; d < PF; ++d) {
                     const int n = n0 + d * NT;
@@ -1687,9 +1733,9 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
     // ... and at the expansion point itself (the first evaluation of the ordinary flow: d = 0 in every channel,
     // where Horner's rule returns A0, A1, A2 = t[0], t[1], t[2] exactly) only the first two coefficient pairs
     // of a row are read: 32 of its 96 bytes (which saves HBM traffic with the blocked row layout only)
-    auto for_channels_at_origin = [&](auto&& body) {
+    auto for_channels_at_origin = [&](const int vt, auto&& body) {
         constexpr int U = 4;
-        for (int n0 = tid; n0 < a.nchan; n0 += U * NT) {
+        for (int n0 = vt; n0 < a.nchan; n0 += U * NT) {
             double2 h[U][2];
 #pragma unroll
             for (int d = 0; d < U; ++d)
@@ -1708,41 +1754,40 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
         const long long ck0 = clock64();
 #endif
         double acc[10];
-#pragma unroll
-        for (int j = 0; j < 10; ++j) acc[j] = 0.0;
         double dmax = 0.0;
         // (a channel out of the fit adds zeros instead of branching around the work: the two channels a thread
         // has in hand then interleave -- with one wave per SIMD a dependent chain costs its full latency)
-        auto add = [&](double w, double p1, double p2, double S0, double A0, double A1, double A2) {
-            const bool in = (w != 0.0);
-            const double r = A0 / S0;
-            const double F = in ? -w * A0 * r : 0.0, Gp = in ? -2.0 * w * r * A1 : 0.0;
-            const double Lpp = in ? -2.0 * w * (A1 * A1 / S0 + r * A2) : 0.0;
-            acc[0] += F;
-            acc[1] += Gp; acc[2] += Gp * p1; acc[3] += Gp * p2;
-            acc[4] += Lpp; acc[5] += Lpp * p1; acc[6] += Lpp * p2;
-            acc[7] += Lpp * p1 * p1; acc[8] += Lpp * p1 * p2; acc[9] += Lpp * p2 * p2;
-        };
-        if (at_origin)
-            for_channels_at_origin([&](int n, double A0, double A1, double A2) {
-                double w, p1, p2, S0;
-                chan_inv(n, w, p1, p2, S0);
-                add(w, p1, p2, S0, A0, A1, A2);
-            });
-        else
-            for_channels([&](int n, const double (&t)[PP_TSTRIDE]) {
-                double w, p1, p2, S0;
-                chan_inv(n, w, p1, p2, S0);
-                const double d = dx[0] + dx[1] * p1 + dx[2] * p2;
-                dmax = fmax(dmax, (w != 0.0) ? fabs(d) : 0.0);
-                double A0, A1, A2;
-                taylor_shift_reg(t, d, A0, A1, A2);
-                add(w, p1, p2, S0, A0, A1, A2);
-            });
+        vblock_sum<10, 10, NT, NVW>(acc, scratch, flip, &dmax, tid, [&](const int vt, double (&ac)[10], double& dm) __attribute__((always_inline)) {
+            auto add = [&](double w, double p1, double p2, double S0, double A0, double A1, double A2) {
+                const bool in = (w != 0.0);
+                const double r = A0 / S0;
+                const double F = in ? -w * A0 * r : 0.0, Gp = in ? -2.0 * w * r * A1 : 0.0;
+                const double Lpp = in ? -2.0 * w * (A1 * A1 / S0 + r * A2) : 0.0;
+                ac[0] += F;
+                ac[1] += Gp; ac[2] += Gp * p1; ac[3] += Gp * p2;
+                ac[4] += Lpp; ac[5] += Lpp * p1; ac[6] += Lpp * p2;
+                ac[7] += Lpp * p1 * p1; ac[8] += Lpp * p1 * p2; ac[9] += Lpp * p2 * p2;
+            };
+            if (at_origin)
+                for_channels_at_origin(vt, [&](int n, double A0, double A1, double A2) {
+                    double w, p1, p2, S0;
+                    chan_inv(n, w, p1, p2, S0);
+                    add(w, p1, p2, S0, A0, A1, A2);
+                });
+            else
+                for_channels(vt, [&](int n, const double (&t)[PP_TSTRIDE]) {
+                    double w, p1, p2, S0;
+                    chan_inv(n, w, p1, p2, S0);
+                    const double d = dx[0] + dx[1] * p1 + dx[2] * p2;
+                    dm = fmax(dm, (w != 0.0) ? fabs(d) : 0.0);
+                    double A0, A1, A2;
+                    taylor_shift_reg(t, d, A0, A1, A2);
+                    add(w, p1, p2, S0, A0, A1, A2);
+                });
+        });
 #ifdef PP_SOLVE_CLOCKS
         const long long ck1 = clock64();
 #endif
-        block_sum_t<10, 10>(acc, scratch, flip, &dmax);
 #ifdef PP_SOLVE_CLOCKS
         ck_loop += ck1 - ck0; ck_red += clock64() - ck1; ++ck_n;
 #endif
@@ -1885,27 +1930,28 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
     const int buf = 1 - st.cur;
     if (ok) {
         double* csum = a.csum + ((size_t)buf * a.nsub + i) * a.nchan * a.ncs;
-        double ev[4] = {0.0, 0.0, 0.0, 0.0};   // err bounds g_phi, g_DM, g_GM; f at the accepted point
+        double ev[4];                          // err bounds g_phi, g_DM, g_GM; f at the accepted point
         double jf = 1.0;
         for (int j = 2; j <= PP_TJ; ++j) jf *= (double)j;   // PP_TJ!
-        for_channels([&](int n, const double (&t)[PP_TSTRIDE]) {
-            double w, p1, p2, S0;
-            chan_inv(n, w, p1, p2, S0);
-            const double d = dx[0] + dx[1] * p1 + dx[2] * p2;
-            double A0, A1, A2;
-            taylor_shift_reg(t, d, A0, A1, A2);
-            csum[(size_t)n * 3] = A0; csum[(size_t)n * 3 + 1] = A1; csum[(size_t)n * 3 + 2] = A2;
-            if (w == 0.0) return;
-            ev[3] += -w * A0 * A0 / S0;
-            // remainder of A1's series (one derivative): Bn |d|^PP_TJ / PP_TJ!
-            const double d2 = d * d, d4 = d2 * d2, d10 = d4 * d4 * d2;
-            static_assert(PP_TJ == 10, "remainder power written for order 10");
-            const double e1 = t[PP_TJ + 1] * d10 / jf;
-            const double r = fabs(t[0] / S0) + 1e-300;
-            const double ge = 2.0 * w * r * e1 * 1.5;   // + remainder through A0 (smaller by |d|/PP_TJ)
-            ev[0] += ge; ev[1] += ge * fabs(p1); ev[2] += ge * fabs(p2);
+        vblock_sum<4, 10, NT, NVW>(ev, scratch, flip, nullptr, tid, [&](const int vt, double (&e4)[4], double&) __attribute__((always_inline)) {
+            for_channels(vt, [&](int n, const double (&t)[PP_TSTRIDE]) {
+                double w, p1, p2, S0;
+                chan_inv(n, w, p1, p2, S0);
+                const double d = dx[0] + dx[1] * p1 + dx[2] * p2;
+                double A0, A1, A2;
+                taylor_shift_reg(t, d, A0, A1, A2);
+                csum[(size_t)n * 3] = A0; csum[(size_t)n * 3 + 1] = A1; csum[(size_t)n * 3 + 2] = A2;
+                if (w == 0.0) return;
+                e4[3] += -w * A0 * A0 / S0;
+                // remainder of A1's series (one derivative): Bn |d|^PP_TJ / PP_TJ!
+                const double d2 = d * d, d4 = d2 * d2, d10 = d4 * d4 * d2;
+                static_assert(PP_TJ == 10, "remainder power written for order 10");
+                const double e1 = t[PP_TJ + 1] * d10 / jf;
+                const double r = fabs(t[0] / S0) + 1e-300;
+                const double ge = 2.0 * w * r * e1 * 1.5;   // + remainder through A0 (smaller by |d|/PP_TJ)
+                e4[0] += ge; e4[1] += ge * fabs(p1); e4[2] += ge * fabs(p2);
+            });
         });
-        block_sum_t<4, 10>(ev, scratch, flip);
         // position error <= gradient error / curvature, per fitted parameter
         // (1e-11 pc cm^-3 of DM is worth ~1e-11 rot of phase at the band edge: two
         // decades inside the parity bars)
@@ -1985,6 +2031,20 @@ __global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a)
                                                                   // loop starts over from st.xe and counts its own)
         st.fresh = 1;
     }
+}
+
+template <int NT, int PF = PP_SOLVE_PF>
+__global__ __launch_bounds__(NT, PP_TAYLOR_WAVES) void k_taylor_solve(FitArgs a) {
+    __shared__ double scratch[PP_BSUM_DOUBLES(NT / 64, 10)];
+    extern __shared__ double inv_lds[];
+    taylor_solve_body<NT, PF, 1>(a, blockIdx.x, threadIdx.x, scratch, inv_lds);
+}
+// one real wave per subint walking the NT / 64 waves of k_taylor_solve<NT, PF> in turn: bitwise its results
+template <int NT, int PF = PP_SOLVE_PF>
+__global__ __launch_bounds__(64, PP_TAYLOR_WAVES) void k_taylor_solve_v(FitArgs a) {
+    __shared__ double scratch[PP_BSUM_DOUBLES(NT / 64, 10)];
+    extern __shared__ double inv_lds[];
+    taylor_solve_body<NT, PF, NT / 64>(a, blockIdx.x, threadIdx.x, scratch, inv_lds);
 }
 
 // unpack the 21 accumulators into g[5], H[25] with the fit flags applied
@@ -2284,13 +2344,15 @@ __device__ __forceinline__ double py_wrap_half(double x) {
 // CPT > 0 (phase / DM / GM fits, nchan <= NT CPT; NT threads): what the four passes read of a channel -- weight,
 // frequency, the three sums, template power, data power -- is fetched ONCE, into registers, with every
 // load in flight together; CPT = 0: any fit, any nchan, read pass by pass.  Same sums in the same order.
-template <int CPT, int NT>
-__global__ __launch_bounds__(NT) void k_finalize(FitArgs a) {
-    const int i = blockIdx.x, tid = threadIdx.x;
+// NVW > 1 (CPT = 0 only): NT / NVW real threads walk the NT / 64 waves of the NT-thread kernel in turn and form its
+// block-wide sums from the same per-wave totals in the same order (vblock_sum, as taylor_solve_body): bitwise its results.
+// `tid`: the real thread.  scratch: PP_BSUM_DOUBLES(NT / 64, 31) doubles of LDS; sh: one double.
+template <int CPT, int NT, int NVW>
+__device__ __forceinline__ void finalize_body(const FitArgs& a, const int i, const int tid, double* scratch, double* sh) {
+    static_assert(NVW == 1 || CPT == 0, "channels held in registers belong to real threads");
+    constexpr int RT = NT / NVW;
     const SubState& s = a.st[i];
-    __shared__ double scratch[PP_BSUM_DOUBLES(NT / 64, 31)];
     int flip = 0;
-    __shared__ double sh[64];
     const double P = a.P[i];
     const double* freqs = a.freqs + (size_t)i * a.freqs_stride;
     const double* wts = a.wts + (size_t)i * a.nchan;
@@ -2320,16 +2382,16 @@ __global__ __launch_bounds__(NT) void k_finalize(FitArgs a) {
             rd[q] = in ? a.sdraw[(size_t)i * a.nchan + n] : 0.0;
         }
     }
-    // body(n, q): channel n = tid + NT q of this thread
-    auto for_channels = [&](auto&& body) {
+    // body(n, q): channel n = vt + NT q of (virtual) thread vt
+    auto for_channels = [&](const int vt, auto&& body) {
         if constexpr (CPT > 0) {
 #pragma unroll
             for (int q = 0; q < CPT; ++q) {
-                const int n = tid + NT * q;
+                const int n = vt + NT * q;
                 if (n < a.nchan) body(n, q);
             }
         } else {
-            for (int n = tid; n < a.nchan; n += NT) body(n, 0);
+            for (int n = vt; n < a.nchan; n += NT) body(n, 0);
         }
     };
     auto wt_of = [&](int n, int q) { if constexpr (CPT > 0) return rw[q]; else return wts[n]; };
@@ -2349,14 +2411,15 @@ __global__ __launch_bounds__(NT) void k_finalize(FitArgs a) {
     const long long fk0 = clock64();
 #endif
     // ---- pass 0: Sd, mean frequency, used channels -------------------------
-    double v3[3] = {0.0, 0.0, 0.0};
-    for_channels([&](int n, int q) {
-        const double w = wt_of(n, q);
-        double sd;
-        if constexpr (CPT > 0) sd = rd[q]; else sd = (w != 0.0) ? a.sdraw[(size_t)i * a.nchan + n] : 0.0;
-        if (w != 0.0) { v3[0] += w * sd; v3[1] += nu_of(n, q); v3[2] += 1.0; }
+    double v3[3];
+    vblock_sum<3, 31, NT, NVW>(v3, scratch, flip, nullptr, tid, [&](const int vt, double (&u3)[3], double&) __attribute__((always_inline)) {
+        for_channels(vt, [&](int n, int q) {
+            const double w = wt_of(n, q);
+            double sd;
+            if constexpr (CPT > 0) sd = rd[q]; else sd = (w != 0.0) ? a.sdraw[(size_t)i * a.nchan + n] : 0.0;
+            if (w != 0.0) { u3[0] += w * sd; u3[1] += nu_of(n, q); u3[2] += 1.0; }
+        });
     });
-    block_sum_t<3, 31>(v3, scratch, flip);
     const double Sd = v3[0], nused = v3[2], fmean = v3[1] / v3[2];
 #ifdef PP_SOLVE_CLOCKS
     const long long fk1 = clock64();
@@ -2374,8 +2437,8 @@ __global__ __launch_bounds__(NT) void k_finalize(FitArgs a) {
         // sums over channels of local terms times powers of frequency
         // v[0..]: see per-pattern use below
         double v[20];
-        for (int j = 0; j < 20; ++j) v[j] = 0.0;
-        for_channels([&](int n, int q) {
+        vblock_sum<20, 31, NT, NVW>(v, scratch, flip, nullptr, tid, [&](const int vt, double (&v)[20], double&) __attribute__((always_inline)) {
+        for_channels(vt, [&](int n, int q) {
             const double w = wt_of(n, q);
             if (w == 0.0) return;
             double cs[PP_NCS];
@@ -2443,10 +2506,10 @@ __global__ __launch_bounds__(NT) void k_finalize(FitArgs a) {
             default: break;
             }
         });
+        });
 #ifdef PP_SOLVE_CLOCKS
         if (tid == 0 && (i % 200) == 0) printf("fin %d: zero-loop %lld\n", i, clock64() - fk1);
 #endif
-        block_sum_t<20, 31>(v, scratch, flip);
         switch (pat) {
         case 0x18: nzDM = 1.0 / sqrt(v[0] / v[1]); break;
         case 0x14: nzGM = pow(v[0] / v[1], -0.25); break;
@@ -2526,8 +2589,8 @@ __global__ __launch_bounds__(NT) void k_finalize(FitArgs a) {
     const long long fk2 = clock64();
 #endif
     double m[31];
-    for (int j = 0; j < 31; ++j) m[j] = 0.0;
-    for_channels([&](int n, int q) {
+    vblock_sum<31, 31, NT, NVW>(m, scratch, flip, nullptr, tid, [&](const int vt, double (&m)[31], double&) __attribute__((always_inline)) {
+    for_channels(vt, [&](int n, int q) {
         const double w = wt_of(n, q);
         if (w == 0.0) return;
         double cs[PP_NCS];
@@ -2559,10 +2622,10 @@ __global__ __launch_bounds__(NT) void k_finalize(FitArgs a) {
             }
         m[30] += w * A0 * r;      // (a_n sqrt(S_n))^2 = w A0^2/S0
     });
+    });
 #ifdef PP_SOLVE_CLOCKS
     const long long fk3 = clock64();
 #endif
-    block_sum_t<31, 31>(m, scratch, flip);
 #ifdef PP_SOLVE_CLOCKS
     const long long fk4 = clock64();
 #endif
@@ -2614,7 +2677,9 @@ __global__ __launch_bounds__(NT) void k_finalize(FitArgs a) {
         fk5 = clock64();
 #endif
         // ---- per-channel outputs -------------------------------------------------
-        for_channels([&](int n, int q) {
+#pragma unroll 1
+        for (int kv = 0; kv < NVW; ++kv)
+        for_channels(tid + RT * kv, [&](int n, int q) {
             const double w = wt_of(n, q);
             double sc = 0.0, se = 0.0, sn = 0.0;
             if (w != 0.0) {
@@ -2691,6 +2756,20 @@ __global__ __launch_bounds__(NT) void k_finalize(FitArgs a) {
         if (a.o_g0) for (int j = 0; j < 5; ++j) a.o_g0[(size_t)i * 5 + j] = s.g0[j];
         if (a.o_H0) for (int j = 0; j < 25; ++j) a.o_H0[(size_t)i * 25 + j] = s.H0[j];
     }
+}
+
+template <int CPT, int NT>
+__global__ __launch_bounds__(NT) void k_finalize(FitArgs a) {
+    __shared__ double scratch[PP_BSUM_DOUBLES(NT / 64, 31)];
+    __shared__ double sh[2];
+    finalize_body<CPT, NT, 1>(a, blockIdx.x, threadIdx.x, scratch, sh);
+}
+// one real wave per subint walking the NT / 64 waves of k_finalize<., NT> in turn: bitwise its results
+template <int NT>
+__global__ __launch_bounds__(64) void k_finalize_v(FitArgs a) {
+    __shared__ double scratch[PP_BSUM_DOUBLES(NT / 64, 31)];
+    __shared__ double sh[2];
+    finalize_body<0, NT, NT / 64>(a, blockIdx.x, threadIdx.x, scratch, sh);
 }
 
 }  // namespace pp

@@ -177,6 +177,8 @@ struct pp_ctx {
     int paired_split = 1;       // 2048-bin rows: last FFT stage + split in registers (k_xspec_p1024)
     int one_exchange = 1;       // 2048-bin rows, mode 2, noise given: one-exchange FFT (k_xspec_q1024)
     int seed_chan_stride = 16;  // device phase seed: pilot pass over every n-th channel (1 = all channels)
+    int tail_virtual = 0;       // experiments: solve (and post-fit stage) by ONE real wave per subint that walks the
+                                // waves of the multi-wave kernels in turn (bitwise the same results)
     int refseed_stride = 0;     // reference-seed flow: its pilot's channel stride on wide bands (0 = 64; >= 32 pilot channels kept)
     double seed_min_snr = 8.0;  // pilot seeds below this peak significance are redone from all channels
     int seed_ndm = 1;           // DM trials of the coarse (phi, DM) seed grid (1 = phase only, at the guessed DM)
@@ -412,7 +414,7 @@ static bool option_ref(pp_ctx* c, const std::string& n, OptRef* out) {
         {"finalize_regs", 'i', &c->finalize_regs, INT32_MIN}, {"solve_cache", 'i', &c->solve_cache, -1},
         {"solve_threads", 'i', &c->solve_threads, 0}, {"copy_kernels", 'i', &c->copy_kernels, INT32_MIN},
         {"solve_prefetch", 'i', &c->solve_prefetch, INT32_MIN}, {"overlap_post", 'i', &c->overlap_post, INT32_MIN},
-        {"refseed_stride", 'i', &c->refseed_stride, 0},
+        {"refseed_stride", 'i', &c->refseed_stride, 0}, {"tail_virtual", 'i', &c->tail_virtual, INT32_MIN},
     };
     for (const OptRef& o : tab)
         if (n == o.name) { *out = o; return true; }
@@ -1211,8 +1213,10 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     auto launch_taylor_solve = [&]() {
         size_t lds = (size_t)fa.solve_cache * 32;
         if (lds > 48 * 1024 && !c->solve_lds_attr) {     // (dynamic LDS beyond the default cap: said once)
-            const void* fns[5] = {(const void*)k_taylor_solve<64>, (const void*)k_taylor_solve<128>, (const void*)k_taylor_solve<256>,
-                                  (const void*)k_taylor_solve<256, 0>, (const void*)k_taylor_solve<512>};
+            const void* fns[9] = {(const void*)k_taylor_solve<64>, (const void*)k_taylor_solve<128>, (const void*)k_taylor_solve<256>,
+                                  (const void*)k_taylor_solve<256, 0>, (const void*)k_taylor_solve<512>,
+                                  (const void*)k_taylor_solve_v<128>, (const void*)k_taylor_solve_v<256>,
+                                  (const void*)k_taylor_solve_v<256, 0>, (const void*)k_taylor_solve_v<512>};
             bool ok = true;
             for (const void* fn : fns)
                 ok = (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32) == hipSuccess) && ok;
@@ -1224,6 +1228,14 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             c->solve_lds_attr = true;
         }
         if (lds > 48 * 1024 && c->solve_cache == 0) { fa.solve_cache = 0; lds = 0; }
+        if (c->tail_virtual && solve_nt > 64) {
+            // (experiments: ONE real wave per subint walks the waves of the kernel below in turn -- same bits)
+            if (solve_nt == 128) hipLaunchKernelGGL(k_taylor_solve_v<128>, dim3(ns), dim3(64), lds, sp, fa);
+            else if (solve_nt == 512) hipLaunchKernelGGL(k_taylor_solve_v<512>, dim3(ns), dim3(64), lds, sp, fa);
+            else if (C > 2048 && c->solve_prefetch <= 0) hipLaunchKernelGGL((k_taylor_solve_v<256, 0>), dim3(ns), dim3(64), lds, sp, fa);
+            else hipLaunchKernelGGL(k_taylor_solve_v<256>, dim3(ns), dim3(64), lds, sp, fa);
+            return;
+        }
         if (solve_nt == 64) hipLaunchKernelGGL(k_taylor_solve<64>, dim3(ns), dim3(64), lds, sp, fa);
         else if (solve_nt == 128) hipLaunchKernelGGL(k_taylor_solve<128>, dim3(ns), dim3(128), lds, sp, fa);
         else if (solve_nt == 512) hipLaunchKernelGGL(k_taylor_solve<512>, dim3(ns), dim3(512), lds, sp, fa);
@@ -1496,6 +1508,12 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             // the band at 8 channels per thread)
             const int fnt = (ff.ncs != 3 || C > 4096 || !c->finalize_regs) ? 0
                             : c->finalize_regs > 1 ? c->finalize_regs : C <= 512 ? 64 : C <= 1024 ? 128 : C <= 2048 ? 256 : 512;
+            if (c->tail_virtual && fnt > 64 && C <= 8 * fnt) {
+                // (experiments: ONE real wave per subint walks the waves of the kernel below in turn -- same bits)
+                if (fnt == 128) hipLaunchKernelGGL((k_finalize_v<128>), dim3(ns), dim3(64), 0, sp, ff);
+                else if (fnt == 256) hipLaunchKernelGGL((k_finalize_v<256>), dim3(ns), dim3(64), 0, sp, ff);
+                else hipLaunchKernelGGL((k_finalize_v<512>), dim3(ns), dim3(64), 0, sp, ff);
+            } else
             if (fnt == 64 && C <= 512) hipLaunchKernelGGL((k_finalize<8, 64>), dim3(ns), dim3(64), 0, sp, ff);
             else if (fnt == 128 && C <= 1024) hipLaunchKernelGGL((k_finalize<8, 128>), dim3(ns), dim3(128), 0, sp, ff);
             else if (fnt == 256 && C <= 2048) hipLaunchKernelGGL((k_finalize<8, 256>), dim3(ns), dim3(256), 0, sp, ff);
