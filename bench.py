@@ -354,8 +354,9 @@ def main():
     ap.add_argument("--variant", default=None, choices=sorted(VARIANTS),
                     help="run the headline workload in one of SURVEY 8(d)'s other regimes (Batch.__init__)")
     ap.add_argument("--pipeline", type=int, default=2,
-                    help="2 = step k + 1 is enqueued on the engine's stream (pp_fit_enqueue) before step k is "
-                         "collected: the host prepares a step while the previous one runs; 1 = synchronous calls")
+                    help="2 / 3 = steps enqueued on the engine's stream (pp_fit_enqueue) before the oldest one is "
+                         "collected: the host prepares a step while the previous ones run (3 when a step's solve and "
+                         "post-fit stage ride in the next step's transform: option fuse_tail); 1 = synchronous calls")
     ap.add_argument("--measured-noise", action="store_true",
                     help="errs=None: the noise of every channel is measured from the top quarter of its "
                          "power spectrum inside the transform (get_noise_PS) instead of being given")
@@ -455,15 +456,17 @@ def main():
             res = None
             if piped:
                 trace = [] if os.environ.get("PP_BENCH_STEP_TIMES") else None
+                depth = max(2, min(3, args.pipeline))       # enqueued steps in flight
                 for k in range(nsteps):
                     t_a = time.perf_counter()
                     batch.enqueue(records=None if out is None else out[k], method=method)
                     t_b = time.perf_counter()
-                    if k > 0:
+                    if k >= depth - 1:
                         res = eng.collect()
                     if trace is not None:
                         trace.append((1e3 * (t_b - t_a), 1e3 * (time.perf_counter() - t_b), torch.cuda.memory_reserved() / 2 ** 20))
-                res = eng.collect()
+                for _ in range(min(depth - 1, nsteps)):
+                    res = eng.collect()
                 if trace:
                     print("step times (enqueue, collect ms; torch MiB reserved): " + " ".join("%.2f/%.2f/%.0f" % t for t in trace), file=sys.stderr)
             else:
@@ -476,7 +479,7 @@ def main():
             # alive at once there -- two pending and the last result -- and the first time torch's caching
             # allocator has to grow for that, hipMalloc waits for the device: a ~20 ms stall that landed in
             # one timed 3-step workload or another)
-            run(3, None)
+            run(4, None)
         eng.set_option("profile", 1)
         eng.kernel_times(reset=True)
         fence()
@@ -591,7 +594,7 @@ def main():
                            "sigma": batch.sigma, "variant": args.variant, "model_harmonics_kept": batch.nharm,
                            "method": args.method, "phase_guesses": batch.guess,
                            "device_phase_seed_ns": args.seed_ns,
-                           "steps_in_flight": 2 if getattr(timed, "piped", False) else 1,
+                           "steps_in_flight": max(2, min(3, args.pipeline)) if getattr(timed, "piped", False) else 1,
                            "parallelism": "subint shards, %d rank(s), records kept in HBM, "
                                           "1 gather at the end" % world},
                 "roofline": roofline,
@@ -648,7 +651,7 @@ def main():
                 sm["steps"], sm["warmup"] = args.other_steps, args.other_warmup
                 if pool is not None and key in cpu_keys:
                     cpu_cases[key] = cpu_case(b, r, 16)
-                sm["steps_in_flight"] = 2 if getattr(timed, "piped", False) else 1
+                sm["steps_in_flight"] = max(2, min(3, args.pipeline)) if getattr(timed, "piped", False) else 1
                 sm.update(workload=wl, input_dtype=dt, seed_ns=max(sns, 0), nsub=b.nsub,
                           method=meth or args.method, phase_guesses=b.guess)
                 # recovered values against the injected ones, in units of the errors

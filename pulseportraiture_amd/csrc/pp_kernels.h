@@ -34,6 +34,11 @@ struct ModelFftArgs {
     int nchan;
 };
 
+// The solve and post-fit stage of the PREVIOUS batch, worked off by the waves of this batch's transform (round 5;
+// defined at the end of this file, behind the bodies it runs): `tail` of XspecArgs, or nullptr.
+struct TailArgs;
+__device__ void tail_work(const TailArgs* t, double* lds, int nlds, int tid, int max_tickets);
+
 struct XspecArgs {
     const void* data;         // [nsub][nchan][B]
     const cplx* const* mft;   // [nslot] device table of model FT base pointers
@@ -70,6 +75,9 @@ struct XspecArgs {
     // rows in use (RowWalk): one word per chunk of PP_ROW_CHUNK rows in the kernel's own row order,
     // or nullptr = every row.  Only with act == nullptr, cstep == 1 (the main pass over a batch).
     const unsigned* mwords;
+    // one-pass flow, enqueued batches: the previous batch's solve + post-fit stage as tickets (one subint each) the
+    // waves of this launch draw -- one before their first row, the rest after their last -- or nullptr
+    const TailArgs* tail;
 };
 
 // one harmonic of the stored cross-spectrum (row pitch Xs elements of 16 or 8 bytes)
@@ -129,6 +137,8 @@ struct FitArgs {
     const double* xstart;     // [nsub][5] or nullptr (= start at the expansion point)
     int nfev_shadow;          // one-pass flow: SciPy's one-point cache compared on the absolute iterate fl(x + p)
     int solve_cache;          // k_taylor_solve: channels whose weight / geometry / template power are kept in LDS (32 B each)
+    int tail_fused;           // the post-fit stage runs as tickets inside the next transform (tail_work): the count of
+                              // unfinished subints is published by the LAST ticket, not by subint 0's
     int x_full;               // the channel subset (coff, cstep, nchan_x) is evaluated over a cross-spectrum stored for
                               // ALL channels: X rows are addressed by the true channel (k_eval_scat)
 };
@@ -2744,7 +2754,7 @@ __device__ __forceinline__ void finalize_body(const FitArgs& a, const int i, con
         a.o_nfev[i] = s.nfev;
         a.o_rc[i] = s.status;
         a.o_npass[i] = s.npass;
-        if (i == 0) a.o_npass[a.nsub] = *a.nactive;     // (subints still unfinished: read back with the outputs)
+        if (i == 0 && !a.tail_fused) a.o_npass[a.nsub] = *a.nactive;     // (subints still unfinished: read back with the outputs)
         if (a.o_rec) {
             double* rec = a.o_rec + (size_t)i * PP_RECORD_WIDTH;
             for (int j = 0; j < 5; ++j) { rec[j] = op[j]; rec[5 + j] = oe[j]; }
@@ -2770,6 +2780,69 @@ __global__ __launch_bounds__(64) void k_finalize_v(FitArgs a) {
     __shared__ double scratch[PP_BSUM_DOUBLES(NT / 64, 31)];
     __shared__ double sh[2];
     finalize_body<0, NT, NT / 64>(a, blockIdx.x, threadIdx.x, scratch, sh);
+}
+
+// --------------------------------------------------------------------------
+// The tail of a batch inside the NEXT batch's transform (round 5).  The solve on the Taylor model and the post-fit
+// stage of batch k need every row of batch k, so they cannot start before its transform ends -- and behind it they
+// are 0.7 ms of a 14.7 ms step during which the f64 pipes idle (the solve re-reads the Taylor rows at the HBM
+// roofline) --; beside the persistent transform of batch k + 1 no other kernel finds a wave slot
+// (profiles/r05_overlap_ab.txt).  So the transform's own waves do the work: a subint of batch k is a TICKET, every
+// wave of batch k + 1's transform draws one before its first row and the waves that run out of rows draw the rest.
+// A wave is out of the transform for the ~1 ms its ticket takes (of ~14), which costs the transform far less than its
+// share of the waves (half the waves keep 81 % of the rate, profiles/r05_grid_scale.txt).  One wave does what four
+// (solve) and eight (post-fit) do in the stand-alone kernels by walking their waves in turn (NVW = NT / 64): the same
+// bits, so an enqueued batch returns what a synchronous call returns.
+// LDS: the transform's own image, free before the first row and after the last.
+// --------------------------------------------------------------------------
+struct TailArgs {
+    FitArgs fa;               // of the batch whose tail this is
+    unsigned ticket, done;    // next subint to hand out; subints finished
+    int nsub;
+    int solve_nt, solve_pf;   // the widths the stand-alone kernels would be launched with
+    int fin_nt;               // 64 (<8, 64>), 128 / 256 / 512 (<8, NT>), 0 (<0, 256>)
+};
+
+__device__ __noinline__ void tail_work(const TailArgs* t, double* lds, int nlds, int tid, int max_tickets) {
+    TailArgs* tw = const_cast<TailArgs*>(t);
+    const int nsub = t->nsub;
+    for (int round = 0; round < max_tickets; ++round) {
+        unsigned tk = 0;
+        if (tid == 0) tk = atomicAdd(&tw->ticket, 1u);
+        tk = (unsigned)__builtin_amdgcn_readfirstlane((int)tk);
+        if (tk >= (unsigned)nsub) return;
+        FitArgs a = t->fa;
+        const int i = (int)tk;
+        // [0, 528): block sums (PP_BSUM_DOUBLES(8, 31) = 512 the larger);  [528, 536): one broadcast value;  the rest:
+        // the solve's cache of channel invariants (4 doubles a channel; results do not depend on its size)
+        double* scratch = lds;
+        double* sh = lds + 528;
+        double* inv = lds + 536;
+        a.solve_cache = max(0, min(a.nchan, (nlds - 536) / 4));
+        a.tail_fused = 1;
+        const int snt = t->solve_nt, spf = t->solve_pf, fnt = t->fin_nt;
+        if (snt == 64) taylor_solve_body<64, PP_SOLVE_PF, 1>(a, i, tid, scratch, inv);
+        else if (snt == 128) taylor_solve_body<128, PP_SOLVE_PF, 2>(a, i, tid, scratch, inv);
+        else if (snt == 512) taylor_solve_body<512, PP_SOLVE_PF, 8>(a, i, tid, scratch, inv);
+        else if (spf == 0) taylor_solve_body<256, 0, 4>(a, i, tid, scratch, inv);
+        else taylor_solve_body<256, PP_SOLVE_PF, 4>(a, i, tid, scratch, inv);
+        __syncthreads();             // (one wave: orders its LDS and global writes before the post-fit stage reads them)
+        if (fnt == 64) finalize_body<8, 64, 1>(a, i, tid, scratch, sh);
+        else if (fnt == 128) finalize_body<0, 128, 2>(a, i, tid, scratch, sh);
+        else if (fnt == 512) finalize_body<0, 512, 8>(a, i, tid, scratch, sh);
+        else finalize_body<0, 256, 4>(a, i, tid, scratch, sh);
+        __syncthreads();
+        // the last ticket to finish publishes the count of unfinished subints (the stand-alone post-fit kernel
+        // runs after the whole solve kernel: its subint 0 does it)
+        if (tid == 0) {
+            __threadfence();
+            const unsigned d = atomicAdd(&tw->done, 1u);
+            if (d + 1u == (unsigned)nsub) {
+                __threadfence();
+                a.o_npass[a.nsub] = atomicAdd(a.nactive, 0);
+            }
+        }
+    }
 }
 
 }  // namespace pp

@@ -94,6 +94,7 @@ enum KernelFamily { KF_MODEL = 0, KF_XSPEC, KF_PREP, KF_SEED, KF_ACCUM, KF_EVAL,
 static const char* kFamilyNames[KF_COUNT] = {"model_fft", "xspec", "prep", "seed", "accum", "eval", "taylor_solve", "step", "finalize",
                                             "synth", "fit_phase_shift", "scat_model"};
 
+#define PP_NSTAGE 3     // enqueued batches that may be pending at once (staging blocks, work-buffer sets)
 struct pp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -129,7 +130,7 @@ struct pp_ctx {
             xdone = nullptr;
         }
     };
-    WorkSet work[2];
+    WorkSet work[PP_NSTAGE];
     hipStream_t stream2 = nullptr;   // solve + post-fit stage of deferred batches (higher priority than `stream`)
     hipStream_t last_post = nullptr; // the stream the last fit_chunk queued its post-fit stage on
     int overlap_post = 0;            // deferred batches: 1 = solve / post-fit stage on stream2, beside the next transform.
@@ -147,8 +148,23 @@ struct pp_ctx {
     // deferred batch (pp_fit_enqueue) keeps its own while the next one is being queued
     struct Stage { void* in_host = nullptr; size_t in_cap = 0; void* o_host = nullptr; size_t o_cap = 0;
                    hipEvent_t t0 = nullptr, done = nullptr; };
-    Stage stage[2];
+    Stage stage[PP_NSTAGE];
     int cur_stage = 0;
+    // The tail of the youngest enqueued batch -- its solve on the Taylor model, its post-fit stage and the copies of its
+    // outputs -- when it has NOT been queued yet (option fuse_tail): the next enqueued batch's transform works it off
+    // as tickets (tail_work in pp_kernels.h), or, if none comes / the next one cannot carry it, flush_tail() queues
+    // the stand-alone kernels.
+    struct PendingTail {
+        bool valid = false;
+        int stage = 0;                   // staging block / work set of the batch it belongs to
+        FitArgs fa;                      // arguments of its solve and post-fit stage
+        int ns = 0, C = 0, solve_nt = 0, solve_pf0 = 0, fin_nt = 0;
+        size_t solve_lds = 0;
+        pp_fit_out out; int s0 = 0; bool chan_dev = false; size_t copy_bytes = 0;
+    } ptail;
+    DevBuf tailbuf[PP_NSTAGE];           // the TailArgs a carrying transform reads
+    void* tail_host[PP_NSTAGE] = {nullptr, nullptr, nullptr};   // ... and their pinned source
+    int fuse_tail = 0;          // enqueued one-pass batches: 1 = solve + post-fit stage as tickets of the NEXT batch's transform
     // pp_fit_enqueue / pp_fit_collect: batches queued on the stream and not yet collected (oldest first)
     struct Deferred { pp_fit_in in; pp_fit_out out; int stage; bool queued; int rc; std::string err; size_t span_end = 0; };
     std::deque<Deferred> pending;
@@ -352,6 +368,8 @@ extern "C" int pp_destroy(pp_ctx* c) {
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     resolve_spans(c);
     for (auto& w : c->work) w.release();
+    for (auto& b : c->tailbuf) b.release();
+    for (void*& h : c->tail_host) { if (h) (void)hipHostFree(h); h = nullptr; }
     for (auto& kv : c->twiddles) kv.second.release();
     for (auto& kv : c->anyplans) { kv.second.chirp.release(); kv.second.bft.release(); }
     for (auto& s : c->slots) { s.mft.release(); s.msum.release(); s.mmax.release(); s.mdc.release(); s.kt.release(); s.msq.release(); }
@@ -415,6 +433,7 @@ static bool option_ref(pp_ctx* c, const std::string& n, OptRef* out) {
         {"solve_threads", 'i', &c->solve_threads, 0}, {"copy_kernels", 'i', &c->copy_kernels, INT32_MIN},
         {"solve_prefetch", 'i', &c->solve_prefetch, INT32_MIN}, {"overlap_post", 'i', &c->overlap_post, INT32_MIN},
         {"refseed_stride", 'i', &c->refseed_stride, 0}, {"tail_virtual", 'i', &c->tail_virtual, INT32_MIN},
+        {"fuse_tail", 'i', &c->fuse_tail, INT32_MIN},
     };
     for (const OptRef& o : tab)
         if (n == o.name) { *out = o; return true; }
@@ -907,6 +926,116 @@ static int unfinished_in_stage(const void* o_host, int ns) {
     return reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(o_host) + (size_t)ns * 41)[3 * (size_t)ns];
 }
 
+// the solve on the Taylor model: NT threads per subint by band width (or option solve_threads), rows fetched in turn
+// for bands wider than 2048 channels.  `fa.solve_cache` may be lowered (dynamic LDS refused by the runtime).
+static int solve_threads_for(pp_ctx* c, int C) { return c->solve_threads > 0 ? c->solve_threads : (C <= 512 ? 64 : C <= 1024 ? 128 : 256); }
+static bool solve_rows_in_turn(pp_ctx* c, int C, int solve_nt) { return solve_nt == 256 && C > 2048 && c->solve_prefetch <= 0; }
+static void solve_launch(pp_ctx* c, FitArgs& fa, int ns, int C, int solve_nt, hipStream_t sp) {
+    size_t lds = (size_t)fa.solve_cache * 32;
+    if (lds > 48 * 1024 && !c->solve_lds_attr) {     // (dynamic LDS beyond the default cap: said once)
+        const void* fns[9] = {(const void*)k_taylor_solve<64>, (const void*)k_taylor_solve<128>, (const void*)k_taylor_solve<256>,
+                              (const void*)k_taylor_solve<256, 0>, (const void*)k_taylor_solve<512>,
+                              (const void*)k_taylor_solve_v<128>, (const void*)k_taylor_solve_v<256>,
+                              (const void*)k_taylor_solve_v<256, 0>, (const void*)k_taylor_solve_v<512>};
+        bool ok = true;
+        for (const void* fn : fns)
+            ok = (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32) == hipSuccess) && ok;
+        if (!ok) {
+            // the runtime refuses that much dynamic LDS: the solve runs without the cache
+            (void)hipGetLastError();
+            c->solve_cache = 0;
+        }
+        c->solve_lds_attr = true;
+    }
+    if (lds > 48 * 1024 && c->solve_cache == 0) { fa.solve_cache = 0; lds = 0; }
+    const bool in_turn = solve_rows_in_turn(c, C, solve_nt);
+    if (c->tail_virtual && solve_nt > 64) {
+        // (experiments: ONE real wave per subint walks the waves of the kernel below in turn -- same bits)
+        if (solve_nt == 128) hipLaunchKernelGGL(k_taylor_solve_v<128>, dim3(ns), dim3(64), lds, sp, fa);
+        else if (solve_nt == 512) hipLaunchKernelGGL(k_taylor_solve_v<512>, dim3(ns), dim3(64), lds, sp, fa);
+        else if (in_turn) hipLaunchKernelGGL((k_taylor_solve_v<256, 0>), dim3(ns), dim3(64), lds, sp, fa);
+        else hipLaunchKernelGGL(k_taylor_solve_v<256>, dim3(ns), dim3(64), lds, sp, fa);
+        return;
+    }
+    if (solve_nt == 64) hipLaunchKernelGGL(k_taylor_solve<64>, dim3(ns), dim3(64), lds, sp, fa);
+    else if (solve_nt == 128) hipLaunchKernelGGL(k_taylor_solve<128>, dim3(ns), dim3(128), lds, sp, fa);
+    else if (solve_nt == 512) hipLaunchKernelGGL(k_taylor_solve<512>, dim3(ns), dim3(512), lds, sp, fa);
+    else if (in_turn) hipLaunchKernelGGL((k_taylor_solve<256, 0>), dim3(ns), dim3(256), lds, sp, fa);
+    else hipLaunchKernelGGL(k_taylor_solve<256>, dim3(ns), dim3(256), lds, sp, fa);
+}
+// the post-fit stage: phase / DM / GM fits of up to 4096 channels hold a channel's numbers in registers over the
+// passes, as few waves per subint as hold the band at 8 channels per thread; everything else pass by pass.
+// Returns the width taken (64 ... 512; 0 = the pass-by-pass kernel of 256 threads).
+static int finalize_threads_for(pp_ctx* c, const FitArgs& ff, int C) {
+    return (ff.ncs != 3 || C > 4096 || !c->finalize_regs) ? 0
+           : c->finalize_regs > 1 ? c->finalize_regs : C <= 512 ? 64 : C <= 1024 ? 128 : C <= 2048 ? 256 : 512;
+}
+static void finalize_launch(pp_ctx* c, const FitArgs& ff, int ns, int C, hipStream_t sp) {
+    const int fnt = finalize_threads_for(c, ff, C);
+    if (c->tail_virtual && fnt > 64 && C <= 8 * fnt) {
+        // (experiments: ONE real wave per subint walks the waves of the kernel below in turn -- same bits)
+        if (fnt == 128) hipLaunchKernelGGL((k_finalize_v<128>), dim3(ns), dim3(64), 0, sp, ff);
+        else if (fnt == 256) hipLaunchKernelGGL((k_finalize_v<256>), dim3(ns), dim3(64), 0, sp, ff);
+        else hipLaunchKernelGGL((k_finalize_v<512>), dim3(ns), dim3(64), 0, sp, ff);
+    } else
+    if (fnt == 64 && C <= 512) hipLaunchKernelGGL((k_finalize<8, 64>), dim3(ns), dim3(64), 0, sp, ff);
+    else if (fnt == 128 && C <= 1024) hipLaunchKernelGGL((k_finalize<8, 128>), dim3(ns), dim3(128), 0, sp, ff);
+    else if (fnt == 256 && C <= 2048) hipLaunchKernelGGL((k_finalize<8, 256>), dim3(ns), dim3(256), 0, sp, ff);
+    else if (fnt == 512) hipLaunchKernelGGL((k_finalize<8, 512>), dim3(ns), dim3(512), 0, sp, ff);
+    else hipLaunchKernelGGL((k_finalize<0, 256>), dim3(ns), dim3(256), 0, sp, ff);
+}
+// which body tail_work runs for the post-fit stage: the width the stand-alone launch above takes
+static int finalize_width_taken(pp_ctx* c, const FitArgs& ff, int C) {
+    const int fnt = finalize_threads_for(c, ff, C);
+    if (fnt == 64 && C <= 512) return 64;
+    if (fnt == 128 && C <= 1024) return 128;
+    if (fnt == 256 && C <= 2048) return 256;
+    if (fnt == 512) return 512;
+    return 0;
+}
+// what follows the post-fit stage of a batch: its packed outputs on their way to the staging block (and the
+// per-channel / objective arrays to the caller's host arrays, when asked for)
+static int queue_outputs(pp_ctx* c, int stage, const pp_fit_out* out, int s0, int ns, int C, bool chan_dev, size_t copy_bytes,
+                         hipStream_t sp) {
+    pp_ctx::Stage& sg = c->stage[stage];
+    pp_ctx::WorkSet& W = c->work[stage];
+    const size_t nc = (size_t)ns * C;
+    int rc;
+#define PP_D2H(dst, buf, off, bytes) \
+    if (dst) HIP_TRY(hipMemcpyAsync((char*)(dst) + (off), (buf).p, (bytes), hipMemcpyDeviceToHost, sp))
+    if ((rc = staged_copy(c, sg.o_host, W.o_pack.p, copy_bytes, hipMemcpyDeviceToHost, sp))) return fail(rc, "output block copy failed");
+    if (!chan_dev) {
+        PP_D2H(out->scales, W.o_scales, (size_t)s0 * C * 8, nc * 8);
+        PP_D2H(out->scale_errs, W.o_serrs, (size_t)s0 * C * 8, nc * 8);
+        PP_D2H(out->channel_snrs, W.o_csnr, (size_t)s0 * C * 8, nc * 8);
+    }
+    PP_D2H(out->obj_f, W.o_f0, (size_t)s0 * 8, (size_t)ns * 8);
+    PP_D2H(out->obj_grad, W.o_g0, (size_t)s0 * 40, (size_t)ns * 40);
+    PP_D2H(out->obj_hess, W.o_H0, (size_t)s0 * 200, (size_t)ns * 200);
+#undef PP_D2H
+    return PP_OK;
+}
+// the pending tail by the stand-alone kernels (nobody carried it): solve, post-fit stage, outputs, the batch's event
+static int flush_tail(pp_ctx* c) {
+    pp_ctx::PendingTail& t = c->ptail;
+    if (!t.valid) return PP_OK;
+    t.valid = false;
+    int rc;
+    {
+        Prof pr(c, KF_TAYLOR);
+        solve_launch(c, t.fa, t.ns, t.C, t.solve_nt, c->stream);
+    }
+    {
+        Prof pr(c, KF_FINAL);
+        finalize_launch(c, t.fa, t.ns, t.C, c->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    if ((rc = queue_outputs(c, t.stage, &t.out, t.s0, t.ns, t.C, t.chan_dev, t.copy_bytes, c->stream))) return rc;
+    HIP_TRY(hipEventRecord(c->stage[t.stage].done, c->stream));
+    if (c->eager_flush) (void)hipStreamQuery(c->stream);
+    return PP_OK;
+}
+
 // `deferred` (pp_fit_enqueue): when non-null and the batch takes the one-pass flow without a host
 // decision in its middle, everything is queued -- outputs on their way to the staging block included --
 // and the call returns WITHOUT waiting (*deferred = true); pp_fit_collect finishes it.
@@ -1196,7 +1325,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     fa.x_f32 = xf32 ? 1 : 0;
     fa.nfev_shadow = c->nfev_shadow;
     // (a band of up to 512 channels: one wave per subint; up to 1024: two; wider: four -- eight measured slower at 4096)
-    const int solve_nt = c->solve_threads > 0 ? c->solve_threads : (C <= 512 ? 64 : C <= 1024 ? 128 : 256);
+    const int solve_nt = solve_threads_for(c, C);
     // (LDS: 32 B per cached channel, 512 channels per wave of the block keep the CU's eight waves within 128 KB)
     fa.solve_cache = std::min(C, c->solve_cache >= 0 ? c->solve_cache : std::min(PP_SOLVE_CACHE_MAX, solve_nt * 8));
     {
@@ -1210,38 +1339,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         const int room = std::max(0, c->max_lds_bytes - 16 * 1024) / 32;
         fa.solve_cache = std::min(fa.solve_cache, room);
     }
-    auto launch_taylor_solve = [&]() {
-        size_t lds = (size_t)fa.solve_cache * 32;
-        if (lds > 48 * 1024 && !c->solve_lds_attr) {     // (dynamic LDS beyond the default cap: said once)
-            const void* fns[9] = {(const void*)k_taylor_solve<64>, (const void*)k_taylor_solve<128>, (const void*)k_taylor_solve<256>,
-                                  (const void*)k_taylor_solve<256, 0>, (const void*)k_taylor_solve<512>,
-                                  (const void*)k_taylor_solve_v<128>, (const void*)k_taylor_solve_v<256>,
-                                  (const void*)k_taylor_solve_v<256, 0>, (const void*)k_taylor_solve_v<512>};
-            bool ok = true;
-            for (const void* fn : fns)
-                ok = (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SOLVE_CACHE_MAX * 32) == hipSuccess) && ok;
-            if (!ok) {
-                // the runtime refuses that much dynamic LDS: the solve runs without the cache
-                (void)hipGetLastError();
-                c->solve_cache = 0;
-            }
-            c->solve_lds_attr = true;
-        }
-        if (lds > 48 * 1024 && c->solve_cache == 0) { fa.solve_cache = 0; lds = 0; }
-        if (c->tail_virtual && solve_nt > 64) {
-            // (experiments: ONE real wave per subint walks the waves of the kernel below in turn -- same bits)
-            if (solve_nt == 128) hipLaunchKernelGGL(k_taylor_solve_v<128>, dim3(ns), dim3(64), lds, sp, fa);
-            else if (solve_nt == 512) hipLaunchKernelGGL(k_taylor_solve_v<512>, dim3(ns), dim3(64), lds, sp, fa);
-            else if (C > 2048 && c->solve_prefetch <= 0) hipLaunchKernelGGL((k_taylor_solve_v<256, 0>), dim3(ns), dim3(64), lds, sp, fa);
-            else hipLaunchKernelGGL(k_taylor_solve_v<256>, dim3(ns), dim3(64), lds, sp, fa);
-            return;
-        }
-        if (solve_nt == 64) hipLaunchKernelGGL(k_taylor_solve<64>, dim3(ns), dim3(64), lds, sp, fa);
-        else if (solve_nt == 128) hipLaunchKernelGGL(k_taylor_solve<128>, dim3(ns), dim3(128), lds, sp, fa);
-        else if (solve_nt == 512) hipLaunchKernelGGL(k_taylor_solve<512>, dim3(ns), dim3(512), lds, sp, fa);
-        else if (C > 2048 && c->solve_prefetch <= 0) hipLaunchKernelGGL((k_taylor_solve<256, 0>), dim3(ns), dim3(256), lds, sp, fa);
-        else hipLaunchKernelGGL(k_taylor_solve<256>, dim3(ns), dim3(256), lds, sp, fa);
-    };
+    auto launch_taylor_solve = [&]() { solve_launch(c, fa, ns, C, solve_nt, sp); };
 
     auto run_xspec = [&](const XspecArgs& x, int mode) -> int {
         Prof pr(c, KF_XSPEC);
@@ -1327,6 +1425,10 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         return PP_OK;
     };
 
+    // (a pending tail of the previous enqueued batch that this batch's transform will not carry -- any flow but the
+    // plain one-pass one -- goes out by the stand-alone kernels now)
+    if (c->ptail.valid && (refseed || seed_full || fuse_scat || !xmom || anyb || !c->one_exchange || !(M == 1024 || M == 512) || !deferred))
+        if ((rc = flush_tail(c))) return rc;
     // ---- phase seed from a pilot pass ----
     if (pilot) {
         const int Cp = (C + cstep - 1) / cstep;
@@ -1492,7 +1594,32 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     } else {
         XspecArgs xm = xa;
         xm.mwords = mw_main;
+        // The previous enqueued batch's tail (solve + post-fit stage), still unqueued: this transform works it off as
+        // tickets if it is one of the kernels that can (k_xspec_q1024 / k_xspec_qf: 2048- and 1024-bin rows, Taylor
+        // sums only); its outputs and its event follow this transform on the stream.
+        const bool carrier = c->ptail.valid && xmom && !anyb && c->one_exchange && (M == 1024 || M == 512) && deferred != nullptr;
+        if (carrier) {
+            pp_ctx::PendingTail& pt = c->ptail;
+            const int st_i = c->cur_stage;
+            const size_t tb = (sizeof(TailArgs) + 7) & ~(size_t)7;
+            if ((rc = c->tailbuf[st_i].reserve(tb))) return rc;
+            if (!c->tail_host[st_i]) HIP_TRY(hipHostMalloc(&c->tail_host[st_i], tb, hipHostMallocDefault));
+            TailArgs* th = reinterpret_cast<TailArgs*>(c->tail_host[st_i]);
+            memset(th, 0, tb);
+            th->fa = pt.fa; th->ticket = 0; th->done = 0; th->nsub = pt.ns;
+            th->solve_nt = pt.solve_nt; th->solve_pf = pt.solve_pf0 ? 0 : PP_SOLVE_PF; th->fin_nt = pt.fin_nt;
+            if ((rc = staged_copy(c, c->tailbuf[st_i].p, th, tb, hipMemcpyHostToDevice))) return fail(rc, "tail block copy failed");
+            xm.tail = c->tailbuf[st_i].as<TailArgs>();
+        } else if (c->ptail.valid) {
+            if ((rc = flush_tail(c))) return rc;
+        }
         if ((rc = run_xspec(xm, xmode))) return rc;
+        if (carrier) {
+            pp_ctx::PendingTail& pt = c->ptail;
+            pt.valid = false;
+            if ((rc = queue_outputs(c, pt.stage, &pt.out, pt.s0, pt.ns, pt.C, pt.chan_dev, pt.copy_bytes, c->stream))) return rc;
+            HIP_TRY(hipEventRecord(c->stage[pt.stage].done, c->stream));
+        }
         if (!wts_early) if ((rc = run_prep())) return rc;
     }
     HIP_TRY(hipGetLastError());
@@ -1503,36 +1630,10 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         ff.act = nullptr; ff.nact = ns;
         {
             Prof pr(c, KF_FINAL, sp);
-            // (phase / DM / GM fits of up to 4096 channels: the channel's numbers held in registers over the passes)
-            // (its passes are separated by block-wide sums and a serial stretch: as few waves per subint as hold
-            // the band at 8 channels per thread)
-            const int fnt = (ff.ncs != 3 || C > 4096 || !c->finalize_regs) ? 0
-                            : c->finalize_regs > 1 ? c->finalize_regs : C <= 512 ? 64 : C <= 1024 ? 128 : C <= 2048 ? 256 : 512;
-            if (c->tail_virtual && fnt > 64 && C <= 8 * fnt) {
-                // (experiments: ONE real wave per subint walks the waves of the kernel below in turn -- same bits)
-                if (fnt == 128) hipLaunchKernelGGL((k_finalize_v<128>), dim3(ns), dim3(64), 0, sp, ff);
-                else if (fnt == 256) hipLaunchKernelGGL((k_finalize_v<256>), dim3(ns), dim3(64), 0, sp, ff);
-                else hipLaunchKernelGGL((k_finalize_v<512>), dim3(ns), dim3(64), 0, sp, ff);
-            } else
-            if (fnt == 64 && C <= 512) hipLaunchKernelGGL((k_finalize<8, 64>), dim3(ns), dim3(64), 0, sp, ff);
-            else if (fnt == 128 && C <= 1024) hipLaunchKernelGGL((k_finalize<8, 128>), dim3(ns), dim3(128), 0, sp, ff);
-            else if (fnt == 256 && C <= 2048) hipLaunchKernelGGL((k_finalize<8, 256>), dim3(ns), dim3(256), 0, sp, ff);
-            else if (fnt == 512) hipLaunchKernelGGL((k_finalize<8, 512>), dim3(ns), dim3(512), 0, sp, ff);
-            else hipLaunchKernelGGL((k_finalize<0, 256>), dim3(ns), dim3(256), 0, sp, ff);
+            finalize_launch(c, ff, ns, C, sp);
         }
         HIP_TRY(hipGetLastError());
-#define PP_D2H(dst, buf, off, bytes) \
-    if (dst) HIP_TRY(hipMemcpyAsync((char*)(dst) + (off), (buf).p, (bytes), hipMemcpyDeviceToHost, sp))
-        if ((rc = staged_copy(c, sg.o_host, W.o_pack.p, d_seedph ? o_stage : o_bytes, hipMemcpyDeviceToHost, sp))) return fail(rc, "output block copy failed");
-        if (!chan_dev) {
-            PP_D2H(out->scales, W.o_scales, (size_t)s0 * C * 8, nc * 8);
-            PP_D2H(out->scale_errs, W.o_serrs, (size_t)s0 * C * 8, nc * 8);
-            PP_D2H(out->channel_snrs, W.o_csnr, (size_t)s0 * C * 8, nc * 8);
-        }
-        PP_D2H(out->obj_f, W.o_f0, (size_t)s0 * 8, (size_t)ns * 8);
-        PP_D2H(out->obj_grad, W.o_g0, (size_t)s0 * 40, (size_t)ns * 40);
-        PP_D2H(out->obj_hess, W.o_H0, (size_t)s0 * 200, (size_t)ns * 200);
-#undef PP_D2H
+        if ((rc = queue_outputs(c, c->cur_stage, out, s0, ns, C, chan_dev, d_seedph ? o_stage : o_bytes, sp))) return rc;
         if (c->eager_flush && sp != c->stream) (void)hipStreamQuery(sp);
         if (wait) HIP_TRY(hipStreamSynchronize(sp));
         return PP_OK;
@@ -1544,6 +1645,17 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         if (xstore) {
             Prof pr(c, KF_EVAL);
             hipLaunchKernelGGL(k_eval_moments, dim3(ns, nchunk), dim3(256), 0, c->stream, fa);
+        }
+        if (defer_ok && c->fuse_tail && !xstore && sp == c->stream) {
+            // nothing of the tail is queued: the next enqueued batch's transform works it off (or flush_tail does)
+            pp_ctx::PendingTail& pt = c->ptail;
+            pt.valid = true; pt.stage = c->cur_stage;
+            pt.fa = fa; pt.fa.act = nullptr; pt.fa.nact = ns;
+            pt.ns = ns; pt.C = C; pt.solve_nt = solve_nt; pt.solve_pf0 = solve_rows_in_turn(c, C, solve_nt) ? 1 : 0;
+            pt.fin_nt = finalize_width_taken(c, pt.fa, C);
+            pt.out = *out; pt.s0 = s0; pt.chan_dev = chan_dev; pt.copy_bytes = d_seedph ? o_stage : o_bytes;
+            *deferred = true;
+            return PP_OK;
         }
         if ((rc = chain_post())) return rc;
         {
@@ -1829,13 +1941,13 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
 extern "C" int pp_fit_enqueue(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out) {
     if (!c || !in || !out) return fail(PP_EINVAL, "pp_fit_enqueue: null argument");
     if (c->job_active) return fail(PP_ESTATE, "pp_fit_enqueue: a submitted fit is pending on this context (pp_fit_wait first)");
-    if (c->pending.size() >= 2) return fail(PP_ESTATE, "pp_fit_enqueue: two batches are pending (pp_fit_collect first)");
+    if (c->pending.size() >= PP_NSTAGE) return fail(PP_ESTATE, "pp_fit_enqueue: %d batches are pending (pp_fit_collect first)", PP_NSTAGE);
     BatchPlan bp;
     int rc = plan_batch(c, in, out, &bp);
     if (rc) return rc;
     pp_ctx::Deferred d;
     d.in = *in; d.out = *out; d.queued = false; d.rc = PP_OK;
-    d.stage = c->pending.empty() ? c->cur_stage : 1 - c->pending.front().stage;
+    d.stage = c->pending.empty() ? c->cur_stage : (c->pending.back().stage + 1) % PP_NSTAGE;
     c->cur_stage = d.stage;
     pp_ctx::Stage& sg = c->stage[d.stage];
     if (bp.cap >= in->nsub) {
@@ -1844,8 +1956,11 @@ extern "C" int pp_fit_enqueue(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out) {
         rc = fit_chunk(c, in, out, 0, in->nsub, bp.Kt, bp.scat, bp.nufit, bp.nuout, &deferred);
         if (rc) return rc;
         c->known_ok[bp.flow_key] = std::max(c->known_ok[bp.flow_key], bp.per_sub * in->nsub);
-        // (a deferred batch ends on the stream of its post-fit stage, which waited for its transform)
-        HIP_TRY(hipEventRecord(sg.done, (deferred && c->last_post) ? c->last_post : c->stream));
+        // (a deferred batch ends on the stream of its post-fit stage, which waited for its transform; one whose tail
+        // is still unqueued -- option fuse_tail -- gets its event when the tail has been queued: by the next batch's
+        // transform, or by flush_tail)
+        if (!(deferred && c->ptail.valid && c->ptail.stage == d.stage))
+            HIP_TRY(hipEventRecord(sg.done, (deferred && c->last_post) ? c->last_post : c->stream));
         d.queued = deferred;
         d.span_end = c->spans.size();
         if (!deferred) {
@@ -1863,6 +1978,7 @@ extern "C" int pp_fit_enqueue(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out) {
         // (more than the work-memory budget holds at once: sub-batches, synchronously -- only with
         // nothing else pending, the sub-batches reuse the staging blocks)
         if (!c->pending.empty()) return fail(PP_ESTATE, "pp_fit_enqueue: a batch that needs sub-batches cannot follow a pending one");
+        if ((rc = flush_tail(c))) return rc;
         if ((rc = run_batch_sync(c, in, out, bp))) return rc;
     }
     c->pending.push_back(d);
@@ -1882,6 +1998,9 @@ extern "C" int pp_fit_collect(pp_ctx* c) {
     if (!d.queued) return d.rc;
     HIP_TRY(hipSetDevice(c->device));
     pp_ctx::Stage& sg = c->stage[d.stage];
+    // (its tail was waiting for a next batch that did not come: the stand-alone kernels)
+    if (c->ptail.valid && c->ptail.stage == d.stage)
+        if (int rcf = flush_tail(c)) return rcf;
     HIP_TRY(hipEventSynchronize(sg.done));
     const int ns = d.in.nsub;
     if (unfinished_in_stage(sg.o_host, ns) <= 0) {

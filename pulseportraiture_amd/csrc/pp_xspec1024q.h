@@ -36,6 +36,9 @@
 #ifndef PP_SLOT_EARLY_EXIT
 #define PP_SLOT_EARLY_EXIT 1
 #endif
+#ifndef PP_TAIL_HOOKS
+#define PP_TAIL_HOOKS 1            // the transform kernels can work off the previous batch's solve / post-fit tickets (tail_work)
+#endif
 #ifndef PP_SLOT_PUBLISH_KEPT
 #define PP_SLOT_PUBLISH_KEPT 0     // k_xspec_q1024: 1 = only the kept slots' partner registers are published to LDS (2.5 fewer
                                    // ds_write_b128 of 65 LDS instructions a row).  Measured neutral to -0.5 %
@@ -85,6 +88,8 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
     const int lam0 = fftq_lambda(tid);
     cplx wb0 = a.twB[lam0 ? lam0 : 64];
     const cplx wbT = a.twB[64];
+    // (the previous batch's solve + post-fit stage: one ticket before the first row, see tail_work)
+    if (PP_TAIL_HOOKS && a.tail) tail_work(a.tail, reinterpret_cast<double*>(lds), 2 * (LDSN + 64 * NML), tid, 1);
     RowWalk<true> rw;
     rw.start(nrows, a.mwords, a.ticket, a.ticket_base);
     long long row = rw.row;
@@ -313,6 +318,8 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
         }
         lds_sync<T>();
     }
+    // (out of rows: the tickets of the previous batch's tail that are left)
+    if (PP_TAIL_HOOKS && a.tail) tail_work(a.tail, reinterpret_cast<double*>(lds), 2 * (LDSN + 64 * NML), tid, 1 << 30);
 }
 
 
@@ -353,6 +360,7 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
     const long long nrows = (long long)a.nsub * a.nchan;
     Raw cur[PER1][R1];
     const cplx wbT = a.twB[64];
+    if (PP_TAIL_HOOKS && a.tail) tail_work(a.tail, reinterpret_cast<double*>(lds), 2 * LDSN, tid, 1);     // (as k_xspec_q1024)
     RowWalk<true> rw;
     rw.start(nrows, a.mwords, a.ticket, a.ticket_base);
     long long row = rw.row;
@@ -515,6 +523,7 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
         }
         lds_sync<T>();
     }
+    if (PP_TAIL_HOOKS && a.tail) tail_work(a.tail, reinterpret_cast<double*>(lds), 2 * LDSN, tid, 1 << 30);
 }
 
 }  // namespace pp
