@@ -353,7 +353,7 @@ def main():
                     help="engine option (pp_set_option), e.g. scat_model=0; repeatable")
     ap.add_argument("--variant", default=None, choices=sorted(VARIANTS),
                     help="run the headline workload in one of SURVEY 8(d)'s other regimes (Batch.__init__)")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=3,
                     help="2 / 3 = steps enqueued on the engine's stream (pp_fit_enqueue) before the oldest one is "
                          "collected: the host prepares a step while the previous ones run (3 when a step's solve and "
                          "post-fit stage ride in the next step's transform: option fuse_tail); 1 = synchronous calls")
@@ -547,6 +547,7 @@ def main():
     line = None
     if rank == 0:
         nsub, C, B = batch.nsub, batch.C, batch.B
+        flags_scat = bool(batch.flags[3] or batch.flags[4])
         fam, per_step_s, abytes, achieved, summ = summary(batch, res, elapsed, ktimes, args.steps,
                                                           nsub * world * args.steps)
         # HBM bytes per launch of that kernel from the PMC passes (FETCH_SIZE x2 +
@@ -578,6 +579,11 @@ def main():
                     "algorithmic_bytes_per_launch": abytes * nsub,
                     "algorithmic_bytes_per_fit": abytes,
                     "fits_per_launch_group": nsub,
+                    "carries": ("each launch also works off the PREVIOUS step's solve + post-fit stage as tickets between its "
+                                "rows (engine option fuse_tail; the last timed step's go out by the stand-alone kernels): "
+                                "its duration is the whole fit's, transform + solve + post-fit stage"
+                                if (getattr(timed, "piped", False) and eng.get_option("fuse_tail") > 0 and B == 2048
+                                    and not flags_scat and args.seed_ns >= 0) else None),
                     "launches_per_step": ktimes[fam][1] / args.steps,
                     "ms_per_step_in_kernel": round(1e3 * per_step_s, 4),
                     "all_kernels_ms_per_step": summ["kernels_ms_per_step"]}
@@ -778,11 +784,13 @@ def strong_scaling(args, make_batch, sync, fence, device, rank, world, use_dist,
         t0 = time.perf_counter()
         results = []
         if piped:
+            depth = 3        # (a batch's solve and post-fit stage ride in the next batch's transform: engine option fuse_tail)
             for k, (b, off, n) in enumerate(todo):
                 b.enqueue(records=recs[off:off + n], n=n)
-                if k > 0:
+                if k >= depth - 1:
                     results.append(collect())
-            results.append(collect())
+            while len(results) < len(todo):
+                results.append(collect())
         else:
             for b, off, n in todo:
                 results.append(b.fit(records=recs[off:off + n], n=n))
@@ -821,7 +829,7 @@ def strong_scaling(args, make_batch, sync, fence, device, rank, world, use_dist,
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "note": note, "total_nsub": args.total_nsub,
                    "fits_per_rank": counts, "sub_batch": nsub, "sub_batches_rank0": sub_batches,
-                   "resident_sub_batches": group, "steps_in_flight": 2 if piped else 1,
+                   "resident_sub_batches": group, "steps_in_flight": 3 if piped else 1,
                    "nchan": C, "nbin": B,
                    "fit_flags": flags, "input_dtype": args.input_dtype, "method": args.method,
                    "phase_guesses": guess,

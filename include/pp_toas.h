@@ -170,6 +170,15 @@ void* pp_stream(pp_ctx* ctx);
  *   "copy_kernels"  1 (default) = the packed block of small inputs and the packed per-subint outputs cross PCIe by a
  *                  kernel that reads / writes the pinned staging block directly; 0 = by hipMemcpyAsync (a copy
  *                  command between two kernels hands the stream to the copy engine and back: ~0.05 ms per batch)
+ *   "fuse_tail"    pp_fit_enqueue, one-pass fits of 2048-bin portraits: 1 (default) = the batch's solve on the Taylor model and
+ *                  its post-fit stage are NOT queued behind its transform; the transform of the next enqueued batch works
+ *                  them off, one subint per ticket, between its own rows (one wave per ticket walking the waves of the
+ *                  stand-alone kernels in turn: bitwise their results), and the batch's outputs and event follow that
+ *                  transform on the stream.  If no batch follows (pp_fit_collect comes first) or the next batch cannot carry
+ *                  them (another row length, scattering, a seed flow), the stand-alone kernels are queued then.  Keep THREE
+ *                  batches enqueued to hide it all (a batch completes one transform later).  +0.6 ... 2.9 % fits/s
+ *                  (profiles/r05_fuse_tail_ab.txt); 0 = solve and post-fit stage queued at once
+ *   "tail_virtual" experiments: 1 = the stand-alone solve / post-fit kernels themselves in their one-wave form
  *   "check_from"   evaluation loop: the first iteration after which the host looks at the count of unfinished subints
  *                  (default 2; trust-ncg scattering fits with the closing model: 5 at least -- none is done before)
  *   "refseed_stride"  pp_seed_ref: channel stride of the pilot pass on wide bands (0 = default 64; at least 32 pilot
@@ -378,10 +387,13 @@ int pp_fit_wait(pp_ctx* ctx);
  * argument blocks and queues the WHOLE batch on the context's stream -- small inputs, every kernel,
  * the outputs on their way to a pinned staging block -- and returns without waiting; pp_fit_collect
  * completes the OLDEST enqueued batch (waits for it, fills the caller's output arrays) and returns what
- * pp_fit_portrait_batch would have returned.  Up to two batches may be pending, so a caller that
- * enqueues batch k + 1 before it collects batch k keeps the GPU busy while the host marshals: stream
- * order keeps batch k's solve and post-fit stage ahead of batch k + 1's transform, on one set of
- * device work buffers.  Batches whose flow needs a host decision in its middle (scattering fits,
+ * pp_fit_portrait_batch would have returned.  Up to THREE batches may be pending (each has its own
+ * staging blocks and its own set of the device work buffers its solve and post-fit stage use), so a
+ * caller that enqueues batches k + 1, k + 2 before it collects batch k keeps the GPU busy while the host
+ * marshals.  One-pass fits of 2048-bin portraits leave their solve and post-fit stage to the transform of
+ * the NEXT enqueued batch (option "fuse_tail", default on): batch k is then complete one transform later,
+ * or when pp_fit_collect finds it the youngest and queues them itself.  Same results either way, to the
+ * bit, as pp_fit_portrait_batch.  Batches whose flow needs a host decision in its middle (scattering fits,
  * device seeds, sub-batching) simply run to their end inside pp_fit_enqueue; the one-pass flow, with
  * the caller's guesses or with the reference's own (pp_seed_ref; phase / DM / GM fits), is deferred whole; a one-pass
  * batch in which some subint fails its certificate (poor guesses) is fitted again by the general

@@ -37,6 +37,8 @@ struct ModelFftArgs {
 // The solve and post-fit stage of the PREVIOUS batch, worked off by the waves of this batch's transform (round 5;
 // defined at the end of this file, behind the bodies it runs): `tail` of XspecArgs, or nullptr.
 struct TailArgs;
+#define PP_TAIL_LDS_DOUBLES 2176     // LDS of the carrying kernels (k_xspec_q1024, k_xspec_qf<1024>: 1088 complex), in doubles
+#define PP_TAIL_CACHE ((PP_TAIL_LDS_DOUBLES - 536) / 4)     // channels whose invariants the in-kernel solve keeps there
 __device__ void tail_work(const TailArgs* t, double* lds, int nlds, int tid, int max_tickets);
 
 struct XspecArgs {
@@ -2796,7 +2798,7 @@ __global__ __launch_bounds__(64) void k_finalize_v(FitArgs a) {
 // LDS: the transform's own image, free before the first row and after the last.
 // --------------------------------------------------------------------------
 struct TailArgs {
-    FitArgs fa;               // of the batch whose tail this is
+    FitArgs fa;               // of the batch whose tail this is (solve_cache <= PP_TAIL_CACHE, tail_fused = 1)
     unsigned ticket, done;    // next subint to hand out; subints finished
     int nsub;
     int solve_nt, solve_pf;   // the widths the stand-alone kernels would be launched with
@@ -2811,15 +2813,16 @@ __device__ __noinline__ void tail_work(const TailArgs* t, double* lds, int nlds,
         if (tid == 0) tk = atomicAdd(&tw->ticket, 1u);
         tk = (unsigned)__builtin_amdgcn_readfirstlane((int)tk);
         if (tk >= (unsigned)nsub) return;
-        FitArgs a = t->fa;
+        // (read where it lies, in device memory: a private copy of the ~600-byte block lives in scratch memory and
+        // every use of a field becomes a scratch load; the host has set solve_cache for PP_TAIL_LDS_DOUBLES and tail_fused)
+        const FitArgs& a = t->fa;
         const int i = (int)tk;
         // [0, 528): block sums (PP_BSUM_DOUBLES(8, 31) = 512 the larger);  [528, 536): one broadcast value;  the rest:
         // the solve's cache of channel invariants (4 doubles a channel; results do not depend on its size)
         double* scratch = lds;
         double* sh = lds + 528;
         double* inv = lds + 536;
-        a.solve_cache = max(0, min(a.nchan, (nlds - 536) / 4));
-        a.tail_fused = 1;
+        (void)nlds;
         const int snt = t->solve_nt, spf = t->solve_pf, fnt = t->fin_nt;
         if (snt == 64) taylor_solve_body<64, PP_SOLVE_PF, 1>(a, i, tid, scratch, inv);
         else if (snt == 128) taylor_solve_body<128, PP_SOLVE_PF, 2>(a, i, tid, scratch, inv);

@@ -164,7 +164,9 @@ struct pp_ctx {
     } ptail;
     DevBuf tailbuf[PP_NSTAGE];           // the TailArgs a carrying transform reads
     void* tail_host[PP_NSTAGE] = {nullptr, nullptr, nullptr};   // ... and their pinned source
-    int fuse_tail = 0;          // enqueued one-pass batches: 1 = solve + post-fit stage as tickets of the NEXT batch's transform
+    int fuse_tail = 1;          // enqueued one-pass batches of 2048-bin rows: 1 (default) = the solve + post-fit stage are
+                                // not queued behind the transform but worked off as tickets by the NEXT enqueued batch's
+                                // transform (tail_work in pp_kernels.h; bitwise the same results); 0 = queued at once
     // pp_fit_enqueue / pp_fit_collect: batches queued on the stream and not yet collected (oldest first)
     struct Deferred { pp_fit_in in; pp_fit_out out; int stage; bool queued; int rc; std::string err; size_t span_end = 0; };
     std::deque<Deferred> pending;
@@ -1427,7 +1429,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
 
     // (a pending tail of the previous enqueued batch that this batch's transform will not carry -- any flow but the
     // plain one-pass one -- goes out by the stand-alone kernels now)
-    if (c->ptail.valid && (refseed || seed_full || fuse_scat || !xmom || anyb || !c->one_exchange || !(M == 1024 || M == 512) || !deferred))
+    if (c->ptail.valid && (refseed || seed_full || fuse_scat || !xmom || anyb || !c->one_exchange || M != 1024 || !deferred))
         if ((rc = flush_tail(c))) return rc;
     // ---- phase seed from a pilot pass ----
     if (pilot) {
@@ -1597,7 +1599,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         // The previous enqueued batch's tail (solve + post-fit stage), still unqueued: this transform works it off as
         // tickets if it is one of the kernels that can (k_xspec_q1024 / k_xspec_qf: 2048- and 1024-bin rows, Taylor
         // sums only); its outputs and its event follow this transform on the stream.
-        const bool carrier = c->ptail.valid && xmom && !anyb && c->one_exchange && (M == 1024 || M == 512) && deferred != nullptr;
+        const bool carrier = c->ptail.valid && xmom && !anyb && c->one_exchange && M == 1024 && deferred != nullptr;
         if (carrier) {
             pp_ctx::PendingTail& pt = c->ptail;
             const int st_i = c->cur_stage;
@@ -1607,6 +1609,8 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             TailArgs* th = reinterpret_cast<TailArgs*>(c->tail_host[st_i]);
             memset(th, 0, tb);
             th->fa = pt.fa; th->ticket = 0; th->done = 0; th->nsub = pt.ns;
+            th->fa.solve_cache = std::min(pt.C, (int)PP_TAIL_CACHE);
+            th->fa.tail_fused = 1;
             th->solve_nt = pt.solve_nt; th->solve_pf = pt.solve_pf0 ? 0 : PP_SOLVE_PF; th->fin_nt = pt.fin_nt;
             if ((rc = staged_copy(c, c->tailbuf[st_i].p, th, tb, hipMemcpyHostToDevice))) return fail(rc, "tail block copy failed");
             xm.tail = c->tailbuf[st_i].as<TailArgs>();
@@ -1646,7 +1650,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             Prof pr(c, KF_EVAL);
             hipLaunchKernelGGL(k_eval_moments, dim3(ns, nchunk), dim3(256), 0, c->stream, fa);
         }
-        if (defer_ok && c->fuse_tail && !xstore && sp == c->stream) {
+        if (defer_ok && c->fuse_tail && !xstore && sp == c->stream && !anyb && M == 1024 && c->one_exchange) {
             // nothing of the tail is queued: the next enqueued batch's transform works it off (or flush_tail does)
             pp_ctx::PendingTail& pt = c->ptail;
             pt.valid = true; pt.stage = c->cur_stage;

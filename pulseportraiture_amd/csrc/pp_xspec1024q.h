@@ -37,7 +37,10 @@
 #define PP_SLOT_EARLY_EXIT 1
 #endif
 #ifndef PP_TAIL_HOOKS
-#define PP_TAIL_HOOKS 1            // the transform kernels can work off the previous batch's solve / post-fit tickets (tail_work)
+#define PP_TAIL_HOOKS 1            // the transform kernels of 2048-bin rows can work off the previous batch's solve / post-fit
+                                   // tickets (tail_work).  Not the 1024-bin kernel: it is compiled for three waves per SIMD
+                                   // (168 registers), and a function called from it inherits that budget -- the tail's code
+                                   // then spills, in EVERY carrier: configs[1] lost 6 % with it, the headline gained less
 #endif
 #ifndef PP_SLOT_PUBLISH_KEPT
 #define PP_SLOT_PUBLISH_KEPT 0     // k_xspec_q1024: 1 = only the kept slots' partner registers are published to LDS (2.5 fewer
@@ -67,6 +70,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
     static_assert(PP_TJ == 10, "power ladder written for order 10");
     constexpr int WRED = PP_WRED_DOUBLES(NRED) / 2;   // in cplx
     constexpr int LDSN = WRED > FFTQ_LDS_ELEMS ? WRED : FFTQ_LDS_ELEMS;
+    static_assert(2 * LDSN >= PP_TAIL_LDS_DOUBLES, "tail_work's layout of this kernel's LDS");
     // TAIL, f64 rows: the template values of the last NML slots live in LDS beside the image instead of in registers
     // (with them held the kernel spilled one of them + three dwords to scratch, and the scratch reload in the middle
     // of the row queues behind the prefetched half row: vector memory returns in order)
@@ -88,8 +92,15 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
     const int lam0 = fftq_lambda(tid);
     cplx wb0 = a.twB[lam0 ? lam0 : 64];
     const cplx wbT = a.twB[64];
-    // (the previous batch's solve + post-fit stage: one ticket before the first row, see tail_work)
-    if (PP_TAIL_HOOKS && a.tail) tail_work(a.tail, reinterpret_cast<double*>(lds), 2 * (LDSN + 64 * NML), tid, 1);
+    // (the previous batch's solve + post-fit stage, see tail_work: this wave draws ONE ticket after tail_after rows --
+    // a different count for every wave, spread over the first three quarters of its share, so that at any time a
+    // few per cent of the waves are out of the transform instead of half of them for the first millisecond --
+    // and whatever is left once it has run out of rows)
+    int tail_after = 0x7fffffff;
+    if (PP_TAIL_HOOKS && a.tail) {
+        const unsigned share = (unsigned)(nrows / (long long)gridDim.x) + 1u;
+        tail_after = 1 + (int)(((blockIdx.x * 2654435761u) >> 8) % (share - share / 4));
+    }
     RowWalk<true> rw;
     rw.start(nrows, a.mwords, a.ticket, a.ticket_base);
     long long row = rw.row;
@@ -105,7 +116,15 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
     cplx mv2[NSL];
     const cplx* mheld = nullptr;
     int i_nx = i, n_nx = n;
-    for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {
+    if (phase == 1) {
+        if (!(PP_TAIL_HOOKS && a.tail)) break;
+        // (between two rows: the next row's loads are in flight, the call keeps what it must across itself)
+        tail_work(a.tail, reinterpret_cast<double*>(lds), 2 * (LDSN + 64 * NML), tid, 1);
+        tail_after = 0x7fffffff;
+    }
+    for (; rw.more && tail_after != 0; rw.advance(), row = rw.row, i = i_nx, n = n_nx, --tail_after) {
         rw.draw(a.ticket);
         rw.peek(nrows, a.ticket_base, a.mwords);
         // (everything derived from the lane number is recomputed per row: held across
@@ -318,6 +337,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
         }
         lds_sync<T>();
     }
+    }
     // (out of rows: the tickets of the previous batch's tail that are left)
     if (PP_TAIL_HOOKS && a.tail) tail_work(a.tail, reinterpret_cast<double*>(lds), 2 * (LDSN + 64 * NML), tid, 1 << 30);
 }
@@ -355,12 +375,17 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
     constexpr int WRED = PP_WRED_DOUBLES(NRED) / 2;   // in cplx
     constexpr int LDSN0 = Q::LDS_ELEMS > 64 * NSL ? Q::LDS_ELEMS : 64 * NSL;     // transpose image | published registers
     constexpr int LDSN = WRED > LDSN0 ? WRED : LDSN0;
+    static_assert(M != 1024 || 2 * LDSN >= PP_TAIL_LDS_DOUBLES, "tail_work's layout of this kernel's LDS");
     __shared__ cplx lds[LDSN];
     int tid = threadIdx.x;
     const long long nrows = (long long)a.nsub * a.nchan;
     Raw cur[PER1][R1];
     const cplx wbT = a.twB[64];
-    if (PP_TAIL_HOOKS && a.tail) tail_work(a.tail, reinterpret_cast<double*>(lds), 2 * LDSN, tid, 1);     // (as k_xspec_q1024)
+    int tail_after = 0x7fffffff;         // (as k_xspec_q1024)
+    if (PP_TAIL_HOOKS && M == 1024 && a.tail) {
+        const unsigned share = (unsigned)(nrows / (long long)gridDim.x) + 1u;
+        tail_after = 1 + (int)(((blockIdx.x * 2654435761u) >> 8) % (share - share / 4));
+    }
     RowWalk<true> rw;
     rw.start(nrows, a.mwords, a.ticket, a.ticket_base);
     long long row = rw.row;
@@ -372,7 +397,14 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
         stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rc * (2 * M), tid);
     }
     int i_nx = i, n_nx = n;
-    for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {
+    if (phase == 1) {
+        if (!(PP_TAIL_HOOKS && M == 1024 && a.tail)) break;
+        tail_work(a.tail, reinterpret_cast<double*>(lds), 2 * LDSN, tid, 1);
+        tail_after = 0x7fffffff;
+    }
+    for (; rw.more && tail_after != 0; rw.advance(), row = rw.row, i = i_nx, n = n_nx, --tail_after) {
         rw.draw(a.ticket);
         rw.peek(nrows, a.ticket_base, a.mwords);
         asm volatile("" : "+v"(tid));
@@ -523,7 +555,8 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
         }
         lds_sync<T>();
     }
-    if (PP_TAIL_HOOKS && a.tail) tail_work(a.tail, reinterpret_cast<double*>(lds), 2 * LDSN, tid, 1 << 30);
+    }
+    if (PP_TAIL_HOOKS && M == 1024 && a.tail) tail_work(a.tail, reinterpret_cast<double*>(lds), 2 * LDSN, tid, 1 << 30);
 }
 
 }  // namespace pp

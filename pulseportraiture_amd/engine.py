@@ -399,7 +399,7 @@ class Engine(object):
 
     def enqueue(self, *args, **kwargs):
         """fit_batch queued on the engine's stream (pp_fit_enqueue): returns without waiting for the
-        GPU; collect() returns the result dict of the OLDEST enqueued batch.  Up to two batches may be
+        GPU; collect() returns the result dict of the OLDEST enqueued batch.  Up to three batches may be
         pending: enqueue batch k + 1, then collect batch k, and the GPU never waits for the host
         between batches.  The caller's arrays must not be modified until the batch is collected."""
         kwargs["_submit"] = "enqueue"

@@ -3298,6 +3298,86 @@ def test_transport_and_prefetch_options_change_nothing(eng):
             eng.set_option(k, saved[k])
 
 
+@pytest.mark.parametrize("C,B,flags", [(2304, 2048, [1, 1, 0, 0, 0]), (640, 2048, [1, 1, 1, 0, 0]), (300, 2048, [1, 0, 0, 0, 0])])
+def test_tail_inside_the_next_transform_returns_the_synchronous_bits(eng, C, B, flags):
+    """Option `fuse_tail` (default on): the solve on the Taylor model and the post-fit stage of an enqueued batch of
+    2048-bin rows are not queued behind its transform; the NEXT enqueued batch's transform works them off as tickets --
+    one wave per subint walking the four / eight waves of the stand-alone kernels in turn -- or, when no batch follows
+    or the next one cannot carry them (another row length, a scattering fit), the stand-alone kernels do.  Every batch
+    must return, bit for bit, what a synchronous call returns, in the order enqueued: plain fits, masks + measured
+    noise, Newton, a batch with poor guesses (collect re-fits it), batches of another size, a 1024-bin batch and a
+    scattering batch in between, three and two deep, and the last batch nobody follows."""
+    nsub = 40
+    data, freqs, P, x0, kw = _medium_batch(eng, nsub, C=C, B=B, seed=C)
+    kw = dict(kw, fit_flags=flags)
+    rng = np.random.default_rng(C)
+    mask = (rng.random((nsub, C)) > 0.2).astype(np.uint8)
+    x_poor = x0.copy()
+    x_poor[[3, 17], 0] = (x_poor[[3, 17], 0] + 0.03 + 0.5) % 1 - 0.5
+    kw_m = dict(kw, chan_mask=mask); kw_m["errs"] = None
+    half = nsub // 2
+    kw_h = dict(kw, errs=kw["errs"][:half], nu_fits=kw["nu_fits"][:half])
+    jobs = [("plain", data, x0, kw), ("masked", data, x0, kw_m), ("poor", data, x_poor, kw),
+            ("newton", data, x0, dict(kw, method="newton")), ("half", data[:half], x0[:half], kw_h),
+            ("plain2", data, x0, kw), ("masked2", data, x0, kw_m)]
+    keys = ("params", "param_errs", "nu_refs", "cov", "chi2", "red_chi2", "snr", "nfeval", "npass", "return_code",
+            "scales", "scale_errs", "channel_snrs")
+    saved = eng.get_option("fuse_tail")
+    try:
+        eng.set_option("fuse_tail", 0)
+        sync = [eng.fit_batch(d, freqs, P[:len(x)], x, **k) for _, d, x, k in jobs]
+        assert (sync[2]["npass"][[3, 17]] > 1).all()
+        for ft, depth in ((1, 3), (1, 2), (0, 3)):
+            eng.set_option("fuse_tail", ft)
+            got = []
+            for j, (_, d, x, k) in enumerate(jobs):
+                eng.enqueue(d, freqs, P[:len(x)], x, **k)
+                if j >= depth - 1:
+                    got.append(eng.collect())
+            while len(got) < len(jobs):
+                got.append(eng.collect())
+            for (name, _, _, _), a, g in zip(jobs, sync, got):
+                for key in keys:
+                    np.testing.assert_array_equal(a[key], g[key], err_msg="fuse_tail=%d depth %d %s %s" % (ft, depth, name, key))
+        # other flows in between -- a 1024-bin batch (its transform carries no tail) and a scattering fit --: the
+        # pending tail goes out by the stand-alone kernels, every batch still returns the synchronous bits
+        import torch
+        from pulseportraiture_amd import gmodel
+        from pulseportraiture_amd.pplib import Dconst
+        freqs1, model1, _ = gmodel.example_model(C, 1024)
+        eng.set_model(model1, slot=1)
+        inj = np.zeros((nsub, 3))
+        inj[:, 0] = rng.uniform(-0.5, 0.5, nsub)
+        inj[:, 1] = 34.56789 + rng.normal(3e-4, 2e-4, nsub)
+        data1 = torch.empty((nsub, C, 1024), dtype=torch.float64, device="cuda:0")
+        eng.synth_portraits(data1, freqs, P, inj, 0.05, 4242, 0, slot=1)
+        nu_fit = float(np.asarray(kw["nu_fits"])[0, 0])
+        x1 = np.zeros((nsub, 5))
+        x1[:, 0] = (inj[:, 0] + Dconst * inj[:, 1] / P / nu_fit ** 2 + 0.5) % 1 - 0.5
+        x1[:, 1] = 34.56789
+        kw1 = dict(kw, fit_flags=[1, 1, 0, 0, 0], model_slot=np.ones(nsub, dtype=np.int32))
+        xs = x0.copy()
+        xs[:, 3], xs[:, 4] = 1e-3, -4.0
+        kws = dict(kw, fit_flags=[1, 1, 0, 1, 0], log10_tau=False)
+        mixed = [("plain", data, x0, kw), ("1024 bins", data1, x1, kw1), ("plain", data, x0, kw), ("scattering", data, xs, kws),
+                 ("masked", data, x0, kw_m)]
+        eng.set_option("fuse_tail", 0)
+        sync = [eng.fit_batch(d, freqs, P, x, **k) for _, d, x, k in mixed]
+        eng.set_option("fuse_tail", 1)
+        got = []
+        for j, (_, d, x, k) in enumerate(mixed):
+            eng.enqueue(d, freqs, P, x, **k)
+            if j >= 2:
+                got.append(eng.collect())
+        while len(got) < len(mixed):
+            got.append(eng.collect())
+        for (name, _, _, _), a, g in zip(mixed, sync, got):
+            for key in keys:
+                np.testing.assert_array_equal(a[key], g[key], err_msg="mixed flows: %s %s" % (name, key))
+    finally:
+        eng.set_option("fuse_tail", saved)
+
+
 def test_post_fit_stage_on_its_own_stream_changes_nothing(eng):
     """Option `overlap_post`: the solve and post-fit stage of an enqueued batch on the context's second stream,
     with a work-buffer set of their own, behind an event of the transform -- so that they MAY run beside the

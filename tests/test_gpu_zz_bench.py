@@ -37,7 +37,7 @@ def test_strong_scaling_bench_in_a_child_process():
     assert line["gathered_records"]["rows"] == total
     # (the rate is no measurement here: five bench children and the test process share the box's one GPU)
     assert line["value"] > 1e3 and line["max_abs_dDM_over_err"] < 6.0
-    assert cfg["resident_sub_batches"] == 2 and cfg["steps_in_flight"] == 2
+    assert cfg["resident_sub_batches"] == 2 and cfg["steps_in_flight"] == 3
     rec = np.load(BENCH_CHILD["records"])
     assert rec.shape == (total, ppdist.RECORD_WIDTH)
     np.testing.assert_allclose(rec.sum(axis=0), line["gathered_records"]["column_sums"], rtol=1e-12)
