@@ -1938,9 +1938,10 @@ extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out*
 // --------------------------------------------------------------------------
 // stream-ordered batches: pp_fit_enqueue queues a whole batch -- inputs, kernels, outputs on their
 // way to a pinned staging block -- and returns without waiting; pp_fit_collect completes the oldest.
-// Two may be pending: while the GPU works on one batch the host marshals and queues the next, so
-// the stream never runs dry between batches.  One stream, one set of device work buffers: stream
-// order keeps a batch's solve and post-fit stage ahead of the next batch's transform.
+// PP_NSTAGE may be pending: while the GPU works on one batch the host marshals and queues the next, so
+// the stream never runs dry between batches.  One stream; a staging block and a set of work buffers per
+// pending batch, because a batch's solve and post-fit stage may run INSIDE the next batch's transform
+// (fuse_tail: pp_ctx::ptail, tail_work) and its outputs leave behind that transform.
 // --------------------------------------------------------------------------
 extern "C" int pp_fit_enqueue(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out) {
     if (!c || !in || !out) return fail(PP_EINVAL, "pp_fit_enqueue: null argument");

@@ -80,7 +80,7 @@ if fb > 0:
     try:
         # GRBM_GUI_ACTIVE / 8 XCDs / duration of the same counter pass
         g = cval("GRBM_GUI_ACTIVE")
-        durs = [float(x) for x in re.findall(r"xspec duration ms ([0-9.]+)", txt)]
+        durs = [float(x) for x in re.findall(r"xspec[^\n]* duration ms ([0-9.]+)", txt)]
         if durs:
             tl["shader_clock_ghz"] = round(g / 8 / (durs[-1] * 1e6), 3)
             tl["counters_source"] += "; GRBM_GUI_ACTIVE / 8 / duration"
