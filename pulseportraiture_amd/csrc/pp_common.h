@@ -40,6 +40,15 @@ __device__ __forceinline__ const T* as_global(const T* p) {
     return (const T*)(gp_t)(uintptr_t)p;
 }
 
+// A value every lane wants from the same address, fetched by the SCALAR unit (constant address space: s_load through
+// the scalar cache) -- it does not queue in the CU's vector-memory path behind the rows in flight.  Only for data no
+// kernel writes while this one runs (the scalar cache is not coherent within a launch).
+template <typename T>
+__device__ __forceinline__ T load_uniform(const T* p) {
+    typedef const T __attribute__((address_space(4)))* cp_t;
+    return *(cp_t)(uintptr_t)p;
+}
+
 // One rounding per operation, as NumPy does it: hipcc contracts a * b + c into an FMA
 // even through __dmul_rn / __dadd_rn, which moves a Nelder-Mead vertex by an ulp -- and
 // turns the grid point 18 * (1/36) - 0.5 = 0 into -2.8e-17, sending SciPy's simplex down

@@ -147,6 +147,37 @@ struct FitArgs {
 
 __device__ __forceinline__ int sub_of(const int* act, int j) { return act ? act[j] : j; }
 
+// a pointer every lane holds the same value of, moved to scalar registers -- whatever load produced it is waited for HERE
+template <typename P>
+__device__ __forceinline__ const P* uniform_ptr(const P* p) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    return as_global(reinterpret_cast<const P*>(((unsigned long long)hi << 32) | (unsigned long long)lo));
+}
+
+// The template row and the template's cut for (subint ia, channel n -> true channel ne), looked up when the CHANNEL
+// changes -- once per chunk of rows; per row only with per-subint templates (a.slot) -- and waited for in here, the
+// results leaving in scalar registers.  Round 5: the CU's vector-memory path returns in order ACROSS its waves, so a
+// 4-byte L1 hit issued at the top of a row and read at once (the cut; and the lookups were written as selects between
+// a loaded and a scalar pointer, which the compiler can only wait for with vmcnt(0)) comes back behind whatever the
+// other rows' prefetches have in flight: a memory latency per wait, two waits per row.  With the lookups inside this
+// branch a row that does not take it waits for nothing but its own data (profiles/r05_quiet_row_top_ab.txt: +3.5 %).
+// Returns true when it looked.
+#ifndef PP_STICKY_LOOKUP
+#define PP_STICKY_LOOKUP 1
+#endif
+__device__ __forceinline__ bool channel_lookup(const XspecArgs& a, int ia, int n, int ne, int M, int& n_held,
+                                               const cplx*& mrow, int& ktn) {
+    if (PP_STICKY_LOOKUP && !a.slot && n == n_held) return false;
+    const cplx* m = as_global(a.slot ? a.mft[a.slot[ia]] : a.mft0) + (size_t)ne * M;
+    const int k = a.ktab ? as_global(a.slot ? a.ktab[a.slot[ia]] : a.kt0)[ne] : a.Kt;
+    mrow = uniform_ptr(m);
+    ktn = __builtin_amdgcn_readfirstlane(k);
+    n_held = n;
+    return true;
+}
+
 // --------------------------------------------------------------------------
 // model rFFT
 // --------------------------------------------------------------------------
@@ -430,6 +461,8 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
     constexpr bool CRES = PAIR && M != 1024;
     cplx mc2[CRES ? KPT : 1];
     const cplx* mheld = nullptr;
+    const cplx* mrow = nullptr;    // the template row and cut of the channel in hand (channel_lookup)
+    int n_held = -1, ktn = 0;
     int i_nx = i, n_nx = n;
     for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
         rw.draw(a.ticket);
@@ -449,10 +482,9 @@ __global__ __launch_bounds__(FftPlan<M>::T, (FftPlan<M>::T >= 256 ? 1 : 2)) void
         // Issue, BEFORE anything waits, every load of this row whose result is
         // needed late: vector-memory results return in order, so these must be
         // older than the prefetch of the next row or consuming them would drain it.
-        const cplx* mrow = as_global(a.slot ? a.mft[a.slot[ia]] : a.mft0) + (size_t)ne * M;
-        // harmonics this channel's template keeps (multiple of 64)
-        const int ktn = a.ktab ? as_global(a.slot ? a.ktab[a.slot[ia]] : a.kt0)[ne] : a.Kt;
-        if (M2 && mrow != mheld) {
+        // (template row; harmonics this channel's template keeps, a multiple of 64)
+        const bool looked = channel_lookup(a, ia, n, ne, M, n_held, mrow, ktn);
+        if (M2 && looked && mrow != mheld) {
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const int k = tid + 1 + j * T;

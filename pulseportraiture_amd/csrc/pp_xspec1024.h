@@ -75,6 +75,8 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
     // this lane's template values (halved), reloaded when the channel changes
     cplx mA[NS], mB[NS];
     const cplx* mheld = nullptr;
+    const cplx* mrow = nullptr;    // the template row and cut of the channel in hand (channel_lookup)
+    int n_held = -1, ktn = 0;
     int i_nx = i, n_nx = n;
     for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
         rw.draw(a.ticket);
@@ -89,12 +91,11 @@ __global__ __launch_bounds__(64, 2) void k_xspec_p1024(XspecArgs a) {
         const bool l0 = (tid == 0);
         const int tb = l0 ? 64 : 128 - tid;
         const size_t rc = (size_t)i * a.nchan + n;
-        const cplx* mrow = as_global(a.slot ? a.mft[a.slot[i]] : a.mft0) + (size_t)n * M;
-        const int ktn = a.ktab ? as_global(a.slot ? a.ktab[a.slot[i]] : a.kt0)[n] : a.Kt;
+        const bool looked = channel_lookup(a, i, n, n, M, n_held, mrow, ktn);
         // slots that hold a kept harmonic in SOME lane (uniform)
         const int nA = ktn / 128 + 1;                               // lane 0: 128 j <= ktn
         const int nB = ktn >= 64 ? (ktn - 64) / 128 + 1 : 0;        // lane 0: 64 + 128 j <= ktn
-        if (mrow != mheld) {
+        if (looked && mrow != mheld) {
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
                 const int ka = tid + 128 * j, kb = tb + 128 * j;

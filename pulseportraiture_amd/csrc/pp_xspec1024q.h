@@ -115,6 +115,8 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
     // when the channel changes
     cplx mv2[NSL];
     const cplx* mheld = nullptr;
+    const cplx* mrow = nullptr;    // the template row and cut of the channel in hand (channel_lookup)
+    int n_held = -1, ktn = 0;
     int i_nx = i, n_nx = n;
 #pragma unroll 1
     for (int phase = 0; phase < 2; ++phase) {
@@ -144,9 +146,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
         const size_t rc = (size_t)ia * a.nchan_full + ne;
         // loads whose results are needed late are issued before the prefetch (vector
         // memory returns in order)
-        const cplx* mrow = as_global(a.slot ? a.mft[a.slot[ia]] : a.mft0) + (size_t)ne * M;
-        const int ktn = a.ktab ? as_global(a.slot ? a.ktab[a.slot[ia]] : a.kt0)[ne] : a.Kt;
-        if (mrow != mheld) {
+        if (channel_lookup(a, ia, n, ne, M, n_held, mrow, ktn) && mrow != mheld) {
 #pragma unroll
             for (int j = 0; j < NSL; ++j) {
                 const cplx mval = mrow[kb + 64 * j - 1];   // k <= 448: inside the row
@@ -397,6 +397,8 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
         stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rc * (2 * M), tid);
     }
     int i_nx = i, n_nx = n;
+    const cplx* mrow = nullptr;    // the template row and cut of the channel in hand (channel_lookup)
+    int n_held = -1, ktn = 0;
 #pragma unroll 1
     for (int phase = 0; phase < 2; ++phase) {
     if (phase == 1) {
@@ -414,8 +416,7 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
         const cplx wb0 = as_global(a.twB)[kb];
         const int ia = sub_of(a.act, i), ne = a.coff + n * a.cstep;   // true subint, channel
         const size_t rc = (size_t)ia * a.nchan_full + ne;
-        const cplx* mrow = as_global(a.slot ? a.mft[a.slot[ia]] : a.mft0) + (size_t)ne * M;
-        const int ktn = a.ktab ? as_global(a.slot ? a.ktab[a.slot[ia]] : a.kt0)[ne] : a.Kt;
+        channel_lookup(a, ia, n, ne, M, n_held, mrow, ktn);
         const double phin = a.ph0[rc];
         double sd = 0.0;
         cplx v[R1];

@@ -94,8 +94,19 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
         const cplx wb0 = as_global(a.twB)[kb];
         const int ne = cc * PP_ROW_CHUNK + r;
         const size_t rc = (size_t)ia * a.nchan_full + ne;
-        const cplx* mrow = as_global(a.slot ? a.mft[a.slot[ia]] : a.mft0) + (size_t)ne * M;
-        const int ktn = a.ktab ? as_global(a.slot ? a.ktab[a.slot[ia]] : a.kt0)[ne] : a.Kt;
+        // (see channel_lookup: a vector load read at the top of a row costs a memory latency -- the channel changes
+        // with every row here, so with ONE template for all subints the cut comes through the scalar unit and the row
+        // pointer is arithmetic; per-subint templates are looked up per row as before.  Nothing is carried over the
+        // rows: this kernel has no register to spare)
+        const cplx* mrow;
+        int ktn;
+        if (PP_STICKY_LOOKUP && !a.slot) {
+            mrow = as_global(a.mft0) + (size_t)ne * M;
+            ktn = a.ktab ? load_uniform(a.kt0 + ne) : a.Kt;
+        } else {
+            mrow = as_global(a.slot ? a.mft[a.slot[ia]] : a.mft0) + (size_t)ne * M;
+            ktn = a.ktab ? as_global(a.slot ? a.ktab[a.slot[ia]] : a.kt0)[ne] : a.Kt;
+        }
         const double phin = a.ph0[rc];
         const double hw = 0.5 * (rs.w ? rs.w[rc] : 1.0);     // (2 d_k below: the half goes here, exact)
         if (rw.fresh) {       // (the first row visited of this chunk)
@@ -141,6 +152,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
         __builtin_amdgcn_sched_barrier(0);
         // this row's template values: read now (L2), behind the first half of the prefetch --
         // which has had the whole transform to arrive -- and in front of the second half
+        // (round 5: queued before the last stage instead, one stage earlier: no difference, profiles/r05_qr_ab.txt)
         cplx mv2[NSL];
 #pragma unroll
         for (int j = 0; j < NSL; ++j) mv2[j] = mrow[kb + 64 * j - 1];

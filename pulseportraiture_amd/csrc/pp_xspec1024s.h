@@ -41,6 +41,8 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qs1024(XspecArgs a, const doubl
     // them with the very operation that filled the table k_eval reads: same bits)
     cplx mv2[NSL];
     const cplx* mheld = nullptr;
+    const cplx* mrow = nullptr;    // the template row and cut of the channel in hand (channel_lookup)
+    int n_held = -1, ktn = 0;
     int i_nx = i, n_nx = n;
     for (; rw.more; rw.advance(), row = rw.row, i = i_nx, n = n_nx) {
         rw.draw(a.ticket);
@@ -52,10 +54,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qs1024(XspecArgs a, const doubl
         const cplx t1 = as_global(a.twB)[2 * tid], t2 = as_global(a.twB)[32 * (tid & 15)];
         const cplx wb0 = as_global(a.twB)[kb];
         const size_t rc = (size_t)i * a.nchan_full + n;          // (no lists, no channel subsets here)
-        const int sl = a.slot ? a.slot[i] : 0;
-        const cplx* mrow = as_global(a.slot ? a.mft[sl] : a.mft0) + (size_t)n * M;
-        const int ktn = a.ktab ? as_global(a.slot ? a.ktab[sl] : a.kt0)[n] : a.Kt;
-        if (mrow != mheld) {
+        if (channel_lookup(a, i, n, n, M, n_held, mrow, ktn) && mrow != mheld) {
 #pragma unroll
             for (int j = 0; j < NSL; ++j) mv2[j] = mrow[kb + 64 * j - 1];
             mheld = mrow;
