@@ -757,12 +757,12 @@ def strong_scaling(args, make_batch, sync, fence, device, rank, world, use_dist,
     piped = collect is not None and all(hasattr(b, "enqueue") and getattr(b, "can_pipeline", lambda: False)() for b in batches)
     batches[0].fit()                             # warm-up (untimed)
     if piped:
-        # (... and two fits in the timed loop's own pattern: the second set of staging / work buffers of
-        # pp_fit_enqueue is allocated on first use)
-        batches[0].enqueue()
-        batches[0].enqueue()
-        collect()
-        collect()
+        # (... and three fits in the timed loop's own pattern: every set of staging / work buffers of
+        # pp_fit_enqueue -- three since the fused tail -- is allocated on first use)
+        for _ in range(3):
+            batches[0].enqueue()
+        for _ in range(3):
+            collect()
     gc.collect()
     gc.disable()                                 # (a full collection takes 30-40 ms with torch loaded: not inside a timed fit)
     fit_s, done = 0.0, 0

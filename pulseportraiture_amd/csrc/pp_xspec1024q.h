@@ -360,6 +360,9 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
 // template keeps them.
 // M = 512 (1024-bin rows, plan 8.4.2.8 of pp_fftq.h): the same with 8 harmonics per lane; serves every
 // template cut (slots beyond it are skipped) -- configs[1]'s template keeps 448 of 512 harmonics.
+#ifndef PP_QF512_HOLD_TEMPLATE
+#define PP_QF512_HOLD_TEMPLATE 1
+#endif
 #ifndef PP_QF512_WPS
 #define PP_QF512_WPS 3
 #endif
@@ -399,6 +402,11 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
     int i_nx = i, n_nx = n;
     const cplx* mrow = nullptr;    // the template row and cut of the channel in hand (channel_lookup)
     int n_held = -1, ktn = 0;
+    // 1024-bin rows: the lane's 8 template values are HELD while the channel does not change (32 registers; the 16
+    // values of a 2048-bin row's lane do not fit beside two rows and are read every row)
+    constexpr bool MHOLD = PP_QF512_HOLD_TEMPLATE && M == 512;
+    cplx mv[NSL];
+    const cplx* mheld = nullptr;
 #pragma unroll 1
     for (int phase = 0; phase < 2; ++phase) {
     if (phase == 1) {
@@ -416,15 +424,20 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
         const cplx wb0 = as_global(a.twB)[kb];
         const int ia = sub_of(a.act, i), ne = a.coff + n * a.cstep;   // true subint, channel
         const size_t rc = (size_t)ia * a.nchan_full + ne;
-        channel_lookup(a, ia, n, ne, M, n_held, mrow, ktn);
+        const bool looked = channel_lookup(a, ia, n, ne, M, n_held, mrow, ktn);
+        if (MHOLD && looked && mrow != mheld) {
+#pragma unroll
+            for (int j = 0; j < NSL; ++j) mv[j] = mrow[kb + 64 * j - 1];
+            mheld = mrow;
+        }
         const double phin = a.ph0[rc];
         double sd = 0.0;
         cplx v[R1];
 #pragma unroll
         for (int k = 0; k < R1; ++k) v[k] = to_cplx(cur[0][k]);
         // this lane's 16 template values, read between the transpose and the last stage
-        cplx mv[NSL];
         auto template_loads = [&]() {
+            if (MHOLD) return;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NSL; ++j) mv[j] = mrow[kb + 64 * j - 1];   // k <= 1024: inside the row
