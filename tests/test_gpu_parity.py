@@ -796,6 +796,53 @@ def test_sub_batching_and_model_slots(eng):
     np.testing.assert_array_equal(single["params"][0], whole["params"][1])
 
 
+@pytest.mark.parametrize("B,dt,errs_given", [(2048, np.float64, True), (2048, np.float32, True), (2048, np.float64, False),
+                                             (1024, np.float64, True), (4096, np.float64, True)])
+def test_template_slots_and_masks_at_the_tuned_row_lengths(eng, B, dt, errs_given):
+    """The transform kernels look the template row and its cut up when the CHANNEL changes (channel_lookup), per row
+    only with per-subint templates: subints that reference different template slots, a subint count that is no
+    multiple of the 32-row chunks (the channel changes in the middle of a chunk) and masked channels must give what
+    each subint gives alone with its own template as the only one -- bit for bit."""
+    from tests.synth_host import make_inputs, caller_guess, model_portrait
+    C, N = 48, 37
+    freqs, model = model_portrait(C, B)
+    model2 = model * 1.3 + 0.002 * np.roll(model, 5, axis=1)
+    eng.set_model(model, slot=0)
+    eng.set_model(model2, slot=2)
+    rng = np.random.default_rng(11)
+    slots = (rng.random(N) < 0.4).astype(np.int32) * 2
+    data, x0, nuf, errs, Ps, masks = [], [], [], [], [], []
+    for i in range(N):
+        inp = make_inputs(C, B, 5200 + i, model=(model2 if slots[i] else model), sigma=0.05)
+        g = caller_guess(inp)
+        data.append(inp["data"].astype(dt)); x0.append(g["init_params"]); nuf.append([g["nu_fit"]] * 3)
+        errs.append(inp["errs"]); Ps.append(inp["P"])
+        m = (rng.random(C) > 0.15).astype(np.uint8); m[:4] = 1
+        masks.append(m)
+    data, x0, nuf, errs, Ps, masks = map(np.array, (data, x0, nuf, errs, Ps, masks))
+    kw = dict(nu_fits=nuf, nu_outs=nuf, fit_flags=[1, 1, 0, 0, 0], chan_mask=masks)
+    if errs_given:
+        kw["errs"] = errs
+    whole = eng.fit_batch(data, freqs, Ps, x0, model_slot=slots, **kw)
+    assert (whole["return_code"] >= 0).all()
+    keys = ("params", "param_errs", "nu_refs", "chi2", "snr", "scales", "scale_errs", "channel_snrs", "nfeval", "npass")
+    for i in (0, 1, 5, 17, 31, 32, 36):
+        sl = slice(i, i + 1)
+        k1 = {k: (v[sl] if isinstance(v, np.ndarray) and v.shape[:1] == (N,) else v) for k, v in kw.items()}
+        one = eng.fit_batch(data[sl], freqs, Ps[sl], x0[sl], model_slot=slots[sl], **k1)
+        for k in keys:
+            np.testing.assert_array_equal(one[k][0], whole[k][i], err_msg="%s of subint %d" % (k, i))
+    # ... and a batch whose subints all use ONE template takes the per-channel path: same bits as the slots' path
+    for sv, mdl in ((0, model), (2, model2)):
+        idx = np.nonzero(slots == sv)[0]
+        eng.set_model(mdl, slot=0)
+        k1 = {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (N,) else v) for k, v in kw.items()}
+        same = eng.fit_batch(data[idx], freqs, Ps[idx], x0[idx], **k1)
+        for k in keys:
+            np.testing.assert_array_equal(same[k], whole[k][idx], err_msg="%s, template %d alone" % (k, sv))
+    eng.set_model(model, slot=0)
+
+
 def test_degenerate_and_bad_inputs(eng):
     """One usable channel (phase-only fit), NaN samples (reported through
     return_code, never raised), and argument errors (negative status + message)."""
