@@ -734,7 +734,7 @@ def strong_scaling(args, make_batch, sync, fence, device, rank, world, use_dist,
     the idle host work around it leave the shader clock ramping: a fit that follows them
     runs 1.3-2.7 ms longer on the device than the same fit repeated, profiles/r04_strong_gap.txt
     -- the same reason `--warmup` steps exist), then the clock runs while the group's fits
-    are ENQUEUED BACK TO BACK (pp_fit_enqueue two deep, as the weak loop does): inputs are
+    are ENQUEUED BACK TO BACK (pp_fit_enqueue three deep, as the weak loop does): inputs are
     resident when their timed region starts, the device never idles inside it.
     Returns the JSON line's dict on rank 0 (None elsewhere).  `make_batch(workload, nsub,
     first)` builds a resident batch (bench's Batch; a stub in the CPU tests), `sync()`
