@@ -3,6 +3,7 @@
 resident in HBM (BASELINE.json metric), one process per GPU.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus N ...          (starts the N ranks itself: self_launch below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
@@ -316,6 +317,43 @@ class Batch(object):
 
 
 # --------------------------------------------------------------------------
+def self_launch(ngpus, argv, script=None):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same args>`
+    in a CHILD process (never an exec, and before this process has imported torch or touched
+    the GPU), hand its one JSON line on to stdout, everything else it writes there to stderr,
+    and return its exit code."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env["PP_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+    print("bench.py: --gpus %d without RANK in the environment: starting %s" % (ngpus, " ".join(cmd)), file=sys.stderr)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=os.getcwd())
+    nlines = 0
+    for raw in proc.stdout:
+        text = raw.decode("utf-8", "replace")
+        if text.lstrip().startswith('{"metric"'):
+            sys.stdout.write(text if text.endswith("\n") else text + "\n")
+            sys.stdout.flush()
+            nlines += 1
+        else:
+            sys.stderr.write(text)
+    rc = proc.wait()
+    if rc == 0 and nlines != 1:
+        print("bench.py: the ranks printed %d JSON lines, expected 1" % nlines, file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -371,6 +409,10 @@ def main():
                     help="override the harmonic-truncation threshold (experiments)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # the plain command (what the driver runs for N = 1) asked for N > 1 ranks
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -386,9 +428,7 @@ def main():
     from pulseportraiture_amd.pplib import guess_fit_freq
 
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d"
-                             % args.gpus)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE = %d" % (args.gpus, world))
     # PP_BENCH_SHARE_GPU=1 (tests on a one-GPU box): the ranks share the GPUs there are and talk
     # over gloo -- the whole N > 1 path (shards, barriers, max over ranks, the gather) with the
     # real engine, minus RCCL, which wants one device per rank
@@ -746,6 +786,8 @@ def strong_scaling(args, make_batch, sync, fence, device, rank, world, use_dist,
     nsub = args.nsub or nsub_def
     lo, hi = ppdist.shard_range(args.total_nsub, rank, world)
     counts = [b - a for a, b in (ppdist.shard_range(args.total_nsub, r, world) for r in range(world))]
+    fence()
+    t_wall0 = time.perf_counter()               # all-in clock: generation, warm-up and ramp fits, the fits, the gather
     recs = torch.zeros((hi - lo, ppdist.RECORD_WIDTH), dtype=torch.float64, device=device)
     nbatches = max(1, -(-(hi - lo) // nsub))
     group = max(1, min(3, nbatches, int(getattr(args, "group", 0) or 3)))
@@ -805,13 +847,14 @@ def strong_scaling(args, make_batch, sync, fence, device, rank, world, use_dist,
     gathered = ppdist.gather_records(recs, counts=counts)
     fence()
     gather_s = time.perf_counter() - t0
+    wall_s = time.perf_counter() - t_wall0
     gc.enable()
     total_s = fit_s + gather_s
     if use_dist:
-        t = torch.tensor([total_s, worst], dtype=torch.float64,
+        t = torch.tensor([total_s, worst, wall_s], dtype=torch.float64,
                          device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        total_s, worst = float(t[0].item()), float(t[1].item())
+        total_s, worst, wall_s = float(t[0].item()), float(t[1].item()), float(t[2].item())
     guess = batches[0].guess
     for b in batches:
         if hasattr(b, "free"):
@@ -839,6 +882,9 @@ def strong_scaling(args, make_batch, sync, fence, device, rank, world, use_dist,
                    "parallelism": "contiguous subint shards over %d rank(s), records kept in "
                                   "HBM, 1 gather at the end" % world},
         "gather_ms": round(1e3 * gather_s, 3),
+        # everything this job did between its first and last barrier, max over ranks: batch construction and
+        # generation of every sub-batch, the warm-up fits, one untimed ramp fit per group, the timed fits, the gather
+        "wall_s": round(wall_s, 4), "fits_per_s_all_in": round(args.total_nsub / wall_s, 2),
         "gathered_records": {"rows": cs["rows"], "checksum": cs["column_sums"][:3],
                              "column_sums": cs["column_sums"],
                              "return_code_sum": cs["column_sums"][17]},

@@ -46,7 +46,7 @@ def pytest_collection_finish(session):
         BENCH_CHILD.update(proc=proc, records=recs, out=out, err=err)
 
 
-    # ... and the N = 2 path with the real engine: two ranks under torch.distributed.run that share
+    # ... and the N = 2 path with the real engine: `python bench.py --gpus 2`, two ranks that share
     # this box's GPU and talk over gloo (PP_BENCH_SHARE_GPU=1), strong and weak scaling
     if any("test_two_ranks_sharing_the_gpu" in it.nodeid for it in session.items):
         import socket
@@ -55,12 +55,14 @@ def pytest_collection_finish(session):
             o = open(os.path.join(tmp, "line2_%s.json" % tag), "w")
             e = open(os.path.join(tmp, "stderr2_%s.txt" % tag), "w")
             r2 = os.path.join(tmp, "records2_%s.npy" % tag)
-            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+            # the PLAIN command, no launcher in front of it: bench.py starts torch.distributed.run itself as a
+            # child process (bench.self_launch) -- the form the driver uses for its N = 1 line
+            cmd = [sys.executable, os.path.join(ROOT, "bench.py"),
                    "--gpus", "2", "--workload", "cfg2-512x1024-phiDM", "--no-cpu-baseline"] + extra
             if tag == "strong":
                 cmd += ["--dump-records", r2]
-            p2 = subprocess.Popen(cmd, stdout=o, stderr=e, cwd=ROOT, env=dict(os.environ, PP_BENCH_SHARE_GPU="1"))
+            env2 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+            p2 = subprocess.Popen(cmd, stdout=o, stderr=e, cwd=ROOT, env=dict(env2, PP_BENCH_SHARE_GPU="1"))
             BENCH_CHILD["two_" + tag] = dict(proc=p2, out=o, err=e, records=r2)
 
 

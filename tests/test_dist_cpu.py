@@ -2,6 +2,7 @@
 records, world_size 2 over gloo."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -202,6 +203,50 @@ def test_strong_scaling_shards_and_gathers_world2_gloo():
                                rtol=1e-13)
     assert abs(line["max_abs_dDM_over_err"] - 0.5) < 1e-9
     assert line["value"] > 0 and line["ms_per_step"] > 0
+    # the all-in wall time (generation, warm-up and ramp fits, fits, gather) beside the timed figure
+    assert line["wall_s"] >= 1e-3 * line["ms_per_step"] and 0 < line["fits_per_s_all_in"] <= line["value"]
+
+
+@pytest.mark.timeout(180)
+def test_plain_bench_command_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` with no launcher around it (the form the driver uses at N = 1) must start
+    the N ranks itself -- torch.distributed.run as a CHILD process -- and hand on exactly the one JSON line
+    and the return code.  Here with a stand-in for the ranks' program (no GPU): two ranks see RANK /
+    WORLD_SIZE / MASTER_ADDR, rank 0 prints a banner and the line, and a failing rank's code comes back."""
+    import json
+    import subprocess
+    stub = tmp_path / "rank_stub.py"
+    stub.write_text(
+        "import json, os, sys\n"
+        "assert os.environ['WORLD_SIZE'] == '2' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "assert os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and '--gpus' in sys.argv\n"
+        "if '--fail' in sys.argv and os.environ['RANK'] == '1':\n"
+        "    sys.exit(7)\n"
+        "if os.environ['RANK'] == '0':\n"
+        "    print('RCCL version banner'); print(json.dumps({'metric': 'm', 'n_gpus': 2, 'argv': sys.argv[1:]}))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.self_launch(2, sys.argv[1:], script=%r))" % (root, str(stub)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", code, "--gpus", "2", "--steps", "2"], capture_output=True, text=True,
+                       env=env, timeout=150)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["argv"] == ["--gpus", "2", "--steps", "2"]
+    assert "RCCL version banner" in r.stderr            # (kept off stdout)
+    r = subprocess.run([sys.executable, "-c", code, "--gpus", "2", "--fail"], capture_output=True, text=True,
+                       env=env, timeout=150)
+    assert r.returncode != 0
+
+
+def test_bench_main_takes_the_self_launch_branch_before_torch():
+    """bench.main() must take that branch before anything imports torch or touches the GPU."""
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    body = src[src.index("def main():"):]
+    assert 0 < body.index("self_launch(args.gpus") < body.index("import torch")
+    assert "start_cpu_pool()" in body and body.index("self_launch(args.gpus") < body.index("start_cpu_pool()")
 
 
 def test_record_layout_matches_the_c_abi():

@@ -63,7 +63,9 @@ def test_strong_scaling_bench_in_a_child_process():
 
 @pytest.mark.timeout(900)
 def test_two_ranks_sharing_the_gpu():
-    """bench.py --gpus 2 under torch.distributed.run, the two ranks sharing this box's GPU and
+    """`python bench.py --gpus 2` -- the plain command, NO launcher in the test: bench.py starts
+    torch.distributed.run itself as a child process (bench.self_launch) and hands on the one JSON
+    line --, the two ranks sharing this box's GPU and
     talking over gloo (PP_BENCH_SHARE_GPU=1; RCCL wants one device per rank): the N > 1 path of
     both modes with the real engine.  Strong scaling (600 subints of configs[1] in contiguous
     shards of 300, sub-batches 256 + 44, ONE gather): every gathered record against fits made
@@ -83,14 +85,19 @@ def test_two_ranks_sharing_the_gpu():
         rc = ch["proc"].wait(timeout=800)
         ch["out"].close(); ch["err"].close()
         text = open(os.path.join(BENCH_CHILD["tmp"], "line2_%s.json" % tag)).read().strip()
-        assert rc == 0 and text, open(os.path.join(BENCH_CHILD["tmp"], "stderr2_%s.txt" % tag)).read()[-3000:]
-        lines[tag] = json.loads(text.splitlines()[-1])
+        err = open(os.path.join(BENCH_CHILD["tmp"], "stderr2_%s.txt" % tag)).read()
+        assert rc == 0 and text, err[-3000:]
+        out_lines = [ln for ln in text.splitlines() if ln.strip()]
+        assert len(out_lines) == 1, out_lines[:5]            # exactly the one JSON line on stdout
+        assert "starting" in err and "torch.distributed.run" in err      # (bench.py launched its own ranks)
+        lines[tag] = json.loads(out_lines[0])
     line = lines["strong"]
     total = 600
     assert line["scaling"] == "strong" and line["n_gpus"] == 2
     cfg = line["config"]
     assert cfg["fits_per_rank"] == [300, 300] and cfg["sub_batches_rank0"] == [256, 44]
     assert line["gathered_records"]["rows"] == total and line["value"] > 0
+    assert line["wall_s"] >= 1e-3 * line["ms_per_step"] and 0 < line["fits_per_s_all_in"] <= line["value"]
     rec = np.load(BENCH_CHILD["two_strong"]["records"])
     assert rec.shape == (total, ppdist.RECORD_WIDTH) and (rec[:, 17] == 2).all()
     ns = argparse.Namespace(seed=20260101, dm0=34.56789, dm_offset=[3e-4, 2e-4], sigma=0.05,

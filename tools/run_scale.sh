@@ -25,8 +25,10 @@ for n in $ngpus; do
     extra="--steps $steps --warmup $warm --no-other-workloads --no-cpu-baseline"
     [ "$mode" = strong ] && extra="--total-nsub $total --no-cpu-baseline --dump-records $out/records_${mode}_n$n.npy"
     port=$((port + 1))
-    if [ "$n" -eq 1 ]; then
-      python bench.py --gpus 1 $extra > "$out/${mode}_n$n.json" 2> "$out/${mode}_n$n.err"
+    # the plain command for every N: bench.py starts its own ranks (torch.distributed.run as a child process) when
+    # --gpus N > 1 and no launcher has set RANK; LAUNCHER=torchrun uses the driver's documented form instead
+    if [ "$n" -eq 1 ] || [ "${LAUNCHER:-plain}" = plain ]; then
+      MASTER_PORT=$port python bench.py --gpus "$n" $extra > "$out/${mode}_n$n.json" 2> "$out/${mode}_n$n.err"
     else
       python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port $port \
         bench.py --gpus "$n" $extra > "$out/${mode}_n$n.json" 2> "$out/${mode}_n$n.err"
