@@ -641,6 +641,123 @@ def test_get_TOAs_with_the_references_seed_returns_the_references_numbers(name):
     assert (nf[2] == 0) and (np.asarray(gt.nfevals[0])[ok] >= 3).all()      # (0 for the zapped subint)
 
 
+OPTION_GOLDENS = ["gettoas_opt_two_archives", "gettoas_opt_DM0", "gettoas_opt_fixalpha", "gettoas_opt_lintau",
+                  "gettoas_opt_nufits"]
+# the result lists of GetTOAs.__init__ that hold one numeric entry per archive (pptoas.py:101-147), with the
+# tolerance each is held to against the reference's own run (rtol, atol)
+_OPT_LISTS = {
+    "doppler_fs": (0, 0), "nu0s": (0, 0), "nu_fits": (1e-14, 0), "nu_refs": (1e-9, 0), "ok_isubs": (0, 0),
+    "MJDs": (0, 0), "Ps": (0, 0), "phi_errs": (1e-7, 0), "TOA_errs": (1e-7, 0), "DM0s": (0, 0),
+    "DM_errs": (1e-7, 0), "DeltaDM_errs": (1e-5, 0), "GMs": (0, 1e-9), "GM_errs": (1e-7, 0),
+    "taus": (0, 1e-10), "tau_errs": (1e-7, 0), "alphas": (0, 1e-9), "alpha_errs": (1e-7, 0),
+    "scales": (1e-8, 1e-10), "scale_errs": (1e-6, 1e-12), "snrs": (1e-9, 0), "channel_snrs": (1e-7, 1e-9),
+    "profile_fluxes": (0, 0), "profile_flux_errs": (0, 0), "fluxes": (0, 0), "flux_errs": (0, 0),
+    "flux_freqs": (0, 0), "red_chi2s": (1e-9, 0), "covariances": (1e-6, 1e-18), "rcs": (0, 0)}
+
+
+@pytest.mark.parametrize("name", OPTION_GOLDENS)
+def test_get_TOAs_options_match_reference_caller(name):
+    """Caller level, RAW, for the options the first set of goldens does not reach
+    (tests/golden/make_golden_gettoas_options.py: the TRUE reference's get_TOAs): a `datafiles`
+    list of two archives with different DM and nsub (per-archive DeltaDM means, DM0s, the order of
+    TOA_list; pptoas.py:247, 665-721), DM0= given (pptoas.py:315-318), fit_scat with fix_alpha
+    (pptoas.py:216-227: nfit 3, flags 11010, 3 x 3 covariances), log10_tau=False (pptoas.py:448-450,
+    614-627: linear-tau flags), nu_fits=(nu1, nu2) (pptoas.py:402-407).  EVERY result list of the
+    object is compared, per archive, and every TOA of TOA_list: archive, frequency, MJD, error,
+    DM, DM error, and the flags -- names in the reference's insertion order, values to the
+    parameter's tolerance."""
+    import json
+    from pulseportraiture_amd.pptoas import GetTOAs, MJD, data_from_arrays
+    g = _load(name)
+    narch = int(g["narchives"])
+    bunches = []
+    for ia in range(narch):
+        q = lambda k: g["in%d_%s" % (ia, k)]
+        epochs = [MJD(int(d), float(f)) for d, f in zip(q("epoch_days"), q("epoch_fracs"))]
+        bunches.append(data_from_arrays(
+            q("subints"), q("freqs"), q("Ps"), epochs, weights=q("weights"), noise_stds=q("noise_stds"),
+            SNRs=q("SNRs"), DM=float(q("scal_DM")), doppler_factors=q("doppler_factors"),
+            backend_delay=float(q("scal_backend_delay")), telescope=str(q("scal_telescope")),
+            telescope_code=str(q("scal_telescope_code")), backend=str(q("scal_backend")),
+            frontend=str(q("scal_frontend")), bw=float(q("scal_bw")), nu0=float(q("scal_nu0")),
+            subtimes=q("subtimes"), source=str(q("scal_source")), filename=str(q("filename"))))
+    kw = {}
+    for k in g.files:
+        if k.startswith("kw_"):
+            v = g[k]
+            kw[k[3:]] = v.item() if v.ndim == 0 else tuple(v.tolist())
+    gt = GetTOAs(bunches if narch > 1 else bunches[0], os.path.join(GOLDEN, "example.gmodel"), quiet=True)
+    gt.get_TOAs(quiet=True, seed='reference', **kw)
+    assert gt.nfit == int(g["out_nfit"]) and list(gt.fit_flags) == list(g["out_fit_flags"])
+    assert [str(o) for o in gt.order] == [str(o) for o in g["out_order"]]
+    np.testing.assert_array_equal(np.asarray(gt.ok_idatafiles), g["out_ok_idatafiles"])
+    assert len(gt.fit_durations) == int(g["out_n_fit_durations"]) == narch
+    for ia in range(narch):
+        want = lambda k: g["out_a%d_%s" % (ia, k)]
+        ok = want("ok_isubs").astype(int)
+        for fld, (rt, at) in _OPT_LISTS.items():
+            got = getattr(gt, fld)[ia]
+            if fld in ("nu_fits", "nu_refs"):
+                got = np.array([[np.nan if x is None else float(x) for x in row] for row in got])
+            got = np.asarray(got, dtype=np.float64)
+            w = want(fld)
+            assert got.shape == w.shape, (fld, got.shape, w.shape)
+            if rt == 0 and at == 0:
+                np.testing.assert_array_equal(got, w, err_msg=fld)
+            else:
+                np.testing.assert_allclose(got, w, rtol=rt, atol=at, err_msg=fld)
+        # the fitted phases and DMs: north_star's bars, and raw (SciPy's iterates retraced) well inside them
+        dphi = _dphi_arr(np.asarray(gt.phis[ia])[ok], want("phis")[ok])
+        assert dphi.max() < PHI_BAR and (dphi < 1e-11).mean() >= 0.5, dphi
+        assert np.abs(np.asarray(gt.DMs[ia])[ok] - want("DMs")[ok]).max() < 1e-10
+        np.testing.assert_allclose(gt.DeltaDM_means[ia], want("DeltaDM_means"), rtol=0, atol=1e-10)
+        nf = np.asarray(gt.nfevals[ia])
+        assert np.abs(nf - want("nfevals")).max() <= 1, (nf, want("nfevals"))
+        for isub in range(len(want("TOA_days"))):
+            t = gt.TOAs[ia][isub]
+            if isub not in ok:
+                assert t == 0
+                continue
+            dt_days = (t.intday() - want("TOA_days")[isub]) + (t.fracday() - want("TOA_fracs")[isub])
+            assert abs(dt_days) * 86400.0 < 1e-10 * g["in%d_Ps" % ia][isub] + 1e-15
+        np.testing.assert_array_equal([e.intday() for e in gt.epochs[ia]], want("epoch_days"))
+        np.testing.assert_array_equal([e.fracday() for e in gt.epochs[ia]], want("epoch_fracs"))
+        o = gt.obs[ia]
+        assert [str(o.telescope), str(o.backend), str(o.frontend)] == [str(v) for v in want("obs")]
+    # ---- TOA_list: order over the archives, and every field of every TOA ----
+    ref_toas = json.loads(str(g["out_TOA_list_json"]))
+    assert len(gt.TOA_list) == len(ref_toas)
+    tol = {"gm": 1e-9, "scat_time": 1e-8, "log10_scat_time": 1e-10, "scat_ref_freq": 1e-9, "scat_ind": 1e-9,
+           "phs": PHI_BAR, "snr": 1e-9, "gof": 1e-9, "phi_DM_cov": 1e-6}
+    for t, r in zip(gt.TOA_list, ref_toas):
+        assert str(t.archive) == r["archive"] and str(t.telescope) == r["telescope"]
+        assert str(t.telescope_code) == r["telescope_code"]
+        np.testing.assert_allclose(t.frequency, r["frequency"], rtol=1e-9)
+        P = 1.0 / 345.0
+        assert abs((t.MJD.intday() - r["day"]) + (t.MJD.fracday() - r["frac"])) * 86400.0 < 1e-10 * P
+        np.testing.assert_allclose(t.TOA_error, r["TOA_error"], rtol=1e-7)
+        if r["DM"] is None:
+            assert t.DM is None and t.DM_error is None
+        else:
+            assert abs(t.DM - r["DM"]) < 1e-10
+            np.testing.assert_allclose(t.DM_error, r["DM_error"], rtol=1e-7)
+        assert list(t.flags.keys()) == [k for k, _ in r["flags"]]          # (insertion order: the .tim line's order)
+        for k, v in r["flags"]:
+            mine = t.flags[k]
+            if k == "tmplt":            # (the model file's path: the reference read its own copy of the example)
+                assert os.path.basename(str(mine)) == os.path.basename(v)
+            elif isinstance(v, str) or v is None:
+                assert (mine is None and v is None) or str(mine) == v, (k, mine, v)
+            elif k in tol:
+                scale = max(1.0, abs(v)) if k not in ("phs", "phi_DM_cov") else 1.0
+                if k == "phi_DM_cov":
+                    np.testing.assert_allclose(mine, v, rtol=1e-6)
+                else:
+                    assert abs(mine - v) <= tol[k] * scale, (k, mine, v)
+            else:
+                np.testing.assert_allclose(mine, v, rtol=1e-7, err_msg=k)
+
+
 @pytest.mark.parametrize("nbin", [32, 64, 128])
 def test_small_nbin_fits_match_oracle(eng, nbin):
     """Shapes below the 64-harmonic granule of the truncated cross-spectrum."""
@@ -1063,16 +1180,22 @@ def test_channel_red_chi2_matches_oracle(eng, name):
     assert 0.5 < np.median(want) < 2.0
 
 
+@pytest.mark.parametrize("shape", [(16, 256), (64, 512)])
 @pytest.mark.parametrize("fit_dm", [True, False])
-def test_align_subints_matches_oracle_loop(eng, fit_dm):
+def test_align_subints_matches_oracle_loop(eng, fit_dm, shape):
     """ppalign's iteration (ppalign.py:110-214) on arrays: fit every subint
     against the current template, rotate by the fit, average with weights
     scales/errs^2, repeat -- against the same loop written with the oracle's
-    fit_portrait_full, fit_phase_shift and rotate_data."""
+    fit_portrait_full, fit_phase_shift and rotate_data.  align_subints runs the REFERENCE'S OWN
+    iteration (ppalign.py:180-195: the phase guess from fit_phase_shift(..., Ns=nbin) of the channel
+    mean rotated to nu_fit, SciPy's simplex finish and trust-ncg retraced on the device; a subint
+    with one usable channel by the 1-channel hack, ppalign.py:196-201), so the averaged portrait
+    agrees to 1e-10 of its peak after two iterations."""
     from oracle import pptoas_oracle as orc
     from pulseportraiture_amd.ppalign import align_subints
     from tests.synth_host import model_portrait
-    C_, nbin, nsub, sigma = 16, 256, 6, 0.05
+    C_, nbin = shape
+    nsub, sigma = 6, 0.05
     freqs, model = model_portrait(C_, nbin)
     rng = np.random.default_rng(77)
     Ps = np.full(nsub, 0.0031) * (1 + 1e-6 * np.arange(nsub))
@@ -1085,6 +1208,8 @@ def test_align_subints_matches_oracle_loop(eng, fit_dm):
     weights = np.ones((nsub, C_))
     weights[1, [2, 9]] = 0.0
     weights[4, :3] = 0.0
+    weights[5, :] = 0.0
+    weights[5, 7] = 1.0              # one usable channel: the 1-channel hack
     errs = np.full((nsub, C_), sigma)
     snrs = rng.uniform(5, 50, (nsub, C_))
     # a deliberately imperfect initial template: smoothed and shifted
@@ -1097,18 +1222,29 @@ def test_align_subints_matches_oracle_loop(eng, fit_dm):
         for i in range(nsub):
             ich = np.where(weights[i] > 0)[0]
             nu_fit = orc.guess_fit_freq(freqs[ich], snrs[i, ich])
-            rp = orc.rotate_data(ports[i, ich], 0.0, 0.0, Ps[i], freqs[ich], nu_fit)
-            guess = orc.fit_phase_shift(np.average(rp, axis=0, weights=weights[i, ich]),
-                                        tmpl[ich].mean(axis=0), Ns=nbin).phase
-            r = orc.fit_portrait_full(ports[i, ich], tmpl[ich], [guess, 0.0, 0.0, 0.0, 0.0], Ps[i],
-                                      freqs[ich], [nu_fit] * 3, [None] * 3, errs[i, ich],
-                                      [1, int(fit_dm), 0, 0, 0], log10_tau=False)
-            w = r.scales / errs[i, ich] ** 2
-            acc[ich] += w[:, None] * orc.rotate_data(ports[i, ich], r.phi, r.DM, Ps[i], freqs[ich],
-                                                     r.nu_DM)
+            if len(ich) > 1:
+                rp = orc.rotate_data(ports[i, ich], 0.0, 0.0, Ps[i], freqs[ich], nu_fit)
+                guess = orc.fit_phase_shift(np.average(rp, axis=0, weights=weights[i, ich]),
+                                            tmpl[ich].mean(axis=0), Ns=nbin).phase
+                r = orc.fit_portrait_full(ports[i, ich], tmpl[ich], [guess, 0.0, 0.0, 0.0, 0.0], Ps[i],
+                                          freqs[ich], [nu_fit] * 3, [None] * 3, errs[i, ich],
+                                          [1, int(fit_dm), 0, 0, 0], log10_tau=False)
+                ph, dm, nu_ref, sc = r.phi, r.DM, r.nu_DM, r.scales
+            else:
+                r = orc.fit_phase_shift(ports[i, ich[0]], tmpl[ich[0]], errs[i, ich[0]], Ns=nbin)
+                ph, dm, nu_ref, sc = r.phase, 0.0, freqs[ich[0]], np.array([r.scale])
+            w = sc / errs[i, ich] ** 2
+            acc[ich] += w[:, None] * orc.rotate_data(ports[i, ich], ph, dm, Ps[i], freqs[ich], nu_ref)
             tw[ich] += w
         tmpl = acc / tw[:, None]
-    np.testing.assert_allclose(got, tmpl, rtol=0, atol=2e-7 * np.abs(tmpl).max())
+    # One draw of the four ends on the other side of one of SciPy's marginal exits: subint 1 of the
+    # 16 x 256 / fit_dm case lands 1.5e-10 rot and 1.3e-9 pc cm^-3 from the oracle in iteration 2 -- seeds bit-identical,
+    # every other fit of both iterations within 1e-12 rot, the accumulation itself within 1e-15 of the oracle's rotation
+    # (tools/dev_align_debug.py prints all of it) -- which moves the average by 1e-8 of its peak.  Listed, not tolerated
+    # silently: every other draw is held to 1e-10 of the peak.
+    marginal = {((16, 256), True): 2e-8}
+    bar = marginal.get((tuple(shape), bool(fit_dm)), 1e-10)
+    np.testing.assert_allclose(got, tmpl, rtol=0, atol=bar * np.abs(tmpl).max())
 
 
 def test_device_gaussian_portrait_matches_reference_and_host(eng):
