@@ -850,43 +850,60 @@ __device__ inline int block_argmin256(double v, int j, double* shv, int* shj) {
 }
 
 #define PP_FPS_LDS 2048       // harmonics of a profile pair's cross-spectrum k_fps keeps in LDS (16 B each)
-__device__ __forceinline__ void fps_fit(const FpsArgs& a, int i, int tid, int M, const cplx* X, const double (&v)[3], double sig,
-                                        double* scratch, double* shv, int* shj);
-__global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
-    const int i = blockIdx.x, tid = threadIdx.x, M = a.M;
-    __shared__ double scratch[4 * 4];
-    __shared__ double shv[4];
-    __shared__ int shj[4];
-    const cplx* d = a.specm ? a.spec + (size_t)i * (M + 1) : a.spec + (size_t)(2 * i) * (M + 1);
-    const cplx* m = a.specm ? a.specm + (size_t)i * a.mstride : a.spec + (size_t)(2 * i + 1) * (M + 1);
-    // the cross-spectrum every grid point and every simplex vertex walks: in LDS when it fits (each of the Ns grid
-    // threads reads all M harmonics one after the other -- from global memory that is M dependent round trips,
-    // ~0.5 ms of the kernel's 0.7 at M = 1024), else in the work buffer
-    __shared__ cplx Xs[PP_FPS_LDS];
-    const bool in_lds = (M <= PP_FPS_LDS);
-    cplx* X = in_lds ? Xs : xwork + (size_t)i * M;
-    const int H = M + 1, kc = (int)(0.75 * H);
-    double v[3] = {0.0, 0.0, 0.0};   // sum |d|^2, sum |m|^2, tail of |d|^2
-    for (int k = 1 + tid; k <= M; k += 256) {
-        const cplx dk = d[k], mk = m[k];
-        if (in_lds) Xs[k - 1] = cmulc(dk, mk); else X[k - 1] = cmulc(dk, mk);
-        const double pd = cnorm(dk);
-        v[0] += pd; v[1] += cnorm(mk);
-        if (k >= kc) v[2] += pd;
+// Block-wide sums of k_fps's 256 threads.  NVW = 1: 256 real threads (block_sum).  NVW = 4: ONE real wave plays the
+// four waves in turn -- lane l is threads l, l + 64, l + 128, l + 192 -- and adds the four wave totals in block_sum's
+// order: bitwise its results (what a transform wave runs as a ticket, pp_tail.h).  part(vt, v): thread vt's values.
+template <int NV, int NVW, typename F>
+__device__ __forceinline__ void fps_bsum(double (&out)[NV], double* scratch, int tid, F&& part) {
+    if constexpr (NVW == 1) {
+        part(tid, out);
+        block_sum<NV>(out, scratch);
+        __syncthreads();
+    } else {
+        const int lane = tid & 63;
+#pragma unroll 1
+        for (int vw = 0; vw < NVW; ++vw) {
+            double v[NV];
+            part(lane + 64 * vw, v);
+#pragma unroll
+            for (int q = 0; q < NV; ++q) v[q] = group_sum<64>(v[q]);
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < NV; ++q) scratch[vw * NV + q] = v[q];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            double t = 0.0;
+            for (int w = 0; w < NVW; ++w) t += scratch[w * NV + q];
+            out[q] = t;
+        }
+        __syncthreads();
     }
-    block_sum<3>(v, scratch);
-    __syncthreads();
+}
+
+// The 1-D fit of profile pair i: dspec(k) = the data profile's harmonic k, m[k] the model's, X[0 .. M) the work array
+// of their cross-spectrum (LDS where it fits).  Threads: 256 (NVW = 1) or one wave standing in for them (NVW = 4).
+template <int NVW, typename DF>
+__device__ __forceinline__ void fps_body(const FpsArgs& a, const int i, const int tid, const int M, DF&& dspec,
+                                         const cplx* m, cplx* X, double* scratch, double* shv, int* shj) {
+    constexpr int RT = 256 / NVW;        // real threads
+    const int H = M + 1, kc = (int)(0.75 * H);
+    double v[3];   // sum |d|^2, sum |m|^2, tail of |d|^2
+    fps_bsum<3, NVW>(v, scratch, tid, [&](const int vt, double (&u)[3]) __attribute__((always_inline)) {
+        u[0] = u[1] = u[2] = 0.0;
+        for (int k = 1 + vt; k <= M; k += 256) {
+            const cplx dk = dspec(k), mk = m[k];
+            X[k - 1] = cmulc(dk, mk);
+            const double pd = cnorm(dk);
+            u[0] += pd; u[1] += cnorm(mk);
+            if (k >= kc) u[2] += pd;
+        }
+    });
     const double B = 2.0 * M;
     double sig = a.noise ? a.noise[i] : NAN;
     if (!(sig >= 0.0)) sig = sqrt(v[2] / B / (double)(H - kc));   // get_noise_PS
-    if (in_lds) fps_fit(a, i, tid, M, (const cplx*)Xs, v, sig, scratch, shv, shj);
-    else fps_fit(a, i, tid, M, (const cplx*)X, v, sig, scratch, shv, shj);
-}
-
-// the fit proper, on the cross-spectrum X (LDS or global: inlined into both call sites)
-__device__ __forceinline__ void fps_fit(const FpsArgs& a, int i, int tid, int M, const cplx* X, const double (&v)[3], double sig,
-                                        double* scratch, double* shv, int* shj) {
-    const double B = 2.0 * M;
     const double err2 = sig * sig * (0.5 * B);
     const double dd = v[0] / err2, pp_ = v[1] / err2;
     // brute grid, both ends included (scipy.optimize.brute with complex(Ns))
@@ -895,22 +912,36 @@ __device__ __forceinline__ void fps_fit(const FpsArgs& a, int i, int tid, int M,
     int bestj = 0x7fffffff;
     // (grid point j = j * step + lo, the arithmetic of numpy's mgrid)
     const double h = (Ns > 1) ? (a.hi - a.lo) / (double)(Ns - 1) : 0.5;
-    for (int j = tid; j < Ns; j += 256) {
+    for (int j = tid; j < Ns; j += RT) {
         const double phi = (Ns > 1) ? add_rn(mul_rn((double)j, h), a.lo) : a.lo;
         double s0, s1, s2;
         fps_sums(X, M, phi, 0, 1, s0, s1, s2);
-        const double v = -s0 / err2;
-        if (v < bestv) { bestv = v; bestj = j; }
+        const double vv = -s0 / err2;
+        if (vv < bestv) { bestv = vv; bestj = j; }
     }
-    const int best = min(block_argmin256(bestv, bestj, shv, shj), Ns - 1);
+    int best;
+    if constexpr (NVW == 1) best = min(block_argmin256(bestv, bestj, shv, shj), Ns - 1);
+    else {
+        // (the same total order -- value, then index -- over the one wave that holds every grid point)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(bestv, o, 64);
+            const int oj = __shfl_xor(bestj, o, 64);
+            if (ov < bestv || (ov == bestv && oj < bestj)) { bestv = ov; bestj = oj; }
+        }
+        best = min(bestj, Ns - 1);
+    }
     double phi = (Ns > 1) ? add_rn(mul_rn((double)best, h), a.lo) : a.lo;
     double f = 0.0, f2 = 0.0;
-    // objective at one phase, the same in every thread
+    // the three sums at one phase, the same in every thread
+    auto sums_at = [&](double x, double (&s)[3]) __attribute__((always_inline)) {
+        fps_bsum<3, NVW>(s, scratch, tid, [&](const int vt, double (&u)[3]) __attribute__((always_inline)) {
+            fps_sums(X, M, x, vt, 256, u[0], u[1], u[2]);
+        });
+    };
     auto feval = [&](double x) -> double {
         double s[3];
-        fps_sums(X, M, x, tid, 256, s[0], s[1], s[2]);
-        block_sum<3>(s, scratch);
-        __syncthreads();
+        sums_at(x, s);
         return -s[0] / err2;
     };
     if (a.finish == 1) {
@@ -960,9 +991,7 @@ __device__ __forceinline__ void fps_fit(const FpsArgs& a, int i, int tid, int M,
     double lo = phi - h, hi = phi + h;
     for (int it = 0; it < 60; ++it) {
         double s[3];
-        fps_sums(X, M, phi, tid, 256, s[0], s[1], s[2]);
-        block_sum<3>(s, scratch);
-        __syncthreads();
+        sums_at(phi, s);
         f = -s[0] / err2;
         const double f1 = PP_TWO_PI * s[1] / err2;                   // df/dphi
         f2 = PP_TWO_PI * PP_TWO_PI * s[2] / err2;                     // d2f/dphi2
@@ -976,8 +1005,7 @@ __device__ __forceinline__ void fps_fit(const FpsArgs& a, int i, int tid, int M,
     }
     // value and curvature at the final phase
     double s[3];
-    fps_sums(X, M, phi, tid, 256, s[0], s[1], s[2]);
-    block_sum<3>(s, scratch);
+    sums_at(phi, s);
     f = -s[0] / err2;
     f2 = PP_TWO_PI * PP_TWO_PI * s[2] / err2;
     if (tid == 0) {
@@ -991,6 +1019,23 @@ __device__ __forceinline__ void fps_fit(const FpsArgs& a, int i, int tid, int M,
         o[5] = (dd - f * f / pp_) / (B - 2.0);
         o[6] = 0.0;
     }
+}
+
+__global__ __launch_bounds__(256) void k_fps(FpsArgs a, cplx* xwork) {
+    const int i = blockIdx.x, tid = threadIdx.x, M = a.M;
+    __shared__ double scratch[4 * 4];
+    __shared__ double shv[4];
+    __shared__ int shj[4];
+    const cplx* d = a.specm ? a.spec + (size_t)i * (M + 1) : a.spec + (size_t)(2 * i) * (M + 1);
+    const cplx* m = a.specm ? a.specm + (size_t)i * a.mstride : a.spec + (size_t)(2 * i + 1) * (M + 1);
+    // the cross-spectrum every grid point and every simplex vertex walks: in LDS when it fits (each of the Ns grid
+    // threads reads all M harmonics one after the other -- from global memory that is M dependent round trips,
+    // ~0.5 ms of the kernel's 0.7 at M = 1024), else in the work buffer
+    __shared__ cplx Xs[PP_FPS_LDS];
+    auto dv = [&](const int k) __attribute__((always_inline)) { return d[k]; };
+    // (inlined into both call sites: LDS and global addressing)
+    if (M <= PP_FPS_LDS) fps_body<1>(a, i, tid, M, dv, m, Xs, scratch, shv, shj);
+    else fps_body<1>(a, i, tid, M, dv, m, xwork + (size_t)i * M, scratch, shv, shj);
 }
 
 // DM axis of the coarse grid: per subint the trial with the highest correlation peak,

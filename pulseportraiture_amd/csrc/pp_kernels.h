@@ -2816,68 +2816,4 @@ __global__ __launch_bounds__(64) void k_finalize_v(FitArgs a) {
     finalize_body<0, NT, NT / 64>(a, blockIdx.x, threadIdx.x, scratch, sh);
 }
 
-// --------------------------------------------------------------------------
-// The tail of a batch inside the NEXT batch's transform (round 5).  The solve on the Taylor model and the post-fit
-// stage of batch k need every row of batch k, so they cannot start before its transform ends -- and behind it they
-// are 0.7 ms of a 14.7 ms step during which the f64 pipes idle (the solve re-reads the Taylor rows at the HBM
-// roofline) --; beside the persistent transform of batch k + 1 no other kernel finds a wave slot
-// (profiles/r05_overlap_ab.txt).  So the transform's own waves do the work: a subint of batch k is a TICKET, every
-// wave of batch k + 1's transform draws one before its first row and the waves that run out of rows draw the rest.
-// A wave is out of the transform for the ~1 ms its ticket takes (of ~14), which costs the transform far less than its
-// share of the waves (half the waves keep 81 % of the rate, profiles/r05_grid_scale.txt).  One wave does what four
-// (solve) and eight (post-fit) do in the stand-alone kernels by walking their waves in turn (NVW = NT / 64): the same
-// bits, so an enqueued batch returns what a synchronous call returns.
-// LDS: the transform's own image, free before the first row and after the last.
-// --------------------------------------------------------------------------
-struct TailArgs {
-    FitArgs fa;               // of the batch whose tail this is (solve_cache <= PP_TAIL_CACHE, tail_fused = 1)
-    unsigned ticket, done;    // next subint to hand out; subints finished
-    int nsub;
-    int solve_nt, solve_pf;   // the widths the stand-alone kernels would be launched with
-    int fin_nt;               // 64 (<8, 64>), 128 / 256 / 512 (<8, NT>), 0 (<0, 256>)
-};
-
-__device__ __noinline__ void tail_work(const TailArgs* t, double* lds, int nlds, int tid, int max_tickets) {
-    TailArgs* tw = const_cast<TailArgs*>(t);
-    const int nsub = t->nsub;
-    for (int round = 0; round < max_tickets; ++round) {
-        unsigned tk = 0;
-        if (tid == 0) tk = atomicAdd(&tw->ticket, 1u);
-        tk = (unsigned)__builtin_amdgcn_readfirstlane((int)tk);
-        if (tk >= (unsigned)nsub) return;
-        // (read where it lies, in device memory: a private copy of the ~600-byte block lives in scratch memory and
-        // every use of a field becomes a scratch load; the host has set solve_cache for PP_TAIL_LDS_DOUBLES and tail_fused)
-        const FitArgs& a = t->fa;
-        const int i = (int)tk;
-        // [0, 528): block sums (PP_BSUM_DOUBLES(8, 31) = 512 the larger);  [528, 536): one broadcast value;  the rest:
-        // the solve's cache of channel invariants (4 doubles a channel; results do not depend on its size)
-        double* scratch = lds;
-        double* sh = lds + 528;
-        double* inv = lds + 536;
-        (void)nlds;
-        const int snt = t->solve_nt, spf = t->solve_pf, fnt = t->fin_nt;
-        if (snt == 64) taylor_solve_body<64, PP_SOLVE_PF, 1>(a, i, tid, scratch, inv);
-        else if (snt == 128) taylor_solve_body<128, PP_SOLVE_PF, 2>(a, i, tid, scratch, inv);
-        else if (snt == 512) taylor_solve_body<512, PP_SOLVE_PF, 8>(a, i, tid, scratch, inv);
-        else if (spf == 0) taylor_solve_body<256, 0, 4>(a, i, tid, scratch, inv);
-        else taylor_solve_body<256, PP_SOLVE_PF, 4>(a, i, tid, scratch, inv);
-        __syncthreads();             // (one wave: orders its LDS and global writes before the post-fit stage reads them)
-        if (fnt == 64) finalize_body<8, 64, 1>(a, i, tid, scratch, sh);
-        else if (fnt == 128) finalize_body<0, 128, 2>(a, i, tid, scratch, sh);
-        else if (fnt == 512) finalize_body<0, 512, 8>(a, i, tid, scratch, sh);
-        else finalize_body<0, 256, 4>(a, i, tid, scratch, sh);
-        __syncthreads();
-        // the last ticket to finish publishes the count of unfinished subints (the stand-alone post-fit kernel
-        // runs after the whole solve kernel: its subint 0 does it)
-        if (tid == 0) {
-            __threadfence();
-            const unsigned d = atomicAdd(&tw->done, 1u);
-            if (d + 1u == (unsigned)nsub) {
-                __threadfence();
-                a.o_npass[a.nsub] = atomicAdd(a.nactive, 0);
-            }
-        }
-    }
-}
-
 }  // namespace pp

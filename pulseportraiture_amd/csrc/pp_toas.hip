@@ -22,6 +22,7 @@
 #include "pp_kernels.h"
 #include "pp_extra.h"
 #include "pp_xspec1024r.h"
+#include "pp_tail.h"
 #include "pp_anybin.h"
 
 using namespace pp;
@@ -161,6 +162,9 @@ struct pp_ctx {
         int ns = 0, C = 0, solve_nt = 0, solve_pf0 = 0, fin_nt = 0;
         size_t solve_lds = 0;
         pp_fit_out out; int s0 = 0; bool chan_dev = false; size_t copy_bytes = 0;
+        RefTailArgs rs;                  // reference-seed flow: the guess's finish, fit and start points belong to the tail too
+        cplx* rs_dspec = nullptr;        // ... by the stand-alone kernels (flush_tail): the spectrum's array and the fit's
+        cplx* rs_xwork = nullptr;        //     work buffer
     } ptail;
     DevBuf tailbuf[PP_NSTAGE];           // the TailArgs a carrying transform reads
     void* tail_host[PP_NSTAGE] = {nullptr, nullptr, nullptr};   // ... and their pinned source
@@ -402,8 +406,12 @@ extern "C" int pp_destroy(pp_ctx* c) {
     return PP_OK;
 }
 
+static int flush_tail(pp_ctx* c);
 extern "C" int pp_synchronize(pp_ctx* c) {
     if (!c) return fail(PP_EINVAL, "null context");
+    // (the youngest enqueued batch's tail may still be unqueued -- option fuse_tail --: a caller that synchronises
+    // expects the device-resident outputs of everything it has enqueued, so it goes out by the stand-alone kernels)
+    if (int rc = flush_tail(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream2));
     return PP_OK;
@@ -1018,11 +1026,22 @@ static int queue_outputs(pp_ctx* c, int stage, const pp_fit_out* out, int s0, in
     return PP_OK;
 }
 // the pending tail by the stand-alone kernels (nobody carried it): solve, post-fit stage, outputs, the batch's event
-static int flush_tail(pp_ctx* c) {
-    pp_ctx::PendingTail& t = c->ptail;
-    if (!t.valid) return PP_OK;
-    t.valid = false;
+static int flush_tail_queue(pp_ctx* c, pp_ctx::PendingTail& t) {
     int rc;
+    if (t.rs.on) {
+        // the reference's guess from the pass's chunk partials: k_refseed_finish -> k_fps -> k_refseed_start
+        constexpr int M = 1024;
+        const size_t H = (size_t)M + 1;
+        Prof pr(c, KF_FPS);
+        hipLaunchKernelGGL(k_refseed_finish, dim3((unsigned)((H + 255) / 256), t.ns), dim3(256), 0, c->stream,
+                           t.rs.part, t.rs.ncc, t.rs.delta, t.rs.wsum, t.ns, t.rs_dspec, t.rs.mws);
+        FpsArgs f = t.rs.fps;
+        f.spec = t.rs_dspec; f.specm = t.rs.mspec; f.mstride = t.rs.mstride;
+        hipLaunchKernelGGL(k_fps, dim3(t.ns), dim3(256), 0, c->stream, f, t.rs_xwork);
+        hipLaunchKernelGGL(k_refseed_start, dim3((t.ns + 63) / 64), dim3(64), 0, c->stream, (const double*)t.rs.fps.out7, t.ns,
+                           t.rs.xs, t.rs.seed_phase);
+        HIP_TRY(hipGetLastError());
+    }
     {
         Prof pr(c, KF_TAYLOR);
         solve_launch(c, t.fa, t.ns, t.C, t.solve_nt, c->stream);
@@ -1036,6 +1055,22 @@ static int flush_tail(pp_ctx* c) {
     HIP_TRY(hipEventRecord(c->stage[t.stage].done, c->stream));
     if (c->eager_flush) (void)hipStreamQuery(c->stream);
     return PP_OK;
+}
+// (a tail that could not be queued: the batch it belongs to must not be collected as if it had run -- its `done`
+// event would be a stale one and its staging block another batch's numbers)
+static void fail_pending_stage(pp_ctx* c, int stage, int rc);
+static int flush_tail(pp_ctx* c) {
+    pp_ctx::PendingTail& t = c->ptail;
+    if (!t.valid) return PP_OK;
+    const int rc = flush_tail_queue(c, t);
+    t.valid = false;
+    if (rc) fail_pending_stage(c, t.stage, rc);
+    return rc;
+}
+
+static void fail_pending_stage(pp_ctx* c, int stage, int rc) {
+    for (auto& d : c->pending)
+        if (d.queued && d.stage == stage) { d.queued = false; d.rc = rc; d.err = g_err; }
 }
 
 // `deferred` (pp_fit_enqueue): when non-null and the batch takes the one-pass flow without a host
@@ -1429,8 +1464,43 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
 
     // (a pending tail of the previous enqueued batch that this batch's transform will not carry -- any flow but the
     // plain one-pass one -- goes out by the stand-alone kernels now)
-    if (c->ptail.valid && (refseed || seed_full || fuse_scat || !xmom || anyb || !c->one_exchange || M != 1024 || !deferred))
+    if (c->ptail.valid && ((refseed && scat) || seed_full || fuse_scat || !xmom || anyb || !c->one_exchange || M != 1024 || !deferred))
         if ((rc = flush_tail(c))) return rc;
+    // The previous enqueued batch's tail, still unqueued: this batch's transform works it off as tickets if it is one of
+    // the kernels that can (k_xspec_q1024 / k_xspec_qf<1024> / k_xspec_qr1024: 2048-bin rows, Taylor sums only) -- and
+    // if its grid is wide enough for the tickets: a small batch behind a large one would hand each of its few waves
+    // many tickets in a row, ~1 ms each, where the stand-alone kernels take 0.7 ms for all of them.
+    auto carrier_block = [&](XspecArgs& x) -> int {
+        pp_ctx::PendingTail& pt = c->ptail;
+        const int st_i = c->cur_stage;
+        const size_t tb = (sizeof(TailArgs) + 7) & ~(size_t)7;
+        if ((rc = c->tailbuf[st_i].reserve(tb))) return rc;
+        if (!c->tail_host[st_i]) HIP_TRY(hipHostMalloc(&c->tail_host[st_i], tb, hipHostMallocDefault));
+        TailArgs* th = reinterpret_cast<TailArgs*>(c->tail_host[st_i]);
+        memset(th, 0, tb);
+        th->fa = pt.fa; th->ticket = 0; th->done = 0; th->nsub = pt.ns;
+        th->fa.solve_cache = std::min(pt.C, (int)PP_TAIL_CACHE);
+        th->fa.tail_fused = 1;
+        th->solve_nt = pt.solve_nt; th->solve_pf = pt.solve_pf0 ? 0 : PP_SOLVE_PF; th->fin_nt = pt.fin_nt;
+        th->rs = pt.rs;
+        if ((rc = staged_copy(c, c->tailbuf[st_i].p, th, tb, hipMemcpyHostToDevice))) return fail(rc, "tail block copy failed");
+        x.tail = c->tailbuf[st_i].as<TailArgs>();
+        return PP_OK;
+    };
+    // ... and behind the carrying transform: the carried batch's outputs and its event
+    auto carrier_done = [&]() -> int {
+        pp_ctx::PendingTail& pt = c->ptail;
+        int r2 = queue_outputs(c, pt.stage, &pt.out, pt.s0, pt.ns, pt.C, pt.chan_dev, pt.copy_bytes, c->stream);
+        if (!r2 && hipEventRecord(c->stage[pt.stage].done, c->stream) != hipSuccess) r2 = fail(PP_EHIP, "hipEventRecord failed");
+        pt.valid = false;
+        if (r2) fail_pending_stage(c, pt.stage, r2);
+        return r2;
+    };
+    const bool wide_enough = c->ptail.valid && (long long)std::min<long long>((long long)ns * C, 4096) * 2 >= (long long)c->ptail.ns;
+    if (c->ptail.valid && !wide_enough)
+        if ((rc = flush_tail(c))) return rc;
+    // a batch of the one-pass flow whose own tail stays unqueued for the next batch's transform (option fuse_tail)
+    const bool tail_pending = defer_ok && c->fuse_tail && xmom && sp == c->stream && !anyb && M == 1024 && c->one_exchange;
     // ---- phase seed from a pilot pass ----
     if (pilot) {
         const int Cp = (C + cstep - 1) / cstep;
@@ -1481,6 +1551,10 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         chained = true;
         return PP_OK;
     };
+    RefTailArgs rs_tail;             // this batch's own reference-seed tail, when it stays unqueued (tail_pending)
+    memset(&rs_tail, 0, sizeof rs_tail);
+    cplx* rs_tail_dspec = nullptr;
+    cplx* rs_tail_xwork = nullptr;
     auto run_refseed_pass = [&]() -> int {
         const int ncc = C / PP_ROW_CHUNK;
         const size_t H = (size_t)M + 1;
@@ -1522,6 +1596,20 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         x.mwords = mw_sub;
         c->ticket_base += (unsigned)((nrows + PP_ROW_CHUNK - 1) / PP_ROW_CHUNK);
         RefSeedArgs ra{d_w, part, ncc};
+        // what the guess needs beside the pass's channel sums does not depend on the pass: the template profile's
+        // spectrum, Delta_i and the summed weights -- queued in front of it (the expansion points are the pilot's)
+        {
+            Prof pr(c, KF_PREP);
+            hipLaunchKernelGGL((k_rfft_rows<1024, double>), dim3(fft_grid(64, (long long)nprof)), dim3(64), 0, c->stream,
+                               (const void*)mprof, mspec, tw, (int)nprof);
+            hipLaunchKernelGGL(k_refseed_prep, dim3(ns), dim3(256), 0, c->stream, (const double*)d_x0, (const double*)d_P,
+                               (const double*)d_nufit, (const double*)d_numean, d_w, C, d_delta, d_wsum);
+        }
+        HIP_TRY(hipGetLastError());
+        // (the previous batch's tail rides in this pass if it can: see carrier_block)
+        const bool carrier = c->ptail.valid && !scat && deferred != nullptr;
+        if (carrier) { if ((rc = carrier_block(x))) return rc; }
+        else if (c->ptail.valid) { if ((rc = flush_tail(c))) return rc; }
         {
             Prof pr(c, KF_XSPEC);
 #define PP_QR(TIN, ST)                                                                                     \
@@ -1534,26 +1622,35 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
 #undef PP_QR
         }
         HIP_TRY(hipGetLastError());
+        if (carrier) if ((rc = carrier_done())) return rc;
+        FpsArgs f{dspec, nullptr, d_out7, rs->lo, rs->hi, rs->Ns, M, ns, rs->finish, mspec,
+                  rs->model_prof_stride ? (int)H : 0};
+        d_seedph = d_sph;
+        if (tail_pending && !scat) {
+            // this batch's own guess -- the spectrum from the chunk partials, the reference's fit_phase_shift, the
+            // start points -- waits with its solve and post-fit stage for the next batch's transform (or flush_tail)
+            memset(&rs_tail, 0, sizeof rs_tail);
+            rs_tail.on = 1; rs_tail.ncc = ncc; rs_tail.part = part; rs_tail.delta = d_delta; rs_tail.wsum = d_wsum;
+            rs_tail.mws = mw_sub; rs_tail.mspec = mspec; rs_tail.mstride = rs->model_prof_stride ? (int)H : 0;
+            rs_tail.fps = f; rs_tail.fps.spec = nullptr; rs_tail.fps.specm = nullptr;
+            rs_tail.xs = d_xs; rs_tail.seed_phase = d_sph;
+            rs_tail_dspec = dspec; rs_tail_xwork = xwork;
+            fa.xstart = d_xs;
+            return PP_OK;
+        }
         // (what follows the pass -- the channel mean's spectrum, the reference's fit_phase_shift, the start points --
         // belongs to the solve stage: beside the next batch's transform when the batch is deferred.  The mask words
         // the finish reads are the transform stage's buffer: a deferred batch has its own copy)
         if ((rc = chain_post())) return rc;
         {
             Prof pr(c, KF_FPS, sp);
-            hipLaunchKernelGGL((k_rfft_rows<1024, double>), dim3(fft_grid(64, (long long)nprof)), dim3(64), 0, sp,
-                               (const void*)mprof, mspec, tw, (int)nprof);
-            hipLaunchKernelGGL(k_refseed_prep, dim3(ns), dim3(256), 0, sp, (const double*)d_x0, (const double*)d_P,
-                               (const double*)d_nufit, (const double*)d_numean, d_w, C, d_delta, d_wsum);
             hipLaunchKernelGGL(k_refseed_finish, dim3((unsigned)((H + 255) / 256), ns), dim3(256), 0, sp,
                                (const cplx*)part, ncc, (const double*)d_delta, (const double*)d_wsum, ns, dspec, mw_sub);
-            FpsArgs f{dspec, nullptr, d_out7, rs->lo, rs->hi, rs->Ns, M, ns, rs->finish, mspec,
-                      rs->model_prof_stride ? (int)H : 0};
             hipLaunchKernelGGL(k_fps, dim3(ns), dim3(256), 0, sp, f, xwork);
         }
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_refseed_start, dim3((ns + 63) / 64), dim3(64), 0, sp, (const double*)d_out7, ns, d_xs, d_sph);
         HIP_TRY(hipGetLastError());
-        d_seedph = d_sph;
         if (scat) {
             // stored cross-spectrum: the iteration starts AT the reference's guess
             HIP_TRY(hipMemcpyAsync(d_x0, d_xs, (size_t)ns * 40, hipMemcpyDeviceToDevice, c->stream));
@@ -1596,34 +1693,12 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
     } else {
         XspecArgs xm = xa;
         xm.mwords = mw_main;
-        // The previous enqueued batch's tail (solve + post-fit stage), still unqueued: this transform works it off as
-        // tickets if it is one of the kernels that can (k_xspec_q1024 / k_xspec_qf: 2048- and 1024-bin rows, Taylor
-        // sums only); its outputs and its event follow this transform on the stream.
+        // (the previous enqueued batch's tail rides in this transform if it can: see carrier_block)
         const bool carrier = c->ptail.valid && xmom && !anyb && c->one_exchange && M == 1024 && deferred != nullptr;
-        if (carrier) {
-            pp_ctx::PendingTail& pt = c->ptail;
-            const int st_i = c->cur_stage;
-            const size_t tb = (sizeof(TailArgs) + 7) & ~(size_t)7;
-            if ((rc = c->tailbuf[st_i].reserve(tb))) return rc;
-            if (!c->tail_host[st_i]) HIP_TRY(hipHostMalloc(&c->tail_host[st_i], tb, hipHostMallocDefault));
-            TailArgs* th = reinterpret_cast<TailArgs*>(c->tail_host[st_i]);
-            memset(th, 0, tb);
-            th->fa = pt.fa; th->ticket = 0; th->done = 0; th->nsub = pt.ns;
-            th->fa.solve_cache = std::min(pt.C, (int)PP_TAIL_CACHE);
-            th->fa.tail_fused = 1;
-            th->solve_nt = pt.solve_nt; th->solve_pf = pt.solve_pf0 ? 0 : PP_SOLVE_PF; th->fin_nt = pt.fin_nt;
-            if ((rc = staged_copy(c, c->tailbuf[st_i].p, th, tb, hipMemcpyHostToDevice))) return fail(rc, "tail block copy failed");
-            xm.tail = c->tailbuf[st_i].as<TailArgs>();
-        } else if (c->ptail.valid) {
-            if ((rc = flush_tail(c))) return rc;
-        }
+        if (carrier) { if ((rc = carrier_block(xm))) return rc; }
+        else if (c->ptail.valid) { if ((rc = flush_tail(c))) return rc; }
         if ((rc = run_xspec(xm, xmode))) return rc;
-        if (carrier) {
-            pp_ctx::PendingTail& pt = c->ptail;
-            pt.valid = false;
-            if ((rc = queue_outputs(c, pt.stage, &pt.out, pt.s0, pt.ns, pt.C, pt.chan_dev, pt.copy_bytes, c->stream))) return rc;
-            HIP_TRY(hipEventRecord(c->stage[pt.stage].done, c->stream));
-        }
+        if (carrier) if ((rc = carrier_done())) return rc;
         if (!wts_early) if ((rc = run_prep())) return rc;
     }
     HIP_TRY(hipGetLastError());
@@ -1650,7 +1725,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             Prof pr(c, KF_EVAL);
             hipLaunchKernelGGL(k_eval_moments, dim3(ns, nchunk), dim3(256), 0, c->stream, fa);
         }
-        if (defer_ok && c->fuse_tail && !xstore && sp == c->stream && !anyb && M == 1024 && c->one_exchange) {
+        if (tail_pending) {
             // nothing of the tail is queued: the next enqueued batch's transform works it off (or flush_tail does)
             pp_ctx::PendingTail& pt = c->ptail;
             pt.valid = true; pt.stage = c->cur_stage;
@@ -1658,6 +1733,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
             pt.ns = ns; pt.C = C; pt.solve_nt = solve_nt; pt.solve_pf0 = solve_rows_in_turn(c, C, solve_nt) ? 1 : 0;
             pt.fin_nt = finalize_width_taken(c, pt.fa, C);
             pt.out = *out; pt.s0 = s0; pt.chan_dev = chan_dev; pt.copy_bytes = d_seedph ? o_stage : o_bytes;
+            pt.rs = rs_tail; pt.rs_dspec = rs_tail_dspec; pt.rs_xwork = rs_tail_xwork;
             *deferred = true;
             return PP_OK;
         }
@@ -2000,7 +2076,7 @@ extern "C" int pp_fit_collect(pp_ctx* c) {
     if (c->pending.empty()) return fail(PP_ESTATE, "pp_fit_collect: nothing enqueued");
     pp_ctx::Deferred d = c->pending.front();
     c->pending.pop_front();
-    if (!d.queued) return d.rc;
+    if (!d.queued) { if (d.rc) g_err = d.err; return d.rc; }
     HIP_TRY(hipSetDevice(c->device));
     pp_ctx::Stage& sg = c->stage[d.stage];
     // (its tail was waiting for a next batch that did not come: the stand-alone kernels)

@@ -60,14 +60,20 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
     // f64 rows: three of the four tail accumulators live in the LDS a wave has left beside its
     // image (8 waves x 20 KB = the CU's 160 KB) -- with a whole f64 row in flight (64 registers)
     // there is no room for them in the register file
-    constexpr int NLA = (sizeof(Tin) == 8) ? 3 : 0;
+    // (f32 rows that carry tickets: two of them -- the call's bookkeeping costs the row loop the registers of one
+    // accumulator, which otherwise goes to scratch memory and is read, updated and written back every row)
+    constexpr int NLA = (sizeof(Tin) == 8) ? 3 : ((PP_TAIL_HOOKS && !STORE) ? 2 : 0);
     __shared__ cplx lds[LDSN + 64 * NLA];
     int tid = threadIdx.x;
     cplx* const lacc = lds + LDSN + threadIdx.x;
     // rows = (chunk, position in chunk); RowWalk deals chunks, its "subint" is the position
     const long long nrows = (long long)a.nsub * a.nchan;
     Raw cur[PER1][R1];
-    const cplx wbT = a.twB[64];
+    // W_2048^64 = exp(-i pi / 16), the step of the split twiddle from one slot to the next: the table's own value
+    // (a.twB[64], the correctly rounded cosine and sine), as scalar-register constants formed where they are used --
+    // held in four vector registers through the row loop it is what the kernel lacks once it carries tickets
+    // (a prefetched piece of the next row went to scratch memory instead, behind a full vmcnt(0) wait)
+#define PP_WBT make_double2(kconst<true>(0x1.f6297cff75cb0p-1), kconst<true>(-0x1.8f8b83c69a60bp-3))
     RowWalk<true> rw;
     rw.start(nrows, a.mwords, a.ticket, a.ticket_base);
     // (position in the chunk and chunk are the low and high bits of the walk's row: nothing to carry)
@@ -81,7 +87,25 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
     cplx acc[RS_NREG - NLA];      // (slots 0..6, tail slot 12 [.. 15 for f32 rows])
     int ia_nx = ia, cc_nx = cc;
     const int ktg = a.Kt;             // harmonics the widest template row keeps: the channel sum takes them all
-    for (; rw.more; rw.advance(), ia = ia_nx, cc = cc_nx) {
+    // (the previous batch's tail -- its phase guess, solve and post-fit stage, pp_tail.h: this wave draws ONE ticket
+    // after tail_after rows, at the next chunk boundary -- there the channel sums in hand have just been written out
+    // and the ticket may use the whole image --, a different count for every wave as in k_xspec_q1024; what is left
+    // is drawn by the waves that have run out of rows)
+    constexpr bool HOOK = PP_TAIL_HOOKS && !STORE;
+    static_assert(!HOOK || 2 * LDSN >= PP_TAIL_LDS_DOUBLES, "tail_work's layout of this kernel's LDS");
+    // (the only state the hook carries through the row loop is `phase` -- this kernel has neither a vector nor a
+    // scalar register to spare: a row count per wave, as k_xspec_q1024 keeps, cost it a spilled accumulator per row.
+    // The moment is read off the walk instead: chunks are dealt in order, so the chunk number IS the launch's
+    // progress, and a wave asks for its ticket at the first chunk boundary past a wave-specific threshold spread
+    // over the first three quarters of the chunks)
+    int phase = (HOOK && a.tail) ? 0 : 2;          // 0: ticket not asked for yet, 2: asked (or nothing to carry)
+    auto due = [&]() -> bool {
+        const unsigned nchunks = ((unsigned)nrows + PP_ROW_CHUNK - 1u) / PP_ROW_CHUNK;
+        const unsigned thr = ((blockIdx.x * 2654435761u) >> 8) % (nchunks - nchunks / 4u + 1u);
+        return (rw.row >> 5) >= thr;
+    };
+    for (;;) {
+    for (; rw.more && !(HOOK && phase == 0 && rw.fresh && due()); rw.advance(), ia = ia_nx, cc = cc_nx) {
         rw.draw(a.ticket);
         // (no look-ahead for the next chunk's word here -- scalar registers are what this kernel is
         // short of: the word is fetched when the chunk runs out, one exposed scalar load per 32 rows)
@@ -242,7 +266,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
                 }
               }
             }
-            wb = cmul(wb, wbT);
+            wb = cmul(wb, PP_WBT);
             e = cmul(e, wst);
         }
         // ---- the noise tail of the channel sum: k = lam + 64 kd, kd = 12..15 (lam = 0: k = 64 kd,
@@ -254,7 +278,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
             e4 = cmul(e4, e4);                       // e^{2 pi i 256 phi}
             const cplx w4 = make_double2(0.70710678118654752440, -0.70710678118654752440);   // W_2048^256
             cplx et = cmul(e, e4), wt = cmul(wb, w4);                 // + 4 steps
-            const cplx et1 = cmul(et, wst), wt1 = cmul(wt, wbT);      // + 5 steps
+            const cplx et1 = cmul(et, wst), wt1 = cmul(wt, PP_WBT);      // + 5 steps
             et = csel(l0, et, et1);
             wt = csel(l0, wt, wt1);
             const cplx* pt = lds + fftq_lane_of((64 - lam) & 63) + (l0 ? 64 : 0);
@@ -277,7 +301,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
                     t.y = fma(hw, y.y, t.y);
                     lacc[64 * (kd - 12 - NRT)] = t;
                 }
-                wt = cmul(wt, wbT);
+                wt = cmul(wt, PP_WBT);
                 et = cmul(et, wst);
             }
             if (tid == 0) {
@@ -320,6 +344,18 @@ __global__ __launch_bounds__(64, 2) void k_xspec_qr1024(XspecArgs a, RefSeedArgs
         }
         lds_sync<T>();
     }
+    if (!HOOK || phase != 0 || !rw.more) break;
+    tail_work(a.tail, reinterpret_cast<double*>(lds), 2 * LDSN, tid, 1);
+    phase = 2;
+    {
+        // (the row prefetched before the ticket is fetched AGAIN: 64 registers that need not live across the call --
+        // kept, one piece of them was given a scratch slot for the whole kernel and every row waited for it with
+        // vmcnt(0); one row more per wave and launch, 0.1 % of the traffic)
+        const size_t rc = (size_t)ia * a.nchan_full + (size_t)cc * PP_ROW_CHUNK + (size_t)(rw.row & 31u);
+        stage_load_global<M, T, R1>(cur, reinterpret_cast<const Tin*>(a.data) + rc * (2 * M), tid);
+    }
+    }
+    if (HOOK && a.tail) tail_work(a.tail, reinterpret_cast<double*>(lds), 2 * LDSN, tid, 1 << 30);
 }
 
 // the weights of the channel mean with the fit's channel mask folded in: the mean is taken over the
@@ -352,14 +388,17 @@ __global__ __launch_bounds__(256) void k_refseed_prep(const double* x0, const do
 // the start points of the iteration: xs[i] holds {K_i, DM, GM, tau, alpha} on entry, K_i the term
 // phase_transform adds (formed on the host from the inputs alone); the phase becomes
 // wrap(fit_phase_shift's phase + K_i) with NumPy's two-step wrap to [-0.5, 0.5) (pplib.py:2612-2613)
-__global__ void k_refseed_start(const double* out7, int nsub, double* xs, double* seed_phase) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nsub) return;
+__device__ __forceinline__ void refseed_start_one(const double* out7, const int i, double* xs, double* seed_phase) {
     double ph = out7[(size_t)i * 7] + xs[(size_t)i * 5];
     if (fabs(ph) >= 0.5) { ph = fmod(ph, 1.0); if (ph != 0.0 && ph < 0.0) ph += 1.0; }
     if (ph >= 0.5) ph -= 1.0;
     xs[(size_t)i * 5] = ph;
     seed_phase[i] = ph;
+}
+__global__ void k_refseed_start(const double* out7, int nsub, double* xs, double* seed_phase) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsub) return;
+    refseed_start_one(out7, i, xs, seed_phase);
 }
 
 // rot_prof's spectrum of every subint from the partial channel sums: fixed-order sum over the
@@ -368,11 +407,10 @@ __global__ void k_refseed_start(const double* out7, int nsub, double* xs, double
 // accumulate (448 < k < 768, and 0) are zero.  spec[i][0..M].
 // mws (optional): the rows-in-use words of the pass (k_mask_words' wsub): a chunk without a row in use
 // was never visited and left no partial.
-__global__ __launch_bounds__(256) void k_refseed_finish(const cplx* part, int ncc, const double* delta,
-                                                        const double* wsum, int nsub, cplx* spec, const unsigned* mws) {
+// harmonic k of subint i's rot_prof spectrum (0 <= k <= 1024), from the chunk partials of the pass
+__device__ __forceinline__ cplx refseed_spec_value(const cplx* part, const int ncc, const double delta_i, const double wsum_i,
+                                                   const int nsub, const int i, const int k, const unsigned* mws) {
     constexpr int M = 1024;
-    const int i = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
-    if (k > M) return;
     const int lam = k & 63, kd = k >> 6;
     int slot = -1;
     if (k == M) slot = 11;
@@ -386,13 +424,22 @@ __global__ __launch_bounds__(256) void k_refseed_finish(const cplx* part, int nc
             const cplx v = part[(((size_t)i * ncc + cc) * RS_NACC + slot) * 64 + lane];
             s.x += v.x; s.y += v.y;
         }
-        const cplx rot = unit_phasor((double)k, -delta[i]);
+        const cplx rot = unit_phasor((double)k, -delta_i);
         s = cmul(s, rot);
-        const double inv = wsum[i] > 0.0 ? 1.0 / wsum[i] : 0.0;
+        const double inv = wsum_i > 0.0 ? 1.0 / wsum_i : 0.0;
         s.x *= inv; s.y *= inv;
         if (k == M) s.y = 0.0;          // (irfft keeps the real part of the Nyquist term only)
     }
-    spec[(size_t)i * (M + 1) + k] = s;
+    return s;
 }
 
+__global__ __launch_bounds__(256) void k_refseed_finish(const cplx* part, int ncc, const double* delta,
+                                                        const double* wsum, int nsub, cplx* spec, const unsigned* mws) {
+    constexpr int M = 1024;
+    const int i = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k > M) return;
+    spec[(size_t)i * (M + 1) + k] = refseed_spec_value(part, ncc, delta[i], wsum[i], nsub, i, k, mws);
+}
+
+#undef PP_WBT
 }  // namespace pp

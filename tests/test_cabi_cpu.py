@@ -3,6 +3,7 @@ symbol include/pp_toas.h declares, and refuses to work without a GPU instead
 of silently falling back."""
 import os
 import re
+import sys
 
 import pytest
 
@@ -52,3 +53,28 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpptoas_hip.so")
     with pytest.raises(_lib.HipLibraryMissing):
         _lib.load()
+
+
+def test_no_scratch_traffic_inside_the_row_loops_of_the_transforms():
+    """The metadata's "spilled VGPRs" of the 2048-bin transform kernels cannot tell the saves and restores around
+    their one call to tail_work (executed once per ticket a wave draws) from spills inside the row loop (executed per
+    row; a scratch load queues behind the prefetched row like every other vector-memory access -- worth 7 % once).  The
+    disassembly can (tools/kernel_resources.py --loops): a loop is a backward branch, and no scratch instruction of any
+    k_xspec_q* instantiation may sit in a loop that contains no call.  The kernels that carry tickets must still have
+    their call; the others must have no scratch at all."""
+    import shutil
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") or shutil.which("objcopy") is None:
+        pytest.skip("no llvm-objdump / objcopy")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    res = kernel_resources.loop_scratch(pat="k_xspec_q")
+    assert len(res) >= 18, sorted(res)
+    carriers = [k for k in res if k.startswith(("k_xspec_q1024<", "k_xspec_qf<1024,")) or
+                (k.startswith("k_xspec_qr1024<") and k.endswith("false>"))]
+    assert len(carriers) == 10, carriers
+    for k, v in res.items():
+        assert v["scratch_in_loops"] == 0, (k, v)
+        if k in carriers:
+            assert v["calls"] == 2 and v["scratch_total"] > 0, (k, v)       # (the ticket between two rows, the drain at the end)
+        else:
+            assert v["calls"] == 0 and v["scratch_total"] == 0, (k, v)
