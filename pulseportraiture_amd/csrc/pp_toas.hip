@@ -31,6 +31,11 @@ using namespace pp;
 // errors
 // --------------------------------------------------------------------------
 static thread_local std::string g_err;
+// the context whose submitted batch this thread is running (pp_fit_submit's worker), or nullptr: set by the worker
+// itself -- comparing thread ids with pp_ctx::job raced with the submitting thread's assignment of that very member
+// (found by ThreadSanitizer, tools/sanitize: the worker could refuse its own batch with PP_ESTATE)
+struct pp_ctx;
+static thread_local const pp_ctx* t_worker_of = nullptr;
 
 static int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -288,7 +293,7 @@ static void resolve_spans(pp_ctx* c, size_t upto = (size_t)-1) {
 // and counters until it has been waited for / collected: every other entry point that uses them refuses
 static int ctx_busy(pp_ctx* c, const char* who) {
     if (!c) return PP_OK;           // (the entry point reports the null context itself)
-    if (c->job_active && std::this_thread::get_id() != c->job.get_id())
+    if (c->job_active && t_worker_of != c)
         return fail(PP_ESTATE, "%s: a submitted fit is pending on this context (pp_fit_wait first)", who);
     if (!c->pending.empty())
         return fail(PP_ESTATE, "%s: %zu enqueued batch(es) not collected yet (pp_fit_collect first)", who, c->pending.size());
@@ -2001,7 +2006,7 @@ static int run_batch_sync(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, const
 extern "C" int pp_fit_portrait_batch(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out) {
     if (!c || !in || !out) return fail(PP_EINVAL, "pp_fit_portrait_batch: null argument");
     // a submitted batch owns the context (work buffers, stream, counters) until pp_fit_wait
-    if (c->job_active && std::this_thread::get_id() != c->job.get_id())
+    if (c->job_active && t_worker_of != c)
         return fail(PP_ESTATE, "pp_fit_portrait_batch: a submitted fit is pending on this context (pp_fit_wait first)");
     if (!c->pending.empty())
         return fail(PP_ESTATE, "pp_fit_portrait_batch: %zu enqueued batch(es) not collected yet (pp_fit_collect first)", c->pending.size());
@@ -2119,6 +2124,7 @@ extern "C" int pp_fit_submit(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out) {
     c->job_done.store(0);
     c->job_active = true;
     c->job = std::thread([c]() {
+        t_worker_of = c;
         c->job_rc = pp_fit_portrait_batch(c, &c->job_in, &c->job_out);
         c->job_err = g_err;              // (the worker's thread-local message)
         c->job_done.store(1);

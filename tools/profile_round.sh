@@ -13,8 +13,11 @@ python3 bench.py > $O/${R}_bench.json 2> $O/raw/bench.err
 # profiled passes: headline only (no CPU pool: nothing may be spawned under rocprofv3)
 B="python3 bench.py --no-cpu-baseline --no-other-workloads"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/trace -- $B --steps 3 --warmup 1 > $O/${R}_bench_under_rocprof.json 2> $O/raw/trace.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_fetch -- $B --steps 1 --warmup 0 > /dev/null 2> $O/raw/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_write -- $B --steps 1 --warmup 0 > /dev/null 2> $O/raw/write.err
+# (THREE enqueued steps: the timed launches of the transform carry the previous step's solve + post-fit stage as
+# tickets -- option fuse_tail -- so the figure that belongs beside the timed kernel is the SECOND dispatch's, not the
+# first's, which carries nothing; both are written to traffic_latest.json)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_fetch -- $B --steps 3 --warmup 0 > /dev/null 2> $O/raw/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/raw/pmc_write -- $B --steps 3 --warmup 0 > /dev/null 2> $O/raw/write.err
 tools/pmc_counters.sh $R --no-other-workloads > $O/${R}_sq_counters.txt 2>&1
 # configs[3] (scattering): kernel stats and HBM counters of its own
 W4="--workload cfg4-2048x2048-scat"
@@ -45,28 +48,42 @@ def counters(d, name):
     fs = glob.glob(f"{O}/raw/{d}/*/*_counter_collection.csv")
     if not fs:
         return out
-    for r in csv.DictReader(open(fs[0])):
-        if r["Counter_Name"] != name:
-            continue
-        e = out.setdefault(r["Kernel_Name"], {"dispatches": 0, "sum_KiB": 0.0})
+    rows = [r for r in csv.DictReader(open(fs[0])) if r["Counter_Name"] == name]
+    rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0) or 0))
+    for r in rows:
+        e = out.setdefault(r["Kernel_Name"], {"dispatches": 0, "sum_KiB": 0.0, "per_dispatch_KiB": []})
         e["dispatches"] += 1
         e["sum_KiB"] += float(r["Counter_Value"])
+        e["per_dispatch_KiB"].append(float(r["Counter_Value"]))
     return out
 bench = json.loads(open(f"{O}/{R}_bench.json").read().strip().splitlines()[-1])
 nsub = bench["config"]["nsub_per_gpu_per_step"]
 fetch, write = counters("pmc_fetch", "FETCH_SIZE"), counters("pmc_write", "WRITE_SIZE")
-json.dump({"units": f"KiB per dispatch group of one bench step ({nsub} fits of {bench['config']['nchan']}x{bench['config']['nbin']} {bench['config']['input_dtype']})",
+json.dump({"units": f"KiB, summed and per dispatch, of three enqueued bench steps ({nsub} fits of {bench['config']['nchan']}x{bench['config']['nbin']} {bench['config']['input_dtype']})",
            "note": "gfx950 FETCH_SIZE counts half of a wide coalesced read: double it (MI355X_MICROARCH.md, HBM); WRITE_SIZE is exact",
            "fetch": fetch, "write": write}, open(f"{O}/{R}_pmc_hbm_counters.json", "w"), indent=1)
 fam = bench["roofline"]["kernel"]
 kname = {"xspec": "k_xspec", "eval": "k_eval"}.get(fam, fam)
-fb = sum(v["sum_KiB"] for k, v in fetch.items() if kname in k) * 1024 * 2
-wb = sum(v["sum_KiB"] for k, v in write.items() if kname in k) * 1024
-nl = max(1, max([v["dispatches"] for k, v in fetch.items() if kname in k] or [1]))
-if fb > 0:
+# the dominant transform kernel's dispatches in order: [0] carries no tail, [1] and [2] carry the previous step's
+def per_dispatch(tab, scale):
+    best = max(((k, v) for k, v in tab.items() if kname in k), key=lambda kv: kv[1]["sum_KiB"], default=(None, None))[1]
+    return [x * scale for x in best["per_dispatch_KiB"]] if best else []
+fd, wd = per_dispatch(fetch, 2048.0), per_dispatch(write, 1024.0)
+fb = sum(fd)
+if fb > 0 and len(fd) == len(wd):
+    tot = [a + b for a, b in zip(fd, wd)]
+    with_tail = tot[1] if len(tot) > 1 else tot[0]
+    # (the stand-alone solve + post-fit kernels of the LAST step, which nobody carries, for comparison)
+    alone = sum(v["per_dispatch_KiB"][-1] * 2048.0 for k, v in fetch.items() if "k_taylor_solve" in k or "k_finalize" in k) + \
+            sum(v["per_dispatch_KiB"][-1] * 1024.0 for k, v in write.items() if "k_taylor_solve" in k or "k_finalize" in k)
     tl = {"workload": bench["config"]["workload"], "input_dtype": bench["config"]["input_dtype"], "nsub": nsub,
-          "kernel": fam, "hbm_bytes_per_launch": (fb + wb) / nl, "hbm_bytes_per_fit": (fb + wb) / nl / nsub,
-          "source": f"profiles/{R}_pmc_hbm_counters.json (FETCH_SIZE x2 + WRITE_SIZE)"}
+          "kernel": fam, "hbm_bytes_per_launch": with_tail, "hbm_bytes_per_fit": with_tail / nsub,
+          "hbm_bytes_per_launch_without_tail": tot[0], "hbm_bytes_per_fit_without_tail": tot[0] / nsub,
+          "dispatches_profiled": len(tot), "hbm_bytes_per_launch_each": tot,
+          "stand_alone_solve_and_post_fit_bytes": alone,
+          "note": "hbm_bytes_per_launch is the SECOND of three enqueued steps' transform: like every timed launch it carries the "
+                  "previous step's solve + post-fit stage as tickets (fuse_tail); the first dispatch carries none",
+          "source": f"profiles/{R}_pmc_hbm_counters.json (FETCH_SIZE x2 + WRITE_SIZE, three enqueued steps)"}
     try:
         import re
         txt = open(f"{O}/{R}_sq_counters.txt").read()
