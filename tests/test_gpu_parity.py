@@ -474,6 +474,31 @@ def _check_against_polished_reference(g, gt, isub, kw):
         assert abs(tau - x[3]) < 1e-7 and abs(gt.alphas[0][isub] - x[4]) < 1e-6
 
 
+# The evaluation counts (`nfeval` = SciPy's `nfev`, pptoaslib.py:1017) are asserted EQUAL to the reference's / the oracle's,
+# fit by fit, except the entries named here: (where, index) -> device count minus reference count.  Every entry is a fit
+# whose count hangs on SciPy's last unit -- (+1) the closing proposal p = -H^-1 g is below half a spacing of the doubles at
+# x in NumPy's arithmetic, so fl(x + p) is x itself and SciPy's one-point cache answers without counting, while the
+# device's p (the rounding noise of ITS gradient) is a new point; or (+-1) the predicted reduction f - m(p) of the last
+# step is below one ulp(f) and rounds to 0 in one arithmetic and to 1 ulp in the other, one iteration apart at the same
+# answer.  profiles/r06_nfeval_full_shape.txt prints SciPy's own walk for the full-shape entries (|p| / spacing(x) = 0.29,
+# 0.24, 0.31 for cfg3[0]; predicted reductions of 0.00 and 2.00 ulp(f) around the exit of headline[2]) and what the oracle
+# counts under 15 channel orders and three SIMD widths of NumPy; tools/dev_nfev_caller.py lists the caller-level ones.  All
+# are phase + DM (+ GM) fits on the Taylor model; no scattering fit differs.  An entry allows that difference or none.
+NFEVAL_TAIL = {
+    ("gettoas_phiDM", 0): +1, ("gettoas_ird", 1): -1,
+    ("gettoas_opt_two_archives/1", 0): +1, ("gettoas_opt_DM0/0", 1): +1,
+    ("headline-f64", 2): +1, ("headline-f32", 2): -1, ("cfg3-4096x2048-phiDMGM", 0): +1,
+}
+
+
+def _assert_nfeval(got, want, where):
+    got, want = np.atleast_1d(np.asarray(got)).astype(int), np.atleast_1d(np.asarray(want)).astype(int)
+    assert got.shape == want.shape
+    for i in np.where(got != want)[0]:
+        assert NFEVAL_TAIL.get((where, int(i))) == int(got[i] - want[i]), \
+            "nfeval of %s[%d]: device %d, reference %d -- not in NFEVAL_TAIL" % (where, i, got[i], want[i])
+
+
 @pytest.mark.parametrize("name", ["gettoas_phiDM", "gettoas_phiDM_nurefs", "gettoas_GM",
                                   "gettoas_scat", "gettoas_zap", "gettoas_ird"])
 def test_get_TOAs_matches_reference_caller(name):
@@ -637,7 +662,7 @@ def test_get_TOAs_with_the_references_seed_returns_the_references_numbers(name):
     # the reference's own with its channels in another order, tools/ref_self_scatter.py -- can
     # stop one evaluation apart at the same answer.
     nf = np.asarray(gt.nfevals[0])
-    assert np.abs(nf - g["out_nfevals"]).max() <= 1 and (nf == g["out_nfevals"]).mean() >= 0.4, (nf, g["out_nfevals"])
+    _assert_nfeval(nf, g["out_nfevals"], name)          # (equal fit by fit, but for the named tail cases: NFEVAL_TAIL)
     assert (nf[2] == 0) and (np.asarray(gt.nfevals[0])[ok] >= 3).all()      # (0 for the zapped subint)
 
 
@@ -711,8 +736,7 @@ def test_get_TOAs_options_match_reference_caller(name):
         assert dphi.max() < PHI_BAR and (dphi < 1e-11).mean() >= 0.5, dphi
         assert np.abs(np.asarray(gt.DMs[ia])[ok] - want("DMs")[ok]).max() < 1e-10
         np.testing.assert_allclose(gt.DeltaDM_means[ia], want("DeltaDM_means"), rtol=0, atol=1e-10)
-        nf = np.asarray(gt.nfevals[ia])
-        assert np.abs(nf - want("nfevals")).max() <= 1, (nf, want("nfevals"))
+        _assert_nfeval(gt.nfevals[ia], want("nfevals"), "%s/%d" % (name, ia))
         for isub in range(len(want("TOA_days"))):
             t = gt.TOAs[ia][isub]
             if isub not in ok:
@@ -1636,6 +1660,7 @@ def test_full_shapes_of_cfg3_and_cfg4_match_oracle(case):
     rw = e.fit_batch(data, freqs, P, x0, method='newton', **kw)
     ii = np.where(flags)[0]
     mFT = np.fft.rfft(model, axis=-1); mFT[:, 0] = 0
+    nfev_dev, nfev_orc = [], []
     for i in range(data.shape[0]):             # every subint of the batch
         host = data[i].cpu().numpy()
         o = orc.fit_portrait_full(host, model, x0[i], P[i], freqs, [nu_fit] * 3, [None] * 3, errs[i],
@@ -1651,7 +1676,7 @@ def test_full_shapes_of_cfg3_and_cfg4_match_oracle(case):
         np.testing.assert_allclose(rn["scales"][i], o.scales, rtol=1e-6, atol=1e-9)
         np.testing.assert_allclose(rn["scale_errs"][i], o.scale_errs, rtol=1e-6)
         np.testing.assert_allclose(rn["snr"][i], o.snr, rtol=1e-8)
-        assert abs(rn["nfeval"][i] - o.nfeval) <= 1, (i, rn["nfeval"], o.nfeval)      # (tail: +-1, see above)
+        nfev_dev.append(int(rn["nfeval"][i])); nfev_orc.append(int(o.nfeval))
         # Newton: at the optimum of the oracle's objective
         dFT = np.fft.rfft(host, axis=-1); dFT[:, 0] = 0
         args = (dFT, mFT, errs[i] * np.sqrt(B / 2.0), P[i], freqs, rw["nu_refs"][i, 0],
@@ -1660,6 +1685,7 @@ def test_full_shapes_of_cfg3_and_cfg4_match_oracle(case):
         assert abs(step[0]) < PHI_BAR and abs(step[1]) < DM_BAR, step
         assert _dphi(rw["params"][i, 0], o.phi) < 5e-9
         np.testing.assert_allclose(rw["chi2"][i], o.chi2, rtol=1e-10)
+    _assert_nfeval(nfev_dev, nfev_orc, case)           # SciPy's count, fit by fit (NFEVAL_TAIL names the one tail case)
     # every subint converged and recovered the injected DM within its error bar
     assert (rn["return_code"] == 2).all() and (rw["return_code"] == 2).all()
 
@@ -1686,6 +1712,7 @@ def test_headline_shape_matches_oracle_raw(dtype):
     assert kt["xspec"][1] == 1 and kt.get("eval", (0, 0))[1] == 0      # one pass, nothing stored
     assert (r["return_code"] == 2).all() and (r["npass"] == 1).all()
     worst = [0.0, 0.0]
+    nfev_orc = []
     for i in range(nsub):
         host = data[i].cpu().numpy().astype(np.float64)
         o = orc.fit_portrait_full(host, model, x0[i], P[i], freqs, [nu_fit] * 3, [None] * 3, errs[i],
@@ -1700,7 +1727,8 @@ def test_headline_shape_matches_oracle_raw(dtype):
         np.testing.assert_allclose(r["snr"][i], o.snr, rtol=1e-8)
         np.testing.assert_allclose(r["scales"][i], o.scales, rtol=1e-6, atol=1e-9)
         np.testing.assert_allclose(r["scale_errs"][i], o.scale_errs, rtol=1e-6)
-        assert abs(r["nfeval"][i] - o.nfeval) <= 1, (i, r["nfeval"], o.nfeval)
+        nfev_orc.append(int(o.nfeval))
+    _assert_nfeval(r["nfeval"], nfev_orc, "headline-" + dtype)
     print("headline shape %s: worst raw |dphi| %.2e |dDM| %.2e over %d subints" % (dtype, worst[0], worst[1], nsub))
 
 
