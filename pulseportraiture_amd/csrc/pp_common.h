@@ -291,7 +291,9 @@ struct SubState {
 #define PP_NACC 21
 // channels per workgroup of the kernels that sum over channels (evaluators, seed accumulation, moments):
 // a property of the band, never of the batch (see fit_chunk's `chunking`)
+#ifndef PP_CHUNK_CHANNELS
 #define PP_CHUNK_CHANNELS 256
+#endif
 // raw per-channel sums kept for the post-fit stage
 #define PP_NCS 9   // A0 A1 A2 T1 T2 A1T S0 S1 S2
 // order of the per-channel Taylor model of C_n(phi_n) about the initial point:
