@@ -727,7 +727,8 @@ def main():
             sl = strong_scaling(sargs, make_batch, sync, fence, device, rank, world, use_dist,
                                 collect=eng.collect if args.pipeline > 1 else None)
             others["strong_3000"] = {"fits_per_s": sl["value"], "ms_total": sl["ms_per_step"],
-                                     "gather_ms": sl["gather_ms"], "rows": sl["gathered_records"]["rows"],
+                                     "gather_ms": sl["gather_ms"], "wall_s_all_in": sl["wall_s"],
+                                     "fits_per_s_all_in": sl["fits_per_s_all_in"], "rows": sl["gathered_records"]["rows"],
                                      "sub_batches": sl["config"]["sub_batches_rank0"],
                                      "resident_sub_batches": sl["config"]["resident_sub_batches"],
                                      "steps_in_flight": sl["config"]["steps_in_flight"],

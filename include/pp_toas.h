@@ -85,7 +85,10 @@ int pp_abi_version(void);
 const char* pp_last_error(void);
 int pp_create(int device_id, pp_ctx** out);
 int pp_destroy(pp_ctx* ctx);
-/* block until everything queued on the context's stream has finished */
+/* block until everything queued on the context's stream has finished.  A batch enqueued with pp_fit_enqueue whose
+ * solve and post-fit stage were still waiting for a next batch to carry them (option "fuse_tail") gets them queued
+ * first, by the stand-alone kernels: after pp_synchronize the DEVICE-resident outputs of every enqueued batch
+ * (records_dev, per-channel arrays with chan_on_device) are written; host outputs are complete after pp_fit_collect. */
 int pp_synchronize(pp_ctx* ctx);
 /* the hipStream_t the context launches on (as void*) */
 void* pp_stream(pp_ctx* ctx);
@@ -174,10 +177,15 @@ void* pp_stream(pp_ctx* ctx);
  *                  its post-fit stage are NOT queued behind its transform; the transform of the next enqueued batch works
  *                  them off, one subint per ticket, between its own rows (one wave per ticket walking the waves of the
  *                  stand-alone kernels in turn: bitwise their results), and the batch's outputs and event follow that
- *                  transform on the stream.  If no batch follows (pp_fit_collect comes first) or the next batch cannot carry
- *                  them (another row length, scattering, a seed flow), the stand-alone kernels are queued then.  Keep THREE
- *                  batches enqueued to hide it all (a batch completes one transform later).  +0.6 ... 2.9 % fits/s
- *                  (profiles/r05_fuse_tail_ab.txt); 0 = solve and post-fit stage queued at once
+ *                  transform on the stream.  The reference-seed flow (pp_seed_ref, what get_TOAs runs by default) is part
+ *                  of this since round 6: its pass (k_xspec_qr1024) carries tickets, and ITS tail -- the guess's spectrum
+ *                  from the pass's chunk partials, fit_phase_shift with SciPy's simplex, the start points, then solve and
+ *                  post-fit stage -- is a ticket of the next pass (+2.7 % fits/s, profiles/r06_refseed_tail_ab.txt).  If no
+ *                  batch follows (pp_fit_collect or pp_synchronize comes first), the next batch cannot carry them (another
+ *                  row length, scattering, a device seed) or is much smaller than the one it would carry (fewer than half
+ *                  as many waves as tickets), the stand-alone kernels are queued then.  Keep THREE batches enqueued to hide
+ *                  it all (a batch completes one transform later).  +0.6 ... 2.9 % fits/s (profiles/r05_fuse_tail_ab.txt);
+ *                  0 = solve and post-fit stage queued at once
  *   "tail_virtual" experiments: 1 = the stand-alone solve / post-fit kernels themselves in their one-wave form
  *   "check_from"   evaluation loop: the first iteration after which the host looks at the count of unfinished subints
  *                  (default 2; trust-ncg scattering fits with the closing model: 5 at least -- none is done before)
