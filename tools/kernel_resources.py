@@ -47,7 +47,7 @@ def loop_scratch(so=None, pat=""):
         dem = subprocess.run(["c++filt"], input="\n".join(want), capture_output=True, text=True).stdout.split("\n")
         out = {}
         for sym, name in zip(want, dem):
-            short = re.sub(r"\(.*\)$", "", re.sub(r"^void pp::", "", name))
+            short = re.sub(r"\(.*\)$", "", re.sub(r"^(void )?pp::", "", name))
             if pat and pat not in short:
                 continue
             if not short.startswith("k_"):
