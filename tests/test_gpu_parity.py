@@ -3603,6 +3603,44 @@ def test_tail_inside_the_next_transform_returns_the_synchronous_bits(eng, C, B, 
         eng.set_option("fuse_tail", saved)
 
 
+@pytest.mark.parametrize("C,nsub", [(256, 7), (512, 33), (1024, 5)])
+def test_reference_seed_tail_with_empty_chunks_and_small_bands(eng, C, nsub):
+    """The reference-seed tail as tickets (round 6) at the edges of its path: the narrowest bands that have the
+    single-pass seed (256 channels = 8 chunks of 32), batches far smaller than the grid, and masks that zap WHOLE
+    32-channel chunks of some subints (a chunk without a row in use leaves no partial: the ticket's chunk walk and
+    k_refseed_finish must skip the same ones) -- enqueued three deep, alternating with plain batches, against the
+    synchronous calls: bitwise, seed phases included."""
+    data, freqs, P, x0, kw = _medium_batch(eng, nsub, C=C, B=2048, seed=100 + C)
+    from pulseportraiture_amd import gmodel as _gm
+    _, model_rs, _ = _gm.example_model(C, 2048)
+    rng = np.random.default_rng(C)
+    mask = (rng.random((nsub, C)) > 0.15).astype(np.uint8)
+    for i in range(0, nsub, 2):                       # every other subint loses one or two whole chunks
+        c0 = int(rng.integers(0, C // 32))
+        mask[i, 32 * c0:32 * c0 + 32] = 0
+        if i % 4 == 0:
+            mask[i, :32] = 0
+    rs = dict(weights=None, model_profs=model_rs.mean(axis=0), nu_mean=np.full(nsub, freqs.mean()), Ns=100, finish='simplex')
+    w = rng.uniform(0.5, 2.0, (nsub, C))
+    rs_w = dict(rs, weights=w)
+    jobs = [dict(kw, ref_seed=rs), dict(kw, chan_mask=mask, ref_seed=rs), dict(kw), dict(kw, chan_mask=mask, ref_seed=rs_w),
+            dict(kw, ref_seed=rs_w), dict(kw, chan_mask=mask)]
+    keys = ("params", "param_errs", "nu_refs", "cov", "chi2", "red_chi2", "snr", "nfeval", "npass", "return_code",
+            "scales", "scale_errs", "channel_snrs")
+    sync = [eng.fit_batch(data, freqs, P, x0, **k) for k in jobs]
+    assert (sync[1]["return_code"] == 2).all()
+    got = []
+    for j, k in enumerate(jobs * 2):
+        eng.enqueue(data, freqs, P, x0, **k)
+        if j >= 2:
+            got.append(eng.collect())
+    while len(got) < 2 * len(jobs):
+        got.append(eng.collect())
+    for j, (a, g) in enumerate(zip(sync * 2, got)):
+        for key in keys + (("seed_phase",) if "seed_phase" in a else ()):
+            np.testing.assert_array_equal(a[key], g[key], err_msg="job %d %s" % (j % len(jobs), key))
+
+
 def test_post_fit_stage_on_its_own_stream_changes_nothing(eng):
     """Option `overlap_post`: the solve and post-fit stage of an enqueued batch on the context's second stream,
     with a work-buffer set of their own, behind an event of the transform -- so that they MAY run beside the
