@@ -54,6 +54,9 @@ __device__ __forceinline__ void refseed_ticket(const RefTailArgs& r, const int n
     constexpr int M = 1024;
     static_assert(128 + 2 * M <= PP_TAIL_LDS_DOUBLES, "the fit's cross-spectrum in the carrying kernel's image");
     cplx* X = reinterpret_cast<cplx*>(lds + 128);
+#ifdef PP_TICKET_TIMING
+    const long long tr0 = wall_clock64();
+#endif
     // ---- rot_prof's spectrum from the chunk partials (k_refseed_finish's arithmetic, harmonic by harmonic: the same
     // sums in the same order), laid out for ONE wave: lane l takes partial-lane l of all twelve slots, so that every
     // chunk is twelve coalesced 1 KB loads with nothing depending on them but twelve running sums -- the harmonic-by-
@@ -98,6 +101,9 @@ __device__ __forceinline__ void refseed_ticket(const RefTailArgs& r, const int n
         }
     }
     __syncthreads();
+#ifdef PP_TICKET_TIMING
+    if (tid == 0 && (i % 128) == 5) printf("ticket %4d: partial sums + spectrum %.1f us\n", i, 0.01 * (double)(wall_clock64() - tr0));
+#endif
     const cplx* m = r.mspec + (size_t)i * r.mstride;
     auto dv = [&](const int k) __attribute__((always_inline)) { return X[k - 1]; };
     fps_body<4>(r.fps, i, tid, M, dv, m, X, lds, nullptr, nullptr);
@@ -124,7 +130,13 @@ __device__ __noinline__ void tail_work(const TailArgs* t, double* lds, int nlds,
         double* sh = lds + 528;
         double* inv = lds + 536;
         (void)nlds;
+#ifdef PP_TICKET_TIMING
+        const long long tk0 = wall_clock64();
+#endif
         if (t->rs.on) refseed_ticket(t->rs, nsub, i, tid, lds);
+#ifdef PP_TICKET_TIMING
+        const long long tk1 = wall_clock64();
+#endif
         const int snt = t->solve_nt, spf = t->solve_pf, fnt = t->fin_nt;
         if (snt == 64) taylor_solve_body<64, PP_SOLVE_PF, 1>(a, i, tid, scratch, inv);
         else if (snt == 128) taylor_solve_body<128, PP_SOLVE_PF, 2>(a, i, tid, scratch, inv);
@@ -132,11 +144,19 @@ __device__ __noinline__ void tail_work(const TailArgs* t, double* lds, int nlds,
         else if (spf == 0) taylor_solve_body<256, 0, 4>(a, i, tid, scratch, inv);
         else taylor_solve_body<256, PP_SOLVE_PF, 4>(a, i, tid, scratch, inv);
         __syncthreads();             // (one wave: orders its LDS and global writes before the post-fit stage reads them)
+#ifdef PP_TICKET_TIMING
+        const long long tk2 = wall_clock64();
+#endif
         if (fnt == 64) finalize_body<8, 64, 1>(a, i, tid, scratch, sh);
         else if (fnt == 128) finalize_body<0, 128, 2>(a, i, tid, scratch, sh);
         else if (fnt == 512) finalize_body<0, 512, 8>(a, i, tid, scratch, sh);
         else finalize_body<0, 256, 4>(a, i, tid, scratch, sh);
         __syncthreads();
+#ifdef PP_TICKET_TIMING
+        if (tid == 0 && (i % 128) == 5)
+            printf("ticket %4d (block %5d): guess %.1f us  solve %.1f us  post-fit %.1f us\n", i, (int)blockIdx.x, 0.01 * (double)(tk1 - tk0),
+                   0.01 * (double)(tk2 - tk1), 0.01 * (double)(wall_clock64() - tk2));
+#endif
         // the last ticket to finish publishes the count of unfinished subints (the stand-alone post-fit kernel
         // runs after the whole solve kernel: its subint 0 does it)
         if (tid == 0) {
