@@ -333,7 +333,6 @@ def self_launch(ngpus, argv, script=None):
         s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
-    env["PP_BENCH_SELF_LAUNCHED"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
     print("bench.py: --gpus %d without RANK in the environment: starting %s" % (ngpus, " ".join(cmd)), file=sys.stderr)
