@@ -434,6 +434,7 @@ class GetTOAs(object):
         start = time.time()
         datafiles = self.datafiles if datafile is None else [datafile]
         eng = default_engine()
+        last_fl = None          # (the reference's `fit_flags` variable lives across subints AND archives of one call)
         for iarch, datafile in enumerate(datafiles):
             try:
                 data, fname = _load(datafile)
@@ -525,10 +526,16 @@ class GetTOAs(object):
                 if len(freqsx) == 1:
                     fl = [1, 0, 0, 0, 0]
                 elif len(freqsx) == 2 and self.fit_DM and self.fit_GM:
-                    fl = list(self.fit_flags)
+                    # the reference writes `fit_flags[2] = 0` into the list LEFT OVER from the subint before
+                    # (pptoas.py:479-481): right after a one-channel subint that list is [1,0,0,0,0] and the
+                    # two-channel subint is fitted for phase only; after a normal one it becomes phase + DM.
+                    # Reproduced -- but for the very first subint of a call, where the
+                    # reference has no list yet and raises NameError: the flags asked for, GM dropped.
+                    fl = list(last_fl) if last_fl is not None else list(self.fit_flags)
                     fl[2] = 0
                 else:
                     fl = list(self.fit_flags)
+                last_fl = fl
                 flags_per.append(tuple(fl))
             port = _dededisperse(eng, _take_subints(d.subints, ok_isubs), d, ok_isubs)
             ref_in = None
@@ -636,6 +643,11 @@ class GetTOAs(object):
                 snrs[isub] = res["snr"][j]
                 channel_snrs[isub, ich] = res["channel_snrs"][j, ich]
                 if cov.shape == covariances[isub].shape:
+                    covariances[isub] = cov
+                elif cov.shape == (1, 1):
+                    # (`covariances[isub] = results.covariance_matrix`, pptoas.py:598: NumPy broadcasts a 1 x 1 matrix
+                    # over the whole nfit x nfit slot instead of raising -- a phase-only fit fills every entry with
+                    # var(phi); reproduced)
                     covariances[isub] = cov
                 else:
                     for ii, a_ in enumerate(ifit):

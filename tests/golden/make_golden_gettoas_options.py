@@ -97,13 +97,28 @@ def main():
          dict(fit_scat=True, log10_tau=True, scat_guess=(30e-6, 1500.0, -4.0), nu_fits=(1450.0, 1550.0),
               nu_refs=(1500.0, 1400.0))),
     ]
+    # subints with one and with two usable channels under fit_GM (pptoas.py:475-486): one channel -> phase only; two
+    # channels -> "fit_flags[2] = 0" on the list LEFT OVER from the previous subint -- [1,0,0,0,0] right after a
+    # one-channel subint (so that two-channel subint is fitted for phase only), [1,1,1,0,0] -> [1,1,0,0,0] after a normal one
+    cases.append(("gettoas_opt_fewchan", [dict(seed=47, nsub=6, GM=0.25, fewchan=True)], dict(fit_GM=True, bary=False)))
     for name, archives, gkw in cases:
         bunches, store = {}, {}
         names = []
         for ia, skw in enumerate(archives):
             skw = dict(skw)
             nsub = skw.get("nsub", 5)
+            fewchan = skw.pop("fewchan", False)
             data, arrays, scal = mgt.synth_archive(ref, **skw)
+            if fewchan:
+                w = np.ones_like(arrays["weights"])
+                w[1, :] = 0.0; w[1, 10] = 1.0
+                w[2, :] = 0.0; w[2, [5, 25]] = 1.0
+                w[4, :] = 0.0; w[4, [3, 30]] = 1.0
+                arrays["weights"] = w
+                data.weights = w
+                data.ok_ichans = [np.where(w[i] > 0)[0] for i in range(nsub)]
+                data.ok_isubs = np.array([i for i in range(nsub) if len(data.ok_ichans[i])])
+                data.masks = (w > 0)[:, None, :, None]
             # (synth_archive zaps subint 2 entirely: keep that for archives that have one)
             fname = "fake_%d.fits" % ia
             data.filename = fname

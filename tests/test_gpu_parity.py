@@ -475,7 +475,7 @@ def _check_against_polished_reference(g, gt, isub, kw):
 
 
 # The evaluation counts (`nfeval` = SciPy's `nfev`, pptoaslib.py:1017) are asserted EQUAL to the reference's / the oracle's,
-# fit by fit, except the entries named here: (where, index) -> device count minus reference count.  Every entry is a fit
+# fit by fit, except the 8 entries named here: (where, index) -> device count minus reference count.  Every entry is a fit
 # whose count hangs on SciPy's last unit -- (+1) the closing proposal p = -H^-1 g is below half a spacing of the doubles at
 # x in NumPy's arithmetic, so fl(x + p) is x itself and SciPy's one-point cache answers without counting, while the
 # device's p (the rounding noise of ITS gradient) is a new point; or (+-1) the predicted reduction f - m(p) of the last
@@ -488,6 +488,9 @@ NFEVAL_TAIL = {
     ("gettoas_phiDM", 0): +1, ("gettoas_ird", 1): -1,
     ("gettoas_opt_two_archives/1", 0): +1, ("gettoas_opt_DM0/0", 1): +1,
     ("headline-f64", 2): +1, ("headline-f32", 2): -1, ("cfg3-4096x2048-phiDMGM", 0): +1,
+    # (a phase-only fit of two channels: one-parameter fits agree with the reference's count least often -- 74-81 % of a
+    # sweep, DESIGN section 2 -- because their closing p is a single number against a single spacing of the doubles)
+    ("gettoas_opt_fewchan/0", 2): -1,
 }
 
 
@@ -667,7 +670,7 @@ def test_get_TOAs_with_the_references_seed_returns_the_references_numbers(name):
 
 
 OPTION_GOLDENS = ["gettoas_opt_two_archives", "gettoas_opt_DM0", "gettoas_opt_fixalpha", "gettoas_opt_lintau",
-                  "gettoas_opt_nufits"]
+                  "gettoas_opt_nufits", "gettoas_opt_fewchan"]
 # the result lists of GetTOAs.__init__ that hold one numeric entry per archive (pptoas.py:101-147), with the
 # tolerance each is held to against the reference's own run (rtol, atol)
 _OPT_LISTS = {
@@ -687,7 +690,10 @@ def test_get_TOAs_options_match_reference_caller(name):
     list of two archives with different DM and nsub (per-archive DeltaDM means, DM0s, the order of
     TOA_list; pptoas.py:247, 665-721), DM0= given (pptoas.py:315-318), fit_scat with fix_alpha
     (pptoas.py:216-227: nfit 3, flags 11010, 3 x 3 covariances), log10_tau=False (pptoas.py:448-450,
-    614-627: linear-tau flags), nu_fits=(nu1, nu2) (pptoas.py:402-407).  EVERY result list of the
+    614-627: linear-tau flags), nu_fits=(nu1, nu2) (pptoas.py:402-407); subints with ONE and with TWO usable channels
+    under fit_GM (pptoas.py:475-486: phase only; `fit_flags[2] = 0` on the list left over from the subint before --
+    phase only right after a one-channel subint, phase + DM after a normal one; a 1 x 1 covariance broadcast over
+    the whole nfit x nfit slot).  EVERY result list of the
     object is compared, per archive, and every TOA of TOA_list: archive, frequency, MJD, error,
     DM, DM error, and the flags -- names in the reference's insertion order, values to the
     parameter's tolerance."""
