@@ -101,6 +101,13 @@ def main():
     # channels -> "fit_flags[2] = 0" on the list LEFT OVER from the previous subint -- [1,0,0,0,0] right after a
     # one-channel subint (so that two-channel subint is fitted for phase only), [1,1,1,0,0] -> [1,1,0,0,0] after a normal one
     cases.append(("gettoas_opt_fewchan", [dict(seed=47, nsub=6, GM=0.25, fewchan=True)], dict(fit_GM=True, bary=False)))
+    # fit_DM=False (phase only everywhere: DM / DM_err None on the TOA lines, unit DM weights in the archive's mean) with the
+    # parallactic-angle flag and caller-supplied flags (pptoas.py:196-215, 606-608, 646-651, 665-682)
+    cases.append(("gettoas_opt_nodm", [dict(seed=48, nsub=4)],
+                  dict(fit_DM=False, print_parangle=True, addtnl_toa_flags={"pta": "NANOGrav", "ver": 0.1})))
+    # the flux estimate of a scattering fit (pptoas.py:554-575: the template scattered by the FITTED tau and alpha before its means are taken)
+    cases.append(("gettoas_opt_scatflux", [dict(seed=49, nsub=4, tau_us=20.0)],
+                  dict(fit_scat=True, print_flux=True, scat_guess=(30e-6, 1500.0, -4.0))))
     for name, archives, gkw in cases:
         bunches, store = {}, {}
         names = []
@@ -134,7 +141,8 @@ def main():
         gt.datafiles = list(names)
         gt.get_TOAs(quiet=True, **gkw)
         out = dump(gt, names)
-        kwargs = {"kw_" + k: np.asarray(v) for k, v in gkw.items()}
+        kwargs = {("kwjson_" + k if isinstance(v, dict) else "kw_" + k): (np.array(json.dumps(v)) if isinstance(v, dict) else np.asarray(v))
+                  for k, v in gkw.items()}
         mg.save(name, narchives=len(archives), **store, **{"out_" + k: v for k, v in out.items()}, **kwargs)
     shutil.rmtree(tmp, ignore_errors=True)
 
