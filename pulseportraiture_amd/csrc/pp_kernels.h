@@ -80,6 +80,7 @@ struct XspecArgs {
     // one-pass flow, enqueued batches: the previous batch's solve + post-fit stage as tickets (one subint each) the
     // waves of this launch draw -- one before their first row, the rest after their last -- or nullptr
     const TailArgs* tail;
+    int tail_nsub;            // ... how many tickets it holds
 };
 
 // one harmonic of the stored cross-spectrum (row pitch Xs elements of 16 or 8 bytes)

@@ -1490,6 +1490,7 @@ static int fit_chunk(pp_ctx* c, const pp_fit_in* in, pp_fit_out* out, int s0, in
         th->rs = pt.rs;
         if ((rc = staged_copy(c, c->tailbuf[st_i].p, th, tb, hipMemcpyHostToDevice))) return fail(rc, "tail block copy failed");
         x.tail = c->tailbuf[st_i].as<TailArgs>();
+        x.tail_nsub = pt.ns;
         return PP_OK;
     };
     // ... and behind the carrying transform: the carried batch's outputs and its event

@@ -36,6 +36,9 @@
 #ifndef PP_SLOT_EARLY_EXIT
 #define PP_SLOT_EARLY_EXIT 1
 #endif
+#ifndef PP_TICKET_SPREAD
+#define PP_TICKET_SPREAD 0
+#endif
 #ifndef PP_TAIL_HOOKS
 #define PP_TAIL_HOOKS 1            // the transform kernels of 2048-bin rows can work off the previous batch's solve / post-fit
                                    // tickets (tail_work).  Not the 1024-bin kernel: it is compiled for three waves per SIMD
@@ -100,6 +103,15 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
     if (PP_TAIL_HOOKS && a.tail) {
         const unsigned share = (unsigned)(nrows / (long long)gridDim.x) + 1u;
         tail_after = 1 + (int)(((blockIdx.x * 2654435761u) >> 8) % (share - share / 4));
+#if PP_TICKET_SPREAD
+        // (experiment: only as many waves ask as there are tickets -- every (grid / tickets)-th one --, so that the tickets
+        // are spread over the first three quarters of the launch instead of being gone after its first fifth)
+        {
+            const unsigned nt = (unsigned)a.tail_nsub;
+            const unsigned div = nt ? gridDim.x / nt : 1u;
+            if (div > 1u && (((blockIdx.x * 2246822519u) >> 11) % div) != 0u) tail_after = 0x7fffffff;   // (hashed: blockIdx mod 8 is the XCD)
+        }
+#endif
     }
     RowWalk<true> rw;
     rw.start(nrows, a.mwords, a.ticket, a.ticket_base);
