@@ -39,6 +39,12 @@
 #ifndef PP_TICKET_SPREAD
 #define PP_TICKET_SPREAD 0
 #endif
+// a wave asks for its ticket after a wave-specific number of rows, uniform over this fraction of its share of the launch
+// (every wave asks, the first `tickets` to ask get one: with 3/4 and four waves per ticket they are gone after the first fifth)
+#ifndef PP_TICKET_WINDOW_NUM
+#define PP_TICKET_WINDOW_NUM 3u
+#define PP_TICKET_WINDOW_DEN 4u
+#endif
 #ifndef PP_TAIL_HOOKS
 #define PP_TAIL_HOOKS 1            // the transform kernels of 2048-bin rows can work off the previous batch's solve / post-fit
                                    // tickets (tail_work).  Not the 1024-bin kernel: it is compiled for three waves per SIMD
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(64, 2) void k_xspec_q1024(XspecArgs a) {
     int tail_after = 0x7fffffff;
     if (PP_TAIL_HOOKS && a.tail) {
         const unsigned share = (unsigned)(nrows / (long long)gridDim.x) + 1u;
-        tail_after = 1 + (int)(((blockIdx.x * 2654435761u) >> 8) % (share - share / 4));
+        tail_after = 1 + (int)(((blockIdx.x * 2654435761u) >> 8) % (share * PP_TICKET_WINDOW_NUM / PP_TICKET_WINDOW_DEN + 1u));
 #if PP_TICKET_SPREAD
         // (experiment: only as many waves ask as there are tickets -- every (grid / tickets)-th one --, so that the tickets
         // are spread over the first three quarters of the launch instead of being gone after its first fifth)
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(64, (M == 1024 ? 2 : PP_QF512_WPS)) void k_xspec_qf
     int tail_after = 0x7fffffff;         // (as k_xspec_q1024)
     if (PP_TAIL_HOOKS && M == 1024 && a.tail) {
         const unsigned share = (unsigned)(nrows / (long long)gridDim.x) + 1u;
-        tail_after = 1 + (int)(((blockIdx.x * 2654435761u) >> 8) % (share - share / 4));
+        tail_after = 1 + (int)(((blockIdx.x * 2654435761u) >> 8) % (share * PP_TICKET_WINDOW_NUM / PP_TICKET_WINDOW_DEN + 1u));
     }
     RowWalk<true> rw;
     rw.start(nrows, a.mwords, a.ticket, a.ticket_base);
