@@ -3673,11 +3673,27 @@ def test_reference_seed_tail_with_empty_chunks_and_small_bands(eng, C, nsub):
         eng.enqueue(data, freqs, P, x0, **k)
         if j >= 2:
             got.append(eng.collect())
+    eng.synchronize()               # (pp_synchronize queues the youngest batch's unqueued tail by the stand-alone kernels)
     while len(got) < 2 * len(jobs):
         got.append(eng.collect())
     for j, (a, g) in enumerate(zip(sync * 2, got)):
         for key in keys + (("seed_phase",) if "seed_phase" in a else ()):
             np.testing.assert_array_equal(a[key], g[key], err_msg="job %d %s" % (j % len(jobs), key))
+    # a reference-seed tail that the NEXT batch cannot carry (a scattering fit): flushed by k_refseed_finish / k_fps / ...
+    xs = x0.copy()
+    xs[:, 3], xs[:, 4] = 1e-3, -4.0
+    kws = dict(kw, fit_flags=[1, 1, 0, 1, 0], log10_tau=False)
+    seq = [(x0, dict(kw, ref_seed=rs)), (xs, kws), (x0, dict(kw, chan_mask=mask, ref_seed=rs_w)), (x0, dict(kw))]
+    want = [eng.fit_batch(data, freqs, P, x, **k) for x, k in seq]
+    got = []
+    for j, (x, k) in enumerate(seq):
+        eng.enqueue(data, freqs, P, x, **k)
+        if j >= 1:
+            got.append(eng.collect())
+    got.append(eng.collect())
+    for a, g in zip(want, got):
+        for key in keys + (("seed_phase",) if "seed_phase" in a else ()):
+            np.testing.assert_array_equal(a[key], g[key], err_msg=key)
 
 
 def test_post_fit_stage_on_its_own_stream_changes_nothing(eng):
